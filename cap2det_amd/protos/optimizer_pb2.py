@@ -1,0 +1,3 @@
+"""Stand-in for the protoc-generated `protos/optimizer_pb2.py` of the reference (schema.py)."""
+from cap2det_amd.protos.schema import (  # noqa: F401
+    Optimizer, GradientDescentOptimizer, AdagradOptimizer, AdamOptimizer, RMSPropOptimizer, MomentumOptimizer)

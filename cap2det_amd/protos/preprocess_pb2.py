@@ -1,0 +1,3 @@
+"""Stand-in for the protoc-generated `protos/preprocess_pb2.py` of the reference (schema.py)."""
+from cap2det_amd.protos.schema import (  # noqa: F401
+    Preprocess)
