@@ -4,18 +4,51 @@ There is NO CPU fallback: if the shared library is missing or a symbol is absent
 product path raises.  `import torch` happens first so that the HIP runtime the library binds
 to (soname libamdhip64.so.7) is the one PyTorch already loaded — device pointers and streams
 are then shared between torch and the kernels.
+
+Argument types are taken from the declarations in include/cap2det_hip.h itself, so the
+binding cannot drift from the header.
 """
 import ctypes
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcap2det_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cap2det_hip.h")
 
 _lib = None
+_SIGS = None
 
 
 class Cap2DetHipError(RuntimeError):
   """Raised when a C-ABI call returns a negative C2D_ERR_* code."""
+
+
+def _ctype(decl):
+  decl = decl.strip()
+  if "*" in decl:
+    return ctypes.c_void_p
+  base = re.sub(r"\b[A-Za-z_]\w*$", "", decl).strip() if " " in decl else decl
+  base = base.replace("const", "").strip()
+  return {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,
+          "unsigned long long": ctypes.c_ulonglong, "int32_t": ctypes.c_int32,
+          "void": None}[base]
+
+
+def header_signatures():
+  """Parses `int c2d_xxx(...)` declarations of the header -> {name: (restype, [argtypes])}."""
+  global _SIGS
+  if _SIGS is not None:
+    return _SIGS
+  with open(HEADER_PATH) as f:
+    text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+  sigs = {}
+  for m in re.finditer(r"(const char\*|int)\s+(c2d_\w+)\s*\(([^)]*)\)\s*;", text):
+    ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+    args = [] if params in ("void", "") else [_ctype(p) for p in params.split(",")]
+    sigs[name] = (ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int, args)
+  _SIGS = sigs
+  return sigs
 
 
 def load():
@@ -29,9 +62,10 @@ def load():
         "g.build()'` (or `make -C cap2det_amd/csrc`). There is no CPU fallback." % LIB_PATH)
   import torch  # noqa: F401  (loads the HIP runtime first, see module docstring)
   lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-  lib.c2d_version.restype = ctypes.c_int
-  lib.c2d_error_string.restype = ctypes.c_char_p
-  lib.c2d_error_string.argtypes = [ctypes.c_int]
+  for name, (restype, argtypes) in header_signatures().items():
+    fn = getattr(lib, name)  # AttributeError => header/library mismatch: fail loudly
+    fn.restype = restype
+    fn.argtypes = argtypes
   _lib = lib
   return lib
 
@@ -43,7 +77,5 @@ def check(code, what):
 
 
 def call(name, *args):
-  """Calls C-ABI function `name` with already-converted ctypes-compatible args."""
-  fn = getattr(load(), name)
-  fn.restype = ctypes.c_int
-  check(fn(*args), name)
+  """Calls C-ABI function `name`; raises Cap2DetHipError on a non-zero return."""
+  check(getattr(load(), name)(*args), name)

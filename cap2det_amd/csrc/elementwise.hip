@@ -1,0 +1,536 @@
+// HBM-bound NHWC kernels around the convolutions: pools, BN/ReLU backward, spatial mean +
+// dropout, preprocessing, im2col for the 7x7 stem, weight transposes, Adagrad.
+// All are float4-vectorised along channels (16 B per lane, coalesced).
+//
+// Reference call sites replaced: slim.max_pool2d / slim.avg_pool2d inside the Inception-V2
+// extractor [3P] (models/utils.py:133-136,165-167), tf.reduce_mean + slim.dropout
+// (models/utils.py:169-174), FasterRCNN preprocess (models/utils.py:127), the BatchNorm/ReLU
+// gradients TF derives for train_op (train/trainer.py:141-146) and
+// tf.train.AdagradOptimizer (core/training_utils.py:45-50).
+#include "c2d_common.h"
+
+namespace {
+
+struct PoolGeom {
+  int ih, iw, oh, ow, stride, pad_t, pad_l;
+};
+
+__host__ __device__ inline PoolGeom make_pool_geom(int ih, int iw, int stride) {
+  PoolGeom g;
+  g.ih = ih; g.iw = iw; g.stride = stride;
+  g.oh = (ih + stride - 1) / stride;
+  g.ow = (iw + stride - 1) / stride;
+  const int pth = (g.oh - 1) * stride + 3 - ih, ptw = (g.ow - 1) * stride + 3 - iw;
+  g.pad_t = (pth > 0 ? pth : 0) / 2;
+  g.pad_l = (ptw > 0 ? ptw : 0) / 2;
+  return g;
+}
+
+// mode 0: max (writes uint8 argmax = ky*3+kx of the first maximum), mode 1: avg over valid cells.
+__global__ __launch_bounds__(256) void pool3x3_fwd_kernel(
+    const float* __restrict__ x, int ldx, int xoff, float* __restrict__ y, int ldy, int yoff,
+    uint8_t* __restrict__ arg, int n, int c4n, PoolGeom g, int mode) {
+  const long long total = (long long)n * g.oh * g.ow * c4n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const long long row = idx / c4n;
+    const int ox = (int)(row % g.ow);
+    const int oy = (int)((row / g.ow) % g.oh);
+    const int img = (int)(row / ((long long)g.ow * g.oh));
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 am = make_uchar4(0, 0, 0, 0);
+    int cnt = 0;
+    bool first = true;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * g.stride - g.pad_t + ky;
+      if (iy < 0 || iy >= g.ih) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * g.stride - g.pad_l + kx;
+        if (ix < 0 || ix >= g.iw) continue;
+        const float4 v = *reinterpret_cast<const float4*>(
+            x + ((size_t)(img * g.ih + iy) * g.iw + ix) * ldx + xoff + c4 * 4);
+        const unsigned char k = (unsigned char)(ky * 3 + kx);
+        if (first) {
+          best = v; am = make_uchar4(k, k, k, k); first = false;
+        } else {
+          if (v.x > best.x) { best.x = v.x; am.x = k; }
+          if (v.y > best.y) { best.y = v.y; am.y = k; }
+          if (v.z > best.z) { best.z = v.z; am.z = k; }
+          if (v.w > best.w) { best.w = v.w; am.w = k; }
+        }
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        ++cnt;
+      }
+    }
+    float4 out;
+    if (mode == 0) {
+      out = best;
+      if (arg) *reinterpret_cast<uchar4*>(arg + (size_t)row * c4n * 4 + c4 * 4) = am;
+    } else {
+      const float d = (float)cnt;
+      out = make_float4(sum.x / d, sum.y / d, sum.z / d, sum.w / d);
+    }
+    *reinterpret_cast<float4*>(y + (size_t)row * ldy + yoff + c4 * 4) = out;
+  }
+}
+
+// Gather form of the pool gradient: one lane per INPUT element loops over the <= 9 outputs
+// whose window contains it (no atomics, deterministic).
+__global__ __launch_bounds__(256) void pool3x3_bwd_kernel(
+    const float* __restrict__ dy, int lddy, int dyoff, const uint8_t* __restrict__ arg,
+    float* __restrict__ dx, int lddx, int dxoff, int n, int c4n, PoolGeom g, int mode,
+    int accumulate) {
+  const long long total = (long long)n * g.ih * g.iw * c4n;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const long long row = idx / c4n;
+    const int ix = (int)(row % g.iw);
+    const int iy = (int)((row / g.iw) % g.ih);
+    const int img = (int)(row / ((long long)g.iw * g.ih));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = iy + g.pad_t - ky;
+      if (ty < 0 || (ty % g.stride) != 0) continue;
+      const int oy = ty / g.stride;
+      if (oy >= g.oh) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = ix + g.pad_l - kx;
+        if (tx < 0 || (tx % g.stride) != 0) continue;
+        const int ox = tx / g.stride;
+        if (ox >= g.ow) continue;
+        const size_t orow = (size_t)(img * g.oh + oy) * g.ow + ox;
+        const float4 gy = *reinterpret_cast<const float4*>(dy + orow * lddy + dyoff + c4 * 4);
+        if (mode == 0) {
+          const uchar4 am = *reinterpret_cast<const uchar4*>(arg + orow * c4n * 4 + c4 * 4);
+          const unsigned char k = (unsigned char)(ky * 3 + kx);
+          if (am.x == k) acc.x += gy.x;
+          if (am.y == k) acc.y += gy.y;
+          if (am.z == k) acc.z += gy.z;
+          if (am.w == k) acc.w += gy.w;
+        } else {
+          // number of valid cells of output (oy,ox)'s window
+          const int y0 = oy * g.stride - g.pad_t, x0 = ox * g.stride - g.pad_l;
+          const int ny = min(y0 + 3, g.ih) - max(y0, 0);
+          const int nx = min(x0 + 3, g.iw) - max(x0, 0);
+          const float d = (float)(ny * nx);
+          acc.x += gy.x / d; acc.y += gy.y / d; acc.z += gy.z / d; acc.w += gy.w / d;
+        }
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(dx + (size_t)row * lddx + dxoff + c4 * 4);
+    if (accumulate) {
+      const float4 o = *dst;
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *dst = acc;
+  }
+}
+
+// dc = dy * (y > 0) * scale[c];  dbeta[c] += sum dz;  dgamma[c] += sum dz * (y - beta)/gamma
+// where dz = dy * (y > 0).  (y = gamma*xhat + beta wherever y > 0, so xhat = (y-beta)/gamma.)
+// Block: TX lanes over float4 channel groups x TY row lanes; LDS reduce over TY.
+template <int TX>
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
+    const float* __restrict__ dy, int lddy, int dyoff, const float* __restrict__ y, int ldy,
+    int yoff, const float* __restrict__ scale, const float* __restrict__ beta,
+    const float* __restrict__ gamma, float* __restrict__ dc, float* __restrict__ dbeta,
+    float* __restrict__ dgamma, int M, int c4n, int rows_per_block) {
+  constexpr int TY = 256 / TX;
+  __shared__ float4 red[2][TY][TX];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  for (int base = 0; base < c4n; base += TX) {  // usually a single trip; uniform for barriers
+    const int cg = base + tx;
+    const bool active = cg < c4n;
+    const int c = (active ? cg : 0) * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+    float4 be = make_float4(0.f, 0.f, 0.f, 0.f), ig = be;
+    if (dgamma) {
+      be = *reinterpret_cast<const float4*>(beta + c);
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+      ig = make_float4(ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
+                       ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f);
+    }
+    if (active) {
+      for (int r = r0 + ty; r < r1; r += TY) {
+        const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + dyoff + c);
+        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * ldy + yoff + c);
+        float4 dz;
+        dz.x = v.x > 0.f ? g.x : 0.f; dz.y = v.y > 0.f ? g.y : 0.f;
+        dz.z = v.z > 0.f ? g.z : 0.f; dz.w = v.w > 0.f ? g.w : 0.f;
+        sb.x += dz.x; sb.y += dz.y; sb.z += dz.z; sb.w += dz.w;
+        sg.x += dz.x * (v.x - be.x) * ig.x; sg.y += dz.y * (v.y - be.y) * ig.y;
+        sg.z += dz.z * (v.z - be.z) * ig.z; sg.w += dz.w * (v.w - be.w) * ig.w;
+        *reinterpret_cast<float4*>(dc + (size_t)r * c4n * 4 + c) =
+            make_float4(dz.x * sc.x, dz.y * sc.y, dz.z * sc.z, dz.w * sc.w);
+      }
+    }
+    red[0][ty][tx] = sb;
+    red[1][ty][tx] = sg;
+    __syncthreads();
+    if (ty == 0 && active) {
+      float4 tb = make_float4(0.f, 0.f, 0.f, 0.f), tg = tb;
+      for (int k = 0; k < TY; ++k) {
+        const float4 b = red[0][k][tx], gq = red[1][k][tx];
+        tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
+        tg.x += gq.x; tg.y += gq.y; tg.z += gq.z; tg.w += gq.w;
+      }
+      if (dbeta) {
+        atomicAdd(dbeta + c + 0, tb.x); atomicAdd(dbeta + c + 1, tb.y);
+        atomicAdd(dbeta + c + 2, tb.z); atomicAdd(dbeta + c + 3, tb.w);
+      }
+      if (dgamma) {
+        atomicAdd(dgamma + c + 0, tg.x); atomicAdd(dgamma + c + 1, tg.y);
+        atomicAdd(dgamma + c + 2, tg.z); atomicAdd(dgamma + c + 3, tg.w);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[j] += sum_m x[m][xoff + j]   (bias gradients)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int ldx,
+                                                      int xoff, float* __restrict__ out, int M,
+                                                      int ncols, int rows_per_block) {
+  __shared__ float red[256];
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  // 64 column lanes x 4 row lanes
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = tx; c < ncols; c += 64) {
+    float s = 0.f;
+    for (int r = r0 + ty; r < r1; r += 4) s += x[(size_t)r * ldx + xoff + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0) atomicAdd(out + c, red[tx] + red[tx + 64] + red[tx + 128] + red[tx + 192]);
+    __syncthreads();
+  }
+}
+
+// y[r][c] = mean_s x[r][s][c] * (mask ? mask[r][c] * inv_keep : 1)
+__global__ __launch_bounds__(256) void spatial_mean_dropout_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const uint8_t* __restrict__ mask,
+    int rows, int spatial, int c4n, float inv_keep) {
+  const long long total = (long long)rows * c4n;
+  const float inv_s = 1.0f / (float)spatial;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const long long r = idx / c4n;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < spatial; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)r * spatial + k) * c4n * 4 + c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x *= inv_s; s.y *= inv_s; s.z *= inv_s; s.w *= inv_s;
+    if (mask) {
+      const uchar4 m = *reinterpret_cast<const uchar4*>(mask + (size_t)idx * 4);
+      s.x = s.x * inv_keep * (float)m.x; s.y = s.y * inv_keep * (float)m.y;
+      s.z = s.z * inv_keep * (float)m.z; s.w = s.w * inv_keep * (float)m.w;
+    }
+    *reinterpret_cast<float4*>(y + (size_t)idx * 4) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void spatial_mean_dropout_bwd_kernel(
+    const float* __restrict__ dy, int lddy, int dyoff, float* __restrict__ dx,
+    const uint8_t* __restrict__ mask, int rows, int spatial, int c4n, float inv_keep) {
+  const long long total = (long long)rows * spatial * c4n;
+  const float inv_s = 1.0f / (float)spatial;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const long long r = idx / ((long long)c4n * spatial);
+    float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + dyoff + c4 * 4);
+    if (mask) {
+      const uchar4 m = *reinterpret_cast<const uchar4*>(mask + ((size_t)r * c4n + c4) * 4);
+      g.x = g.x * inv_keep * (float)m.x; g.y = g.y * inv_keep * (float)m.y;
+      g.z = g.z * inv_keep * (float)m.z; g.w = g.w * inv_keep * (float)m.w;
+    }
+    g.x *= inv_s; g.y *= inv_s; g.z *= inv_s; g.w *= inv_s;
+    *reinterpret_cast<float4*>(dx + (size_t)idx * 4) = g;
+  }
+}
+
+// Counter-based RNG (splitmix64 finaliser) -> keep mask; reproducible from (seed, offset).
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask,
+                                                           long long n, unsigned long long seed,
+                                                           float keep_prob) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // [0,1)
+    mask[i] = u < keep_prob ? 1 : 0;
+  }
+}
+
+// out[p][0..2] = (2/255)*img[p][0..2] - 1, out[p][3] = 0   (FasterRCNN preprocess + pad to 4ch)
+__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img,
+                                                         float4* __restrict__ out,
+                                                         long long pixels) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < pixels;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float s = 2.0f / 255.0f;
+    out[i] = make_float4(s * img[i * 3 + 0] - 1.0f, s * img[i * 3 + 1] - 1.0f,
+                         s * img[i * 3 + 2] - 1.0f, 0.0f);
+  }
+}
+
+// im2col with SAME padding for a 4-channel image: out[row][(ky*kw+kx)*4 + c], zero padded to kpad.
+__global__ __launch_bounds__(256) void im2col4_kernel(const float4* __restrict__ x,
+                                                      float4* __restrict__ out, int n, int ih,
+                                                      int iw, int oh, int ow, int kh, int kw,
+                                                      int stride, int pad_t, int pad_l,
+                                                      int kpad4) {
+  const long long total = (long long)n * oh * ow * kpad4;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % kpad4);
+    const long long row = idx / kpad4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < kh * kw) {
+      const int ox = (int)(row % ow);
+      const int oy = (int)((row / ow) % oh);
+      const int img = (int)(row / ((long long)ow * oh));
+      const int ky = t / kw, kx = t % kw;
+      const int iy = oy * stride - pad_t + ky, ix = ox * stride - pad_l + kx;
+      if (iy >= 0 && iy < ih && ix >= 0 && ix < iw) v = x[((size_t)img * ih + iy) * iw + ix];
+    }
+    out[idx] = v;
+  }
+}
+
+// wt[t][j][i] = w[t][i][j]
+__global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ w,
+                                                             float* __restrict__ wt, int taps,
+                                                             int I, int J) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* src = w + (size_t)t * I * J;
+  float* dst = wt + (size_t)t * I * J;
+  for (int k = ty; k < 32; k += 8) {
+    const int i = i0 + k, j = j0 + tx;
+    tile[k][tx] = (i < I && j < J) ? src[(size_t)i * J + j] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int j = j0 + k, i = i0 + tx;
+    if (i < I && j < J) dst[(size_t)j * I + i] = tile[tx][k];
+  }
+}
+
+// g' = mult * (g + l2 * w); acc += g'^2; w -= lr * g' / sqrt(acc)       (TF ApplyAdagrad)
+__global__ __launch_bounds__(256) void adagrad_kernel(float* __restrict__ w,
+                                                      const float* __restrict__ g,
+                                                      float* __restrict__ acc, long long n,
+                                                      float lr, float l2, float mult,
+                                                      float grad_scale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float wi = w[i];
+    const float gi = mult * (g[i] * grad_scale + l2 * wi);
+    const float a = acc[i] + gi * gi;
+    acc[i] = a;
+    w[i] = wi - lr * gi / sqrtf(a);
+  }
+}
+
+// out[0] += 0.5 * weight * sum w^2
+__global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ w, long long n,
+                                                      float weight, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    s += w[i] * w[i];
+  s = c2d_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, 0.5f * weight * (red[0] + red[1] + red[2] + red[3]));
+}
+
+// scale[c] = gamma[c] * rsqrt(var[c] + eps); shift[c] = beta[c] - mean[c] * scale[c]
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var,
+                               float eps, float* __restrict__ scale, float* __restrict__ shift,
+                               int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const float s = (gamma ? gamma[i] : 1.0f) / sqrtf(var[i] + eps);
+  scale[i] = s;
+  shift[i] = beta[i] - mean[i] * s;
+}
+
+inline int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int c2d_pool3x3_fwd(const float* x, int ldx, int xoff, float* y, int ldy, int yoff,
+                               uint8_t* argmax, int n, int ih, int iw, int c, int stride,
+                               int mode, void* stream) {
+  C2D_CHECK_ARG(x && y && n > 0 && ih > 0 && iw > 0 && c > 0 && c % 4 == 0);
+  C2D_CHECK_ARG((stride == 1 || stride == 2) && (mode == 0 || mode == 1));
+  C2D_CHECK_ARG(ldx % 4 == 0 && xoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
+  const PoolGeom g = make_pool_geom(ih, iw, stride);
+  const long long total = (long long)n * g.oh * g.ow * (c / 4);
+  hipLaunchKernelGGL(pool3x3_fwd_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, xoff, y, ldy, yoff, argmax, n, c / 4, g, mode);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_pool3x3_bwd(const float* dy, int lddy, int dyoff, const uint8_t* argmax,
+                               float* dx, int lddx, int dxoff, int n, int ih, int iw, int c,
+                               int stride, int mode, int accumulate, void* stream) {
+  C2D_CHECK_ARG(dy && dx && n > 0 && ih > 0 && iw > 0 && c > 0 && c % 4 == 0);
+  C2D_CHECK_ARG((stride == 1 || stride == 2) && (mode == 0 || mode == 1));
+  C2D_CHECK_ARG(mode == 1 || argmax);
+  C2D_CHECK_ARG(lddx % 4 == 0 && dxoff % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0);
+  const PoolGeom g = make_pool_geom(ih, iw, stride);
+  const long long total = (long long)n * ih * iw * (c / 4);
+  hipLaunchKernelGGL(pool3x3_bwd_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     (hipStream_t)stream, dy, lddy, dyoff, argmax, dx, lddx, dxoff, n, c / 4, g,
+                     mode, accumulate);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ldy,
+                               int yoff, const float* scale, const float* beta,
+                               const float* gamma, float* dc, float* dbeta, float* dgamma,
+                               int rows, int c, void* stream) {
+  C2D_CHECK_ARG(dy && y && scale && dc && rows > 0 && c > 0 && c % 4 == 0);
+  C2D_CHECK_ARG(!dgamma || (beta && gamma));
+  C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
+  const int c4n = c / 4;
+  const int rows_per_block = 128;
+  const int blocks = c2d_ceil_div(rows, rows_per_block);
+  hipStream_t s = (hipStream_t)stream;
+#define C2D_BNB(TX)                                                                          \
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<TX>), dim3(blocks), dim3(256), 0, s, dy, lddy, dyoff, \
+                     y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, rows, c4n,        \
+                     rows_per_block)
+  if (c4n <= 16) C2D_BNB(16);
+  else if (c4n <= 32) C2D_BNB(32);
+  else if (c4n <= 64) C2D_BNB(64);
+  else C2D_BNB(128);
+#undef C2D_BNB
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_col_sum(const float* x, int ldx, int xoff, float* out, int rows, int ncols,
+                           void* stream) {
+  C2D_CHECK_ARG(x && out && rows > 0 && ncols > 0);
+  const int rows_per_block = 256;
+  hipLaunchKernelGGL(col_sum_kernel, dim3(c2d_ceil_div(rows, rows_per_block)), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, xoff, out, rows, ncols, rows_per_block);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_spatial_mean_dropout_fwd(const float* x, float* y, const uint8_t* mask,
+                                            int rows, int spatial, int c, float keep_prob,
+                                            void* stream) {
+  C2D_CHECK_ARG(x && y && rows > 0 && spatial > 0 && c > 0 && c % 4 == 0 && keep_prob > 0.f);
+  hipLaunchKernelGGL(spatial_mean_dropout_fwd_kernel, dim3(grid_for((long long)rows * c / 4)),
+                     dim3(256), 0, (hipStream_t)stream, x, y, mask, rows, spatial, c / 4,
+                     1.0f / keep_prob);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_spatial_mean_dropout_bwd(const float* dy, int lddy, int dyoff, float* dx,
+                                            const uint8_t* mask, int rows, int spatial, int c,
+                                            float keep_prob, void* stream) {
+  C2D_CHECK_ARG(dy && dx && rows > 0 && spatial > 0 && c > 0 && c % 4 == 0 && keep_prob > 0.f);
+  C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0);
+  hipLaunchKernelGGL(spatial_mean_dropout_bwd_kernel,
+                     dim3(grid_for((long long)rows * spatial * c / 4)), dim3(256), 0,
+                     (hipStream_t)stream, dy, lddy, dyoff, dx, mask, rows, spatial, c / 4,
+                     1.0f / keep_prob);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_dropout_mask(uint8_t* mask, long long n, unsigned long long seed,
+                                float keep_prob, void* stream) {
+  C2D_CHECK_ARG(mask && n >= 0);
+  if (n == 0) return C2D_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     mask, n, seed, keep_prob);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_preprocess_pad4(const float* image, float* out, long long pixels,
+                                   void* stream) {
+  C2D_CHECK_ARG(image && out && pixels > 0);
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(pixels)), dim3(256), 0,
+                     (hipStream_t)stream, image, (float4*)out, pixels);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_im2col4(const float* x, float* out, int n, int ih, int iw, int kh, int kw,
+                           int stride, int kpad, void* stream) {
+  C2D_CHECK_ARG(x && out && n > 0 && ih > 0 && iw > 0 && kh > 0 && kw > 0 && stride > 0);
+  C2D_CHECK_ARG(kpad % 4 == 0 && kpad >= kh * kw * 4);
+  const int oh = (ih + stride - 1) / stride, ow = (iw + stride - 1) / stride;
+  const int pth = (oh - 1) * stride + kh - ih, ptw = (ow - 1) * stride + kw - iw;
+  const int pad_t = (pth > 0 ? pth : 0) / 2, pad_l = (ptw > 0 ? ptw : 0) / 2;
+  const long long total = (long long)n * oh * ow * (kpad / 4);
+  hipLaunchKernelGGL(im2col4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)x, (float4*)out, n, ih, iw, oh, ow, kh, kw, stride, pad_t,
+                     pad_l, kpad / 4);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_transpose_taps(const float* w, float* wt, int taps, int rows, int cols,
+                                  void* stream) {
+  C2D_CHECK_ARG(w && wt && taps > 0 && rows > 0 && cols > 0);
+  dim3 grid(c2d_ceil_div(cols, 32), c2d_ceil_div(rows, 32), taps);
+  hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt,
+                     taps, rows, cols);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_adagrad_step(float* w, const float* g, float* acc, long long n, float lr,
+                                float l2, float mult, float grad_scale, void* stream) {
+  C2D_CHECK_ARG(w && g && acc && n >= 0);
+  if (n == 0) return C2D_OK;
+  hipLaunchKernelGGL(adagrad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, g,
+                     acc, n, lr, l2, mult, grad_scale);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_l2_loss(const float* w, long long n, float weight, float* out,
+                           void* stream) {
+  C2D_CHECK_ARG(w && out && n >= 0);
+  if (n == 0) return C2D_OK;
+  long long b = (n + 255) / 256;
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(l2_loss_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, w, n,
+                     weight, out);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_bn_fold(const float* gamma, const float* beta, const float* mean,
+                           const float* var, float eps, float* scale, float* shift, int c,
+                           void* stream) {
+  C2D_CHECK_ARG(beta && mean && var && scale && shift && c > 0);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(c2d_ceil_div(c, 256)), dim3(256), 0,
+                     (hipStream_t)stream, gamma, beta, mean, var, eps, scale, shift, c);
+  return c2d_launch_status();
+}

@@ -1,0 +1,406 @@
+// MIDN / OICR / label kernels (latency-bound, tiny): column softmax over proposals with
+// wave64 shuffle reductions, OICR pseudo-label + cross-entropy, caption -> label MLP.
+//
+// Reference call sites replaced:
+//   c2d_midn_fwd/bwd            models/cap2det_model.py:53-109  (+ core/utils.py:101-113,172-184)
+//   c2d_sigmoid_ce_fwd_bwd      models/cap2det_model.py:293-297
+//   c2d_oicr_select             models/utils.py:39-62           (+ core/utils.py:187-199)
+//   c2d_oicr_loss_fwd_bwd       models/utils.py:64-103, models/cap2det_model.py:314-328
+//   c2d_labels_from_ids         models/label_extractor.py:15-39,183-207
+//   c2d_text_classifier_fwd     models/label_extractor.py:353-421,442-472
+#include "c2d_common.h"
+
+namespace {
+
+constexpr float kBig = 1e10f;     // core/utils.py:10
+constexpr float kSmall = 1e-10f;  // core/utils.py:11
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = c2d_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = c2d_wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) s = fmaxf(s, red[i]);
+  return s;
+}
+__device__ __forceinline__ float block_min(float v, float* red) {
+  v = c2d_wave_min(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) s = fminf(s, red[i]);
+  return s;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// grid (C, B).  logits: [B*N][ld], r|c logits at column off_r / off_c.
+__global__ __launch_bounds__(256) void midn_fwd_kernel(
+    const float* __restrict__ logits, int ld, int off_r, int off_c,
+    const int32_t* __restrict__ num_proposals, float* __restrict__ proba,
+    float* __restrict__ class_logits, float* __restrict__ scores, int N, int C) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int nb = num_proposals[b];
+  const float* L = logits + (size_t)b * N * ld;
+  // u_r = mask*Lr - 1e10*(1-mask)   (models/cap2det_model.py:92-93, core/utils.py:183-184)
+  float mx = -INFINITY;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    const float m = r < nb ? 1.0f : 0.0f;
+    const float u = m * L[(size_t)r * ld + off_r + c] - kBig * (1.0f - m);
+    mx = fmaxf(mx, u);
+  }
+  mx = block_max(mx, red);
+  float se = 0.f;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    const float m = r < nb ? 1.0f : 0.0f;
+    const float u = m * L[(size_t)r * ld + off_r + c] - kBig * (1.0f - m);
+    se += expf(u - mx);
+  }
+  se = block_sum(se, red);
+  float cl = 0.f;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    const float m = r < nb ? 1.0f : 0.0f;
+    const float u = m * L[(size_t)r * ld + off_r + c] - kBig * (1.0f - m);
+    const float p = m * (expf(u - mx) / se);
+    proba[((size_t)b * N + r) * C + c] = p;
+    cl += m * (L[(size_t)r * ld + off_c + c] * p);
+  }
+  cl = block_sum(cl, red);
+  if (threadIdx.x == 0) class_logits[b * C + c] = cl;
+  const float sg = sigmoidf(cl);
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    const size_t i = ((size_t)b * N + r) * C + c;
+    scores[i] = sg * proba[i];
+  }
+}
+
+// dLc = g*P ; dLr = g*P*(mask*Lc - cl)      (P already carries the mask)
+__global__ __launch_bounds__(256) void midn_bwd_kernel(
+    const float* __restrict__ dclass_logits, const float* __restrict__ logits, int ld, int off_r,
+    int off_c, const int32_t* __restrict__ num_proposals, const float* __restrict__ proba,
+    const float* __restrict__ class_logits, float* __restrict__ dlogits, int lddl, int N,
+    int C) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int nb = num_proposals[b];
+  const float g = dclass_logits[b * C + c];
+  const float cl = class_logits[b * C + c];
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    const size_t row = (size_t)b * N + r;
+    const float m = r < nb ? 1.0f : 0.0f;
+    const float p = proba[row * C + c];
+    const float lc = logits[row * ld + off_c + c];
+    dlogits[row * lddl + off_c + c] = g * p;
+    dlogits[row * lddl + off_r + c] = g * p * (m * lc - cl);
+  }
+}
+
+// loss[0] += weight * mean(bce);  dlogits = weight * (sigmoid(x) - z) / n
+__global__ __launch_bounds__(256) void sigmoid_ce_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ labels,
+                                                         int n, float weight,
+                                                         float* __restrict__ loss,
+                                                         float* __restrict__ dlogits) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float x = logits[i], z = labels[i];
+    s += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+    if (dlogits) dlogits[i] = weight * (sigmoidf(x) - z) / (float)n;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, weight * s / (float)n);
+}
+
+// grid (C, B): picks the most confident proposal of class c (masked_argmax, first index on
+// ties, axis minimum taken over padded rows too) and stores its index and box.
+__global__ __launch_bounds__(256) void oicr_select_kernel(
+    const float* __restrict__ s0, int ld, int off, const int32_t* __restrict__ num_proposals,
+    const float* __restrict__ boxes, int32_t* __restrict__ idx_out, float* __restrict__ box_out,
+    int N, int C) {
+  __shared__ float red[4];
+  __shared__ float sval[4];
+  __shared__ int sidx[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int nb = num_proposals[b];
+  const float* S = s0 + (size_t)b * N * ld + off + c;
+  float mn = INFINITY;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) mn = fminf(mn, S[(size_t)r * ld]);
+  mn = block_min(mn, red);
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int r = threadIdx.x; r < N; r += blockDim.x) {
+    const float v = (S[(size_t)r * ld] - mn) * (r < nb ? 1.0f : 0.0f);
+    if (v > best) { best = v; bi = r; }   // r ascending per thread: keeps the first
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sval[threadIdx.x >> 6] = best; sidx[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i)
+      if (sval[i] > best || (sval[i] == best && sidx[i] < bi)) { best = sval[i]; bi = sidx[i]; }
+    idx_out[b * C + c] = bi;
+    const float* bx = boxes + ((size_t)b * N + bi) * 4;
+    float* o = box_out + ((size_t)b * C + c) * 4;
+    o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3];
+  }
+}
+
+__device__ __forceinline__ float box_area(float y0, float x0, float y1, float x1) {
+  return fmaxf(x1 - x0, 0.0f) * fmaxf(y1 - y0, 0.0f);
+}
+
+// One wave per proposal row; lanes stride over the C+1 columns.
+__global__ __launch_bounds__(256) void oicr_loss_kernel(
+    const float* __restrict__ S, int ld, int off, const float* __restrict__ top_boxes,
+    const float* __restrict__ boxes, const float* __restrict__ labels,
+    const int32_t* __restrict__ num_proposals, float iou_thr, float weight, int B, int N, int C,
+    float* __restrict__ loss, float* __restrict__ dS, int lddS, int doff,
+    float* __restrict__ Q) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  float contrib = 0.f;
+  if (row < (long long)B * N) {
+    const int b = (int)(row / N), r = (int)(row % N);
+    const int nb = num_proposals[b];
+    const float m = r < nb ? 1.0f : 0.0f;
+    const float* bx = boxes + row * 4;
+    const float y0 = bx[0], x0 = bx[1], y1 = bx[2], x1 = bx[3];
+    const float a1 = box_area(y0, x0, y1, x1);
+    const float* s = S + row * ld + off;
+    const int C1 = C + 1;
+    // pass 1: targets (classes live at columns 1..C) and the row max
+    float tsum = 0.f, mx = -INFINITY;
+    for (int j = lane; j < C1; j += 64) {
+      mx = fmaxf(mx, s[j]);
+      if (j >= 1) {
+        const int c = j - 1;
+        const float* tb = top_boxes + ((size_t)b * C + c) * 4;
+        const float iy0 = fmaxf(y0, tb[0]), ix0 = fmaxf(x0, tb[1]);
+        const float iy1 = fminf(y1, tb[2]), ix1 = fminf(x1, tb[3]);
+        const float inter = box_area(iy0, ix0, iy1, ix1);
+        const float uni = a1 + box_area(tb[0], tb[1], tb[2], tb[3]) - inter;
+        const float iou = inter / uni;  // 0/0 -> NaN -> compares false (models/utils.py:73)
+        const float t = (labels[b * C + c] > 0.f && iou >= iou_thr) ? 1.0f : 0.0f;
+        tsum += t;
+      }
+    }
+    tsum = c2d_wave_sum(tsum);
+    mx = c2d_wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < C1; j += 64) se += expf(s[j] - mx);
+    se = c2d_wave_sum(se);
+    const float lse = logf(se);
+    const float bkg = tsum > 0.f ? 0.0f : 1.0f;
+    const float tot = bkg + tsum;
+    const float denom = fmaxf(kSmall, (float)nb);
+    float ce = 0.f;
+    for (int j = lane; j < C1; j += 64) {
+      float t;
+      if (j == 0) {
+        t = bkg;
+      } else {
+        const int c = j - 1;
+        const float* tb = top_boxes + ((size_t)b * C + c) * 4;
+        const float iy0 = fmaxf(y0, tb[0]), ix0 = fmaxf(x0, tb[1]);
+        const float iy1 = fminf(y1, tb[2]), ix1 = fminf(x1, tb[3]);
+        const float inter = box_area(iy0, ix0, iy1, ix1);
+        const float uni = a1 + box_area(tb[0], tb[1], tb[2], tb[3]) - inter;
+        const float iou = inter / uni;
+        t = (labels[b * C + c] > 0.f && iou >= iou_thr) ? 1.0f : 0.0f;
+      }
+      const float lab = t / tot;
+      const float z = s[j] - mx;
+      const float q = expf(z) / se;
+      ce -= lab * (z - lse);
+      if (Q) Q[row * C1 + j] = q;
+      if (dS) dS[row * lddS + doff + j] = weight * (q - lab) * m / denom / (float)B;
+    }
+    ce = c2d_wave_sum(ce);
+    contrib = weight * ce * m / denom / (float)B;
+  }
+  if (lane != 0) contrib = 0.f;
+  const float tot = block_sum(contrib, red);
+  if (threadIdx.x == 0 && loss && tot != 0.f) atomicAdd(loss, tot);
+}
+
+// labels[b][c] = 1 if any ids[b][t] == c (ids >= C are out-of-vocabulary)
+__global__ __launch_bounds__(256) void labels_from_ids_kernel(const int32_t* __restrict__ ids,
+                                                              int T, int C,
+                                                              float* __restrict__ labels) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) labels[b * C + c] = 0.f;
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const int id = ids[b * T + t];
+    if (id >= 0 && id < C) labels[b * C + id] = 1.0f;
+  }
+}
+
+// One block per caption.  hidden = relu(masked_maximum_t(E[id_t] . W1 + b1)); logits = hidden . W2 + b2.
+__global__ __launch_bounds__(256) void text_classifier_kernel(
+    const int32_t* __restrict__ ids, int T, const float* __restrict__ emb, int vocab, int E,
+    const float* __restrict__ w1, const float* __restrict__ b1, int H,
+    const float* __restrict__ w2, const float* __restrict__ b2, int C,
+    float* __restrict__ logits) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hid = smem;       // [H]
+  float* erow = smem + H;  // [E] current token embedding
+  const int b = blockIdx.x;
+  // per hidden unit h (thread-strided): running min over all tokens, max over (v - min)*mask is
+  // evaluated in two sweeps like the reference formula max((h - min_T h) * m) + min_T h.
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int h0 = 0; h0 < H; h0 += blockDim.x) {
+      const int h = h0 + threadIdx.x;
+      float mn = INFINITY, best = -INFINITY;
+      if (pass == 1 && h < H) mn = hid[h];
+      for (int t = 0; t < T; ++t) {
+        int id = ids[b * T + t];
+        if (id < 0 || id > vocab) id = vocab;
+        __syncthreads();
+        for (int e = threadIdx.x; e < E; e += blockDim.x) erow[e] = emb[(size_t)id * E + e];
+        __syncthreads();
+        if (h < H) {
+          float v = 0.f;
+          for (int e = 0; e < E; ++e) v += erow[e] * w1[(size_t)e * H + h];
+          v += b1[h];
+          if (pass == 0) mn = fminf(mn, v);
+          else best = fmaxf(best, (v - mn) * (id != vocab ? 1.0f : 0.0f));
+        }
+      }
+      __syncthreads();
+      if (h < H) hid[h] = pass == 0 ? mn : fmaxf(best + mn, 0.0f);
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float v = 0.f;
+    for (int h = 0; h < H; ++h) v += hid[h] * w2[(size_t)h * C + c];
+    logits[b * C + c] = v + b2[c];
+  }
+}
+
+// labels = any(exact > 0) ? exact : (sigmoid(logits) > thr)
+__global__ __launch_bounds__(256) void text_labels_merge_kernel(const float* __restrict__ logits,
+                                                                const float* __restrict__ exact,
+                                                                float thr, int C,
+                                                                float* __restrict__ labels) {
+  __shared__ int any_exact;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) any_exact = 0;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    if (exact[b * C + c] > 0.f) any_exact = 1;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float ml = sigmoidf(logits[b * C + c]) > thr ? 1.0f : 0.0f;
+    labels[b * C + c] = any_exact ? exact[b * C + c] : ml;
+  }
+}
+
+}  // namespace
+
+extern "C" int c2d_midn_fwd(const float* logits, int ld, int off_r, int off_c,
+                            const int32_t* num_proposals, float* proba, float* class_logits,
+                            float* scores, int batch, int n, int num_classes, void* stream) {
+  C2D_CHECK_ARG(logits && num_proposals && proba && class_logits && scores);
+  C2D_CHECK_ARG(batch > 0 && n > 0 && num_classes > 0);
+  hipLaunchKernelGGL(midn_fwd_kernel, dim3(num_classes, batch), dim3(256), 0,
+                     (hipStream_t)stream, logits, ld, off_r, off_c, num_proposals, proba,
+                     class_logits, scores, n, num_classes);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_midn_bwd(const float* dclass_logits, const float* logits, int ld, int off_r,
+                            int off_c, const int32_t* num_proposals, const float* proba,
+                            const float* class_logits, float* dlogits, int lddl, int batch,
+                            int n, int num_classes, void* stream) {
+  C2D_CHECK_ARG(dclass_logits && logits && num_proposals && proba && class_logits && dlogits);
+  C2D_CHECK_ARG(batch > 0 && n > 0 && num_classes > 0);
+  hipLaunchKernelGGL(midn_bwd_kernel, dim3(num_classes, batch), dim3(256), 0,
+                     (hipStream_t)stream, dclass_logits, logits, ld, off_r, off_c,
+                     num_proposals, proba, class_logits, dlogits, lddl, n, num_classes);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, int n,
+                                      float weight, float* loss, float* dlogits, void* stream) {
+  C2D_CHECK_ARG(logits && labels && n > 0);
+  hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits,
+                     labels, n, weight, loss, dlogits);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_oicr_select(const float* s0, int ld, int off, const int32_t* num_proposals,
+                               const float* boxes, int32_t* idx, float* top_boxes, int batch,
+                               int n, int num_classes, void* stream) {
+  C2D_CHECK_ARG(s0 && num_proposals && boxes && idx && top_boxes);
+  C2D_CHECK_ARG(batch > 0 && n > 0 && num_classes > 0);
+  hipLaunchKernelGGL(oicr_select_kernel, dim3(num_classes, batch), dim3(256), 0,
+                     (hipStream_t)stream, s0, ld, off, num_proposals, boxes, idx, top_boxes, n,
+                     num_classes);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_oicr_loss_fwd_bwd(const float* scores, int ld, int off,
+                                     const float* top_boxes, const float* boxes,
+                                     const float* labels, const int32_t* num_proposals,
+                                     float iou_threshold, float weight, int batch, int n,
+                                     int num_classes, float* loss, float* dscores, int lddl,
+                                     int doff, float* softmax_out, void* stream) {
+  C2D_CHECK_ARG(scores && top_boxes && boxes && labels && num_proposals);
+  C2D_CHECK_ARG(batch > 0 && n > 0 && num_classes > 0);
+  const long long rows = (long long)batch * n;
+  hipLaunchKernelGGL(oicr_loss_kernel, dim3(c2d_ceil_div(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, scores, ld, off, top_boxes, boxes, labels,
+                     num_proposals, iou_threshold, weight, batch, n, num_classes, loss, dscores,
+                     lddl, doff, softmax_out);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_labels_from_ids(const int32_t* ids, int batch, int num_tokens,
+                                   int num_classes, float* labels, void* stream) {
+  C2D_CHECK_ARG(labels && batch > 0 && num_classes > 0 && num_tokens >= 0);
+  C2D_CHECK_ARG(ids || num_tokens == 0);
+  hipLaunchKernelGGL(labels_from_ids_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream,
+                     ids, num_tokens, num_classes, labels);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_text_classifier_fwd(const int32_t* ids, int batch, int num_tokens,
+                                       const float* embedding, int vocab_size, int emb_dims,
+                                       const float* w1, const float* b1, int hidden_units,
+                                       const float* w2, const float* b2, int num_classes,
+                                       const float* exact_labels, float label_threshold,
+                                       float* logits, float* labels, void* stream) {
+  C2D_CHECK_ARG(ids && embedding && w1 && b1 && w2 && b2 && logits);
+  C2D_CHECK_ARG(batch > 0 && num_tokens > 0 && vocab_size > 0 && emb_dims > 0);
+  C2D_CHECK_ARG(hidden_units > 0 && num_classes > 0);
+  C2D_CHECK_ARG(!labels || exact_labels);
+  const size_t smem = (size_t)(hidden_units + emb_dims) * sizeof(float);
+  if (smem > 64 * 1024) return C2D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(text_classifier_kernel, dim3(batch), dim3(256), smem, (hipStream_t)stream,
+                     ids, num_tokens, embedding, vocab_size, emb_dims, w1, b1, hidden_units, w2,
+                     b2, num_classes, logits);
+  if (labels)
+    hipLaunchKernelGGL(text_labels_merge_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream,
+                       logits, exact_labels, label_threshold, num_classes, labels);
+  return c2d_launch_status();
+}

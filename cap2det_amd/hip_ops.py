@@ -1,0 +1,181 @@
+"""Thin typed wrappers: torch CUDA tensors -> raw device pointers -> C-ABI (include/cap2det_hip.h).
+
+PyTorch is plumbing only (allocation, streams); every arithmetic op on the hot path runs in
+the hand-written HIP kernels behind these calls.  No fallback: a missing library raises.
+"""
+import torch
+
+from cap2det_amd import _lib
+
+
+def _p(t):
+  if t is None:
+    return None
+  assert t.is_cuda and t.is_contiguous(), "C-ABI buffers must be contiguous device tensors"
+  return t.data_ptr()
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(*ts):
+  for t in ts:
+    assert t is None or t.dtype == torch.float32
+
+
+# -- ROI crop ---------------------------------------------------------------------------
+
+def crop_and_resize(feat, boxes, box_ind, crop):
+  b, hf, wf, d = feat.shape
+  _f32(feat, boxes)
+  out = torch.zeros(boxes.shape[0], crop, crop, d, device=feat.device, dtype=torch.float32)
+  _lib.call("c2d_crop_and_resize_fwd", _p(feat), _p(boxes), _p(box_ind), _p(out), b, hf, wf, d,
+            boxes.shape[0], crop, _stream())
+  return out
+
+
+def roi_crop_pool_fwd(feat, boxes, box_ind, crop, pool_k, pool_s, out=None, argmax=None,
+                      want_argmax=True):
+  b, hf, wf, d = feat.shape
+  r = boxes.shape[0]
+  p = (crop - pool_k) // pool_s + 1
+  if out is None:
+    out = torch.zeros(r, p, p, d, device=feat.device, dtype=torch.float32)
+  if argmax is None and want_argmax:
+    argmax = torch.zeros(r, p, p, d, device=feat.device, dtype=torch.uint8)
+  _lib.call("c2d_roi_crop_pool_fwd", _p(feat), _p(boxes), _p(box_ind), _p(out), _p(argmax), b, hf,
+            wf, d, r, crop, pool_k, pool_s, _stream())
+  return out, argmax
+
+
+def roi_crop_pool_bwd(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool_s):
+  b, hf, wf, d = dfeat.shape
+  _lib.call("c2d_roi_crop_pool_bwd", _p(dout), _p(argmax), _p(boxes), _p(box_ind), _p(dfeat), b,
+            hf, wf, d, boxes.shape[0], crop, pool_k, pool_s, _stream())
+  return dfeat
+
+
+# -- convolution ------------------------------------------------------------------------
+
+def conv_fwd(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride,
+             relu):
+  _lib.call("c2d_conv_fwd", _p(x), ldx, xoff, _p(wt), _p(scale), _p(shift), _p(y), ldy, yoff, n,
+            ih, iw, cin, cout, kh, kw, stride, int(relu), _stream())
+
+
+def conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
+               accumulate):
+  _lib.call("c2d_conv_dgrad", _p(dc), ldc, coff, _p(w), _p(dx), lddx, dxoff, n, ih, iw, cin, cout,
+            kh, kw, stride, int(accumulate), _stream())
+
+
+def conv_wgrad(x, ldx, xoff, dc, ldc, coff, dw, n, ih, iw, cin, cout, kh, kw, stride):
+  _lib.call("c2d_conv_wgrad", _p(x), ldx, xoff, _p(dc), ldc, coff, _p(dw), n, ih, iw, cin, cout,
+            kh, kw, stride, _stream())
+
+
+def transpose_taps(w, wt, taps, rows, cols):
+  _lib.call("c2d_transpose_taps", _p(w), _p(wt), taps, rows, cols, _stream())
+
+
+def bn_fold(gamma, beta, mean, var, eps, scale, shift):
+  _lib.call("c2d_bn_fold", _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(scale),
+            _p(shift), beta.numel(), _stream())
+
+
+def bn_relu_bwd(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, rows, c):
+  _lib.call("c2d_bn_relu_bwd", _p(dy), lddy, dyoff, _p(y), ldy, yoff, _p(scale), _p(beta),
+            _p(gamma), _p(dc), _p(dbeta), _p(dgamma), rows, c, _stream())
+
+
+def col_sum(x, ldx, xoff, out, rows, ncols):
+  _lib.call("c2d_col_sum", _p(x), ldx, xoff, _p(out), rows, ncols, _stream())
+
+
+def pool3x3_fwd(x, ldx, xoff, y, ldy, yoff, argmax, n, ih, iw, c, stride, mode):
+  _lib.call("c2d_pool3x3_fwd", _p(x), ldx, xoff, _p(y), ldy, yoff, _p(argmax), n, ih, iw, c,
+            stride, mode, _stream())
+
+
+def pool3x3_bwd(dy, lddy, dyoff, argmax, dx, lddx, dxoff, n, ih, iw, c, stride, mode, accumulate):
+  _lib.call("c2d_pool3x3_bwd", _p(dy), lddy, dyoff, _p(argmax), _p(dx), lddx, dxoff, n, ih, iw, c,
+            stride, mode, int(accumulate), _stream())
+
+
+def spatial_mean_dropout_fwd(x, y, mask, rows, spatial, c, keep_prob):
+  _lib.call("c2d_spatial_mean_dropout_fwd", _p(x), _p(y), _p(mask), rows, spatial, c,
+            float(keep_prob), _stream())
+
+
+def spatial_mean_dropout_bwd(dy, lddy, dyoff, dx, mask, rows, spatial, c, keep_prob):
+  _lib.call("c2d_spatial_mean_dropout_bwd", _p(dy), lddy, dyoff, _p(dx), _p(mask), rows, spatial,
+            c, float(keep_prob), _stream())
+
+
+def dropout_mask(mask, seed, keep_prob):
+  _lib.call("c2d_dropout_mask", _p(mask), mask.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            float(keep_prob), _stream())
+
+
+def preprocess_pad4(image, out):
+  _lib.call("c2d_preprocess_pad4", _p(image), _p(out), image.numel() // 3, _stream())
+
+
+def im2col4(x, out, n, ih, iw, kh, kw, stride, kpad):
+  _lib.call("c2d_im2col4", _p(x), _p(out), n, ih, iw, kh, kw, stride, kpad, _stream())
+
+
+# -- heads / losses ---------------------------------------------------------------------
+
+def midn_fwd(logits, ld, off_r, off_c, num_proposals, proba, class_logits, scores, batch, n, c):
+  _lib.call("c2d_midn_fwd", _p(logits), ld, off_r, off_c, _p(num_proposals), _p(proba),
+            _p(class_logits), _p(scores), batch, n, c, _stream())
+
+
+def midn_bwd(dclass_logits, logits, ld, off_r, off_c, num_proposals, proba, class_logits, dlogits,
+             lddl, batch, n, c):
+  _lib.call("c2d_midn_bwd", _p(dclass_logits), _p(logits), ld, off_r, off_c, _p(num_proposals),
+            _p(proba), _p(class_logits), _p(dlogits), lddl, batch, n, c, _stream())
+
+
+def sigmoid_ce_fwd_bwd(logits, labels, weight, loss, dlogits):
+  _lib.call("c2d_sigmoid_ce_fwd_bwd", _p(logits), _p(labels), logits.numel(), float(weight),
+            _p(loss), _p(dlogits), _stream())
+
+
+def oicr_select(s0, ld, off, num_proposals, boxes, idx, top_boxes, batch, n, c):
+  _lib.call("c2d_oicr_select", _p(s0), ld, off, _p(num_proposals), _p(boxes), _p(idx),
+            _p(top_boxes), batch, n, c, _stream())
+
+
+def oicr_loss_fwd_bwd(scores, ld, off, top_boxes, boxes, labels, num_proposals, iou_threshold,
+                      weight, batch, n, c, loss, dscores, lddl, doff, softmax_out):
+  _lib.call("c2d_oicr_loss_fwd_bwd", _p(scores), ld, off, _p(top_boxes), _p(boxes), _p(labels),
+            _p(num_proposals), float(iou_threshold), float(weight), batch, n, c, _p(loss),
+            _p(dscores), lddl, doff, _p(softmax_out), _stream())
+
+
+def labels_from_ids(ids, num_classes, labels):
+  batch, t = ids.shape
+  _lib.call("c2d_labels_from_ids", _p(ids) if t > 0 else None, batch, t, num_classes, _p(labels),
+            _stream())
+
+
+def text_classifier_fwd(ids, embedding, w1, b1, w2, b2, exact_labels, label_threshold, logits,
+                        labels):
+  batch, t = ids.shape
+  _lib.call("c2d_text_classifier_fwd", _p(ids), batch, t, _p(embedding), embedding.shape[0] - 1,
+            embedding.shape[1], _p(w1), _p(b1), w1.shape[1], _p(w2), _p(b2), w2.shape[1],
+            _p(exact_labels), float(label_threshold), _p(logits), _p(labels), _stream())
+
+
+# -- optimiser --------------------------------------------------------------------------
+
+def adagrad_step(w, g, acc, lr, l2, mult, grad_scale=1.0):
+  _lib.call("c2d_adagrad_step", _p(w), _p(g), _p(acc), w.numel(), float(lr), float(l2),
+            float(mult), float(grad_scale), _stream())
+
+
+def l2_loss(w, weight, out):
+  _lib.call("c2d_l2_loss", _p(w), w.numel(), float(weight), _p(out), _stream())

@@ -70,6 +70,147 @@ int c2d_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax, const float*
                           int depth, int num_boxes, int crop, int pool_k, int pool_s,
                           void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on the fp32 MFMA pipe  (replaces slim.conv2d + inference
+ * BatchNorm + ReLU of the Inception-V2 extractor [third party] called at
+ * models/utils.py:133-136 and :165-167, slim.fully_connected at
+ * models/cap2det_model.py:79-88,191-197, and the gradients TF derives for them when
+ * train/trainer.py:141-146 builds train_op).  SAME padding (TF rule), NHWC, fp32.
+ *   x   rows n*ih*iw, row stride ldx floats, channels [xoff, xoff+cin)
+ *   y   rows n*oh*ow (oh = ceil(ih/stride)), row stride ldy, channels [yoff, yoff+cout)
+ * ------------------------------------------------------------------------------------- */
+
+/* y = act(scale[co] * conv(x, W) + shift[co]).  wt is W transposed per tap:
+ * [kh*kw][cout][cin] (see c2d_transpose_taps).  scale/shift may be NULL (1 / 0); relu != 0
+ * applies max(.,0).  cin % 16 == 0. */
+int c2d_conv_fwd(const float* x, int ldx, int xoff, const float* wt, const float* scale,
+                 const float* shift, float* y, int ldy, int yoff, int n, int ih, int iw,
+                 int cin, int cout, int kh, int kw, int stride, int relu, void* stream);
+
+/* dx (+)= Conv2DBackpropInput(dc, W).  w is HWIO [kh*kw][cin][cout]; dc has the conv OUTPUT
+ * geometry (rows n*oh*ow, stride ldc, channels [coff, coff+cout)); dx has the input geometry.
+ * cout % 16 == 0.  accumulate != 0 adds into dx (sum over Inception branches). */
+int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w, float* dx, int lddx,
+                   int dxoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                   int stride, int accumulate, void* stream);
+
+/* dw[kh*kw][cin][cout] += Conv2DBackpropFilter(x, dc)  (fp32 atomics over row splits; the
+ * caller zero-fills dw once per step). */
+int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, int coff,
+                   float* dw, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                   int stride, void* stream);
+
+/* wt[t][j][i] = w[t][i][j] for t < taps (HWIO <-> per-tap transposed weights). */
+int c2d_transpose_taps(const float* w, float* wt, int taps, int rows, int cols, void* stream);
+
+/* Inference BatchNorm folded to an affine: scale = gamma*rsqrt(var+eps) (gamma NULL => 1),
+ * shift = beta - mean*scale. */
+int c2d_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                float eps, float* scale, float* shift, int c, void* stream);
+
+/* Backward of y = relu(scale*c + shift): dc[rows][c] (dense) = dy*(y>0)*scale;
+ * dbeta[c] += sum dy*(y>0); dgamma[c] += sum dy*(y>0)*(y-beta)/gamma (skipped when NULL). */
+int c2d_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ldy, int yoff,
+                    const float* scale, const float* beta, const float* gamma, float* dc,
+                    float* dbeta, float* dgamma, int rows, int c, void* stream);
+
+/* out[j] += sum_rows x[row][xoff+j]  (bias gradients). */
+int c2d_col_sum(const float* x, int ldx, int xoff, float* out, int rows, int ncols,
+                void* stream);
+
+/* 3x3 SAME pooling, stride 1 or 2 (slim.max_pool2d / slim.avg_pool2d inside Inception-V2).
+ * mode 0 = max (argmax[rows_out][c] uint8 = ky*3+kx of the first maximum, may be NULL in
+ * inference), mode 1 = average over the valid cells (TF AvgPool SAME divisor). */
+int c2d_pool3x3_fwd(const float* x, int ldx, int xoff, float* y, int ldy, int yoff,
+                    uint8_t* argmax, int n, int ih, int iw, int c, int stride, int mode,
+                    void* stream);
+int c2d_pool3x3_bwd(const float* dy, int lddy, int dyoff, const uint8_t* argmax, float* dx,
+                    int lddx, int dxoff, int n, int ih, int iw, int c, int stride, int mode,
+                    int accumulate, void* stream);
+
+/* tf.reduce_mean over the spatial axis + slim.dropout (models/utils.py:169-174).
+ * x [rows][spatial][c] -> y [rows][c]; mask [rows][c] uint8 {0,1} or NULL (no dropout). */
+int c2d_spatial_mean_dropout_fwd(const float* x, float* y, const uint8_t* mask, int rows,
+                                 int spatial, int c, float keep_prob, void* stream);
+int c2d_spatial_mean_dropout_bwd(const float* dy, int lddy, int dyoff, float* dx,
+                                 const uint8_t* mask, int rows, int spatial, int c,
+                                 float keep_prob, void* stream);
+/* Counter-based keep mask: mask[i] = u(seed, i) < keep_prob. */
+int c2d_dropout_mask(uint8_t* mask, long long n, unsigned long long seed, float keep_prob,
+                     void* stream);
+
+/* FasterRCNN preprocess (2/255)*x - 1 [third party, models/utils.py:127] fused with a pad of
+ * the RGB image to 4 channels: image [pixels][3] -> out [pixels][4]. */
+int c2d_preprocess_pad4(const float* image, float* out, long long pixels, void* stream);
+/* SAME-padded im2col of a 4-channel image for the 7x7/2 stem:
+ * out[n*oh*ow][kpad], column (ky*kw+kx)*4 + c, zero filled up to kpad (kpad % 16 == 0). */
+int c2d_im2col4(const float* x, float* out, int n, int ih, int iw, int kh, int kw, int stride,
+                int kpad, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MIDN / OICR / losses  (models/cap2det_model.py:53-109,274-330; models/utils.py:15-105)
+ * logits buffers are [batch*n][ld] with one column block per head.
+ * ------------------------------------------------------------------------------------- */
+
+/* proba = softmax_r(mask*Lr - 1e10*(1-mask))*mask; class_logits = sum_r mask*Lc*proba;
+ * scores = sigmoid(class_logits)*proba.   proba/scores [batch][n][C], class_logits [batch][C]. */
+int c2d_midn_fwd(const float* logits, int ld, int off_r, int off_c,
+                 const int32_t* num_proposals, float* proba, float* class_logits, float* scores,
+                 int batch, int n, int num_classes, void* stream);
+/* Given dloss/dclass_logits writes dloss/dLr and dloss/dLc into dlogits[batch*n][lddl] at the
+ * same column offsets. */
+int c2d_midn_bwd(const float* dclass_logits, const float* logits, int ld, int off_r, int off_c,
+                 const int32_t* num_proposals, const float* proba, const float* class_logits,
+                 float* dlogits, int lddl, int batch, int n, int num_classes, void* stream);
+/* tf.nn.sigmoid_cross_entropy_with_logits, mean over n elements, times weight:
+ * *loss += weight*mean; dlogits = weight*(sigmoid(x)-z)/n (either output may be NULL). */
+int c2d_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, int n, float weight,
+                           float* loss, float* dlogits, void* stream);
+/* masked_argmax over proposals for every class column of s0[batch*n][ld] (+off): stores the
+ * winning proposal index idx[batch][C] and its box top_boxes[batch][C][4]. */
+int c2d_oicr_select(const float* s0, int ld, int off, const int32_t* num_proposals,
+                    const float* boxes, int32_t* idx, float* top_boxes, int batch, int n,
+                    int num_classes, void* stream);
+/* One OICR refinement loss (models/utils.py:64-103): pseudo labels from IoU(box, top box) >=
+ * thr gated by the image labels, soft-label softmax CE over the C+1 columns of
+ * scores[batch*n][ld] (+off), masked mean over proposals, mean over batch, times weight.
+ * *loss += value; dscores[batch*n][lddl] (+doff) = gradient; softmax_out [batch*n][C+1] =
+ * softmax(scores) (the next iteration's s0).  Outputs may be NULL. */
+int c2d_oicr_loss_fwd_bwd(const float* scores, int ld, int off, const float* top_boxes,
+                          const float* boxes, const float* labels,
+                          const int32_t* num_proposals, float iou_threshold, float weight,
+                          int batch, int n, int num_classes, float* loss, float* dscores,
+                          int lddl, int doff, float* softmax_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Caption -> label branch  (models/label_extractor.py)
+ * ------------------------------------------------------------------------------------- */
+
+/* `_match_labels` / ExtendMatch after the host resolved strings to ids: labels[b][c] = 1 iff
+ * some ids[b][t] == c; ids >= num_classes are out-of-vocabulary. */
+int c2d_labels_from_ids(const int32_t* ids, int batch, int num_tokens, int num_classes,
+                        float* labels, void* stream);
+/* TextClassifierMatchExtractor: embedding gather ([vocab_size+1][emb_dims], last row = OOV) ->
+ * FC emb_dims->hidden (no activation) -> masked_maximum over tokens (mask = id != OOV) ->
+ * ReLU -> FC hidden->C = logits[batch][C].  If labels != NULL also
+ * labels = any(exact_labels>0) ? exact_labels : (sigmoid(logits) > label_threshold). */
+int c2d_text_classifier_fwd(const int32_t* ids, int batch, int num_tokens,
+                            const float* embedding, int vocab_size, int emb_dims,
+                            const float* w1, const float* b1, int hidden_units, const float* w2,
+                            const float* b2, int num_classes, const float* exact_labels,
+                            float label_threshold, float* logits, float* labels, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimiser  (train/trainer.py:55-61,104-146; core/training_utils.py:45-50)
+ * ------------------------------------------------------------------------------------- */
+
+/* g' = mult*(grad_scale*g + l2*w); acc += g'^2; w -= lr*g'/sqrt(acc)   (tf.train.Adagrad;
+ * grad_scale = 1/world_size after the RCCL sum all-reduce). */
+int c2d_adagrad_step(float* w, const float* g, float* acc, long long n, float lr, float l2,
+                     float mult, float grad_scale, void* stream);
+/* *out += 0.5*weight*sum(w^2)  (slim l2_regularizer). */
+int c2d_l2_loss(const float* w, long long n, float weight, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,321 @@
+"""GPU parity tests, kernel by kernel: the HIP path (through the C-ABI) against the numpy oracle
+on identical seeded inputs.  Tolerances are written per test; index/byte outputs are exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_labels, ref_model, ref_ops
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+  return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(DEV).contiguous()
+
+
+def _n(t):
+  return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+  from cap2det_amd import hip_ops
+  return hip_ops
+
+
+def _edge_boxes(rng, n):
+  c = rng.uniform(0, 1, (n, 2))
+  s = np.exp(rng.uniform(np.log(0.04), 0.0, (n, 2)))
+  b = np.concatenate([np.clip(c - s / 2, 0, 1), np.clip(c + s / 2, 0, 1)], 1).astype(np.float32)
+  b[0] = [0, 0, 0, 0]               # zero-padded proposal (readers/cap2det_reader.py:237)
+  b[1] = [0, 0, 1, 1]               # whole image, touches both borders
+  b[2] = [0.5, 0.5, 0.5, 0.5]       # single point
+  b[3] = [0.7, 0.2, 0.3, 0.9]       # y2 < y1
+  b[4] = [0.25, 0.25, 1.0, 1.0]
+  b[5] = [-0.1, -0.2, 0.5, 1.3]     # partly outside: extrapolation rows/cols
+  return b
+
+
+@pytest.mark.parametrize("hf,wf,d,n", [(9, 11, 16, 37), (32, 32, 576, 64)])
+def test_crop_and_resize_matches_oracle(ops, hf, wf, d, n):
+  rng = np.random.default_rng(1234)
+  feat = rng.standard_normal((2, hf, wf, d)).astype(np.float32)
+  boxes = _edge_boxes(rng, n)
+  ind = rng.integers(0, 2, n).astype(np.int32)
+  want = ref_ops.crop_and_resize(feat, boxes, ind, 14)
+  got = _n(ops.crop_and_resize(_t(feat), _t(boxes), _t(ind), 14))
+  # same fp32 operation order as the oracle: bit-exact
+  np.testing.assert_array_equal(got, want)
+
+
+def test_roi_crop_pool_fwd_bwd_matches_oracle(ops):
+  rng = np.random.default_rng(7)
+  hf, wf, d, n = 12, 10, 32, 41
+  feat = np.maximum(rng.standard_normal((2, hf, wf, d)), 0).astype(np.float32)  # post-ReLU map
+  boxes = _edge_boxes(rng, n)
+  ind = rng.integers(0, 2, n).astype(np.int32)
+  crop = ref_ops.crop_and_resize(feat, boxes, ind, 14)
+  want, want_arg = ref_ops.max_pool(crop, 2, 2, "VALID")
+  out, arg = ops.roi_crop_pool_fwd(_t(feat), _t(boxes), _t(ind), 14, 2, 2)
+  np.testing.assert_array_equal(_n(out), want)
+  np.testing.assert_array_equal(_n(arg), want_arg)
+  dout = rng.standard_normal(want.shape).astype(np.float32)
+  dcrop = ref_ops.max_pool_backward(crop.shape, want_arg, dout, 2, 2, "VALID")
+  want_df = ref_ops.crop_and_resize_grad_image(dcrop.astype(np.float64), boxes, ind, feat.shape)
+  dfeat = torch.zeros(feat.shape, device=DEV)
+  ops.roi_crop_pool_bwd(_t(dout), arg, _t(boxes), _t(ind), dfeat, 14, 2, 2)
+  # fp32 atomics in arbitrary order vs a float64 sum
+  np.testing.assert_allclose(_n(dfeat), want_df, rtol=1e-4, atol=1e-4)
+
+
+CONV_CASES = [
+    # n, ih, iw, cin, cout, k, stride
+    (3, 7, 7, 32, 64, 1, 1),
+    (5, 7, 7, 48, 96, 3, 1),
+    (5, 7, 7, 32, 64, 3, 2),
+    (2, 4, 4, 64, 352, 3, 1),
+    (1, 13, 9, 16, 32, 3, 2),
+    (300, 7, 7, 64, 160, 3, 1),   # M large enough for the 128x128 tile path
+]
+
+
+def _conv_inputs(rng, n, ih, iw, cin, cout, k):
+  x = rng.standard_normal((n, ih, iw, cin)).astype(np.float32)
+  w = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+  return x, w
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bn_relu(ops, case):
+  n, ih, iw, cin, cout, k, s = case
+  rng = np.random.default_rng(11)
+  x, w = _conv_inputs(rng, n, ih, iw, cin, cout, k)
+  gamma = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+  beta = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+  mean = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+  var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+  c = ref_ops.conv2d(x.astype(np.float64), w.astype(np.float64), s)
+  want = np.maximum(ref_ops.batch_norm_inference(c, gamma.astype(np.float64), beta, mean,
+                                                 var.astype(np.float64)), 0)
+  oh, ow = want.shape[1:3]
+  # input lives in a wider concat buffer (channel slice), output too
+  ldx, xoff, ldy, yoff = cin + 16, 8, cout + 32, 16
+  xb = np.zeros((n, ih, iw, ldx), np.float32); xb[..., xoff:xoff + cin] = x
+  yb = torch.full((n, oh, ow, ldy), -7.0, device=DEV)
+  wt = torch.empty(k * k, cout, cin, device=DEV)
+  ops.transpose_taps(_t(w), wt, k * k, cin, cout)
+  scale = torch.empty(cout, device=DEV); shift = torch.empty(cout, device=DEV)
+  ops.bn_fold(_t(gamma), _t(beta), _t(mean), _t(var), 0.001, scale, shift)
+  ops.conv_fwd(_t(xb), ldx, xoff, wt, scale, shift, yb, ldy, yoff, n, ih, iw, cin, cout, k, k, s, 1)
+  got = _n(yb)
+  np.testing.assert_allclose(got[..., yoff:yoff + cout], want, rtol=2e-5, atol=2e-5)
+  assert np.all(got[..., :yoff] == -7.0) and np.all(got[..., yoff + cout:] == -7.0)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_wgrad(ops, case):
+  n, ih, iw, cin, cout, k, s = case
+  rng = np.random.default_rng(13)
+  x, w = _conv_inputs(rng, n, ih, iw, cin, cout, k)
+  oh, ow = -(-ih // s), -(-iw // s)
+  dc = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+  want_dx, want_dw = ref_ops.conv2d_backward(x.astype(np.float64), w.astype(np.float64),
+                                             dc.astype(np.float64), s)
+  dx = torch.full((n, ih, iw, cin), 0.5, device=DEV)
+  ops.conv_dgrad(_t(dc), cout, 0, _t(w), dx, cin, 0, n, ih, iw, cin, cout, k, k, s, 1)
+  np.testing.assert_allclose(_n(dx) - 0.5, want_dx, rtol=1e-4, atol=1e-4)
+  dw = torch.zeros(k, k, cin, cout, device=DEV)
+  ops.conv_wgrad(_t(x), cin, 0, _t(dc), cout, 0, dw, n, ih, iw, cin, cout, k, k, s)
+  scale = np.abs(want_dw).max()
+  np.testing.assert_allclose(_n(dw), want_dw, rtol=1e-4, atol=1e-5 * scale + 1e-5)
+
+
+@pytest.mark.parametrize("mode,stride", [(0, 1), (0, 2), (1, 1)])
+@pytest.mark.parametrize("ih,iw", [(7, 7), (4, 4), (9, 5)])
+def test_pool3x3(ops, mode, stride, ih, iw):
+  rng = np.random.default_rng(17)
+  n, c = 6, 24
+  x = np.maximum(rng.standard_normal((n, ih, iw, c)), 0).astype(np.float32)  # ties at 0
+  if mode == 0:
+    want, want_arg = ref_ops.max_pool(x, 3, stride, "SAME")
+  else:
+    want, want_arg = ref_ops.avg_pool_same(x, 3), None
+  oh, ow = want.shape[1:3]
+  y = torch.empty(n, oh, ow, c, device=DEV)
+  arg = torch.empty(n, oh, ow, c, dtype=torch.uint8, device=DEV)
+  ops.pool3x3_fwd(_t(x), c, 0, y, c, 0, arg, n, ih, iw, c, stride, mode)
+  np.testing.assert_allclose(_n(y), want, rtol=1e-6, atol=1e-6)
+  dy = rng.standard_normal(want.shape).astype(np.float32)
+  if mode == 0:
+    # the oracle's argmax numbering is over the padded window; map both to input coordinates
+    want_dx = ref_ops.max_pool_backward(x.shape, want_arg, dy, 3, stride, "SAME")
+  else:
+    want_dx = ref_ops.avg_pool_same_backward(x.shape, dy, 3)
+  dx = torch.zeros(n, ih, iw, c, device=DEV)
+  ops.pool3x3_bwd(_t(dy), c, 0, arg, dx, c, 0, n, ih, iw, c, stride, mode, 0)
+  np.testing.assert_allclose(_n(dx), want_dx, rtol=1e-5, atol=1e-6)
+
+
+def test_bn_relu_bwd(ops):
+  rng = np.random.default_rng(19)
+  rows, c = 1000, 96
+  y = np.maximum(rng.standard_normal((rows, c)), 0).astype(np.float32)
+  dy = rng.standard_normal((rows, c)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+  scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  dz = dy * (y > 0)
+  dc = torch.empty(rows, c, device=DEV)
+  dbeta = torch.zeros(c, device=DEV); dgamma = torch.zeros(c, device=DEV)
+  ops.bn_relu_bwd(_t(dy), c, 0, _t(y), c, 0, _t(scale), _t(beta), _t(gamma), dc, dbeta, dgamma,
+                  rows, c)
+  np.testing.assert_allclose(_n(dc), dz * scale, rtol=1e-6, atol=1e-6)
+  np.testing.assert_allclose(_n(dbeta), dz.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
+  np.testing.assert_allclose(_n(dgamma),
+                             (dz.astype(np.float64) * (y - beta) / gamma).sum(0),
+                             rtol=1e-4, atol=1e-3)
+
+
+def test_spatial_mean_dropout(ops):
+  rng = np.random.default_rng(23)
+  rows, sp, c = 50, 16, 64
+  x = rng.standard_normal((rows, sp, c)).astype(np.float32)
+  mask = torch.empty(rows, c, dtype=torch.uint8, device=DEV)
+  ops.dropout_mask(mask, 1234, 0.5)
+  m = _n(mask)
+  assert 0.4 < m.mean() < 0.6 and set(np.unique(m)) <= {0, 1}
+  y = torch.empty(rows, c, device=DEV)
+  ops.spatial_mean_dropout_fwd(_t(x), y, mask, rows, sp, c, 0.5)
+  np.testing.assert_allclose(_n(y), x.mean(1) * 2.0 * m, rtol=1e-5, atol=1e-6)
+  dy = rng.standard_normal((rows, c)).astype(np.float32)
+  dx = torch.empty(rows, sp, c, device=DEV)
+  ops.spatial_mean_dropout_bwd(_t(dy), c, 0, dx, mask, rows, sp, c, 0.5)
+  np.testing.assert_allclose(_n(dx), np.broadcast_to((dy * 2.0 * m / sp)[:, None, :], x.shape),
+                             rtol=1e-6, atol=1e-7)
+
+
+def test_stem_preprocess_im2col(ops):
+  rng = np.random.default_rng(29)
+  img = rng.uniform(0, 255, (1, 21, 17, 3)).astype(np.float32)
+  x4 = torch.empty(1, 21, 17, 4, device=DEV)
+  ops.preprocess_pad4(_t(img), x4)
+  want = ref_model.preprocess(img)
+  np.testing.assert_allclose(_n(x4)[..., :3], want, rtol=1e-6, atol=1e-6)
+  assert np.all(_n(x4)[..., 3] == 0)
+  oh, ow = 11, 9
+  cols = torch.empty(oh * ow, 208, device=DEV)
+  ops.im2col4(x4, cols, 1, 21, 17, 7, 7, 2, 208)
+  w = rng.standard_normal((7, 7, 3, 5)).astype(np.float32)
+  want_c = ref_ops.conv2d(want, w, 2)
+  w4 = np.zeros((7, 7, 4, 5), np.float32); w4[:, :, :3] = w
+  got_c = _n(cols)[:, :196] @ w4.reshape(196, 5)
+  np.testing.assert_allclose(got_c.reshape(1, oh, ow, 5), want_c, rtol=1e-4, atol=1e-4)
+  assert np.all(_n(cols)[:, 196:] == 0)
+
+
+@pytest.mark.parametrize("nb", [[37, 20], [37, 0], [1, 5]])
+def test_midn_and_bce(ops, nb):
+  rng = np.random.default_rng(31)
+  b, n, c, d = 2, 37, 5, 32
+  x = rng.standard_normal((b, n, d)).astype(np.float32)
+  P = ref_model.init_head_params(rng, d, c, 0, stddev=0.5)
+  num = np.asarray(nb, np.int32)
+  cl, scores, proba, saved = ref_model.build_midn_network(num, x, P)
+  ld = 16
+  logits = np.zeros((b * n, ld), np.float32)
+  logits[:, 0:c] = (x @ P["midn/proba_r_given_c/weights"]).reshape(-1, c)
+  logits[:, 8:8 + c] = (x @ P["midn/proba_c_given_r/weights"]).reshape(-1, c)
+  tl = _t(logits); tn = _t(num)
+  proba_g = torch.empty(b, n, c, device=DEV); cl_g = torch.empty(b, c, device=DEV)
+  sc_g = torch.empty(b, n, c, device=DEV)
+  ops.midn_fwd(tl, ld, 0, 8, tn, proba_g, cl_g, sc_g, b, n, c)
+  np.testing.assert_allclose(_n(proba_g), proba, rtol=1e-5, atol=1e-7)
+  np.testing.assert_allclose(_n(cl_g), cl, rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(_n(sc_g), scores, rtol=1e-5, atol=1e-7)
+  labels = (rng.uniform(size=(b, c)) > 0.6).astype(np.float32)
+  loss = torch.zeros(1, device=DEV); dcl = torch.empty(b, c, device=DEV)
+  ops.sigmoid_ce_fwd_bwd(cl_g, _t(labels), 1.0, loss, dcl)
+  want_loss = ref_ops.sigmoid_cross_entropy_with_logits(labels, cl).mean()
+  np.testing.assert_allclose(_n(loss)[0], want_loss, rtol=1e-5)
+  want_dcl = (ref_ops.sigmoid(cl) - labels) / labels.size
+  np.testing.assert_allclose(_n(dcl), want_dcl, rtol=1e-5, atol=1e-7)
+  dlr, dlc = ref_model.build_midn_network_backward(want_dcl, saved)
+  dl = torch.zeros(b * n, ld, device=DEV)
+  ops.midn_bwd(dcl, tl, ld, 0, 8, tn, proba_g, cl_g, dl, ld, b, n, c)
+  np.testing.assert_allclose(_n(dl)[:, 0:c].reshape(b, n, c), dlr, rtol=1e-4, atol=1e-7)
+  np.testing.assert_allclose(_n(dl)[:, 8:8 + c].reshape(b, n, c), dlc, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("c", [5, 80])
+def test_oicr_select_and_loss(ops, c):
+  rng = np.random.default_rng(37)
+  b, n = 2, 61
+  num = np.asarray([61, 40], np.int32)
+  boxes = np.stack([_edge_boxes(rng, n), _edge_boxes(rng, n)]).astype(np.float32)
+  s0 = rng.uniform(0, 1, (b, n, c + 1)).astype(np.float32)
+  s0[0, 3, 2] = s0[0, 9, 2] = 5.0        # tied maxima -> first index
+  s1 = rng.standard_normal((b, n, c + 1)).astype(np.float32)
+  labels = (rng.uniform(size=(b, c)) > 0.5).astype(np.float32)
+  labels[1, :] = 0; labels[1, 0] = 1
+  want_loss, want_ds, _ = ref_model.calc_oicr_loss(labels, num, boxes, s0, s1, 0.6)
+  mask = ref_ops.sequence_mask(num, n)
+  want_idx = ref_ops.masked_argmax(s0[:, :, 1:], mask[..., None], dim=1)
+  idx = torch.empty(b, c, dtype=torch.int32, device=DEV)
+  top = torch.empty(b, c, 4, device=DEV)
+  ops.oicr_select(_t(s0), c + 1, 1, _t(num), _t(boxes), idx, top, b, n, c)
+  np.testing.assert_array_equal(_n(idx), want_idx)
+  loss = torch.zeros(1, device=DEV)
+  ds = torch.zeros(b * n, c + 1, device=DEV); q = torch.empty(b * n, c + 1, device=DEV)
+  ops.oicr_loss_fwd_bwd(_t(s1), c + 1, 0, top, _t(boxes), _t(labels), _t(num), 0.6, 0.5, b, n, c,
+                        loss, ds, c + 1, 0, q)
+  np.testing.assert_allclose(_n(loss)[0], 0.5 * want_loss, rtol=2e-5)
+  np.testing.assert_allclose(_n(ds).reshape(b, n, c + 1), 0.5 * want_ds, rtol=1e-4, atol=1e-8)
+  np.testing.assert_allclose(_n(q).reshape(b, n, c + 1), ref_ops.softmax(s1), rtol=1e-5, atol=1e-8)
+
+
+def test_labels_and_text_classifier(ops):
+  rng = np.random.default_rng(41)
+  b, t, v, e, h, c = 4, 9, 50, 300, 400, 7
+  ids = rng.integers(0, v + 1, (b, t)).astype(np.int32)
+  ids[2, :] = v                      # all-OOV caption
+  ids[3, :3] = [1, 2, 3]
+  lab = torch.empty(b, c, device=DEV)
+  ops.labels_from_ids(_t(ids), c, lab)
+  want = np.zeros((b, c), np.float32)
+  for i in range(b):
+    for j in ids[i]:
+      if j < c:
+        want[i, j] = 1
+  np.testing.assert_array_equal(_n(lab), want)
+  emb = (0.4 * rng.standard_normal((v + 1, e))).astype(np.float32)
+  w1 = (rng.standard_normal((e, h)) / np.sqrt(e)).astype(np.float32)
+  b1 = (0.1 * rng.standard_normal(h)).astype(np.float32)
+  w2 = (rng.standard_normal((h, c)) / np.sqrt(h)).astype(np.float32)
+  b2 = (0.1 * rng.standard_normal(c)).astype(np.float32)
+  exact = np.zeros((b, c), np.float32); exact[3, 2] = 1
+  want_logits = ref_labels.text_classifier_logits(ids, emb, w1, b1, w2, b2)
+  want_labels = ref_labels.text_classifier_match_extract(ids, exact, emb, w1, b1, w2, b2, 0.5)
+  logits = torch.empty(b, c, device=DEV); labels = torch.empty(b, c, device=DEV)
+  ops.text_classifier_fwd(_t(ids), _t(emb), _t(w1), _t(b1), _t(w2), _t(b2), _t(exact), 0.5, logits,
+                          labels)
+  np.testing.assert_allclose(_n(logits), want_logits, rtol=1e-4, atol=1e-4)
+  safe = np.abs(ref_ops.sigmoid(want_logits) - 0.5) > 1e-3
+  np.testing.assert_array_equal(_n(labels)[safe], want_labels[safe])
+
+
+def test_adagrad_and_l2(ops):
+  rng = np.random.default_rng(43)
+  n = 10007
+  w = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+  acc = np.full(n, 0.1, np.float32)
+  tw, ta = _t(w), _t(acc)
+  ops.adagrad_step(tw, _t(g), ta, 0.01, 1e-4, 1.0, 0.5)
+  g2 = 0.5 * g + 1e-4 * w
+  acc2 = acc + g2 * g2
+  np.testing.assert_allclose(_n(ta), acc2, rtol=1e-6)
+  np.testing.assert_allclose(_n(tw), w - 0.01 * g2 / np.sqrt(acc2), rtol=1e-6, atol=1e-7)
+  out = torch.zeros(1, device=DEV)
+  ops.l2_loss(_t(w), 1e-2, out)
+  np.testing.assert_allclose(_n(out)[0], 0.5e-2 * (w.astype(np.float64) ** 2).sum(), rtol=1e-5)
