@@ -1,0 +1,321 @@
+"""Cap2Det / WSOD model on MI355X (reference: models/cap2det_model.py:29-346).
+
+Same plugin surface as the reference (`Model(model_proto, is_training)`, `build_prediction`,
+`build_loss`, `build_evaluation`, registered under `Cap2DetModel.ext`) with the TF graph
+replaced by a static launch plan over hand-written HIP kernels.  Because there is no autograd
+graph, `build_loss` also produces d(loss)/d(head logits) and `backward()` runs the explicit
+gradient kernels into the flat gradient buffer consumed by `train/trainer.py`.
+"""
+import math
+
+import numpy as np
+import torch
+
+from cap2det_amd import hip_ops as ops
+from cap2det_amd.core.standard_fields import (Cap2DetPredictions, DetectionResultFields,
+                                              InputDataFields)
+from cap2det_amd.models.frcnn_engine import FrcnnEngine, VariableStore
+from cap2det_amd.models.label_extractor import build_label_extractor
+from cap2det_amd.models.model_base import ModelBase
+from cap2det_amd.models.registry import register_model_class
+from cap2det_amd.protos import cap2det_model_pb2
+from cap2det_amd.protos.message import unwrap
+
+HEADS_W = "heads/fused_weights"
+HEADS_B = "heads/fused_biases"
+
+
+class Model(ModelBase):
+  """Cap2Det model."""
+
+  def __init__(self, model_proto, is_training=False, device="cuda:0", depth_multiplier=1.0,
+               bn_scale=True, seed=0):
+    model_proto = unwrap(model_proto)
+    super(Model, self).__init__(model_proto, is_training)
+    if not isinstance(model_proto, cap2det_model_pb2.Cap2DetModel):
+      raise ValueError('The model_proto has to be an instance of Cap2DetModel.')
+    options = model_proto
+    fe_type = options.frcnn_options.feature_extractor.type
+    if fe_type != 'faster_rcnn_inception_v2':
+      raise ValueError('Unknown Faster R-CNN feature_extractor: {}'.format(fe_type))
+    self._device = torch.device(device)
+    self._label_extractor = build_label_extractor(options.label_extractor, self._device)
+    self._num_classes = self._label_extractor.num_classes
+    self._oicr_iterations = options.oicr_iterations
+
+    self.store = VariableStore(self._device)
+    self.engine = FrcnnEngine(self.store, options.frcnn_options, bn_scale, depth_multiplier)
+    # Five fully-connected heads fused into one [D, Npad] GEMM operand:
+    # columns = [r|c (C), c|r (C), oicr_1 (C+1), ..., oicr_K (C+1)], zero padded to 16.
+    c, k = self._num_classes, self._oicr_iterations
+    self._head_cols = [("midn/proba_r_given_c", 0, c), ("midn/proba_c_given_r", c, c)]
+    for i in range(k):
+      self._head_cols.append(("oicr/iter%d" % (i + 1), 2 * c + i * (c + 1), c + 1))
+    self._ncols = 2 * c + k * (c + 1)
+    self._npad = -(-self._ncols // 16) * 16
+    d = self.engine.feature_dims
+    self.store.declare(HEADS_W, (d, self._npad))
+    self.store.declare(HEADS_B, (self._npad,))
+    self.store.finalize()
+    self._heads_wt = torch.empty(1, self._npad, d, device=self._device)
+    self._l2_weight = 0.0
+    reg = options.fc_hyperparams.regularizer
+    if reg.WhichOneof('regularizer_oneof') == 'l2_regularizer':
+      self._l2_weight = reg.l2_regularizer.weight
+    elif reg.WhichOneof('regularizer_oneof') == 'l1_regularizer':
+      raise NotImplementedError('l1_regularizer is not used by any shipped config')
+    self._losses = torch.zeros(2 + k, device=self._device)   # midn, oicr_1..K, regularisation
+    self._cache = {}
+    self._ctx = None
+    self.initialize(seed)
+
+  # -- variables ----------------------------------------------------------------------
+  @property
+  def num_classes(self):
+    return self._num_classes
+
+  @property
+  def label_extractor(self):
+    return self._label_extractor
+
+  @property
+  def l2_weight(self):
+    return self._l2_weight
+
+  def head_view(self, name):
+    """Strided view of one head inside the fused buffers, under the reference variable name
+    (`midn/proba_r_given_c/weights`, `oicr/iter2/biases`, ...)."""
+    scope, leaf = name.rsplit("/", 1)
+    for hname, off, width in self._head_cols:
+      if hname == scope:
+        if leaf == "weights":
+          return self.store.var[HEADS_W][:, off:off + width]
+        return self.store.var[HEADS_B][off:off + width]
+    raise KeyError(name)
+
+  def variable_names(self):
+    """All variables under the reference's names (SURVEY.md §5 'Checkpoint / resume')."""
+    names = list(self.engine.stem_vars) + [n for n in self.store.names()
+                                           if not n.startswith("heads/")]
+    names += list(self.engine.stats)
+    for hname, _, _ in self._head_cols:
+      names += [hname + "/weights", hname + "/biases"]
+    return names
+
+  def get_variables_to_train(self):
+    """Trainable-capable variables (tf.trainable_variables() in the reference): everything
+    except BatchNorm moving statistics."""
+    return [n for n in self.variable_names()
+            if not (n.endswith("moving_mean") or n.endswith("moving_variance"))]
+
+  def _var_tensor(self, name):
+    if name in self.engine.stem_vars:
+      return self.engine.stem_vars[name]
+    if name in self.engine.stats:
+      return self.engine.stats[name]
+    if name in self.store.var:
+      return self.store.var[name]
+    return self.head_view(name)
+
+  def state_dict(self):
+    return {n: self._var_tensor(n).detach().cpu().numpy().copy() for n in self.variable_names()}
+
+  def load_state_dict(self, arrays, strict=True):
+    """arrays: {reference variable name: numpy array}."""
+    missing = []
+    for n in self.variable_names():
+      if n not in arrays:
+        missing.append(n)
+        continue
+      t = self._var_tensor(n)
+      a = torch.from_numpy(np.ascontiguousarray(arrays[n], dtype=np.float32)).to(self._device)
+      if tuple(a.shape) != tuple(t.shape):
+        raise ValueError("shape mismatch for %s: %s vs %s" % (n, tuple(a.shape), tuple(t.shape)))
+      t.copy_(a)
+    if strict and missing:
+      raise KeyError("missing variables: %s ..." % missing[:5])
+    self.refresh()
+
+  def grad_dict(self):
+    """Gradients of the last step under the reference variable names (numpy)."""
+    out = {}
+    for n in self.store.names():
+      if n == HEADS_W or n == HEADS_B:
+        continue
+      out[n] = self.store.grad[n].detach().cpu().numpy().copy()
+    for hname, off, width in self._head_cols:
+      out[hname + "/weights"] = self.store.grad[HEADS_W][:, off:off + width].cpu().numpy().copy()
+      out[hname + "/biases"] = self.store.grad[HEADS_B][off:off + width].cpu().numpy().copy()
+    return out
+
+  def initialize(self, seed=0):
+    """Synthetic initial values (no checkpoint can be read here): He-normal convolutions,
+    identity BatchNorm, heads per `fc_hyperparams.initializer` (truncated normal 0.01 in every
+    shipped config, configs/*.pbtxt:58-72), zero biases."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    eng = self.engine
+
+    def fill(t, std):
+      t.copy_((torch.randn(t.shape, generator=gen) * std).to(self._device))
+
+    sv = eng.stem_vars
+    fill(sv[eng.STEM + "/depthwise_weights"], math.sqrt(2.0 / 49))
+    fill(sv[eng.STEM + "/pointwise_weights"], math.sqrt(2.0 / (3 * eng.stem_mult)))
+    for net in (eng.first, eng.second):
+      for L in net.layers.values():
+        fill(self.store.var[L.name + "/weights"], math.sqrt(2.0 / (L.k * L.k * L.cin)))
+        if L.bn_scale:
+          self.store.var[L.name + "/BatchNorm/gamma"].fill_(1.0)
+        self.store.var[L.name + "/BatchNorm/beta"].zero_()
+    init = self._model_proto.fc_hyperparams.initializer
+    which = init.WhichOneof('initializer_oneof')
+    std, mean = 0.01, 0.0
+    if which == 'truncated_normal_initializer':
+      std, mean = init.truncated_normal_initializer.stddev, init.truncated_normal_initializer.mean
+    elif which == 'random_normal_initializer':
+      std, mean = init.random_normal_initializer.stddev, init.random_normal_initializer.mean
+    w = torch.empty(self.engine.feature_dims, self._ncols)
+    torch.nn.init.trunc_normal_(w, mean=mean, std=std, a=mean - 2 * std, b=mean + 2 * std,
+                                generator=gen)
+    self.store.var[HEADS_W].zero_()
+    self.store.var[HEADS_W][:, :self._ncols] = w.to(self._device)
+    self.store.var[HEADS_B].zero_()
+    self.refresh()
+
+  def refresh(self, only_trainable=False):
+    """Re-derives kernel operands (transposed weights, folded BN) from the variables."""
+    self.engine.refresh(only_trainable)
+    ops.transpose_taps(self.store.var[HEADS_W], self._heads_wt, 1, self.engine.feature_dims,
+                       self._npad)
+
+  def set_trainable(self, trainable_names):
+    self.engine.set_trainable(set(trainable_names))
+
+  # -- buffers ------------------------------------------------------------------------
+  def _bufs(self, b, n):
+    key = (b, n)
+    if key not in self._cache:
+      dev, c, k = self._device, self._num_classes, self._oicr_iterations
+      self._cache[key] = dict(
+          logits=torch.empty(b * n, self._npad, device=dev),
+          dlogits=torch.zeros(b * n, self._npad, device=dev),
+          proba=torch.empty(b, n, c, device=dev),
+          class_logits=torch.empty(b, c, device=dev),
+          dclass_logits=torch.empty(b, c, device=dev),
+          scores0=torch.empty(b, n, c, device=dev),
+          softmax=[torch.empty(b * n, c + 1, device=dev) for _ in range(k)],
+          idx=torch.empty(b, c, dtype=torch.int32, device=dev),
+          top_boxes=torch.empty(b, c, 4, device=dev),
+          dfeatures=torch.empty(b * n, self.engine.feature_dims, device=dev))
+    return self._cache[key]
+
+  # -- reference API ------------------------------------------------------------------
+  def _build_prediction(self, examples, dropout_seed=None, dropout_mask=None):
+    """models/cap2det_model.py:152-216."""
+    image = examples[InputDataFields.image]
+    num_proposals = examples[InputDataFields.num_proposals]
+    proposals = examples[InputDataFields.proposals]
+    b, n = proposals.shape[0], proposals.shape[1]
+    c, k = self._num_classes, self._oicr_iterations
+    features, fctx = self.engine.forward(image, proposals, self._is_training, dropout_seed,
+                                         dropout_mask)
+    bufs = self._bufs(b, n)
+    d = self.engine.feature_dims
+    # all five heads in one GEMM: logits = X . W + b  (activation_fn=None, :79-88,:191-197)
+    ops.conv_fwd(features, d, 0, self._heads_wt, None, self.store.var[HEADS_B], bufs["logits"],
+                 self._npad, 0, b * n, 1, 1, d, self._npad, 1, 1, 1, False)
+    ops.midn_fwd(bufs["logits"], self._npad, 0, c, num_proposals, bufs["proba"],
+                 bufs["class_logits"], bufs["scores0"], b, n, c)
+    predictions = {
+        DetectionResultFields.class_labels: list(self._label_extractor.classes),
+        DetectionResultFields.num_proposals: num_proposals,
+        DetectionResultFields.proposal_boxes: proposals,
+        Cap2DetPredictions.midn_class_logits: bufs["class_logits"],
+        Cap2DetPredictions.midn_proba_r_given_c: bufs["proba"],
+        Cap2DetPredictions.oicr_proposal_scores + '_at_0': bufs["scores0"],
+    }
+    lg = bufs["logits"].view(b, n, self._npad)
+    for i in range(k):
+      off = 2 * c + i * (c + 1)
+      predictions[Cap2DetPredictions.oicr_proposal_scores + '_at_{}'.format(i + 1)] = \
+          lg[:, :, off:off + c + 1]
+    self._ctx = dict(fctx=fctx, bufs=bufs, b=b, n=n, features=features,
+                     num_proposals=num_proposals, proposals=proposals)
+    return predictions
+
+  def build_prediction(self, examples, **kwargs):
+    """models/cap2det_model.py:218-272.  Training mode / no eval_min_dimension: one pass.
+    (Multi-scale inference + NMS post-processing are SURVEY.md §8f rows, not the train step.)"""
+    options = self._model_proto
+    if self._is_training or len(options.eval_min_dimension) == 0 or kwargs.get("single_scale"):
+      return self._build_prediction(examples, kwargs.get("dropout_seed"),
+                                    kwargs.get("dropout_mask"))
+    raise NotImplementedError(
+        "multi-scale inference (eval_min_dimension) is outside the training hot path; pass "
+        "single_scale=True for a single-resolution forward")
+
+  def build_loss(self, predictions, examples=None, **kwargs):
+    """models/cap2det_model.py:274-330.  Also leaves d(loss)/d(head logits) in the step
+    context for `backward()`."""
+    options = self._model_proto
+    ctx = self._ctx
+    if ctx is None:
+      raise RuntimeError("build_prediction must run before build_loss")
+    bufs, b, n = ctx["bufs"], ctx["b"], ctx["n"]
+    c, k = self._num_classes, self._oicr_iterations
+    labels = kwargs.get("labels")
+    if labels is None:
+      labels = self._label_extractor.extract_labels(examples)
+    ctx["labels"] = labels
+    losses = self._losses
+    losses.zero_()
+    num_proposals, proposals = ctx["num_proposals"], ctx["proposals"]
+    ops.sigmoid_ce_fwd_bwd(bufs["class_logits"], labels, options.midn_loss_weight, losses[0:1],
+                           bufs["dclass_logits"])
+    ops.midn_bwd(bufs["dclass_logits"], bufs["logits"], self._npad, 0, c, num_proposals,
+                 bufs["proba"], bufs["class_logits"], bufs["dlogits"], self._npad, b, n, c)
+    loss_dict = {'midn_cross_entropy_loss': losses[0]}
+    # s0 = concat(0, proba or scores): the class columns are searched directly (:306-312)
+    s0 = bufs["proba"] if options.oicr_use_proba_r_given_c else bufs["scores0"]
+    s0_ld, s0_off = c, 0
+    for i in range(k):
+      off = 2 * c + i * (c + 1)
+      ops.oicr_select(s0, s0_ld, s0_off, num_proposals, proposals, bufs["idx"], bufs["top_boxes"],
+                      b, n, c)
+      ops.oicr_loss_fwd_bwd(bufs["logits"], self._npad, off, bufs["top_boxes"], proposals, labels,
+                            num_proposals, options.oicr_iou_threshold, options.oicr_loss_weight, b,
+                            n, c, losses[i + 1:i + 2], bufs["dlogits"], self._npad, off,
+                            bufs["softmax"][i])
+      loss_dict['oicr_cross_entropy_loss_at_{}'.format(i + 1)] = losses[i + 1]
+      s0, s0_ld, s0_off = bufs["softmax"][i], c + 1, 1       # softmax(scores_1)[..., 1:] (:328)
+    return loss_dict
+
+  def regularization_loss(self):
+    """Sum of the slim L2 regularisers (FC weights only), as a 0-d tensor."""
+    out = self._losses[-1:]
+    out.zero_()
+    if self._l2_weight > 0:
+      ops.l2_loss(self.store.var[HEADS_W], self._l2_weight, out)
+    return self._losses[-1]
+
+  def backward(self):
+    """Gradients of sum(losses) w.r.t. every trainable variable, accumulated into
+    `self.store.grads` (caller zeroes it once per step)."""
+    ctx = self._ctx
+    bufs, b, n = ctx["bufs"], ctx["b"], ctx["n"]
+    d = self.engine.feature_dims
+    g = self.store.grad
+    x = ctx["features"]
+    ops.conv_wgrad(x, d, 0, bufs["dlogits"], self._npad, 0, g[HEADS_W], b * n, 1, 1, d, self._npad,
+                   1, 1, 1)
+    ops.col_sum(bufs["dlogits"], self._npad, 0, g[HEADS_B], b * n, self._npad)
+    ops.conv_dgrad(bufs["dlogits"], self._npad, 0, self.store.var[HEADS_W], bufs["dfeatures"], d, 0,
+                   b * n, 1, 1, d, self._npad, 1, 1, 1, False)
+    self.engine.backward(bufs["dfeatures"], d, 0, ctx["fctx"])
+
+  def build_evaluation(self, predictions, examples=None, **kwargs):
+    """models/cap2det_model.py:332-343 returns {} in the reference."""
+    return {}
+
+
+register_model_class(cap2det_model_pb2.Cap2DetModel.ext, Model)

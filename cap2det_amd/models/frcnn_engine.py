@@ -1,0 +1,580 @@
+"""Host-side execution engine of the Fast-RCNN feature path on MI355X.
+
+Builds, for fixed tensor shapes, a static launch plan over the HIP kernels of
+`include/cap2det_hip.h` that computes what the reference computes in
+`models/utils.py:108-188` (`extract_frcnn_feature`: Inception-V2 first stage -> crop_and_resize
+-> max-pool -> Inception-V2 second stage -> spatial mean -> dropout) and its gradient.
+
+The Inception-V2 layer tables restate tf.contrib.slim `nets/inception_v2.py` and the
+`FasterRCNNInceptionV2FeatureExtractor` of the object_detection fork the reference imports
+(models/utils.py:9) — third-party code that is not vendored in the reference.
+
+Memory layout (HBM, fp32): activations NHWC as [rows = n*h*w][channels]; every Inception block
+owns ONE concat buffer and its branches write channel slices of it in place; variables live
+in one flat parameter buffer with a mirrored flat gradient buffer (the RCCL all-reduce bucket)
+and a mirrored Adagrad accumulator.
+"""
+import math
+
+import torch
+
+from cap2det_amd import hip_ops as ops
+
+BN_EPS = 0.001
+FIRST_SCOPE = "first_stage_feature_extraction/InceptionV2/"
+SECOND_SCOPE = "second_stage_feature_extraction/InceptionV2/"
+
+
+# ----------------------------------------------------------------------------------------
+# layer tables
+# ----------------------------------------------------------------------------------------
+
+def _mixed(name, b0, b1, b2, b3, pool="avg"):
+  pool_name = "AvgPool_0a_3x3" if pool == "avg" else "MaxPool_0a_3x3"
+  return ("block", name, [
+      [("conv", "Branch_0/Conv2d_0a_1x1", b0, 1, 1)],
+      [("conv", "Branch_1/Conv2d_0a_1x1", b1[0], 1, 1),
+       ("conv", "Branch_1/Conv2d_0b_3x3", b1[1], 3, 1)],
+      [("conv", "Branch_2/Conv2d_0a_1x1", b2[0], 1, 1),
+       ("conv", "Branch_2/Conv2d_0b_3x3", b2[1], 3, 1),
+       ("conv", "Branch_2/Conv2d_0c_3x3", b2[2], 3, 1)],
+      [(pool, "Branch_3/" + pool_name, 1), ("conv", "Branch_3/Conv2d_0b_1x1", b3, 1, 1)],
+  ])
+
+
+def _reduction(name, b0, b1):
+  return ("block", name, [
+      [("conv", "Branch_0/Conv2d_0a_1x1", b0[0], 1, 1),
+       ("conv", "Branch_0/Conv2d_1a_3x3", b0[1], 3, 2)],
+      [("conv", "Branch_1/Conv2d_0a_1x1", b1[0], 1, 1),
+       ("conv", "Branch_1/Conv2d_0b_3x3", b1[1], 3, 1),
+       ("conv", "Branch_1/Conv2d_1a_3x3", b1[2], 3, 2)],
+      [("max", "Branch_2/MaxPool_1a_3x3", 2)],
+  ])
+
+
+# The 7x7/2 separable stem ("Conv2d_1a_7x7") is handled apart (see FrcnnEngine._stem_*).
+FIRST_STAGE_AFTER_STEM = [
+    ("max", "MaxPool_2a_3x3", 2),
+    ("conv", "Conv2d_2b_1x1", 64, 1, 1),
+    ("conv", "Conv2d_2c_3x3", 192, 3, 1),
+    ("max", "MaxPool_3a_3x3", 2),
+    _mixed("Mixed_3b", 64, (64, 64), (64, 96, 96), 32),
+    _mixed("Mixed_3c", 64, (64, 96), (64, 96, 96), 64),
+    _reduction("Mixed_4a", (128, 160), (64, 96, 96)),
+    _mixed("Mixed_4b", 224, (64, 96), (96, 128, 128), 128),
+    _mixed("Mixed_4c", 192, (96, 128), (96, 128, 128), 128),
+    _mixed("Mixed_4d", 160, (128, 160), (128, 160, 160), 96),
+    _mixed("Mixed_4e", 96, (128, 192), (160, 192, 192), 96),
+]
+
+SECOND_STAGE = [
+    _reduction("Mixed_5a", (128, 192), (192, 256, 256)),
+    _mixed("Mixed_5b", 352, (192, 320), (160, 224, 224), 128),
+    _mixed("Mixed_5c", 352, (192, 320), (192, 224, 224), 128, pool="max"),
+]
+
+
+def _out_hw(h, w, stride):
+  return -(-h // stride), -(-w // stride)
+
+
+# ----------------------------------------------------------------------------------------
+# variables
+# ----------------------------------------------------------------------------------------
+
+class VariableStore(object):
+  """Flat fp32 buffers (values / gradients / Adagrad accumulators) with named views.
+
+  Variables are laid out in creation order (network order), so the trainable suffix
+  [Mixed_4e?, second stage, heads] is one contiguous range = one all-reduce bucket."""
+
+  ALIGN = 4  # floats (16 B)
+
+  def __init__(self, device):
+    self.device = device
+    self._specs = []     # (name, shape, offset, numel)
+    self._size = 0
+    self.values = None
+    self.grads = None
+    self.accum = None
+    self.var = {}
+    self.grad = {}
+    self.acc = {}
+    self.offset = {}
+
+  def declare(self, name, shape):
+    if self.values is not None:
+      raise RuntimeError("VariableStore already finalized")
+    numel = int(math.prod(shape))
+    self._specs.append((name, tuple(shape), self._size, numel))
+    self._size += -(-numel // self.ALIGN) * self.ALIGN
+
+  def finalize(self, initial_accumulator_value=0.1):
+    self.values = torch.zeros(self._size, device=self.device, dtype=torch.float32)
+    self.grads = torch.zeros(self._size, device=self.device, dtype=torch.float32)
+    self.accum = torch.full((self._size,), float(initial_accumulator_value), device=self.device,
+                            dtype=torch.float32)
+    for name, shape, off, numel in self._specs:
+      self.var[name] = self.values[off:off + numel].view(shape)
+      self.grad[name] = self.grads[off:off + numel].view(shape)
+      self.acc[name] = self.accum[off:off + numel].view(shape)
+      self.offset[name] = (off, numel)
+
+  def names(self):
+    return [s[0] for s in self._specs]
+
+  def span(self, names):
+    """Smallest [lo, hi) flat range covering `names` (aligned ends)."""
+    lo = min(self.offset[n][0] for n in names)
+    hi = max(self.offset[n][0] + -(-self.offset[n][1] // self.ALIGN) * self.ALIGN for n in names)
+    return lo, hi
+
+
+class ConvBN(object):
+  """conv (SAME, no bias) + inference BatchNorm + ReLU; owns its variables and folded forms."""
+
+  def __init__(self, store, stats, name, cin, cout, k, stride, bn_scale):
+    self.name, self.cin, self.cout, self.k, self.stride = name, cin, cout, k, stride
+    self.store, self.stats = store, stats
+    self.bn_scale = bn_scale
+    store.declare(name + "/weights", (k, k, cin, cout))
+    if bn_scale:
+      store.declare(name + "/BatchNorm/gamma", (cout,))
+    store.declare(name + "/BatchNorm/beta", (cout,))
+    stats[name + "/BatchNorm/moving_mean"] = torch.zeros(cout, device=store.device)
+    stats[name + "/BatchNorm/moving_variance"] = torch.ones(cout, device=store.device)
+    self.wt = torch.empty(k * k, cout, cin, device=store.device)
+    self.scale = torch.empty(cout, device=store.device)
+    self.shift = torch.empty(cout, device=store.device)
+    self.trainable = False
+
+  def var_names(self):
+    n = [self.name + "/weights", self.name + "/BatchNorm/beta"]
+    if self.bn_scale:
+      n.insert(1, self.name + "/BatchNorm/gamma")
+    return n
+
+  def refresh(self):
+    """Re-derives the kernel operands (per-tap transposed weights, folded BN) from the
+    variables; called after every optimiser step for trainable layers."""
+    v = self.store.var
+    ops.transpose_taps(v[self.name + "/weights"], self.wt, self.k * self.k, self.cin, self.cout)
+    ops.bn_fold(v.get(self.name + "/BatchNorm/gamma"), v[self.name + "/BatchNorm/beta"],
+                self.stats[self.name + "/BatchNorm/moving_mean"],
+                self.stats[self.name + "/BatchNorm/moving_variance"], BN_EPS, self.scale,
+                self.shift)
+
+
+class Ref(object):
+  """A channel slice [off, off+c) of a [rows][ld] activation buffer."""
+  __slots__ = ("t", "ld", "off", "c")
+
+  def __init__(self, t, ld, off, c):
+    self.t, self.ld, self.off, self.c = t, ld, off, c
+
+
+# ----------------------------------------------------------------------------------------
+# network executor
+# ----------------------------------------------------------------------------------------
+
+class Net(object):
+  """A stack of conv / pool / Inception-block ops with a static plan per input shape."""
+
+  def __init__(self, store, stats, spec, scope, cin, bn_scale, depth_multiplier=1.0):
+    self.store, self.stats, self.spec, self.scope = store, stats, spec, scope
+    self.dm = depth_multiplier
+    self.layers = {}      # name -> ConvBN
+    self.order = []       # top-level op index -> [conv names]
+    c = cin
+    for op in spec:
+      names = []
+      if op[0] == "conv":
+        c = self._add_conv(op, c, scope, bn_scale, names)
+      elif op[0] == "block":
+        total = 0
+        for branch in op[2]:
+          bc = c
+          for bop in branch:
+            if bop[0] == "conv":
+              bc = self._add_conv(bop, bc, scope + op[1] + "/", bn_scale, names)
+          total += bc
+        c = total
+      self.order.append(names)
+    self.cout = c
+    self.cin = cin
+    self._plans = {}
+
+  def _depth(self, d):
+    return max(int(d * self.dm), 16)
+
+  def _add_conv(self, op, cin, prefix, bn_scale, names):
+    cout = self._depth(op[2])
+    name = prefix + op[1]
+    self.layers[name] = ConvBN(self.store, self.stats, name, cin, cout, op[3], op[4], bn_scale)
+    names.append(name)
+    return cout
+
+  def refresh(self, only_trainable=False):
+    for layer in self.layers.values():
+      if layer.trainable or not only_trainable:
+        layer.refresh()
+
+  # -- plan -----------------------------------------------------------------------
+  def plan(self, n, ih, iw, training):
+    key = (n, ih, iw, training)
+    if key not in self._plans:
+      self._plans[key] = self._build_plan(n, ih, iw, training)
+    return self._plans[key]
+
+  def _new(self, rows, c, dtype=torch.float32):
+    return torch.empty(rows, c, device=self.store.device, dtype=dtype)
+
+  def _build_plan(self, n, ih, iw, training):
+    steps = []
+    h, w, c = ih, iw, self.cin
+    x = None  # Ref of the running activation; None = the net input supplied at run time
+    scratch_rows_c = 0
+    for op in self.spec:
+      kind = op[0]
+      if kind == "conv":
+        layer = self.layers[self.scope + op[1]]
+        oh, ow = _out_hw(h, w, layer.stride)
+        y = Ref(self._new(n * oh * ow, layer.cout), layer.cout, 0, layer.cout)
+        st = dict(kind="conv", layer=layer, x=x, y=y, n=n, ih=h, iw=w, oh=oh, ow=ow)
+        scratch_rows_c = max(scratch_rows_c, n * oh * ow * layer.cout)
+        steps.append(st)
+        x, h, w, c = y, oh, ow, layer.cout
+      elif kind in ("max", "avg"):
+        stride = op[2]
+        oh, ow = _out_hw(h, w, stride)
+        y = Ref(self._new(n * oh * ow, c), c, 0, c)
+        arg = self._new(n * oh * ow, c, torch.uint8) if (kind == "max" and training) else None
+        steps.append(dict(kind="pool", mode=0 if kind == "max" else 1, stride=stride, x=x, y=y,
+                          arg=arg, n=n, ih=h, iw=w, oh=oh, ow=ow, c=c))
+        x, h, w = y, oh, ow
+      elif kind == "block":
+        widths, strides = [], []
+        for branch in op[2]:
+          bc, bs = c, 1
+          for bop in branch:
+            if bop[0] == "conv":
+              bc = self.layers[self.scope + op[1] + "/" + bop[1]].cout
+              bs *= bop[4]
+            else:
+              bs *= bop[2]
+          widths.append(bc)
+          strides.append(bs)
+        oh, ow = _out_hw(h, w, strides[0])
+        ctot = sum(widths)
+        ybuf = self._new(n * oh * ow, ctot)
+        branches, off = [], 0
+        for branch, wdt in zip(op[2], widths):
+          bsteps = []
+          bx, bh, bw, bc = x, h, w, c
+          for i, bop in enumerate(branch):
+            last = i == len(branch) - 1
+            if bop[0] == "conv":
+              layer = self.layers[self.scope + op[1] + "/" + bop[1]]
+              boh, bow = _out_hw(bh, bw, layer.stride)
+              y = (Ref(ybuf, ctot, off, layer.cout) if last else
+                   Ref(self._new(n * boh * bow, layer.cout), layer.cout, 0, layer.cout))
+              bsteps.append(dict(kind="conv", layer=layer, x=bx, y=y, n=n, ih=bh, iw=bw, oh=boh,
+                                 ow=bow))
+              scratch_rows_c = max(scratch_rows_c, n * boh * bow * layer.cout)
+              bx, bh, bw, bc = y, boh, bow, layer.cout
+            else:
+              stride = bop[2]
+              boh, bow = _out_hw(bh, bw, stride)
+              y = (Ref(ybuf, ctot, off, bc) if last else
+                   Ref(self._new(n * boh * bow, bc), bc, 0, bc))
+              arg = (self._new(n * boh * bow, bc, torch.uint8)
+                     if (bop[0] == "max" and training) else None)
+              bsteps.append(dict(kind="pool", mode=0 if bop[0] == "max" else 1, stride=stride,
+                                 x=bx, y=y, arg=arg, n=n, ih=bh, iw=bw, oh=boh, ow=bow, c=bc))
+              bx, bh, bw = y, boh, bow
+          branches.append(bsteps)
+          off += wdt
+        y = Ref(ybuf, ctot, 0, ctot)
+        steps.append(dict(kind="block", name=op[1], branches=branches, x=x, y=y, n=n, ih=h, iw=w,
+                          oh=oh, ow=ow, cin=c))
+        x, h, w, c = y, oh, ow, ctot
+    plan = dict(steps=steps, out=x, oh=h, ow=w, n=n, ih=ih, iw=iw, bwd_ready=False,
+                scratch_elems=scratch_rows_c)
+    return plan
+
+  # -- forward ----------------------------------------------------------------------
+  def forward(self, plan, x_in):
+    for st in plan["steps"]:
+      self._fwd_step(st, x_in)
+    return plan["out"]
+
+  def _fwd_step(self, st, x_in):
+    kind = st["kind"]
+    x = st["x"] if st["x"] is not None else x_in
+    if kind == "conv":
+      L = st["layer"]
+      ops.conv_fwd(x.t, x.ld, x.off, L.wt, L.scale, L.shift, st["y"].t, st["y"].ld, st["y"].off,
+                   st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, True)
+    elif kind == "pool":
+      ops.pool3x3_fwd(x.t, x.ld, x.off, st["y"].t, st["y"].ld, st["y"].off, st["arg"], st["n"],
+                      st["ih"], st["iw"], st["c"], st["stride"], st["mode"])
+    else:
+      for bsteps in st["branches"]:
+        for bst in bsteps:
+          self._fwd_step(bst, x)
+
+  # -- backward ---------------------------------------------------------------------
+  def _prepare_backward(self, plan, first_idx):
+    """Allocates gradient buffers for steps[first_idx:] (dense, one per activation)."""
+    if plan["bwd_ready"]:
+      return
+    dev = self.store.device
+    plan["dc"] = torch.empty(plan["scratch_elems"], device=dev)
+    steps = plan["steps"]
+    for i in range(first_idx, len(steps)):
+      st = steps[i]
+      y = st["y"]
+      rows = st["n"] * st["oh"] * st["ow"]
+      st["gy"] = Ref(torch.empty(rows, y.c, device=dev), y.c, 0, y.c)   # grad of the op output
+      if st["kind"] == "block":
+        for bsteps in st["branches"]:
+          for j, bst in enumerate(bsteps):
+            if j == len(bsteps) - 1:
+              by = bst["y"]
+              bst["gy"] = Ref(st["gy"].t, st["gy"].ld, by.off, by.c)
+            else:
+              brow = bst["n"] * bst["oh"] * bst["ow"]
+              bst["gy"] = Ref(torch.empty(brow, bst["y"].c, device=dev), bst["y"].c, 0,
+                              bst["y"].c)
+    plan["bwd_ready"] = True
+    plan["first_idx"] = first_idx
+
+  def out_grad(self, plan, first_idx=0):
+    """Buffer into which the caller writes d(loss)/d(net output) before `backward`."""
+    self._prepare_backward(plan, first_idx)
+    return plan["steps"][-1]["gy"]
+
+  def backward(self, plan, x_in, first_idx=0, dx_in=None):
+    """Backpropagates plan['steps'][-1]['gy'] down to steps[first_idx]; gradients of the
+    variables are ACCUMULATED into the store's flat gradient buffer (zeroed once per step by
+    the trainer).  dx_in: Ref receiving d(loss)/d(net input) (overwritten) or None."""
+    self._prepare_backward(plan, first_idx)
+    steps = plan["steps"]
+    for i in range(len(steps) - 1, first_idx - 1, -1):
+      st = steps[i]
+      if i > first_idx:
+        gx = steps[i - 1]["gy"]
+      else:
+        gx = dx_in
+      x = st["x"] if st["x"] is not None else x_in
+      self._bwd_step(plan, st, x, gx, False)
+
+  def _bwd_step(self, plan, st, x, gx, accumulate):
+    kind = st["kind"]
+    gy, y = st["gy"], st["y"]
+    if kind == "conv":
+      L = st["layer"]
+      rows = st["n"] * st["oh"] * st["ow"]
+      dc = plan["dc"][:rows * L.cout].view(rows, L.cout)
+      g = self.store.grad
+      gamma = self.store.var.get(L.name + "/BatchNorm/gamma")
+      beta = self.store.var[L.name + "/BatchNorm/beta"]
+      tr = L.trainable
+      ops.bn_relu_bwd(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
+                      g[L.name + "/BatchNorm/beta"] if tr else None,
+                      g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
+                      rows, L.cout)
+      if tr:
+        ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
+                       st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+      if gx is not None:
+        ops.conv_dgrad(dc, L.cout, 0, self.store.var[L.name + "/weights"], gx.t, gx.ld, gx.off,
+                       st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
+    elif kind == "pool":
+      if gx is not None:
+        ops.pool3x3_bwd(gy.t, gy.ld, gy.off, st["arg"], gx.t, gx.ld, gx.off, st["n"], st["ih"],
+                        st["iw"], st["c"], st["stride"], st["mode"], accumulate)
+    else:
+      first = True
+      for bsteps in st["branches"]:
+        for j in range(len(bsteps) - 1, -1, -1):
+          bst = bsteps[j]
+          if j > 0:
+            self._bwd_step(plan, bst, bst["x"], bsteps[j - 1]["gy"], False)
+          else:
+            self._bwd_step(plan, bst, x, gx, not first)
+            if gx is not None:
+              first = False
+
+
+# ----------------------------------------------------------------------------------------
+# the Fast-RCNN feature path
+# ----------------------------------------------------------------------------------------
+
+class FrcnnEngine(object):
+  """extract_frcnn_feature (models/utils.py:108-188) on MI355X."""
+
+  STEM = FIRST_SCOPE + "Conv2d_1a_7x7"
+
+  def __init__(self, store, options, bn_scale=True, depth_multiplier=1.0):
+    """options: FRCNN proto (protos/frcnn.proto:4-33)."""
+    self.store = store
+    self.device = store.device
+    self.options = options
+    self.crop = options.initial_crop_size
+    self.pool_k = options.maxpool_kernel_size
+    self.pool_s = options.maxpool_stride
+    self.keep_prob = options.dropout_keep_prob
+    if options.dropout_on_feature_map:
+      # true only by proto default; every shipped config sets it false (configs/*.pbtxt:55)
+      raise NotImplementedError("dropout_on_feature_map is not supported on the HIP path")
+    self.stats = {}
+    dm = depth_multiplier
+    self.stem_cout = max(int(64 * dm), 16)
+    self.stem_mult = min(int(self.stem_cout / 3), 8)
+    # stem variables (frozen in every config: first_stage multiplier 0.0); kept outside the
+    # flat trainable store.
+    dev = self.device
+    self.stem_vars = {
+        self.STEM + "/depthwise_weights": torch.zeros(7, 7, 3, self.stem_mult, device=dev),
+        self.STEM + "/pointwise_weights": torch.zeros(1, 1, 3 * self.stem_mult, self.stem_cout,
+                                                      device=dev),
+        self.STEM + "/BatchNorm/beta": torch.zeros(self.stem_cout, device=dev),
+        self.STEM + "/BatchNorm/moving_mean": torch.zeros(self.stem_cout, device=dev),
+        self.STEM + "/BatchNorm/moving_variance": torch.ones(self.stem_cout, device=dev),
+    }
+    if bn_scale:
+      self.stem_vars[self.STEM + "/BatchNorm/gamma"] = torch.ones(self.stem_cout, device=dev)
+    self.stem_kpad = 208  # 7*7*4 = 196 padded to a multiple of 16
+    self.stem_wt = torch.zeros(1, self.stem_cout, self.stem_kpad, device=dev)
+    self.stem_scale = torch.empty(self.stem_cout, device=dev)
+    self.stem_shift = torch.empty(self.stem_cout, device=dev)
+    self.first = Net(store, self.stats, FIRST_STAGE_AFTER_STEM, FIRST_SCOPE, self.stem_cout,
+                     bn_scale, dm)
+    self.second = Net(store, self.stats, SECOND_STAGE, SECOND_SCOPE, self.first.cout, bn_scale, dm)
+    self.feature_dims = self.second.cout
+    self._shape_cache = {}
+    self.first_trainable_idx = None
+
+  # -- variables --------------------------------------------------------------------
+  def refresh(self, only_trainable=False):
+    if not only_trainable:
+      self._refresh_stem()
+    self.first.refresh(only_trainable)
+    self.second.refresh(only_trainable)
+
+  def _refresh_stem(self):
+    """Folds depthwise(7x7, x8) o pointwise(1x1) into one 7x7 kernel over the 4-channel padded
+    image (setup-time, frozen layer): W[ky,kx,ci,co] = sum_m dw[ky,kx,ci,m] * pw[ci*8+m, co]."""
+    sv = self.stem_vars
+    dw = sv[self.STEM + "/depthwise_weights"]
+    pw = sv[self.STEM + "/pointwise_weights"].view(3, self.stem_mult, self.stem_cout)
+    weff = torch.einsum("klcm,cmo->klco", dw, pw)                     # [7,7,3,cout]
+    w4 = torch.zeros(7, 7, 4, self.stem_cout, device=self.device)
+    w4[:, :, :3] = weff
+    self.stem_wt.zero_()
+    self.stem_wt[0, :, :196] = w4.reshape(196, self.stem_cout).t()
+    ops.bn_fold(sv.get(self.STEM + "/BatchNorm/gamma"), sv[self.STEM + "/BatchNorm/beta"],
+                sv[self.STEM + "/BatchNorm/moving_mean"],
+                sv[self.STEM + "/BatchNorm/moving_variance"], BN_EPS, self.stem_scale,
+                self.stem_shift)
+
+  def set_trainable(self, trainable_names):
+    """trainable_names: set of variable names with a positive gradient multiplier."""
+    idx = None
+    for net in (self.first, self.second):
+      for layer in net.layers.values():
+        layer.trainable = (layer.name + "/weights") in trainable_names
+    for i, names in enumerate(self.first.order):
+      if any(self.first.layers[n].trainable for n in names):
+        idx = i
+        break
+    self.first_trainable_idx = idx
+
+  # -- shapes -----------------------------------------------------------------------
+  def _buffers(self, b, h, w, n, training):
+    key = (b, h, w, n, training)
+    if key in self._shape_cache:
+      return self._shape_cache[key]
+    dev = self.device
+    sh, sw = _out_hw(h, w, 2)
+    bufs = dict(
+        x4=torch.empty(b * h * w, 4, device=dev),
+        cols=torch.empty(b * sh * sw, self.stem_kpad, device=dev),
+        stem=Ref(torch.empty(b * sh * sw, self.stem_cout, device=dev), self.stem_cout, 0,
+                 self.stem_cout),
+        sh=sh, sw=sw)
+    bufs["plan1"] = self.first.plan(b, sh, sw, training)
+    fh, fw = bufs["plan1"]["oh"], bufs["plan1"]["ow"]
+    p = (self.crop - self.pool_k) // self.pool_s + 1
+    d = self.first.cout
+    bufs.update(fh=fh, fw=fw, p=p,
+                pooled=Ref(torch.empty(b * n * p * p, d, device=dev), d, 0, d),
+                pool_arg=torch.empty(b * n * p * p, d, dtype=torch.uint8, device=dev),
+                box_ind=torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(n)
+                .contiguous())
+    bufs["plan2"] = self.second.plan(b * n, p, p, training)
+    bufs["spatial"] = bufs["plan2"]["oh"] * bufs["plan2"]["ow"]
+    bufs["features"] = torch.empty(b * n, self.feature_dims, device=dev)
+    bufs["mask"] = torch.empty(b * n, self.feature_dims, dtype=torch.uint8, device=dev)
+    self._shape_cache[key] = bufs
+    return bufs
+
+  # -- forward / backward -------------------------------------------------------------
+  def forward(self, image, proposals, is_training, dropout_seed=None, dropout_mask=None):
+    """image [B,H,W,3] fp32 0..255; proposals [B,N,4].  Returns (features [B*N, D], ctx)."""
+    b, h, w, _ = image.shape
+    n = proposals.shape[1]
+    bufs = self._buffers(b, h, w, n, is_training)
+    ops.preprocess_pad4(image, bufs["x4"])
+    ops.im2col4(bufs["x4"], bufs["cols"], b, h, w, 7, 7, 2, self.stem_kpad)
+    st = bufs["stem"]
+    ops.conv_fwd(bufs["cols"], self.stem_kpad, 0, self.stem_wt, self.stem_scale, self.stem_shift,
+                 st.t, st.ld, 0, b * bufs["sh"] * bufs["sw"], 1, 1, self.stem_kpad, self.stem_cout,
+                 1, 1, 1, True)
+    feat = self.first.forward(bufs["plan1"], st)
+    boxes = proposals.reshape(-1, 4)
+    feat4 = feat.t.view(b, bufs["fh"], bufs["fw"], feat.c)
+    ops.roi_crop_pool_fwd(feat4, boxes, bufs["box_ind"], self.crop, self.pool_k, self.pool_s,
+                          out=bufs["pooled"].t.view(b * n, bufs["p"], bufs["p"], feat.c),
+                          argmax=bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], feat.c))
+    net = self.second.forward(bufs["plan2"], bufs["pooled"])
+    mask = None
+    if is_training and self.keep_prob < 1.0:
+      mask = bufs["mask"]
+      if dropout_mask is not None:
+        mask.copy_(dropout_mask.reshape(mask.shape))
+      else:
+        ops.dropout_mask(mask, 0 if dropout_seed is None else dropout_seed, self.keep_prob)
+    ops.spatial_mean_dropout_fwd(net.t, bufs["features"], mask, b * n, bufs["spatial"], net.c,
+                                 self.keep_prob if mask is not None else 1.0)
+    ctx = dict(bufs=bufs, b=b, n=n, boxes=boxes, mask=mask, feat4=feat4)
+    return bufs["features"], ctx
+
+  def backward(self, dfeatures, lddf, dfoff, ctx):
+    """dfeatures: [B*N][lddf] buffer holding d(loss)/d(features) at columns [dfoff, dfoff+D)."""
+    bufs, b, n = ctx["bufs"], ctx["b"], ctx["n"]
+    plan2 = bufs["plan2"]
+    gnet = self.second.out_grad(plan2, 0)
+    ops.spatial_mean_dropout_bwd(dfeatures, lddf, dfoff, gnet.t, ctx["mask"], b * n,
+                                 bufs["spatial"], self.feature_dims,
+                                 self.keep_prob if ctx["mask"] is not None else 1.0)
+    need_first = self.first_trainable_idx is not None
+    dpooled = None
+    if need_first:
+      if "dpooled" not in bufs:
+        bufs["dpooled"] = Ref(torch.empty_like(bufs["pooled"].t), bufs["pooled"].ld, 0,
+                              bufs["pooled"].c)
+      dpooled = bufs["dpooled"]
+    self.second.backward(plan2, bufs["pooled"], 0, dpooled)
+    if need_first:
+      plan1 = bufs["plan1"]
+      gfeat = self.first.out_grad(plan1, self.first_trainable_idx)
+      gfeat.t.zero_()
+      d = self.first.cout
+      ops.roi_crop_pool_bwd(dpooled.t.view(b * n, bufs["p"], bufs["p"], d),
+                            bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], d), ctx["boxes"],
+                            bufs["box_ind"], gfeat.t.view(b, bufs["fh"], bufs["fw"], d), self.crop,
+                            self.pool_k, self.pool_s)
+      self.first.backward(plan1, bufs["stem"], self.first_trainable_idx, None)

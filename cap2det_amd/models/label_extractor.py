@@ -1,0 +1,226 @@
+"""Caption / annotation -> image-level label extractors (reference: models/label_extractor.py).
+
+Strings are resolved to integer ids on the host (a dict lookup per token); the multi-hot
+reduction and the text-classifier MLP run in HIP kernels (`c2d_labels_from_ids`,
+`c2d_text_classifier_fwd`).  Class names, constructor signatures, `classes`, `num_classes`,
+`extract_labels(examples)` and the `ValueError`s mirror the reference.
+"""
+import abc
+
+import numpy as np
+import torch
+
+from cap2det_amd import hip_ops as ops
+from cap2det_amd.core.standard_fields import InputDataFields
+from cap2det_amd.protos import label_extractor_pb2
+from cap2det_amd.protos.message import unwrap
+
+
+def _replace_class_names(class_names):
+  """models/label_extractor.py:42-68."""
+  synonyms = {
+      'traffic light': 'stoplight', 'fire hydrant': 'hydrant', 'stop sign': 'sign',
+      'parking meter': 'meter', 'sports ball': 'ball', 'baseball bat': 'bat',
+      'baseball glove': 'glove', 'tennis racket': 'racket', 'wine glass': 'wineglass',
+      'hot dog': 'hotdog', 'potted plant': 'plant', 'dining table': 'table',
+      'cell phone': 'cellphone', 'teddy bear': 'teddy', 'hair drier': 'hairdryer',
+  }
+  return [synonyms.get(x, x) for x in class_names]
+
+
+def _read_lines(path):
+  with open(path, "r") as fid:
+    return [line.strip('\n') for line in fid.readlines()]
+
+
+def tokens_to_ids(texts, table, oov, device, min_tokens=0):
+  """Host side of `HashTable.lookup` / `index_table_from_tensor`: [B][T] strings (ragged rows
+  are padded with OOV, like the reference's '' padding) -> int32 [B, T] device tensor."""
+  if isinstance(texts, torch.Tensor):
+    return texts.to(device=device, dtype=torch.int32).contiguous()
+  batch = len(texts)
+  t = max([len(r) for r in texts] + [min_tokens])
+  ids = np.full((batch, t), oov, dtype=np.int32)
+  for b, row in enumerate(texts):
+    for i, tok in enumerate(row):
+      if isinstance(tok, bytes):
+        tok = tok.decode("utf-8")
+      ids[b, i] = table.get(tok, oov)
+  return torch.from_numpy(ids).to(device)
+
+
+def _match_labels(class_texts, table, num_classes, device):
+  """models/label_extractor.py:15-39: lookup, one-hot (depth C+1), max over tokens, drop OOV;
+  zero tokens => zeros."""
+  ids = tokens_to_ids(class_texts, table, num_classes, device)
+  labels = torch.empty(ids.shape[0], num_classes, device=device, dtype=torch.float32)
+  ops.labels_from_ids(ids, num_classes, labels)
+  return labels
+
+
+class LabelExtractor(abc.ABC):
+  """Label extractor (models/label_extractor.py:71-93)."""
+
+  def __init__(self, options, device="cuda:0"):
+    self._options = options
+    self._classes = None
+    self._num_classes = None
+    self._device = device
+
+  @property
+  def classes(self):
+    return self._classes
+
+  @property
+  def num_classes(self):
+    return self._num_classes
+
+  @abc.abstractmethod
+  def extract_labels(self, examples):
+    """Extracts the pseudo labels: [batch, num_classes] float tensor."""
+
+
+class GroundtruthExtractor(LabelExtractor):
+  """models/label_extractor.py:96-121."""
+
+  def __init__(self, options, device="cuda:0"):
+    super(GroundtruthExtractor, self).__init__(options, device)
+    self._classes = _read_lines(options.label_file)
+    self._num_classes = len(self._classes)
+    self._table = {name: i for i, name in enumerate(self._classes)}
+
+  def extract_labels(self, examples):
+    return _match_labels(examples[InputDataFields.object_texts], self._table, self._num_classes,
+                         self._device)
+
+
+class ExactMatchExtractor(LabelExtractor):
+  """models/label_extractor.py:124-150."""
+
+  def __init__(self, options, device="cuda:0"):
+    super(ExactMatchExtractor, self).__init__(options, device)
+    self._classes = _read_lines(options.label_file)
+    self._num_classes = len(self._classes)
+    self._table = {name: i for i, name in enumerate(_replace_class_names(self._classes))}
+
+  def extract_labels(self, examples):
+    return _match_labels(examples[InputDataFields.concat_caption_string], self._table,
+                         self._num_classes, self._device)
+
+
+class ExtendMatchExtractor(LabelExtractor):
+  """models/label_extractor.py:153-207."""
+
+  def __init__(self, options, device="cuda:0"):
+    super(ExtendMatchExtractor, self).__init__(options, device)
+    self._name2id = {}
+    self._classes = []
+    with open(options.label_file, "r") as fid:
+      for class_id, line in enumerate(fid):
+        class_name, synonyms = line.strip('\n').split('\t')
+        self._name2id[class_name] = class_id
+        self._classes.append(class_name)
+        for synonym in [x for x in synonyms.split(',') if x]:
+          self._name2id[synonym] = class_id
+    self._num_classes = len(self._classes)
+
+  def extract_labels(self, examples):
+    return _match_labels(examples[InputDataFields.concat_caption_string], self._name2id,
+                         self._num_classes, self._device)
+
+
+class _OpenVocabularyExtractor(LabelExtractor):
+  """Shared loading of label file + open vocabulary + GloVe table
+  (models/label_extractor.py:217-230,338-351)."""
+
+  def __init__(self, options, device="cuda:0"):
+    super(_OpenVocabularyExtractor, self).__init__(options, device)
+    self._classes = _read_lines(options.label_file)
+    self._num_classes = len(self._classes)
+    self._open_vocabulary_list = _read_lines(options.open_vocabulary_file)
+    with open(options.open_vocabulary_word_embedding_file, 'rb') as fid:
+      emb = np.load(fid)
+    self._vocab_table = {w: i for i, w in enumerate(self._open_vocabulary_list)}
+    self.set_embedding(emb)
+
+  def set_embedding(self, emb, oov_row=None):
+    """[V, E] GloVe rows; the OOV row (id V) is uniform(-0.03, 0.03) in the reference
+    (models/label_extractor.py:373-377, un-seeded there)."""
+    emb = np.asarray(emb, np.float32)
+    if oov_row is None:
+      oov_row = 0.03 * (np.random.rand(1, emb.shape[-1]) * 2 - 1)
+    full = np.concatenate([emb, np.asarray(oov_row, np.float32).reshape(1, -1)], axis=0)
+    self._embedding = torch.from_numpy(full.astype(np.float32)).to(self._device).contiguous()
+
+
+class TextClassifierMatchExtractor(_OpenVocabularyExtractor):
+  """models/label_extractor.py:331-472."""
+
+  def __init__(self, options, device="cuda:0"):
+    super(TextClassifierMatchExtractor, self).__init__(options, device)
+    self._raw_table = {name: i for i, name in enumerate(self._classes)}
+    self._weights = None
+    ckpt = options.text_classifier_checkpoint_file
+    if ckpt and ckpt.endswith(".npz"):
+      self.load_weights(dict(np.load(ckpt)))
+
+  def load_weights(self, arrays):
+    """arrays: text_classifier/layer{1,2}/{weights,biases} (the reference restores these names
+    from the text checkpoint, models/label_extractor.py:455-457)."""
+    dev = self._device
+    self._weights = tuple(
+        torch.from_numpy(np.asarray(arrays[k], np.float32)).to(dev).contiguous()
+        for k in ("text_classifier/layer1/weights", "text_classifier/layer1/biases",
+                  "text_classifier/layer2/weights", "text_classifier/layer2/biases"))
+    if self._weights[0].shape[1] != self._options.hidden_units:
+      raise ValueError("text classifier hidden_units mismatch")
+
+  def _ids(self, examples):
+    return tokens_to_ids(examples[InputDataFields.concat_caption_string], self._vocab_table,
+                         len(self._open_vocabulary_list), self._device, min_tokens=1)
+
+  def predict(self, examples, is_training=False):
+    """Logits [batch, num_classes] (models/label_extractor.py:423-440)."""
+    if is_training:
+      raise NotImplementedError("text-classifier training is out of the hot-path scope")
+    if self._weights is None:
+      raise ValueError("text classifier weights are not loaded (text_classifier_checkpoint_file)")
+    ids = self._ids(examples)
+    w1, b1, w2, b2 = self._weights
+    logits = torch.empty(ids.shape[0], self._num_classes, device=self._device)
+    ops.text_classifier_fwd(ids, self._embedding, w1, b1, w2, b2, None, 0.0, logits, None)
+    return logits
+
+  def extract_labels(self, examples):
+    if self._weights is None:
+      raise ValueError("text classifier weights are not loaded (text_classifier_checkpoint_file)")
+    ids = self._ids(examples)
+    # exact match against the RAW class names (models/label_extractor.py:465-467)
+    exact = _match_labels(examples[InputDataFields.concat_caption_string], self._raw_table,
+                          self._num_classes, self._device)
+    w1, b1, w2, b2 = self._weights
+    logits = torch.empty(ids.shape[0], self._num_classes, device=self._device)
+    labels = torch.empty_like(logits)
+    ops.text_classifier_fwd(ids, self._embedding, w1, b1, w2, b2, exact,
+                            self._options.label_threshold, logits, labels)
+    return labels
+
+
+def build_label_extractor(config, device="cuda:0"):
+  """models/label_extractor.py:475-504."""
+  config = unwrap(config)
+  if not isinstance(config, label_extractor_pb2.LabelExtractor):
+    raise ValueError('Config has to be an instance of LabelExtractor proto.')
+  oneof = config.WhichOneof('label_extractor_oneof')
+  if 'groundtruth_extractor' == oneof:
+    return GroundtruthExtractor(config.groundtruth_extractor, device)
+  elif 'exact_match_extractor' == oneof:
+    return ExactMatchExtractor(config.exact_match_extractor, device)
+  elif 'extend_match_extractor' == oneof:
+    return ExtendMatchExtractor(config.extend_match_extractor, device)
+  elif 'word_vector_match_extractor' == oneof:
+    raise NotImplementedError(
+        'word_vector_match_extractor is not on the MI355X hot path yet (SURVEY.md §8 A10)')
+  elif 'text_classifier_match_extractor' == oneof:
+    return TextClassifierMatchExtractor(config.text_classifier_match_extractor, device)
+  raise ValueError('Invalid label extractor %s' % oneof)

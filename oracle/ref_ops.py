@@ -147,9 +147,12 @@ def iou(box1, box2):
 # third-party TF op semantics (PARITY UNPINNED — see module docstring)
 # ----------------------------------------------------------------------------------------
 
-def _axis_samples(a1, a2, n, crop, dtype):
-  """Sampling coordinates of one box axis, TF crop_and_resize_op.cc order of operations."""
-  f = dtype
+def _axis_samples(a1, a2, n, crop, dtype=None):
+  """Sampling coordinates of one box axis, TF crop_and_resize_op.cc order of operations.
+  Coordinates are ALWAYS computed in float32 as the TF kernel does (also when the arbiter runs
+  the rest of the arithmetic in float64), because `in > size-1` is a discontinuous test."""
+  f = np.float32
+  a1, a2 = f(a1), f(a2)
   nm1 = f(n - 1)
   if crop > 1:
     scale = f(f(f(a2 - a1) * nm1) / f(crop - 1))
