@@ -1,0 +1,264 @@
+"""Benchmark of the Cap2Det hot path: images/s of one full WSOD training step
+(forward + losses + backward + Adagrad [+ RCCL all-reduce]) on synthetic 500x500x3 images with
+2000 proposals each — BASELINE.json's metric on configs[1] (voc07_groundtruth, Inception-V2,
+fp32, B=1 image per GPU).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (implicit-GEMM convolution on
+the fp32 MFMA pipe): algorithmic FLOPs of its launches / their duration, timed with HIP events on
+the launch stream inside the timed region.  `roofline_roi_crop` is the HBM-bound ROI crop named
+by the metric.  `cpu_baseline` times the numpy oracle (a port of the reference semantics — the
+TF reference cannot run here) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+IMAGE_HW = 500
+NUM_PROPOSALS = 2000
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def synthetic_batch(seed, device, classes):
+  """SURVEY.md §8d synthetic inputs (seeded)."""
+  import numpy as np
+  import torch
+  from tests import util_model
+  rng = np.random.default_rng(seed)
+  ex = util_model.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, NUM_PROPOSALS, [NUM_PROPOSALS], classes)
+  out = dict(ex)
+  for k in ("image", "proposals", "number_of_proposals"):
+    out[k] = torch.from_numpy(ex[k]).to(device).contiguous()
+  return out, ex
+
+
+class KernelTimer(object):
+  """Wraps cap2det_amd.hip_ops entry points with torch.cuda events (same stream as the launch)
+  and accumulates per-family durations and algorithmic work."""
+
+  def __init__(self):
+    import torch
+    self.torch = torch
+    self.records = []   # (family, work, start_event, end_event)
+    self.enabled = False
+
+  def wrap(self, ops):
+    t = self
+
+    def conv_work(kind):
+      def work(args):
+        # conv_fwd(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride, relu)
+        if kind == "fwd":
+          n, ih, iw, cin, cout, kh, kw, stride = args[9:17]
+          oh, ow = -(-ih // stride), -(-iw // stride)
+          return 2.0 * n * oh * ow * cin * cout * kh * kw
+        # conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride, acc)
+        n, ih, iw, cin, cout, kh, kw, stride = args[7:15]
+        oh, ow = -(-ih // stride), -(-iw // stride)
+        return 2.0 * n * oh * ow * cin * cout * kh * kw
+      return work
+
+    def wgrad_work(args):
+      # conv_wgrad(x, ldx, xoff, dc, ldc, coff, dw, n, ih, iw, cin, cout, kh, kw, stride)
+      n, ih, iw, cin, cout, kh, kw, stride = args[7:15]
+      oh, ow = -(-ih // stride), -(-iw // stride)
+      return 2.0 * n * oh * ow * cin * cout * kh * kw
+
+    def crop_work(args, kwargs):
+      feat, boxes = args[0], args[1]
+      crop, pk, ps = args[3:6]
+      p = (crop - pk) // ps + 1
+      return 4.0 * (boxes.shape[0] * p * p * feat.shape[3] + feat.numel() + boxes.numel())
+
+    def timed(fn, family, work_fn):
+      def inner(*args, **kwargs):
+        if not t.enabled:
+          return fn(*args, **kwargs)
+        s = t.torch.cuda.Event(enable_timing=True)
+        e = t.torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn(*args, **kwargs)
+        e.record()
+        w = work_fn(args, kwargs) if family == "roi_crop_pool_fwd" else work_fn(args)
+        t.records.append((family, w, s, e))
+        return r
+      return inner
+
+    ops.conv_fwd = timed(ops.conv_fwd, "igemm_nt", conv_work("fwd"))
+    ops.conv_dgrad = timed(ops.conv_dgrad, "igemm_nt", conv_work("dgrad"))
+    ops.conv_wgrad = timed(ops.conv_wgrad, "wgrad_tn", wgrad_work)
+    ops.roi_crop_pool_fwd = timed(ops.roi_crop_pool_fwd, "roi_crop_pool_fwd", crop_work)
+
+  def summary(self):
+    out = {}
+    for family, work, s, e in self.records:
+      d = out.setdefault(family, dict(launches=0, work=0.0, ms=0.0))
+      d["launches"] += 1
+      d["work"] += work
+      d["ms"] += s.elapsed_time(e)
+    return out
+
+
+def cpu_baseline(classes):
+  """Times the numpy oracle (port of the reference semantics) on a bounded sample: one 500x500
+  image through the first stage + a full training step with 1/20 of the proposals, then
+  extrapolates the proposal-proportional part to 2000 proposals."""
+  import numpy as np
+  from oracle import ref_labels, ref_model
+  from tests import util_model
+  sample_n = 100
+  rng = np.random.default_rng(0)
+  P, d = util_model.oracle_state(0, len(classes), 3, 1.0)
+  acc = {k: np.full(v.shape, 0.1, np.float32) for k, v in P.items()}
+  ex = util_model.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, sample_n, [sample_n], classes)
+  labels = ref_labels.groundtruth_extract(ex["object_texts"], classes)
+  mask = (rng.uniform(size=(sample_n, d)) < 0.5).astype(np.uint8)
+  opts = ref_model.FrcnnOptions()
+  loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
+                   oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+  mults = [("first_stage_feature_extraction", 0.0), ("second_stage_feature_extraction", 1.0),
+           ("first_stage_feature_extraction/InceptionV2/Mixed_4e", 1.0)]
+  t0 = time.perf_counter()
+  x = ref_model.preprocess(ex["image"])
+  ref_model.net_forward(ref_model.FIRST_STAGE, x, P, ref_model.FIRST_SCOPE)
+  t_first = time.perf_counter() - t0
+  t0 = time.perf_counter()
+  ref_model.train_step(P, acc, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
+  t_step = time.perf_counter() - t0
+  t_full = t_first + max(t_step - t_first, 0.0) * (NUM_PROPOSALS / float(sample_n))
+  try:
+    import threadpoolctl
+    cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+  except Exception:
+    cores = os.cpu_count() or 1
+  return dict(value=1.0 / t_full, unit="images/s", cores=int(cores), kind="port",
+              sample=("numpy oracle, 1 image 500x500, first stage %.2fs + full train step with %d "
+                      "proposals %.2fs; proposal-proportional part scaled x%d to 2000 proposals"
+                      % (t_first, sample_n, t_step, NUM_PROPOSALS // sample_n)))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-kernel-timing", action="store_true")
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+  elif args.gpus > 1:
+    raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+  device = "cuda:%d" % local_rank
+  torch.cuda.set_device(local_rank)
+
+  from cap2det_amd import hip_ops
+  from cap2det_amd.train.trainer import Trainer
+  from tests import util_model
+  timer = KernelTimer()
+  if not args.no_kernel_timing:
+    timer.wrap(hip_ops)
+  pipeline = util_model.load_pipeline("voc07_groundtruth_hotpath")
+  trainer = Trainer(pipeline, device=device, seed=1234)
+  classes = trainer.model.label_extractor.classes
+  batch, _ = synthetic_batch(1000 + rank, device, classes)
+
+  def sync():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for i in range(args.warmup):
+    trainer.train_step(batch, dropout_seed=i)
+  sync()
+  timer.enabled = not args.no_kernel_timing
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    losses = trainer.train_step(batch, dropout_seed=args.warmup + i)
+  sync()
+  elapsed = time.perf_counter() - t0
+  timer.enabled = False
+  total_loss = float(losses["total_loss"].item())
+  if world > 1:
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  if rank == 0:
+    images = world * args.steps * 1
+    result = {
+        "metric": "images/sec (500x500, 2000 proposals), full WSOD training step",
+        "value": images / elapsed,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: voc07_groundtruth (Inception-V2, 20 classes, OICR x3, "
+                               "Mixed_4e + second stage + heads trainable), 1 image 500x500x3 per GPU, "
+                               "2000 proposals, fp32, Adagrad; fwd+loss+bwd+optimizer"
+                               + ("+RCCL all-reduce" if world > 1 else ""),
+                   "images_per_gpu": 1, "parallelism": "dp%d" % world},
+        "final_total_loss": total_loss,
+    }
+    if not args.no_kernel_timing:
+      summ = timer.summary()
+      ig = summ.get("igemm_nt")
+      if ig:
+        tf = ig["work"] / (ig["ms"] * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "igemm_nt_kernel (conv fwd + dgrad, fp32 MFMA 32x32x2)",
+            "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": ig["launches"] / args.steps,
+            "avg_launch_ms": ig["ms"] / ig["launches"],
+            "algorithmic_gflop_per_step": ig["work"] / args.steps / 1e9}
+      wg = summ.get("wgrad_tn")
+      if wg:
+        tf = wg["work"] / (wg["ms"] * 1e-3) / 1e12
+        result["roofline_wgrad"] = {
+            "kernel": "wgrad_tn_kernel (conv filter gradient, fp32 MFMA)", "bound": "mfma",
+            "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "avg_launch_ms": wg["ms"] / wg["launches"]}
+      rc = summ.get("roi_crop_pool_fwd")
+      if rc:
+        gbs = rc["work"] / (rc["ms"] * 1e-3) / 1e9
+        result["roofline_roi_crop"] = {
+            "kernel": "roi_crop_pool_fwd_kernel (crop_and_resize 14x14 fused with 2x2 max-pool)",
+            "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": gbs / PEAK_HBM_GBPS, "traffic": None,
+            "avg_launch_ms": rc["ms"] / rc["launches"],
+            "algorithmic_bytes_per_launch": rc["work"] / rc["launches"]}
+    if not args.no_cpu_baseline and world == 1:
+      result["cpu_baseline"] = cpu_baseline(classes)
+    print(json.dumps(result))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()
