@@ -1,0 +1,35 @@
+"""Data-parallel plumbing: one process per GPU, images sharded across ranks, ONE all-reduce of
+the flat gradient bucket per step (RCCL over xGMI on MI355X; gloo in the CPU tests).
+
+The reference shards records across its async workers with a hash filter
+(`shard_indicator 'k/G'`, readers/cap2det_reader.py:201-211) and never synchronises gradients
+(TF parameter server, train_wsod.sh:46-88); the synchronous mean used here is what its
+`SyncReplicasOptimizer` option computes (train/trainer.py:90-94).
+"""
+import torch.distributed as dist
+
+
+def world_info():
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_rank(), dist.get_world_size()
+  return 0, 1
+
+
+def shard_range(num_items, rank, world):
+  """Contiguous, disjoint, exhaustive shard [lo, hi) of `num_items` for `rank`."""
+  if not (0 <= rank < world):
+    raise ValueError("rank %d outside world %d" % (rank, world))
+  base, rem = divmod(num_items, world)
+  lo = rank * base + min(rank, rem)
+  return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_bucket(flat, group=None):
+  """Sums `flat` (a contiguous 1-D slice of the flat gradient buffer) over all ranks in place.
+  Returns the factor the optimiser must scale the sum by (1 / world size)."""
+  _, world = world_info()
+  if world > 1:
+    if not flat.is_contiguous():
+      raise ValueError("gradient bucket must be contiguous")
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+  return 1.0 / world

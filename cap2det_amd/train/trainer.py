@@ -11,13 +11,13 @@ reference's `SyncReplicasOptimizer` option, train/trainer.py:90-94).
 import math
 
 import torch
-import torch.distributed as dist
 
 from cap2det_amd import hip_ops as ops
 from cap2det_amd.models import builder
 from cap2det_amd.models.cap2det_model import HEADS_B, HEADS_W
 from cap2det_amd.protos import pipeline_pb2
 from cap2det_amd.protos.message import unwrap
+from cap2det_amd.train import data_parallel
 
 
 def resolve_gradient_multipliers(var_names, gradient_multipliers):
@@ -96,7 +96,7 @@ class Trainer(object):
     if not segs:
       raise ValueError("no trainable variables")
     self.bucket = (min(s[0] for s in segs), max(s[1] for s in segs))
-    self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+    self.rank, self.world_size = data_parallel.world_info()
 
   def learning_rate(self):
     tc = self.train_config
@@ -112,15 +112,12 @@ class Trainer(object):
     model, store = self.model, self.model.store
     lo, hi = self.bucket
     store.grads[lo:hi].zero_()
-    model._cache and [b["dlogits"].zero_() for b in model._cache.values()]
     predictions = model.build_prediction(examples, **kwargs)
     losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
     reg = model.regularization_loss()
     model.backward()
-    if self.world_size > 1:
-      dist.all_reduce(store.grads[lo:hi], op=dist.ReduceOp.SUM)
+    scale = data_parallel.allreduce_bucket(store.grads[lo:hi])
     lr = self.learning_rate()
-    scale = 1.0 / self.world_size
     for off, end, m, l2 in self.segments:
       ops.adagrad_step(store.values[off:end], store.grads[off:end], store.accum[off:end], lr, l2,
                        m, scale)

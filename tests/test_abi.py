@@ -1,0 +1,58 @@
+"""The C-ABI shared library loads without a GPU and exports exactly what include/*.h declares."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from cap2det_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _exported():
+  out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+  return set(re.findall(r" T (c2d_\w+)", out))
+
+
+def test_library_exports_every_declared_symbol_and_nothing_else():
+  if not os.path.exists(_lib.LIB_PATH):
+    import __graft_entry__
+    __graft_entry__.build()
+  declared = set(_lib.header_signatures())
+  assert len(declared) >= 28
+  assert declared == _exported()
+  lib = _lib.load()
+  assert lib.c2d_version() == 100
+  assert lib.c2d_error_string(0) == b"ok"
+  assert lib.c2d_error_string(-1) == b"invalid argument"
+
+
+def test_header_has_no_torch_or_cpp_types():
+  text = open(_lib.HEADER_PATH).read()
+  assert 'extern "C"' in text
+  code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  for banned in ("torch", "at::", "std::", "hipStream_t", "template", "class "):
+    assert banned not in code
+  # every entry point cites the reference interface it replaces
+  assert text.count("models/") >= 10
+
+
+def test_invalid_arguments_are_rejected_before_any_launch():
+  """Argument validation happens on the host before a kernel is enqueued (no GPU needed)."""
+  lib = _lib.load()
+  null = None
+  assert lib.c2d_conv_fwd(null, 0, 0, null, null, null, null, 0, 0, 1, 7, 7, 16, 16, 1, 1, 1, 1,
+                          null) == -1
+  assert lib.c2d_crop_and_resize_fwd(null, null, null, null, 1, 4, 4, 16, 1, 14, null) == -1
+  assert lib.c2d_adagrad_step(null, null, null, 10, 0.1, 0.0, 1.0, 1.0, null) == -1
+  with pytest.raises(_lib.Cap2DetHipError):
+    _lib.call("c2d_pool3x3_fwd", null, 0, 0, null, 0, 0, null, 1, 4, 4, 16, 1, 0, null)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+  monkeypatch.setattr(_lib, "_lib", None)
+  monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+  with pytest.raises(ImportError):
+    _lib.load()

@@ -1,0 +1,87 @@
+"""N>1 path on CPU: two processes (gloo, 127.0.0.1) each own one image shard, compute the step
+gradients with the oracle, sum them with the product's `allreduce_bucket`, and must land on the
+gradient of the reference's batch-mean loss over both images (train/trainer.py:55-61 reduces the
+losses with reduce_mean over the batch, so mean-of-per-image-gradients == batch gradient)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cap2det_amd.train import data_parallel
+from oracle import ref_labels, ref_model
+from tests import util_model
+
+DM = 0.25
+CLASSES = ["c%d" % i for i in range(5)]
+LOSS_OPTS = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=2,
+                 oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+MULTS = [("first_stage_feature_extraction", 0.0), ("second_stage_feature_extraction", 1.0)]
+
+
+def _grads(P32, ex, lo, hi):
+  P = {k: v.astype(np.float64) for k, v in P32.items()}
+  acc = {k: np.full(v.shape, 0.1) for k, v in P.items()}
+  sub = dict(image=ex["image"][lo:hi].astype(np.float64),
+             number_of_proposals=ex["number_of_proposals"][lo:hi],
+             proposals=ex["proposals"][lo:hi].astype(np.float64))
+  labels = ref_labels.groundtruth_extract(ex["object_texts"][lo:hi], CLASSES).astype(np.float64)
+  out = ref_model.train_step(P, acc, sub, labels, ref_model.FrcnnOptions(depth_multiplier=DM,
+                                                                        dropout_keep_prob=1.0),
+                             LOSS_OPTS, MULTS, 0.01, 0.0, None)
+  names = sorted(out["applied"])
+  return names, np.concatenate([out["applied"][n].ravel() for n in names])
+
+
+def _inputs():
+  rng = np.random.default_rng(123)
+  P32, _ = util_model.oracle_state(7, len(CLASSES), 2, DM)
+  ex = util_model.make_examples(rng, 2, 48, 48, 5, [5, 3], CLASSES)
+  return P32, ex
+
+
+def _worker(rank, world, port, out_path):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  torch.set_num_threads(2)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    P32, ex = _inputs()
+    lo, hi = data_parallel.shard_range(2, rank, world)
+    assert (lo, hi) == (rank, rank + 1)
+    _, flat = _grads(P32, ex, lo, hi)
+    bucket = torch.from_numpy(flat.copy())
+    scale = data_parallel.allreduce_bucket(bucket)
+    assert data_parallel.world_info() == (rank, world)
+    if rank == 0:
+      np.save(out_path, bucket.numpy() * scale)
+  finally:
+    dist.destroy_process_group()
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_equals_batch_gradient(tmp_path):
+  out_path = str(tmp_path / "reduced.npy")
+  mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+  reduced = np.load(out_path)
+  P32, ex = _inputs()
+  _, want = _grads(P32, ex, 0, 2)            # single process, batch of both images
+  assert reduced.shape == want.shape and want.size > 1000
+  np.testing.assert_allclose(reduced, want, rtol=1e-9, atol=1e-12)
+
+
+def test_single_process_bucket_is_identity():
+  t = torch.arange(8, dtype=torch.float32)
+  assert data_parallel.allreduce_bucket(t) == 1.0
+  assert t.tolist() == list(range(8))

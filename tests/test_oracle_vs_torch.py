@@ -1,0 +1,230 @@
+"""Independent cross-check of the PARITY-UNPINNED parts of the oracle (TF op semantics restated
+from published algorithms, hand-derived backward passes) against torch-CPU float64 ops and
+autograd.  torch is used here ONLY as a second opinion on the checker, never by the product."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_model, ref_ops
+
+torch.set_num_threads(4)
+
+
+def _same_pad(x, k, s, value=0.0):
+  n, c, h, w = x.shape
+  _, pt, pb = ref_ops.same_padding(h, k, s)
+  _, pl, pr = ref_ops.same_padding(w, k, s)
+  return F.pad(x, (pl, pr, pt, pb), value=value)
+
+
+def t_conv(x, w, s):
+  """x NHWC, w HWIO -> NHWC, TF SAME."""
+  xt = _same_pad(x.permute(0, 3, 1, 2), w.shape[0], s)
+  return F.conv2d(xt, w.permute(3, 2, 0, 1), stride=s).permute(0, 2, 3, 1)
+
+
+def t_maxpool_same(x, k, s):
+  xt = _same_pad(x.permute(0, 3, 1, 2), k, s, float("-inf"))
+  return F.max_pool2d(xt, k, s).permute(0, 2, 3, 1)
+
+
+def t_avgpool_same(x, k=3):
+  xt = x.permute(0, 3, 1, 2)
+  return F.avg_pool2d(xt, k, 1, padding=k // 2, count_include_pad=False).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("h,w,k,s", [(7, 7, 3, 1), (7, 7, 3, 2), (4, 4, 3, 1), (9, 6, 1, 1),
+                                      (10, 13, 7, 2), (8, 8, 3, 2)])
+def test_conv_same_forward_backward(h, w, k, s):
+  rng = np.random.default_rng(0)
+  x = rng.standard_normal((2, h, w, 5)); wt = rng.standard_normal((k, k, 5, 4))
+  y = ref_ops.conv2d(x, wt, s)
+  xt = torch.tensor(x, requires_grad=True); wtt = torch.tensor(wt, requires_grad=True)
+  yt = t_conv(xt, wtt, s)
+  np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-10, atol=1e-10)
+  dy = rng.standard_normal(y.shape)
+  yt.backward(torch.tensor(dy))
+  dx, dw = ref_ops.conv2d_backward(x, wt, dy, s)
+  np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-10, atol=1e-10)
+  np.testing.assert_allclose(dw, wtt.grad.numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_depthwise_and_bn():
+  rng = np.random.default_rng(1)
+  x = rng.standard_normal((1, 11, 9, 3)); w = rng.standard_normal((7, 7, 3, 8))
+  y = ref_ops.depthwise_conv2d(x, w, 2)
+  xt = _same_pad(torch.tensor(x).permute(0, 3, 1, 2), 7, 2)
+  wt = torch.tensor(w).permute(2, 3, 0, 1).reshape(24, 1, 7, 7)      # out channel = ci*8 + m
+  yt = F.conv2d(xt, wt, stride=2, groups=3).permute(0, 2, 3, 1)
+  np.testing.assert_allclose(y, yt.numpy(), rtol=1e-10, atol=1e-10)
+  g, b, m, v = (rng.uniform(0.5, 1.5, 24), rng.standard_normal(24), rng.standard_normal(24),
+                rng.uniform(0.5, 1.5, 24))
+  bn = ref_ops.batch_norm_inference(y, g, b, m, v, 0.001)
+  bt = F.batch_norm(yt.permute(0, 3, 1, 2), torch.tensor(m), torch.tensor(v), torch.tensor(g),
+                    torch.tensor(b), False, 0.0, 0.001).permute(0, 2, 3, 1)
+  np.testing.assert_allclose(bn, bt.numpy(), rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("h,w,s", [(7, 7, 1), (7, 7, 2), (4, 4, 1), (125, 5, 2), (6, 9, 2)])
+def test_pools(h, w, s):
+  rng = np.random.default_rng(2)
+  x = rng.standard_normal((2, h, w, 3))
+  y, arg = ref_ops.max_pool(x, 3, s, "SAME")
+  xt = torch.tensor(x, requires_grad=True)
+  yt = t_maxpool_same(xt, 3, s)
+  np.testing.assert_array_equal(y, yt.detach().numpy())
+  dy = rng.standard_normal(y.shape)
+  yt.backward(torch.tensor(dy))
+  np.testing.assert_allclose(ref_ops.max_pool_backward(x.shape, arg, dy, 3, s, "SAME"),
+                             xt.grad.numpy(), rtol=1e-12, atol=1e-12)
+  if s == 1:
+    xa = torch.tensor(x, requires_grad=True)
+    ya = t_avgpool_same(xa)
+    np.testing.assert_allclose(ref_ops.avg_pool_same(x), ya.detach().numpy(), rtol=1e-12)
+    ya.backward(torch.tensor(dy))
+    np.testing.assert_allclose(ref_ops.avg_pool_same_backward(x.shape, dy), xa.grad.numpy(),
+                               rtol=1e-12, atol=1e-12)
+
+
+def test_max_pool_valid_first_max_tie_rule():
+  x = np.zeros((1, 2, 2, 1)); x[0, 0, 1, 0] = 1.0; x[0, 1, 0, 0] = 1.0     # tie between k=1, k=2
+  y, arg = ref_ops.max_pool(x, 2, 2, "VALID")
+  assert y[0, 0, 0, 0] == 1.0 and arg[0, 0, 0, 0] == 1
+  dx = ref_ops.max_pool_backward(x.shape, arg, np.ones_like(y), 2, 2, "VALID")
+  assert dx[0, 0, 1, 0] == 1.0 and dx.sum() == 1.0
+
+
+def t_crop_and_resize(image, boxes, box_ind, crop):
+  """Differentiable torch restatement (coordinates from the oracle's fp32 sampler)."""
+  nb, h, w, d = image.shape
+  outs = []
+  for b in range(boxes.shape[0]):
+    ys = ref_ops._axis_samples(boxes[b, 0], boxes[b, 2], h, crop)
+    xs = ref_ops._axis_samples(boxes[b, 1], boxes[b, 3], w, crop)
+    rows = []
+    for sy in ys:
+      cols = []
+      for sx in xs:
+        if sy is None or sx is None:
+          cols.append(torch.zeros(d, dtype=image.dtype))
+          continue
+        img = image[int(box_ind[b])]
+        top = img[sy[0], sx[0]] + (img[sy[0], sx[1]] - img[sy[0], sx[0]]) * float(sx[2])
+        bot = img[sy[1], sx[0]] + (img[sy[1], sx[1]] - img[sy[1], sx[0]]) * float(sx[2])
+        cols.append(top + (bot - top) * float(sy[2]))
+      rows.append(torch.stack(cols))
+    outs.append(torch.stack(rows))
+  return torch.stack(outs)
+
+
+def test_crop_and_resize_forward_backward_and_edge_rules():
+  rng = np.random.default_rng(3)
+  img = rng.standard_normal((2, 6, 5, 3))
+  boxes = np.array([[0.1, 0.2, 0.8, 0.9], [0, 0, 1, 1], [0.5, 0.5, 0.5, 0.5], [0.9, 0.1, 0.2, 0.7],
+                    [-0.2, 0.0, 0.5, 1.2], [0, 0, 0, 0]], np.float32)
+  ind = np.array([0, 1, 1, 0, 1, 0], np.int32)
+  out = ref_ops.crop_and_resize(img, boxes, ind, 4)
+  it = torch.tensor(img, requires_grad=True)
+  ot = t_crop_and_resize(it, boxes, ind, 4)
+  np.testing.assert_allclose(out, ot.detach().numpy(), rtol=1e-12, atol=1e-12)
+  dy = rng.standard_normal(out.shape)
+  ot.backward(torch.tensor(dy))
+  np.testing.assert_allclose(ref_ops.crop_and_resize_grad_image(dy, boxes, ind, img.shape),
+                             it.grad.numpy(), rtol=1e-10, atol=1e-12)
+  # documented TF rules: whole image box samples the corner pixels exactly; a [0,0,0,0] box
+  # replicates pixel (0,0); y2<y1 flips; coordinates outside [0, H-1] give 0
+  np.testing.assert_allclose(out[1, 0, 0], img[1, 0, 0]); np.testing.assert_allclose(out[1, 3, 3], img[1, 5, 4])
+  np.testing.assert_allclose(out[5], np.broadcast_to(img[0, 0, 0], out[5].shape))
+  assert np.all(out[4, 0] == 0) and np.all(out[4, :, 3] == 0)
+  assert np.any(out[3] != 0)
+
+
+def _torch_net(spec, x, P, prefix):
+  for op in spec:
+    kind = op[0]
+    if kind == "conv":
+      name = prefix + op[1]
+      c = t_conv(x, P[name + "/weights"], op[4])
+      bn = name + "/BatchNorm/"
+      c = (c - P[bn + "moving_mean"]) * (torch.rsqrt(P[bn + "moving_variance"] + 0.001) *
+                                          P[bn + "gamma"]) + P[bn + "beta"]
+      x = torch.relu(c)
+    elif kind == "maxpool":
+      x = t_maxpool_same(x, op[2], op[3])
+    elif kind == "avgpool":
+      x = t_avgpool_same(x, op[2])
+    else:
+      outs = []
+      for branch in op[2]:
+        outs.append(_torch_net(branch, x, P, prefix + op[1] + "/"))
+      x = torch.cat(outs, dim=-1)
+  return x
+
+
+def test_second_stage_backward_matches_autograd():
+  rng = np.random.default_rng(4)
+  dm = 0.25
+  P = ref_model.init_backbone_params(rng, dm=dm, dtype=np.float64)
+  cin = ref_model.spec_out_channels(ref_model.FIRST_STAGE, 3, dm)
+  x = np.maximum(rng.standard_normal((3, 7, 7, cin)), 0)
+  y, tape = ref_model.net_forward(ref_model.SECOND_STAGE, x, P, ref_model.SECOND_SCOPE)
+  Pt = {k: torch.tensor(v, requires_grad=True) for k, v in P.items()
+        if k.startswith(ref_model.SECOND_SCOPE)}
+  xt = torch.tensor(x, requires_grad=True)
+  yt = _torch_net(ref_model.SECOND_STAGE, xt, Pt, ref_model.SECOND_SCOPE)
+  np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-9, atol=1e-10)
+  dy = rng.standard_normal(y.shape)
+  yt.backward(torch.tensor(dy))
+  dx, grads = ref_model.net_backward(ref_model.SECOND_STAGE, tape, dy, P, ref_model.SECOND_SCOPE,
+                                     0, True)
+  np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-8, atol=1e-10)
+  assert len(grads) == 19 * 3
+  for k, g in grads.items():
+    np.testing.assert_allclose(g, Pt[k].grad.numpy(), rtol=1e-8, atol=1e-9, err_msg=k)
+
+
+def test_midn_oicr_loss_gradients_match_autograd():
+  rng = np.random.default_rng(5)
+  b, n, c, d, k = 2, 11, 4, 16, 3
+  num = np.array([11, 7])
+  x = rng.standard_normal((b, n, d))
+  P = ref_model.init_head_params(rng, d, c, k, stddev=0.5, dtype=np.float64)
+  boxes = np.sort(rng.uniform(0, 1, (b, n, 2, 2)), axis=2).transpose(0, 1, 3, 2).reshape(b, n, 4)
+  boxes = boxes[..., [0, 2, 1, 3]]
+  labels = np.array([[1, 0, 1, 0], [0, 1, 0, 0]], np.float64)
+  opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=k,
+              oicr_iou_threshold=0.3, oicr_use_proba_r_given_c=True)
+
+  cl, scores, proba, saved = ref_model.build_midn_network(num, x, P)
+  pred = {"num_proposals": num, "proposal_boxes": boxes, "midn_class_logits": cl,
+          "midn_proba_r_given_c": proba, "oicr_proposal_scores_at_0": scores}
+  for i in range(k):
+    pred["oicr_proposal_scores_at_%d" % (i + 1)] = x @ P["oicr/iter%d/weights" % (i + 1)] + \
+        P["oicr/iter%d/biases" % (i + 1)]
+  loss_dict, lgrads = ref_model.build_loss(pred, labels, opts)
+  dfeat, grads = ref_model.heads_backward(lgrads, dict(features=x, midn=saved), P, k)
+
+  # torch restatement with autograd; pseudo labels are constants (stop_gradient, utils.py:101)
+  xt = torch.tensor(x, requires_grad=True)
+  Pt = {kk: torch.tensor(v, requires_grad=True) for kk, v in P.items()}
+  mask = torch.tensor(ref_ops.sequence_mask(num, n, np.float64))[..., None]
+  lr = xt @ Pt["midn/proba_r_given_c/weights"] + Pt["midn/proba_r_given_c/biases"]
+  lc = xt @ Pt["midn/proba_c_given_r/weights"] + Pt["midn/proba_c_given_r/biases"]
+  pr = torch.softmax(mask * lr - 1e10 * (1 - mask), dim=1) * mask
+  clt = (lc * pr * mask).sum(1)
+  total = F.binary_cross_entropy_with_logits(clt, torch.tensor(labels)) * 1.0
+  np.testing.assert_allclose(clt.detach().numpy(), cl, rtol=1e-10)
+  s0 = np.concatenate([np.zeros((b, n, 1)), proba], -1)
+  for i in range(k):
+    s1 = xt @ Pt["oicr/iter%d/weights" % (i + 1)] + Pt["oicr/iter%d/biases" % (i + 1)]
+    _, _, plabels = ref_model.calc_oicr_loss(labels, num, boxes, s0, s1.detach().numpy(), 0.3)
+    ce = -(torch.tensor(plabels) * torch.log_softmax(s1, -1)).sum(-1)
+    m2 = mask[..., 0]
+    total = total + 0.5 * ((ce * m2).sum(1) / m2.sum(1).clamp(min=1e-10)).mean()
+    s0 = ref_ops.softmax(s1.detach().numpy())
+  np.testing.assert_allclose(total.item(), sum(loss_dict.values()), rtol=1e-10)
+  total.backward()
+  np.testing.assert_allclose(dfeat, xt.grad.numpy(), rtol=1e-8, atol=1e-12)
+  for kk, g in grads.items():
+    np.testing.assert_allclose(g, Pt[kk].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=kk)
