@@ -13,63 +13,78 @@
 //   wgrad_tn  dW[tap][i][j] += sum_m A[src(m,tap)][i] * G[m][j]      (split over m, fp32 atomics)
 //
 // MFMA mapping (cdna_hip_programming.md §3): one wave owns MT x NT tiles of 32x32; lane
-// l = (h = l>>5, i = l&31) feeds A[i][k], B[k][i]; a BK = 16 slab is consumed as 8 MFMA steps
-// where half-wave h takes k = 8h + s (a permutation of the k order common to A and B, which
-// lets each lane fetch its 8 k-values with two ds_read_b128).  fp32 in, fp32 accumulate:
+// l = (h = l>>5, i = l&31) feeds A[i][k], B[k][i]; a BK = 32 slab is consumed as 16 MFMA steps
+// where half-wave h takes k = 16h + s (a permutation of the k order common to A and B, which
+// lets each lane fetch its 16 k-values with four ds_read_b128).  fp32 in, fp32 accumulate:
 // bit-for-bit an fmaf chain, no reduced precision anywhere.
 #include "c2d_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Native vector type for register staging: HIP's float4 struct is copied with memcpy, which
+// keeps staged arrays in scratch memory (private segment) instead of VGPRs.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
-constexpr int LDS_STRIDE = BK + 4;  // floats; 80-byte rows: 16-B aligned, b128 reads conflict-free
+constexpr int BK = 32;                // floats of K per LDS slab (one 128-B line per row)
+constexpr int LDS_STRIDE = BK + 4;    // 144-byte rows: 16-B aligned, ds_read_b128 conflict-free
 
 struct ConvGeom {
   int ih, iw;      // conv input spatial size
   int oh, ow;      // conv output spatial size
   int kh, kw;      // taps
-  int stride;
+  int stride;      // 1 or 2
   int pad_t, pad_l;
   int mode;        // 0: rows index conv OUTPUT pixels (forward / wgrad); 1: rows index conv
                    // INPUT pixels and src() yields OUTPUT pixels (dgrad)
+  unsigned long long magic_hw, magic_w;  // ceil(2^40 / (h*w)), ceil(2^40 / w) of the ROW space
+  int rh, rw;      // row-space extent: (oh, ow) in mode 0, (ih, iw) in mode 1
 };
 
-// Row m of the iteration space -> (image, y, x).
+// Row m of the iteration space -> (image, y, x).  Exact for m * d < 2^40 (always here).
 struct RowPos {
   int img, y, x;
   bool valid;
 };
 
-__device__ __forceinline__ RowPos decompose(int m, int M, int h, int w) {
+__device__ __forceinline__ RowPos decompose(int m, int M, const ConvGeom& g) {
   RowPos p;
   p.valid = m < M;
-  const int mm = p.valid ? m : 0;
-  p.img = mm / (h * w);
-  const int r = mm - p.img * h * w;
-  p.y = r / w;
-  p.x = r - p.y * w;
+  const unsigned mm = p.valid ? (unsigned)m : 0u;
+  p.img = (int)(((unsigned long long)mm * g.magic_hw) >> 40);
+  const unsigned r = mm - (unsigned)p.img * (unsigned)(g.rh * g.rw);
+  p.y = (int)(((unsigned long long)r * g.magic_w) >> 40);
+  p.x = (int)r - p.y * g.rw;
   return p;
 }
 
 // Source row (in the A operand's row space) for iteration row `p` and tap (ky,kx); -1 if none.
+// Branch-free (bitwise predicates) so that the loads that follow can be issued back to back.
+template <int MODE>
 __device__ __forceinline__ int src_row(const ConvGeom& g, const RowPos& p, int ky, int kx) {
-  if (!p.valid) return -1;
-  if (g.mode == 0) {
+  if (MODE == 0) {
     const int iy = p.y * g.stride - g.pad_t + ky;
     const int ix = p.x * g.stride - g.pad_l + kx;
-    if (iy < 0 || iy >= g.ih || ix < 0 || ix >= g.iw) return -1;
-    return (p.img * g.ih + iy) * g.iw + ix;
+    const int ok = (int)p.valid & (int)(iy >= 0) & (int)(iy < g.ih) & (int)(ix >= 0) &
+                   (int)(ix < g.iw);
+    const int row = (p.img * g.ih + iy) * g.iw + ix;
+    return ok ? row : -1;
   } else {
     const int ty = p.y + g.pad_t - ky;
     const int tx = p.x + g.pad_l - kx;
-    if (ty < 0 || tx < 0) return -1;
-    if (g.stride > 1 && ((ty % g.stride) != 0 || (tx % g.stride) != 0)) return -1;
-    const int oy = ty / g.stride, ox = tx / g.stride;
-    if (oy >= g.oh || ox >= g.ow) return -1;
-    return (p.img * g.oh + oy) * g.ow + ox;
+    const int sh = g.stride - 1;  // stride is 1 or 2
+    const int oy = ty >> sh, ox = tx >> sh;
+    const int ok = (int)p.valid & (int)(ty >= 0) & (int)(tx >= 0) &
+                   (int)(((ty | tx) & sh) == 0) & (int)(oy < g.oh) & (int)(ox < g.ow);
+    const int row = (p.img * g.oh + oy) * g.ow + ox;
+    return ok ? row : -1;
   }
+}
+
+__device__ __forceinline__ f32x4 mask4(f32x4 v, bool keep) {
+  v.x = keep ? v.x : 0.0f; v.y = keep ? v.y : 0.0f;
+  v.z = keep ? v.z : 0.0f; v.w = keep ? v.w : 0.0f;
+  return v;
 }
 
 struct IgemmArgs {
@@ -81,16 +96,27 @@ struct IgemmArgs {
   int relu;
   int accumulate;           // C += result
   int M, N, K;
+  int m_tiles, n_tiles;
   ConvGeom g;
 };
 
-template <int WM, int WN, int MT, int NT>
+// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): consecutive logical tiles
+// run on one XCD, and the n-tiles of one m-tile are consecutive, so the A rows they share are
+// served by that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int id, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = id & 7, local = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+template <int MODE, int WM, int WN, int MT, int NT>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
   constexpr int NTHREADS = WM * WN * 64;
-  constexpr int A_LOADS = BM * (BK / 4) / NTHREADS;  // float4 per thread per slab
-  constexpr int B_LOADS = BN * (BK / 4) / NTHREADS;
+  constexpr int ROWS_PER_PASS = NTHREADS / 8;   // 8 lanes x float4 = one 128-B row segment
+  constexpr int A_LOADS = BM / ROWS_PER_PASS;
+  constexpr int B_LOADS = BN / ROWS_PER_PASS;
   static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small for the block");
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_STRIDE];
@@ -100,26 +126,28 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const int tile = xcd_remap(blockIdx.x, a.m_tiles * a.n_tiles);
+  const int m0 = (tile / a.n_tiles) * BM;
+  const int n0 = (tile % a.n_tiles) * BN;
 
   // loader coordinates
-  const int q = tid & 3;  // which float4 of the 16-float k slab
+  const int q4 = (tid & 7) * 4;  // float offset inside the 32-float k slab
   RowPos apos[A_LOADS];
   int arow_l[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
-    arow_l[i] = (tid >> 2) + i * (NTHREADS / 4);
-    apos[i] = decompose(m0 + arow_l[i], a.M, a.g.mode == 0 ? a.g.oh : a.g.ih,
-                        a.g.mode == 0 ? a.g.ow : a.g.iw);
+    arow_l[i] = (tid >> 3) + i * ROWS_PER_PASS;
+    apos[i] = decompose(m0 + arow_l[i], a.M, a.g);
   }
+  const float* bptr[B_LOADS];
   int brow_l[B_LOADS];
-  bool bvalid[B_LOADS];
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i) {
-    brow_l[i] = (tid >> 2) + i * (NTHREADS / 4);
-    bvalid[i] = (n0 + brow_l[i]) < a.N;
+    brow_l[i] = (tid >> 3) + i * ROWS_PER_PASS;
+    const int n = min(n0 + brow_l[i], a.N - 1);   // columns >= N are never stored: clamp only
+    bptr[i] = a.Bt + (size_t)n * a.K + q4;
   }
+  const float* abase = a.A + a.a_off + q4;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -129,67 +157,93 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int ksteps = a.K / BK;
   const int ntaps = a.g.kh * a.g.kw;
-  const int total = ntaps * ksteps;
+  const int total = ntaps * ((a.K + BK - 1) / BK);
+  const size_t tap_stride = (size_t)a.N * a.K;
 
-  float4 ra[A_LOADS], rb[B_LOADS];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 ra[A_LOADS], rb[B_LOADS];
+  unsigned amask = 0;       // bit i: A load i hit a real pixel (else SAME-padding zero)
+  int ky = 0, kx = 0, kc = 0, tap = 0;   // wave-uniform slab cursor
 
-  auto load_slab = [&](int it) {
-    const int tap = it / ksteps;
-    const int kc = (it - tap * ksteps) * BK + q * 4;
-    const int ky = tap / a.g.kw, kx = tap - ky * a.g.kw;
+  // Prologue: loads of slab 0.  Inside the loop the loads of slab it+1 are issued
+  // unconditionally right after the barrier (the last iteration harmlessly re-loads the last
+  // slab) so that the loop body is straight-line code and the loads fly under the MFMAs.
+  // K is a multiple of 16, not necessarily of BK: lanes past the end of the last slab re-read
+  // the row's last float4 (in bounds) and contribute zeros through the A mask.
+  {
+    const int koff = min(kc, a.K - 4 - q4);
+    const unsigned kok = (kc + q4 < a.K) ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      const int s = src_row(a.g, apos[i], ky, kx);
-      ra[i] = s >= 0 ? *reinterpret_cast<const float4*>(a.A + (size_t)s * a.lda + a.a_off + kc)
-                     : zero4;
+      const int sr = src_row<MODE>(a.g, apos[i], ky, kx);
+      amask |= ((sr >= 0 ? 1u : 0u) & kok) << i;
+      ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda + koff);
     }
-    const float* bt = a.Bt + (size_t)tap * a.N * a.K;
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      rb[i] = bvalid[i]
-                  ? *reinterpret_cast<const float4*>(bt + (size_t)(n0 + brow_l[i]) * a.K + kc)
-                  : zero4;
-    }
-  };
-
-  load_slab(0);
+    for (int i = 0; i < B_LOADS; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + tap * tap_stride + koff);
+  }
   for (int it = 0; it < total; ++it) {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i)
-      *reinterpret_cast<float4*>(&As[arow_l[i] * LDS_STRIDE + q * 4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&As[arow_l[i] * LDS_STRIDE + q4]) =
+          mask4(ra[i], (amask >> i) & 1u);
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
-      *reinterpret_cast<float4*>(&Bs[brow_l[i] * LDS_STRIDE + q * 4]) = rb[i];
+      *reinterpret_cast<f32x4*>(&Bs[brow_l[i] * LDS_STRIDE + q4]) = rb[i];
     __syncthreads();
-    if (it + 1 < total) load_slab(it + 1);  // in flight during the MFMAs below
+    {
+      // advance the wave-uniform cursor (saturating at the last slab)
+      if (it + 1 < total) {
+        kc += BK;
+        if (kc >= a.K) {
+          kc = 0; ++tap; ++kx;
+          if (kx == a.g.kw) { kx = 0; ++ky; }
+        }
+      }
+      const int koff = min(kc, a.K - 4 - q4);
+      const unsigned kok = (kc + q4 < a.K) ? 1u : 0u;
+      amask = 0;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        const int sr = src_row<MODE>(a.g, apos[i], ky, kx);
+        amask |= ((sr >= 0 ? 1u : 0u) & kok) << i;
+        ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda + koff);
+      }
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i)
+        rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + tap * tap_stride + koff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
-    float af[MT][8], bf[NT][8];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * 8];
-      const float4 v0 = *reinterpret_cast<const float4*>(p);
-      const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
-      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
-      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    for (int half = 0; half < 2; ++half) {
+      float af[MT][8], bf[NT][8];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * 16 + half * 8];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
+        af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+        af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * 16 + half * 8];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
+        bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
+        bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * 8];
-      const float4 v0 = *reinterpret_cast<const float4*>(p);
-      const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
-      bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
-      bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     __syncthreads();
   }
 
@@ -222,16 +276,17 @@ struct WgradArgs {
   float* dW;                            // [taps][I][J], pre-zeroed or accumulated into
   int M;                                // conv output rows (reduction length)
   int I, J;                             // cin, cout
-  int rows_per_split;                   // multiple of BK
+  int rows_per_split;                   // multiple of WBK
   ConvGeom g;                           // mode 0
 };
 
-constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [BK][128] tiles
+constexpr int WBK = 16;             // rows of M per slab
+constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
 
 // Block tile 128(i) x 128(j); 4 waves as 2x2, each 64x64 (2x2 MFMA tiles).
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[BK * WG_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Gs[BK * WG_STRIDE];
+  __shared__ __attribute__((aligned(16))) float As[WBK * WG_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Gs[WBK * WG_STRIDE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -244,11 +299,12 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
   const int mbeg = blockIdx.z * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
-  // loader: thread -> (k row kr and kr+8, float4 column c4)
+  // loader: thread -> (k row kr and kr+8, float4 column c4); columns beyond I/J are clamped
+  // (their products land in dW rows/cols that are never stored).
   const int kr = tid >> 5;   // 0..7
   const int c4 = (tid & 31) * 4;
-  const bool ivalid = (i0 + c4) < a.I;   // I, J multiples of 4
-  const bool jvalid = (j0 + c4) < a.J;
+  const float* abase = a.A + a.a_off + min(i0 + c4, a.I - 4);
+  const float* gbase = a.G + a.g_off + min(j0 + c4, a.J - 4);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -258,32 +314,45 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ra[2], rg[2];
-  auto load_slab = [&](int mb) {
+  f32x4 ra[2], rg[2];
+  unsigned vmask = 0;   // bit u: A row valid, bit 2+u: G row valid
+  {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int m = mb + kr + u * 8;
-      const RowPos p = decompose(m, mend, a.g.oh, a.g.ow);
-      const int s = src_row(a.g, p, ky, kx);
-      ra[u] = (s >= 0 && ivalid)
-                  ? *reinterpret_cast<const float4*>(a.A + (size_t)s * a.lda + a.a_off + i0 + c4)
-                  : zero4;
-      rg[u] = (p.valid && jvalid)
-                  ? *reinterpret_cast<const float4*>(a.G + (size_t)m * a.ldg + a.g_off + j0 + c4)
-                  : zero4;
+      const int m = mbeg + kr + u * 8;
+      const RowPos p = decompose(m, mend, a.g);
+      const int sr = src_row<0>(a.g, p, ky, kx);
+      vmask |= (sr >= 0 ? 1u : 0u) << u;
+      vmask |= (p.valid ? 1u : 0u) << (2 + u);
+      ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
+      rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
     }
-  };
-
-  if (mbeg < mend) load_slab(mbeg);
-  for (int mb = mbeg; mb < mend; mb += BK) {
+  }
+  for (int mb = mbeg; mb < mend; mb += WBK) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      *reinterpret_cast<float4*>(&As[(kr + u * 8) * WG_STRIDE + c4]) = ra[u];
-      *reinterpret_cast<float4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) = rg[u];
+      *reinterpret_cast<f32x4*>(&As[(kr + u * 8) * WG_STRIDE + c4]) =
+          mask4(ra[u], (vmask >> u) & 1u);
+      *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) =
+          mask4(rg[u], (vmask >> (2 + u)) & 1u);
     }
     __syncthreads();
-    if (mb + BK < mend) load_slab(mb + BK);
+    {
+      // loads of the next slab (rows past `mend` are masked; addresses stay in bounds)
+      const int nb = mb + WBK;
+      vmask = 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int m = nb + kr + u * 8;
+        const RowPos p = decompose(m, mend, a.g);
+        const int sr = src_row<0>(a.g, p, ky, kx);
+        vmask |= (sr >= 0 ? 1u : 0u) << u;
+        vmask |= (p.valid ? 1u : 0u) << (2 + u);
+        ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
+        rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int k = lh * 8 + s;
@@ -318,7 +387,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
 }
 
 int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode) {
-  if (ih <= 0 || iw <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return C2D_ERR_INVALID_ARG;
+  if (ih <= 0 || iw <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || stride > 2) return C2D_ERR_INVALID_ARG;
   g->ih = ih; g->iw = iw; g->kh = kh; g->kw = kw; g->stride = stride; g->mode = mode;
   g->oh = (ih + stride - 1) / stride;
   g->ow = (iw + stride - 1) / stride;
@@ -326,14 +395,24 @@ int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode)
   const int pth = (g->oh - 1) * stride + kh - ih, ptw = (g->ow - 1) * stride + kw - iw;
   g->pad_t = (pth > 0 ? pth : 0) / 2;
   g->pad_l = (ptw > 0 ? ptw : 0) / 2;
+  g->rh = mode == 0 ? g->oh : ih;
+  g->rw = mode == 0 ? g->ow : iw;
+  const unsigned long long one = 1ull << 40;
+  g->magic_hw = (one + (unsigned long long)(g->rh * g->rw) - 1) / (unsigned long long)(g->rh * g->rw);
+  g->magic_w = (one + (unsigned long long)g->rw - 1) / (unsigned long long)g->rw;
   return C2D_OK;
 }
 
 template <int WM, int WN, int MT, int NT>
-void launch_igemm(const IgemmArgs& a, hipStream_t s) {
+void launch_igemm(IgemmArgs a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  dim3 grid(c2d_ceil_div(a.M, BM), c2d_ceil_div(a.N, BN));
-  hipLaunchKernelGGL((igemm_nt_kernel<WM, WN, MT, NT>), grid, dim3(WM * WN * 64), 0, s, a);
+  a.m_tiles = c2d_ceil_div(a.M, BM);
+  a.n_tiles = c2d_ceil_div(a.N, BN);
+  const dim3 grid(a.m_tiles * a.n_tiles), block(WM * WN * 64);
+  if (a.g.mode == 0)
+    hipLaunchKernelGGL((igemm_nt_kernel<0, WM, WN, MT, NT>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((igemm_nt_kernel<1, WM, WN, MT, NT>), grid, block, 0, s, a);
 }
 
 int run_igemm(const IgemmArgs& a, hipStream_t s) {
@@ -352,7 +431,7 @@ extern "C" int c2d_conv_fwd(const float* x, int ldx, int xoff, const float* wt,
                             int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
                             int stride, int relu, void* stream) {
   C2D_CHECK_ARG(x && wt && y && n > 0 && cin > 0 && cout > 0);
-  C2D_CHECK_ARG(cin % BK == 0 && ldx % 4 == 0 && xoff % 4 == 0);
+  C2D_CHECK_ARG(cin % 16 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   IgemmArgs a;
   int rc = fill_geom(&a.g, ih, iw, kh, kw, stride, 0);
   if (rc) return rc;
@@ -366,7 +445,7 @@ extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w
                               int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
                               int kh, int kw, int stride, int accumulate, void* stream) {
   C2D_CHECK_ARG(dc && w && dx && n > 0 && cin > 0 && cout > 0);
-  C2D_CHECK_ARG(cout % BK == 0 && ldc % 4 == 0 && coff % 4 == 0);
+  C2D_CHECK_ARG(cout % 16 == 0 && ldc % 4 == 0 && coff % 4 == 0);
   IgemmArgs a;
   int rc = fill_geom(&a.g, ih, iw, kh, kw, stride, 1);
   if (rc) return rc;
@@ -389,10 +468,10 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
   a.M = n * a.g.oh * a.g.ow; a.I = cin; a.J = cout;
   const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, 128);
   int splits = c2d_ceil_div(1024, tiles);                 // aim at ~4 blocks per CU
-  const int max_splits = c2d_ceil_div(a.M, 4 * BK);       // at least 4 slabs per block
+  const int max_splits = c2d_ceil_div(a.M, 4 * WBK);       // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), BK) * BK;
+  a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), WBK) * WBK;
   splits = c2d_ceil_div(a.M, a.rows_per_split);
   dim3 grid(kh * kw * c2d_ceil_div(cin, 128), c2d_ceil_div(cout, 128), splits);
   hipLaunchKernelGGL(wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
