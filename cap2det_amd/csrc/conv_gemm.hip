@@ -38,7 +38,11 @@ struct ConvGeom {
   int mode;        // 0: rows index conv OUTPUT pixels (forward / wgrad); 1: rows index conv
                    // INPUT pixels and src() yields OUTPUT pixels (dgrad)
   unsigned long long magic_hw, magic_w;  // ceil(2^40 / (h*w)), ceil(2^40 / w) of the ROW space
-  int rh, rw;      // row-space extent: (oh, ow) in mode 0, (ih, iw) in mode 1
+  int rh, rw;      // row-space extent: (oh, ow) in mode 0; in mode 1 the sub-grid of input
+                   // pixels (y0 + sub*yy, x0 + sub*xx) handled by this launch
+  int sub, y0, x0; // mode 1 only: stride-2 dgrad is split into the 4 parity classes of the
+                   // input pixel, each of which sees only the taps of matching parity
+  int ky0, kx0, kstep, nky, nkx;  // tap subset: ky = ky0 + kstep*t, t < nky (same for kx)
 };
 
 // Row m of the iteration space -> (image, y, x).  Exact for m * d < 2^40 (always here).
@@ -70,8 +74,8 @@ __device__ __forceinline__ int src_row(const ConvGeom& g, const RowPos& p, int k
     const int row = (p.img * g.ih + iy) * g.iw + ix;
     return ok ? row : -1;
   } else {
-    const int ty = p.y + g.pad_t - ky;
-    const int tx = p.x + g.pad_l - kx;
+    const int ty = p.y * g.sub + g.y0 + g.pad_t - ky;
+    const int tx = p.x * g.sub + g.x0 + g.pad_l - kx;
     const int sh = g.stride - 1;  // stride is 1 or 2
     const int oy = ty >> sh, ox = tx >> sh;
     const int ok = (int)p.valid & (int)(ty >= 0) & (int)(tx >= 0) &
@@ -157,20 +161,21 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int ntaps = a.g.kh * a.g.kw;
+  const int ntaps = a.g.nky * a.g.nkx;
   const int total = ntaps * ((a.K + BK - 1) / BK);
   const size_t tap_stride = (size_t)a.N * a.K;
 
   f32x4 ra[A_LOADS], rb[B_LOADS];
   unsigned amask = 0;       // bit i: A load i hit a real pixel (else SAME-padding zero)
-  int ky = 0, kx = 0, kc = 0, tap = 0;   // wave-uniform slab cursor
+  int ky = a.g.ky0, kx = a.g.kx0, kc = 0;   // wave-uniform slab cursor
+  int tap = ky * a.g.kw + kx;
 
   // Prologue: loads of slab 0.  Inside the loop the loads of slab it+1 are issued
   // unconditionally right after the barrier (the last iteration harmlessly re-loads the last
   // slab) so that the loop body is straight-line code and the loads fly under the MFMAs.
   // K is a multiple of 16, not necessarily of BK: lanes past the end of the last slab re-read
   // the row's last float4 (in bounds) and contribute zeros through the A mask.
-  {
+  if (total > 0) {   // (a stride-2 parity class can have no tap at all: it just stores zeros)
     const int koff = min(kc, a.K - 4 - q4);
     const unsigned kok = (kc + q4 < a.K) ? 1u : 0u;
 #pragma unroll
@@ -197,8 +202,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
       if (it + 1 < total) {
         kc += BK;
         if (kc >= a.K) {
-          kc = 0; ++tap; ++kx;
-          if (kx == a.g.kw) { kx = 0; ++ky; }
+          kc = 0; kx += a.g.kstep;
+          if (kx >= a.g.kw) { kx = a.g.kx0; ky += a.g.kstep; }
+          tap = ky * a.g.kw + kx;
         }
       }
       const int koff = min(kc, a.K - 4 - q4);
@@ -262,7 +268,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
         if (m >= a.M) continue;
         float v = acc[i][j][r] * sc + sh;
         if (a.relu) v = fmaxf(v, 0.0f);
-        float* dst = a.C + (size_t)m * a.ldc + a.c_off + n;
+        int drow = m;
+        if (MODE == 1 && a.g.sub > 1) {   // scattered rows of a parity class
+          const RowPos p = decompose(m, a.M, a.g);
+          drow = (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw + p.x * a.g.sub + a.g.x0;
+        }
+        float* dst = a.C + (size_t)drow * a.ldc + a.c_off + n;
         if (a.accumulate) v += *dst;
         *dst = v;
       }
@@ -386,6 +397,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
   }
 }
 
+void set_magic(ConvGeom* g);
+
 int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode) {
   if (ih <= 0 || iw <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || stride > 2) return C2D_ERR_INVALID_ARG;
   g->ih = ih; g->iw = iw; g->kh = kh; g->kw = kw; g->stride = stride; g->mode = mode;
@@ -397,10 +410,16 @@ int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode)
   g->pad_l = (ptw > 0 ? ptw : 0) / 2;
   g->rh = mode == 0 ? g->oh : ih;
   g->rw = mode == 0 ? g->ow : iw;
+  g->sub = 1; g->y0 = 0; g->x0 = 0;
+  g->ky0 = 0; g->kx0 = 0; g->kstep = 1; g->nky = kh; g->nkx = kw;
+  set_magic(g);
+  return C2D_OK;
+}
+
+void set_magic(ConvGeom* g) {
   const unsigned long long one = 1ull << 40;
   g->magic_hw = (one + (unsigned long long)(g->rh * g->rw) - 1) / (unsigned long long)(g->rh * g->rw);
   g->magic_w = (one + (unsigned long long)g->rw - 1) / (unsigned long long)g->rw;
-  return C2D_OK;
 }
 
 template <int WM, int WN, int MT, int NT>
@@ -451,8 +470,31 @@ extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w
   if (rc) return rc;
   a.A = dc; a.lda = ldc; a.a_off = coff; a.Bt = w; a.C = dx; a.ldc = lddx; a.c_off = dxoff;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate;
-  a.M = n * ih * iw; a.N = cin; a.K = cout;
-  return run_igemm(a, (hipStream_t)stream);
+  a.N = cin; a.K = cout;
+  if (stride == 1) {
+    a.M = n * ih * iw;
+    return run_igemm(a, (hipStream_t)stream);
+  }
+  // stride 2: one launch per parity class (py, px) of the input pixel; a pixel of the class
+  // only meets the taps with ky = (py + pad_t) mod 2 (+2, ...), i.e. 2.25 taps per pixel on
+  // average for a 3x3 kernel instead of 9 mostly-empty ones.
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      IgemmArgs b = a;
+      b.g.sub = 2; b.g.y0 = py; b.g.x0 = px;
+      b.g.rh = (ih - py + 1) / 2; b.g.rw = (iw - px + 1) / 2;
+      if (b.g.rh <= 0 || b.g.rw <= 0) continue;
+      b.g.kstep = 2;
+      b.g.ky0 = (py + b.g.pad_t) & 1; b.g.kx0 = (px + b.g.pad_l) & 1;
+      b.g.nky = b.g.ky0 < kh ? (kh - b.g.ky0 + 1) / 2 : 0;
+      b.g.nkx = b.g.kx0 < kw ? (kw - b.g.kx0 + 1) / 2 : 0;
+      if (b.g.nky == 0 || b.g.nkx == 0) { b.g.nky = 0; b.g.nkx = 0; }
+      set_magic(&b.g);
+      b.M = n * b.g.rh * b.g.rw;
+      rc = run_igemm(b, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  return C2D_OK;
 }
 
 extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc,
