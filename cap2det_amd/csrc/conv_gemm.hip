@@ -122,8 +122,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
   constexpr int A_LOADS = BM / ROWS_PER_PASS;
   constexpr int B_LOADS = BN / ROWS_PER_PASS;
   static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small for the block");
-  __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_STRIDE];
+  float* const As = smem;
+  float* const Bs = smem + BM * LDS_STRIDE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -160,6 +161,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  bool tile_on[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      tile_on[i][j] = (m0 + (wm * MT + i) * 32 < a.M) && (n0 + (wn * NT + j) * 32 < a.N);
 
   const int ntaps = a.g.nky * a.g.nkx;
   const int total = ntaps * ((a.K + BK - 1) / BK);
@@ -247,37 +255,59 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] =
-                __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            if (tile_on[i][j])   // wave-uniform: 32x32 tiles beyond M / N cost no MFMA time
+              acc[i][j] =
+                  __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 
-  // Epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Epilogue.  C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5),
+  // i.e. 4 B per lane per store.  Each wave transposes 32-row strips through its private slice
+  // of the (now idle) staging LDS so that the global stores are 16 B per lane on contiguous
+  // 128*NT-byte row segments (4x fewer store instructions, cdna_hip_programming.md T21).
+  constexpr int SCOLS = NT * 32;
+  constexpr int SSTR = SCOLS + 4;
+  static_assert(WM * WN * 32 * SSTR <= (BM + BN) * LDS_STRIDE, "epilogue staging exceeds LDS");
+  float* stage = smem + wave * (32 * SSTR);   // (the K loop ended with a block barrier)
+  constexpr int C4 = SCOLS / 4;          // float4 per strip row
+  constexpr int RPP = 64 / C4;           // rows per pass over the strip
+  const int ec4 = lane % C4, er = lane / C4;
+  const int ncol = n0 + wn * SCOLS + ec4 * 4;
+  f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+  const bool ncol_ok = ncol < a.N;       // N is a multiple of 4
+  if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
+  if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * NT * 32 + j * 32 + li;
-    if (n >= a.N) continue;
-    const float sc = a.scale ? a.scale[n] : 1.0f;
-    const float sh = a.shift ? a.shift[n] : 0.0f;
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= a.M) continue;
-        float v = acc[i][j][r] * sc + sh;
-        if (a.relu) v = fmaxf(v, 0.0f);
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+      const int row = pass * RPP + er;
+      const int m = m0 + (wm * MT + i) * 32 + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
+      if (m < a.M && ncol_ok) {
+        v = v * esc + esh;
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
         int drow = m;
         if (MODE == 1 && a.g.sub > 1) {   // scattered rows of a parity class
           const RowPos p = decompose(m, a.M, a.g);
           drow = (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw + p.x * a.g.sub + a.g.x0;
         }
-        float* dst = a.C + (size_t)drow * a.ldc + a.c_off + n;
+        f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
         if (a.accumulate) v += *dst;
         *dst = v;
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -288,64 +318,85 @@ struct WgradArgs {
   int M;                                // conv output rows (reduction length)
   int I, J;                             // cin, cout
   int rows_per_split;                   // multiple of WBK
+  int itiles, jtiles, tiles, splits;    // tiles = taps*itiles*jtiles
   ConvGeom g;                           // mode 0
 };
 
-constexpr int WBK = 16;             // rows of M per slab
+constexpr int WBK = 32;             // rows of M per slab
 constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
+constexpr int WG_LOADS = WBK / 8;   // float4 loads per thread per operand per slab
 
-// Block tile 128(i) x 128(j); 4 waves as 2x2, each 64x64 (2x2 MFMA tiles).
+// Block tile 128(i) x 128(j) = 16 MFMA tiles dealt to 4 waves.  1-D grid with the
+// XCD-aware order: all (tap, i-tile, j-tile) blocks of one row split are consecutive logical
+// ids on one XCD, so the x / dC rows of the split are fetched from HBM once and re-read by the
+// other taps / tiles from that XCD's L2.
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float As[WBK * WG_STRIDE];
   __shared__ __attribute__((aligned(16))) float Gs[WBK * WG_STRIDE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int itiles = (a.I + 127) / 128;
-  const int tap = blockIdx.x / itiles;
-  const int i0 = (blockIdx.x - tap * itiles) * 128;
-  const int j0 = blockIdx.y * 128;
+  const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
+  const int split = logical / a.tiles;
+  int t = logical - split * a.tiles;
+  const int jt = t % a.jtiles; t /= a.jtiles;
+  const int it_ = t % a.itiles;
+  const int tap = t / a.itiles;
+  const int i0 = it_ * 128, j0 = jt * 128;
   const int ky = tap / a.g.kw, kx = tap - ky * a.g.kw;
-  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mbeg = split * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
-  // loader: thread -> (k row kr and kr+8, float4 column c4); columns beyond I/J are clamped
+  // loader: thread -> (k rows kr + 8u, float4 column c4); columns beyond I/J are clamped
   // (their products land in dW rows/cols that are never stored).
   const int kr = tid >> 5;   // 0..7
   const int c4 = (tid & 31) * 4;
   const float* abase = a.A + a.a_off + min(i0 + c4, a.I - 4);
   const float* gbase = a.G + a.g_off + min(j0 + c4, a.J - 4);
 
-  f32x16 acc[2][2];
+  f32x16 acc[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
-  f32x4 ra[2], rg[2];
-  unsigned vmask = 0;   // bit u: A row valid, bit 2+u: G row valid
+  // Dynamic tile assignment: the valid 32x32 tiles of the block (I and J are multiples of 32
+  // but not of 128) are dealt round-robin to the 4 waves, so a partial block tile keeps every
+  // wave equally busy instead of idling the waves that own the out-of-range quadrant.
+  const int nvi = min(4, (a.I - i0 + 31) / 32), nvj = min(4, (a.J - j0 + 31) / 32);
+  const int nvalid = nvi * nvj;
+  int ti[4], tj[4];
+  bool on[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = wave + 4 * q;
+    on[q] = t < nvalid;
+    const int tt = on[q] ? t : 0;
+    ti[q] = tt / nvj;
+    tj[q] = tt - ti[q] * nvj;
+  }
+
+  f32x4 ra[WG_LOADS], rg[WG_LOADS];
+  unsigned vmask = 0;   // bit u: A row valid, bit 8+u: G row valid
   {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < WG_LOADS; ++u) {
       const int m = mbeg + kr + u * 8;
       const RowPos p = decompose(m, mend, a.g);
       const int sr = src_row<0>(a.g, p, ky, kx);
       vmask |= (sr >= 0 ? 1u : 0u) << u;
-      vmask |= (p.valid ? 1u : 0u) << (2 + u);
+      vmask |= (p.valid ? 1u : 0u) << (8 + u);
       ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
       rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
     }
   }
   for (int mb = mbeg; mb < mend; mb += WBK) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < WG_LOADS; ++u) {
       *reinterpret_cast<f32x4*>(&As[(kr + u * 8) * WG_STRIDE + c4]) =
           mask4(ra[u], (vmask >> u) & 1u);
       *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) =
-          mask4(rg[u], (vmask >> (2 + u)) & 1u);
+          mask4(rg[u], (vmask >> (8 + u)) & 1u);
     }
     __syncthreads();
     {
@@ -353,47 +404,52 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
       const int nb = mb + WBK;
       vmask = 0;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < WG_LOADS; ++u) {
         const int m = nb + kr + u * 8;
         const RowPos p = decompose(m, mend, a.g);
         const int sr = src_row<0>(a.g, p, ky, kx);
         vmask |= (sr >= 0 ? 1u : 0u) << u;
-        vmask |= (p.valid ? 1u : 0u) << (2 + u);
+        vmask |= (p.valid ? 1u : 0u) << (8 + u);
         ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
         rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int k = lh * 8 + s;
-      float af[2], bf[2];
+    for (int part = 0; part < WBK / 8; ++part) {
+      // fragments of 4 k-steps first (32 independent ds_read_b32), then up to 16 MFMAs
+      float af[4][4], bf[4][4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = As[k * WG_STRIDE + wm * 64 + i * 32 + li];
+      for (int s = 0; s < 4; ++s) {
+        const int k = lh * (WBK / 2) + part * 4 + s;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = Gs[k * WG_STRIDE + wn * 64 + j * 32 + li];
+        for (int q = 0; q < 4; ++q) {
+          af[q][s] = As[k * WG_STRIDE + ti[q] * 32 + li];
+          bf[q][s] = Gs[k * WG_STRIDE + tj[q] * 32 + li];
+        }
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int q = 0; q < 4; ++q)
+          if (on[q])   // wave-uniform
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][s], bf[q][s], acc[q], 0, 0, 0);
     }
     __syncthreads();
   }
 
   float* dw = a.dW + (size_t)tap * a.I * a.J;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int jj = j0 + wn * 64 + j * 32 + li;
+  for (int q = 0; q < 4; ++q) {
+    if (!on[q]) continue;
+    const int jj = j0 + tj[q] * 32 + li;
     if (jj >= a.J) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ii = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ii >= a.I) continue;
-        atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int ii = i0 + ti[q] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ii >= a.I) continue;
+      atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
+    }
   }
 }
 
@@ -438,8 +494,16 @@ int run_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return C2D_OK;
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
-  if (big_blocks >= 256) launch_igemm<2, 2, 2, 2>(a, s);
-  else launch_igemm<2, 2, 1, 1>(a, s);
+  if (big_blocks < 256) {
+    launch_igemm<2, 2, 1, 1>(a, s);          // small problems (first stage): 64x64 tiles
+  } else if (a.N % 128 != 0 && a.N % 128 <= 64 && a.M >= 65536) {
+    // last 128-wide n-tile at most half full and plenty of rows: 256x64 tiles with the 4 waves
+    // stacked along M, so a partial n-tile shortens every wave equally (measured: 576->192
+    // at 98k rows 272 -> 250 us; loses at 32k rows where 256-row tiles leave CUs idle).
+    launch_igemm<4, 1, 2, 2>(a, s);
+  } else {
+    launch_igemm<2, 2, 2, 2>(a, s);          // 128x128, waves 2x2
+  }
   return c2d_launch_status();
 }
 
@@ -508,14 +572,16 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
   if (rc) return rc;
   a.A = x; a.lda = ldx; a.a_off = xoff; a.G = dc; a.ldg = ldc; a.g_off = coff; a.dW = dw;
   a.M = n * a.g.oh * a.g.ow; a.I = cin; a.J = cout;
-  const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, 128);
-  int splits = c2d_ceil_div(1024, tiles);                 // aim at ~4 blocks per CU
-  const int max_splits = c2d_ceil_div(a.M, 4 * WBK);       // at least 4 slabs per block
+  a.itiles = c2d_ceil_div(cin, 128);
+  a.jtiles = c2d_ceil_div(cout, 128);
+  a.tiles = kh * kw * a.itiles * a.jtiles;
+  int splits = c2d_ceil_div(768, a.tiles);                // ~3 blocks per CU, one round
+  const int max_splits = c2d_ceil_div(a.M, 4 * WBK);      // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), WBK) * WBK;
-  splits = c2d_ceil_div(a.M, a.rows_per_split);
-  dim3 grid(kh * kw * c2d_ceil_div(cin, 128), c2d_ceil_div(cout, 128), splits);
+  a.splits = c2d_ceil_div(a.M, a.rows_per_split);
+  dim3 grid(a.tiles * a.splits);
   hipLaunchKernelGGL(wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return c2d_launch_status();
 }

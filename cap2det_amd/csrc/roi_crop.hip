@@ -176,6 +176,75 @@ __global__ __launch_bounds__(256) void roi_crop_pool_bwd_kernel(
   }
 }
 
+
+// LDS-privatised backward: a workgroup owns the gradient image of CH channels
+// ([hf*wf][CH] fp32 in LDS), sweeps a group of ROIs with LDS float atomics, then flushes the
+// non-zero entries with one global atomic each.  Cuts the global atomic traffic from
+// 4 * N*49*D adds (903 MB at the BASELINE point, ~0.7 ms at the chip's 1.3 TB/s atomic rate)
+// to groups * hf*wf*D adds.  grid = (D/CH, groups, batch), block = 512.
+template <int CH>
+__global__ __launch_bounds__(512) void roi_crop_pool_bwd_lds_kernel(
+    const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
+    const float* __restrict__ boxes, const int32_t* __restrict__ box_ind,
+    float* __restrict__ dfeat, int hf, int wf, int depth, int num_boxes, int crop, int pk,
+    int ps, int pout) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  const int npix = hf * wf;
+  for (int i = threadIdx.x; i < npix * CH; i += 512) acc[i] = 0.0f;
+  __syncthreads();
+  const int c0 = blockIdx.x * CH;
+  const int b = blockIdx.z;
+  const int per = (num_boxes + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per;
+  const int r1 = min(num_boxes, r0 + per);
+  const int p2 = pout * pout;
+  const int ch = threadIdx.x % CH;
+  constexpr int CELLS = 512 / CH;
+  constexpr int U = 4;   // independent (roi, cell) items per lane per trip: loads issued together
+  const long long end = (long long)r1 * p2;
+  for (long long base = (long long)r0 * p2 + threadIdx.x / CH; base < end; base += U * CELLS) {
+    float g[U];
+    int k[U], roi[U];
+    float bx[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long idx = base + (long long)u * CELLS;
+      const bool in = idx < end;
+      const long long ci = in ? idx : (end - 1);
+      roi[u] = (int)(ci / p2);
+      const size_t o = (size_t)ci * depth + c0 + ch;
+      g[u] = in ? dout[o] : 0.0f;
+      k[u] = argmax[o];
+      if (box_ind[roi[u]] != b) g[u] = 0.0f;
+      const float4 bb = *reinterpret_cast<const float4*>(boxes + (size_t)roi[u] * 4);
+      bx[u][0] = bb.x; bx[u][1] = bb.y; bx[u][2] = bb.z; bx[u][3] = bb.w;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (g[u] == 0.0f) continue;
+      const long long idx = base + (long long)u * CELLS;
+      const int cell = (int)(idx - (long long)roi[u] * p2);
+      const int py = cell / pout, px = cell - py * pout;
+      const SampleAxis sy = sample_axis(bx[u][0], bx[u][2], hf, crop, py * ps + k[u] / pk);
+      const SampleAxis sx = sample_axis(bx[u][1], bx[u][3], wf, crop, px * ps + k[u] % pk);
+      if (sy.lo < 0 || sx.lo < 0) continue;
+      const float dtop = (1.0f - sy.lerp) * g[u], dbot = sy.lerp * g[u];
+      float* top = acc + (size_t)sy.lo * wf * CH + ch;
+      float* bot = acc + (size_t)sy.hi * wf * CH + ch;
+      atomicAdd(top + sx.lo * CH, (1.0f - sx.lerp) * dtop);
+      atomicAdd(top + sx.hi * CH, sx.lerp * dtop);
+      atomicAdd(bot + sx.lo * CH, (1.0f - sx.lerp) * dbot);
+      atomicAdd(bot + sx.hi * CH, sx.lerp * dbot);
+    }
+  }
+  __syncthreads();
+  float* dimg = dfeat + (size_t)b * npix * depth + c0;
+  for (int i = threadIdx.x; i < npix * CH; i += 512) {
+    const float v = acc[i];
+    if (v != 0.0f) atomicAdd(dimg + (size_t)(i / CH) * depth + (i % CH), v);
+  }
+}
+
 }  // namespace
 
 extern "C" int c2d_crop_and_resize_fwd(const float* feat, const float* boxes,
@@ -218,6 +287,30 @@ extern "C" int c2d_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax,
   C2D_CHECK_ARG(pool_k > 0 && pool_s > 0 && pool_k <= crop && pool_k * pool_k <= 255);
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
+  // LDS-privatised path when a [hf*wf][CH] fp32 image fits 128 KiB of the CU's 160 KiB LDS.
+  const size_t pix_bytes = (size_t)hf * wf * sizeof(float);
+  int ch = 0;
+  for (int c : {16, 8})   // <= 64 KiB per workgroup: two 512-thread workgroups per CU
+    if (depth % c == 0 && pix_bytes * c <= 64 * 1024) { ch = c; break; }
+  if (ch != 0 && num_boxes >= 64) {
+    const int chunks = depth / ch;
+    int groups = (4 * 256 + chunks * batch - 1) / (chunks * batch);   // ~4 workgroups per CU
+    if (groups > num_boxes / 16) groups = num_boxes / 16 > 0 ? num_boxes / 16 : 1;
+    const dim3 grid(chunks, groups, batch);
+    const size_t smem = pix_bytes * ch;
+#define C2D_BWD_LDS(CHV)                                                                      \
+  static const hipError_t attr_##CHV = hipFuncSetAttribute(                                   \
+      (const void*)roi_crop_pool_bwd_lds_kernel<CHV>,                                         \
+      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                \
+  (void)attr_##CHV;                                                                           \
+  hipLaunchKernelGGL((roi_crop_pool_bwd_lds_kernel<CHV>), grid, dim3(512), smem,              \
+                     (hipStream_t)stream, dout, argmax, boxes, box_ind, dfeat, hf, wf, depth, \
+                     num_boxes, crop, pool_k, pool_s, pout)
+    if (ch == 16) { C2D_BWD_LDS(16); }
+    else { C2D_BWD_LDS(8); }
+#undef C2D_BWD_LDS
+    return c2d_launch_status();
+  }
   hipLaunchKernelGGL(roi_crop_pool_bwd_kernel, dim3(num_boxes), dim3(256), 0,
                      (hipStream_t)stream, dout, argmax, boxes, box_ind, dfeat, batch, hf, wf,
                      depth, crop, pool_k, pool_s, pout);

@@ -1,0 +1,20 @@
+import sys, torch
+sys.path.insert(0, ".")
+from cap2det_amd import hip_ops as ops
+dev="cuda:0"; torch.manual_seed(0)
+hf=wf=32; D=576; N=2000
+feat=torch.relu(torch.randn(1,hf,wf,D,device=dev))
+c=torch.rand(N,2,device=dev); s=torch.exp(torch.rand(N,2,device=dev)*3.2-3.2)
+boxes=torch.cat([(c-s/2).clamp(0,1),(c+s/2).clamp(0,1)],1).contiguous()
+ind=torch.zeros(N,dtype=torch.int32,device=dev)
+out,arg=ops.roi_crop_pool_fwd(feat,boxes,ind,14,2,2)
+dout=torch.randn_like(out); dfeat=torch.zeros_like(feat)
+def t(fn,it=20):
+    for _ in range(3): fn()
+    a=torch.cuda.Event(enable_timing=True); b=torch.cuda.Event(enable_timing=True); a.record()
+    for _ in range(it): fn()
+    b.record(); torch.cuda.synchronize(); return a.elapsed_time(b)/it
+tf=t(lambda: ops.roi_crop_pool_fwd(feat,boxes,ind,14,2,2,out=out,argmax=arg))
+tb=t(lambda: ops.roi_crop_pool_bwd(dout,arg,boxes,ind,dfeat,14,2,2))
+byts=4.0*(N*49*D+feat.numel()+boxes.numel())
+print("fwd %.1f us %.0f GB/s | bwd %.1f us" % (tf*1e3, byts/tf/1e6, tb*1e3))
