@@ -101,6 +101,13 @@ struct IgemmArgs {
   int accumulate;           // C += result
   int M, N, K;
   int m_tiles, n_tiles;
+  // Multi-segment 1x1 mode (nseg > 1): the reduction runs over the concatenation of `nseg`
+  // (A_s [rows][lda_s] (+off_s), Bt_s [N][K_s]) pairs — one GEMM for the input gradient of an
+  // Inception block whose branches all start with a 1x1 convolution of the same input.
+  int nseg;
+  const float* segA[4]; const float* segB[4];
+  int seg_lda[4], seg_off[4], segK[4];
+  int total_slabs;
   ConvGeom g;
 };
 
@@ -153,6 +160,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
     bptr[i] = a.Bt + (size_t)n * a.K + q4;
   }
   const float* abase = a.A + a.a_off + q4;
+  int lda = a.lda, Kc = a.K, sgi = 0;   // current segment (wave-uniform)
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -170,8 +178,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
       tile_on[i][j] = (m0 + (wm * MT + i) * 32 < a.M) && (n0 + (wn * NT + j) * 32 < a.N);
 
   const int ntaps = a.g.nky * a.g.nkx;
-  const int total = ntaps * ((a.K + BK - 1) / BK);
+  const int total = a.nseg > 1 ? a.total_slabs : ntaps * ((a.K + BK - 1) / BK);
   const size_t tap_stride = (size_t)a.N * a.K;
+  (void)ntaps;
 
   f32x4 ra[A_LOADS], rb[B_LOADS];
   unsigned amask = 0;       // bit i: A load i hit a real pixel (else SAME-padding zero)
@@ -184,13 +193,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
   // K is a multiple of 16, not necessarily of BK: lanes past the end of the last slab re-read
   // the row's last float4 (in bounds) and contribute zeros through the A mask.
   if (total > 0) {   // (a stride-2 parity class can have no tap at all: it just stores zeros)
-    const int koff = min(kc, a.K - 4 - q4);
-    const unsigned kok = (kc + q4 < a.K) ? 1u : 0u;
+    const int koff = min(kc, Kc - 4 - q4);
+    const unsigned kok = (kc + q4 < Kc) ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int sr = src_row<MODE>(a.g, apos[i], ky, kx);
       amask |= ((sr >= 0 ? 1u : 0u) & kok) << i;
-      ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda + koff);
+      ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * lda + koff);
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
@@ -209,20 +218,30 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
       // advance the wave-uniform cursor (saturating at the last slab)
       if (it + 1 < total) {
         kc += BK;
-        if (kc >= a.K) {
-          kc = 0; kx += a.g.kstep;
-          if (kx >= a.g.kw) { kx = a.g.kx0; ky += a.g.kstep; }
-          tap = ky * a.g.kw + kx;
+        if (kc >= Kc) {
+          kc = 0;
+          if (a.nseg > 1) {          // next (A, Bt) segment of a multi-segment 1x1 GEMM
+            ++sgi;
+            lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
+            abase = a.segA[sgi] + a.seg_off[sgi] + q4;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i)
+              bptr[i] = a.segB[sgi] + (size_t)min(n0 + brow_l[i], a.N - 1) * Kc + q4;
+          } else {
+            kx += a.g.kstep;
+            if (kx >= a.g.kw) { kx = a.g.kx0; ky += a.g.kstep; }
+            tap = ky * a.g.kw + kx;
+          }
         }
       }
-      const int koff = min(kc, a.K - 4 - q4);
-      const unsigned kok = (kc + q4 < a.K) ? 1u : 0u;
+      const int koff = min(kc, Kc - 4 - q4);
+      const unsigned kok = (kc + q4 < Kc) ? 1u : 0u;
       amask = 0;
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) {
         const int sr = src_row<MODE>(a.g, apos[i], ky, kx);
         amask |= ((sr >= 0 ? 1u : 0u) & kok) << i;
-        ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda + koff);
+        ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * lda + koff);
       }
 #pragma unroll
       for (int i = 0; i < B_LOADS; ++i)
@@ -519,7 +538,7 @@ extern "C" int c2d_conv_fwd(const float* x, int ldx, int xoff, const float* wt,
   int rc = fill_geom(&a.g, ih, iw, kh, kw, stride, 0);
   if (rc) return rc;
   a.A = x; a.lda = ldx; a.a_off = xoff; a.Bt = wt; a.C = y; a.ldc = ldy; a.c_off = yoff;
-  a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = 0;
+  a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = 0; a.nseg = 1;
   a.M = n * a.g.oh * a.g.ow; a.N = cout; a.K = cin;
   return run_igemm(a, (hipStream_t)stream);
 }
@@ -533,7 +552,7 @@ extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w
   int rc = fill_geom(&a.g, ih, iw, kh, kw, stride, 1);
   if (rc) return rc;
   a.A = dc; a.lda = ldc; a.a_off = coff; a.Bt = w; a.C = dx; a.ldc = lddx; a.c_off = dxoff;
-  a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate;
+  a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate; a.nseg = 1;
   a.N = cin; a.K = cout;
   if (stride == 1) {
     a.M = n * ih * iw;
@@ -559,6 +578,31 @@ extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w
       if (rc) return rc;
     }
   return C2D_OK;
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs,
+                                       const int* coffs, const float* const* ws,
+                                       const int* couts, float* dx, int lddx, int dxoff,
+                                       int rows, int cin, int accumulate, void* stream) {
+  C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && dcs && ldcs && coffs && ws && couts && dx);
+  C2D_CHECK_ARG(rows > 0 && cin > 0 && cin % 4 == 0 && lddx % 4 == 0 && dxoff % 4 == 0);
+  IgemmArgs a;
+  int rc = fill_geom(&a.g, 1, 1, 1, 1, 1, 1);
+  if (rc) return rc;
+  a.total_slabs = 0;
+  for (int i = 0; i < nseg; ++i) {
+    C2D_CHECK_ARG(dcs[i] && ws[i] && couts[i] > 0 && couts[i] % 16 == 0);
+    C2D_CHECK_ARG(ldcs[i] % 4 == 0 && coffs[i] % 4 == 0);
+    a.segA[i] = dcs[i]; a.segB[i] = ws[i]; a.seg_lda[i] = ldcs[i]; a.seg_off[i] = coffs[i];
+    a.segK[i] = couts[i];
+    a.total_slabs += (couts[i] + BK - 1) / BK;
+  }
+  a.nseg = nseg;
+  a.A = dcs[0]; a.lda = ldcs[0]; a.a_off = coffs[0]; a.Bt = ws[0]; a.K = couts[0];
+  a.C = dx; a.ldc = lddx; a.c_off = dxoff;
+  a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate;
+  a.M = rows; a.N = cin;
+  return run_igemm(a, (hipStream_t)stream);
 }
 
 extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc,

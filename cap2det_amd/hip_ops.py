@@ -3,6 +3,8 @@
 PyTorch is plumbing only (allocation, streams); every arithmetic op on the hot path runs in
 the hand-written HIP kernels behind these calls.  No fallback: a missing library raises.
 """
+import ctypes
+
 import torch
 
 from cap2det_amd import _lib
@@ -68,6 +70,16 @@ def conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, 
                accumulate):
   _lib.call("c2d_conv_dgrad", _p(dc), ldc, coff, _p(w), _p(dx), lddx, dxoff, n, ih, iw, cin, cout,
             kh, kw, stride, int(accumulate), _stream())
+
+
+def conv1x1_dgrad_multi(dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin, accumulate):
+  """dx (+)= sum_s dc_s . W_s^T over up to 4 (dc, W) segments (see include/cap2det_hip.h)."""
+  n = len(dcs)
+  ptrs = ctypes.c_void_p * n
+  ints = ctypes.c_int * n
+  _lib.call("c2d_conv1x1_dgrad_multi", n, ptrs(*[_p(t) for t in dcs]), ints(*ldcs), ints(*coffs),
+            ptrs(*[_p(t) for t in ws]), ints(*couts), _p(dx), lddx, dxoff, rows, cin,
+            int(accumulate), _stream())
 
 
 def conv_wgrad(x, ldx, xoff, dc, ldc, coff, dw, n, ih, iw, cin, cout, kh, kw, stride):

@@ -339,6 +339,11 @@ class Net(object):
       st["gy"] = Ref(torch.empty(rows, y.c, device=dev), y.c, 0, y.c)   # grad of the op output
       if st["kind"] == "block":
         for bsteps in st["branches"]:
+          b0 = bsteps[0]
+          if (b0["kind"] == "conv" and b0["layer"].k == 1 and b0["layer"].stride == 1 and
+              (i > first_idx or plan.get("need_input_grad", True))):
+            b0["dc_entry"] = torch.empty(b0["n"] * b0["oh"] * b0["ow"], b0["layer"].cout,
+                                         device=dev)
           for j, bst in enumerate(bsteps):
             if j == len(bsteps) - 1:
               by = bst["y"]
@@ -370,42 +375,67 @@ class Net(object):
       x = st["x"] if st["x"] is not None else x_in
       self._bwd_step(plan, st, x, gx, False)
 
+  def _conv_bwd(self, plan, st, x, gx, accumulate, dc=None):
+    """BN/ReLU backward -> dc, filter gradient, and (when gx is given) the input gradient."""
+    L = st["layer"]
+    gy, y = st["gy"], st["y"]
+    rows = st["n"] * st["oh"] * st["ow"]
+    if dc is None:
+      dc = plan["dc"][:rows * L.cout].view(rows, L.cout)
+    g = self.store.grad
+    gamma = self.store.var.get(L.name + "/BatchNorm/gamma")
+    beta = self.store.var[L.name + "/BatchNorm/beta"]
+    tr = L.trainable
+    ops.bn_relu_bwd(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
+                    g[L.name + "/BatchNorm/beta"] if tr else None,
+                    g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
+                    rows, L.cout)
+    if tr:
+      ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
+                     st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+    if gx is not None:
+      ops.conv_dgrad(dc, L.cout, 0, self.store.var[L.name + "/weights"], gx.t, gx.ld, gx.off,
+                     st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
+
   def _bwd_step(self, plan, st, x, gx, accumulate):
     kind = st["kind"]
-    gy, y = st["gy"], st["y"]
     if kind == "conv":
-      L = st["layer"]
-      rows = st["n"] * st["oh"] * st["ow"]
-      dc = plan["dc"][:rows * L.cout].view(rows, L.cout)
-      g = self.store.grad
-      gamma = self.store.var.get(L.name + "/BatchNorm/gamma")
-      beta = self.store.var[L.name + "/BatchNorm/beta"]
-      tr = L.trainable
-      ops.bn_relu_bwd(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
-                      g[L.name + "/BatchNorm/beta"] if tr else None,
-                      g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
-                      rows, L.cout)
-      if tr:
-        ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
-                       st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
-      if gx is not None:
-        ops.conv_dgrad(dc, L.cout, 0, self.store.var[L.name + "/weights"], gx.t, gx.ld, gx.off,
-                       st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
+      self._conv_bwd(plan, st, x, gx, accumulate)
     elif kind == "pool":
       if gx is not None:
+        gy = st["gy"]
         ops.pool3x3_bwd(gy.t, gy.ld, gy.off, st["arg"], gx.t, gx.ld, gx.off, st["n"], st["ih"],
                         st["iw"], st["c"], st["stride"], st["mode"], accumulate)
     else:
-      first = True
+      # Inception block.  Everything but each branch's first op runs branch by branch; the
+      # first ops all produce a gradient w.r.t. the shared block input, which TF sums (AddN):
+      # the stride-1 1x1 entry convolutions are fused into ONE multi-segment GEMM that writes
+      # the sum once, the remaining first ops (pools) accumulate into it afterwards.
+      firsts = []
       for bsteps in st["branches"]:
-        for j in range(len(bsteps) - 1, -1, -1):
-          bst = bsteps[j]
-          if j > 0:
-            self._bwd_step(plan, bst, bst["x"], bsteps[j - 1]["gy"], False)
-          else:
-            self._bwd_step(plan, bst, x, gx, not first)
-            if gx is not None:
-              first = False
+        for j in range(len(bsteps) - 1, 0, -1):
+          self._bwd_step(plan, bsteps[j], bsteps[j]["x"], bsteps[j - 1]["gy"], False)
+        firsts.append(bsteps[0])
+      fused = [b for b in firsts if gx is not None and b["kind"] == "conv" and
+               b["layer"].k == 1 and b["layer"].stride == 1 and "dc_entry" in b]
+      written = False
+      if len(fused) >= 2:
+        for b in fused:
+          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"])
+        rows = st["n"] * st["ih"] * st["iw"]
+        ops.conv1x1_dgrad_multi(
+            [b["dc_entry"] for b in fused], [b["layer"].cout for b in fused], [0] * len(fused),
+            [self.store.var[b["layer"].name + "/weights"] for b in fused],
+            [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off, rows, st["cin"], False)
+        written = True
+      else:
+        fused = []
+      for b in firsts:
+        if any(b is f for f in fused):
+          continue
+        self._bwd_step(plan, b, x, gx, written)
+        if gx is not None:
+          written = True
 
 
 # ----------------------------------------------------------------------------------------

@@ -94,6 +94,15 @@ int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w, float* dx
                    int dxoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
                    int stride, int accumulate, void* stream);
 
+/* Input gradient of an Inception block whose branches all start with a stride-1 1x1
+ * convolution of the same input (the sum TF's AddN forms over the branches): one GEMM over the
+ * concatenated reduction dx[rows][cin] (+)= sum_s dc_s[rows][cout_s] . W_s^T, with nseg <= 4
+ * segments given as HOST arrays of device pointers / leading dims / channel offsets / widths.
+ * W_s is HWIO 1x1 = [cin][cout_s]. */
+int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs, const int* coffs,
+                            const float* const* ws, const int* couts, float* dx, int lddx,
+                            int dxoff, int rows, int cin, int accumulate, void* stream);
+
 /* dw[kh*kw][cin][cout] += Conv2DBackpropFilter(x, dc)  (fp32 atomics over row splits; the
  * caller zero-fills dw once per step). */
 int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, int coff,
