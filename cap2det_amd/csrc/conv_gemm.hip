@@ -472,6 +472,152 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride-1 filter gradient with ALL NINE TAPS per block.
+//
+// The per-tap kernel above re-reads the x and dC rows once per (tap, i-tile, j-tile): 36 passes
+// over 175 MB for the 192->256 layer, which made it memory-bound (PMC: MFMA busy 59 %, a third
+// of it on padding tiles).  Here a block owns 32 input channels x 128 output channels x a row
+// range and keeps 9 accumulators (one per tap) per wave: the dC slab is staged once and used by
+// all taps, and x is staged once with a (w+1)-row halo because tap (ky,kx) of output row m reads
+// input row m + (ky-1)*w + (kx-1) of the same image.  SAME padding = a 9-bit validity mask per
+// output row (LDS), applied to the A operand at fragment-read time.
+// ---------------------------------------------------------------------------------------------
+constexpr int W3_ASTR = 32 + 4;
+constexpr int W3_GSTR = 128 + 4;
+
+struct Wgrad3Args {
+  const float* A; int lda; int a_off;
+  const float* G; int ldg; int g_off;
+  float* dW;
+  int M, I, J;
+  int rows_per_split, itiles, jtiles, tiles, splits;
+  int h, w;
+};
+
+// WC = compile-time (square) map width, IMGS = whole images per slab.  The x slab is staged in
+// ZERO-PADDED image coordinates (every image gets a one-pixel border of zeros in LDS), so tap
+// (ky,kx) of output pixel at padded index P is simply LDS row P + (ky-1)*(WC+2) + (kx-1): SAME
+// padding needs no predicate, and because a slab is a whole number of images every LDS row
+// index is a compile-time constant.  Wave v owns output columns [j0+32v, j0+32v+32), all taps.
+template <int WC, int IMGS>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
+  constexpr int PW = WC + 2;
+  constexpr int HW = WC * WC;
+  constexpr int PIMG = PW * PW;              // padded pixels per image
+  constexpr int R = IMGS * HW;               // output rows per slab
+  constexpr int STEPS = (R + 1) / 2;         // MFMA k-steps (2 rows each; odd R: one zero row)
+  constexpr int RP = STEPS * 2;
+  constexpr int AROWS = IMGS * PIMG;
+  constexpr int A_LD = (AROWS + 31) / 32;    // x loads per thread (rows ar0 + 32u)
+  constexpr int G_LD = (RP + 7) / 8;         // dC loads per thread (rows gkr + 8u)
+  __shared__ __attribute__((aligned(16))) float As[AROWS * W3_ASTR];
+  __shared__ __attribute__((aligned(16))) float Gs[RP * W3_GSTR];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
+  const int split = logical / a.tiles;
+  const int t = logical - split * a.tiles;
+  const int jt = t % a.jtiles, it_ = t / a.jtiles;
+  const int i0 = it_ * 32, j0 = jt * 128;
+  const int mbeg = split * a.rows_per_split;           // multiple of R
+  const int mend = min(a.M, mbeg + a.rows_per_split);  // M is a multiple of HW
+  const bool wave_on = j0 + wave * 32 < a.J;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+  // loaders: everything about WHERE a staged row comes from is slab-invariant
+  const int gkr = tid >> 5, gc4 = (tid & 31) * 4;       // dC: rows gkr + 8u, float4 column gc4
+  const float* gbase = a.G + a.g_off + min(j0 + gc4, a.J - 4);
+  const int aq4 = (tid & 7) * 4, ar0 = tid >> 3;        // x: LDS rows ar0 + 32u, float4 col aq4
+  const float* abase = a.A + a.a_off + i0 + aq4;
+  int apix[A_LD];                                       // pixel offset inside the slab, or -1
+#pragma unroll
+  for (int u = 0; u < A_LD; ++u) {
+    const int r = ar0 + u * 32;
+    const int im = r / PIMG, rr = r - im * PIMG;
+    const int yp = rr / PW, xp = rr - yp * PW;
+    const bool real = r < AROWS && yp >= 1 && yp <= WC && xp >= 1 && xp <= WC;
+    apix[u] = real ? im * HW + (yp - 1) * WC + (xp - 1) : -1;
+  }
+  f32x4 rg[G_LD], ra[A_LD];
+  unsigned amask = 0, gmask = 0;
+
+#define C2D_W3_LOAD(MB)                                                                        \
+  {                                                                                            \
+    gmask = 0;                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < G_LD; ++u) {                                         \
+      const int k = gkr + u * 8;                                                               \
+      const int m = (MB) + k;                                                                  \
+      gmask |= ((k < R && m < mend) ? 1u : 0u) << u;                                           \
+      rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);        \
+    }                                                                                          \
+    amask = 0;                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < A_LD; ++u) {                                         \
+      const int gm = (MB) + apix[u];                                                           \
+      const bool ok = apix[u] >= 0 && gm < mend;                                               \
+      amask |= (ok ? 1u : 0u) << u;                                                            \
+      ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)(ok ? gm : 0) * a.lda);          \
+    }                                                                                          \
+  }
+
+  C2D_W3_LOAD(mbeg);
+  for (int mb = mbeg; mb < mend; mb += R) {
+#pragma unroll
+    for (int u = 0; u < G_LD; ++u)
+      if (gkr + u * 8 < RP)
+        *reinterpret_cast<f32x4*>(&Gs[(gkr + u * 8) * W3_GSTR + gc4]) =
+            mask4(rg[u], (gmask >> u) & 1u);
+#pragma unroll
+    for (int u = 0; u < A_LD; ++u)
+      if (ar0 + u * 32 < AROWS)
+        *reinterpret_cast<f32x4*>(&As[(ar0 + u * 32) * W3_ASTR + aq4]) =
+            mask4(ra[u], (amask >> u) & 1u);
+    __syncthreads();
+    C2D_W3_LOAD(mb + R);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_on) {
+      const float* gcol = &Gs[lh * W3_GSTR + wave * 32 + li];
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        // rows k = 2s (lower half-wave) and 2s+1 (upper); padded LDS row of pixel k
+        constexpr int dummy = 0; (void)dummy;
+        const int k0 = 2 * s, k1 = (2 * s + 1 < R) ? 2 * s + 1 : 2 * s;
+        const int p0 = (k0 / HW) * PIMG + ((k0 % HW) / WC + 1) * PW + (k0 % WC) + 1;
+        const int p1 = (k1 / HW) * PIMG + ((k1 % HW) / WC + 1) * PW + (k1 % WC) + 1;
+        const float* ap = &As[(lh ? p1 : p0) * W3_ASTR + li];
+        const float bv = gcol[2 * s * W3_GSTR];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int off = ((q / 3) - 1) * PW + ((q % 3) - 1);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[off * W3_ASTR], bv, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#undef C2D_W3_LOAD
+
+  if (wave_on) {
+    const int jj = j0 + wave * 32 + li;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      float* dw = a.dW + (size_t)q * a.I * a.J;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
+      }
+    }
+  }
+}
+
 void set_magic(ConvGeom* g);
 
 int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode) {
@@ -611,6 +757,24 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
   C2D_CHECK_ARG(x && dc && dw && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   C2D_CHECK_ARG(ldc % 4 == 0 && coff % 4 == 0);
+  if (kh == 3 && kw == 3 && stride == 1 && ih == iw && (iw == 4 || iw == 7) && cin % 32 == 0 &&
+      cout % 32 == 0 && n >= 256) {
+    Wgrad3Args b;
+    b.A = x; b.lda = ldx; b.a_off = xoff; b.G = dc; b.ldg = ldc; b.g_off = coff; b.dW = dw;
+    b.M = n * ih * iw; b.I = cin; b.J = cout; b.h = ih; b.w = iw;
+    b.itiles = cin / 32; b.jtiles = c2d_ceil_div(cout, 128); b.tiles = b.itiles * b.jtiles;
+    const int slab = iw == 4 ? 32 : 49;                    // whole images per slab
+    const int nslabs = c2d_ceil_div(b.M, slab);
+    int splits = c2d_ceil_div(512, b.tiles);               // 2 blocks per CU, one round
+    if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
+    b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
+    b.splits = c2d_ceil_div(b.M, b.rows_per_split);
+    const dim3 grid(b.tiles * b.splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (iw == 4) hipLaunchKernelGGL((wgrad3x3_kernel<4, 2>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((wgrad3x3_kernel<7, 1>), grid, dim3(256), 0, st, b);
+    return c2d_launch_status();
+  }
   WgradArgs a;
   int rc = fill_geom(&a.g, ih, iw, kh, kw, stride, 0);
   if (rc) return rc;
