@@ -27,7 +27,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;                // floats of K per LDS slab (one 128-B line per row)
-constexpr int LDS_STRIDE = BK + 4;    // 144-byte rows: 16-B aligned, ds_read_b128 conflict-free
 
 struct ConvGeom {
   int ih, iw;      // conv input spatial size
@@ -120,12 +119,17 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-template <int MODE, int WM, int WN, int MT, int NT>
+template <int MODE, int WM, int WN, int MT, int NT, int BKT>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
+  // BKT = floats of K per slab: 32 for the big tiles; 128 for the 64x64 small-problem tile, whose
+  // grids (16-126 workgroups) leave one block per CU, so a deeper slab is the only way to keep
+  // enough bytes in flight to cover the global-load latency (measured ~1 us per 32-deep slab).
+  constexpr int LDS_STRIDE = BKT + 4;
+  constexpr int LPR = BKT / 4;                  // lanes per row (float4 each)
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
   constexpr int NTHREADS = WM * WN * 64;
-  constexpr int ROWS_PER_PASS = NTHREADS / 8;   // 8 lanes x float4 = one 128-B row segment
+  constexpr int ROWS_PER_PASS = NTHREADS / LPR;
   constexpr int A_LOADS = BM / ROWS_PER_PASS;
   constexpr int B_LOADS = BN / ROWS_PER_PASS;
   static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small for the block");
@@ -143,19 +147,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
   const int n0 = (tile % a.n_tiles) * BN;
 
   // loader coordinates
-  const int q4 = (tid & 7) * 4;  // float offset inside the 32-float k slab
+  const int q4 = (tid % LPR) * 4;  // float offset inside the k slab
   RowPos apos[A_LOADS];
   int arow_l[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
-    arow_l[i] = (tid >> 3) + i * ROWS_PER_PASS;
+    arow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
     apos[i] = decompose(m0 + arow_l[i], a.M, a.g);
   }
   const float* bptr[B_LOADS];
   int brow_l[B_LOADS];
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i) {
-    brow_l[i] = (tid >> 3) + i * ROWS_PER_PASS;
+    brow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
     const int n = min(n0 + brow_l[i], a.N - 1);   // columns >= N are never stored: clamp only
     bptr[i] = a.Bt + (size_t)n * a.K + q4;
   }
@@ -178,7 +182,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
       tile_on[i][j] = (m0 + (wm * MT + i) * 32 < a.M) && (n0 + (wn * NT + j) * 32 < a.N);
 
   const int ntaps = a.g.nky * a.g.nkx;
-  const int total = a.nseg > 1 ? a.total_slabs : ntaps * ((a.K + BK - 1) / BK);
+  int total = ntaps * ((a.K + BKT - 1) / BKT);
+  if (a.nseg > 1) {
+    total = 0;
+    for (int sg = 0; sg < a.nseg; ++sg) total += (a.segK[sg] + BKT - 1) / BKT;
+  }
   const size_t tap_stride = (size_t)a.N * a.K;
   (void)ntaps;
 
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
     {
       // advance the wave-uniform cursor (saturating at the last slab)
       if (it + 1 < total) {
-        kc += BK;
+        kc += BKT;
         if (kc >= Kc) {
           kc = 0;
           if (a.nseg > 1) {          // next (A, Bt) segment of a multi-segment 1x1 GEMM
@@ -250,11 +258,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < BKT / 16; ++half) {
       float af[MT][8], bf[NT][8];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * 16 + half * 8];
+        const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
         af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * 16 + half * 8];
+        const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
         bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
@@ -643,16 +651,16 @@ void set_magic(ConvGeom* g) {
   g->magic_w = (one + (unsigned long long)g->rw - 1) / (unsigned long long)g->rw;
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int BKT>
 void launch_igemm(IgemmArgs a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   a.m_tiles = c2d_ceil_div(a.M, BM);
   a.n_tiles = c2d_ceil_div(a.N, BN);
   const dim3 grid(a.m_tiles * a.n_tiles), block(WM * WN * 64);
   if (a.g.mode == 0)
-    hipLaunchKernelGGL((igemm_nt_kernel<0, WM, WN, MT, NT>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((igemm_nt_kernel<0, WM, WN, MT, NT, BKT>), grid, block, 0, s, a);
   else
-    hipLaunchKernelGGL((igemm_nt_kernel<1, WM, WN, MT, NT>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((igemm_nt_kernel<1, WM, WN, MT, NT, BKT>), grid, block, 0, s, a);
 }
 
 int run_igemm(const IgemmArgs& a, hipStream_t s) {
@@ -660,14 +668,14 @@ int run_igemm(const IgemmArgs& a, hipStream_t s) {
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
   if (big_blocks < 256) {
-    launch_igemm<2, 2, 1, 1>(a, s);          // small problems (first stage): 64x64 tiles
+    launch_igemm<2, 2, 1, 1, 32>(a, s);          // small problems (first stage): 64x64 tiles
   } else if (a.N % 128 != 0 && a.N % 128 <= 64 && a.M >= 65536) {
     // last 128-wide n-tile at most half full and plenty of rows: 256x64 tiles with the 4 waves
     // stacked along M, so a partial n-tile shortens every wave equally (measured: 576->192
     // at 98k rows 272 -> 250 us; loses at 32k rows where 256-row tiles leave CUs idle).
-    launch_igemm<4, 1, 2, 2>(a, s);
+    launch_igemm<4, 1, 2, 2, 32>(a, s);
   } else {
-    launch_igemm<2, 2, 2, 2>(a, s);          // 128x128, waves 2x2
+    launch_igemm<2, 2, 2, 2, 32>(a, s);          // 128x128, waves 2x2
   }
   return c2d_launch_status();
 }

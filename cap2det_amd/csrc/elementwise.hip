@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256) void spatial_mean_dropout_bwd_kernel(
 // Counter-based RNG (splitmix64 finaliser) -> keep mask; reproducible from (seed, offset).
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask,
                                                            long long n, unsigned long long seed,
+                                                           const long long* __restrict__ seed_dev,
                                                            float keep_prob) {
+  if (seed_dev) seed = (unsigned long long)seed_dev[0];   // graph replays: seed lives in HBM
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
@@ -471,7 +473,16 @@ extern "C" int c2d_dropout_mask(uint8_t* mask, long long n, unsigned long long s
   C2D_CHECK_ARG(mask && n >= 0);
   if (n == 0) return C2D_OK;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                     mask, n, seed, keep_prob);
+                     mask, n, seed, (const long long*)nullptr, keep_prob);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_dropout_mask_dev(uint8_t* mask, long long n, const long long* seed_dev,
+                                    float keep_prob, void* stream) {
+  C2D_CHECK_ARG(mask && seed_dev && n >= 0);
+  if (n == 0) return C2D_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     mask, n, 0ull, seed_dev, keep_prob);
   return c2d_launch_status();
 }
 

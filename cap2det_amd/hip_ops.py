@@ -130,6 +130,12 @@ def dropout_mask(mask, seed, keep_prob):
             float(keep_prob), _stream())
 
 
+def dropout_mask_dev(mask, seed_dev, keep_prob):
+  assert seed_dev.dtype == torch.int64
+  _lib.call("c2d_dropout_mask_dev", _p(mask), mask.numel(), _p(seed_dev), float(keep_prob),
+            _stream())
+
+
 def preprocess_pad4(image, out):
   _lib.call("c2d_preprocess_pad4", _p(image), _p(out), image.numel() // 3, _stream())
 

@@ -575,6 +575,8 @@ class FrcnnEngine(object):
       mask = bufs["mask"]
       if dropout_mask is not None:
         mask.copy_(dropout_mask.reshape(mask.shape))
+      elif isinstance(dropout_seed, torch.Tensor):
+        ops.dropout_mask_dev(mask, dropout_seed, self.keep_prob)   # seed read on the device
       else:
         ops.dropout_mask(mask, 0 if dropout_seed is None else dropout_seed, self.keep_prob)
     ops.spatial_mean_dropout_fwd(net.t, bufs["features"], mask, b * n, bufs["spatial"], net.c,

@@ -46,7 +46,8 @@ def exponential_decay(lr, step, decay_steps, decay_rate, staircase):
 class Trainer(object):
   """Owns the model, the optimiser state and the data-parallel reduction."""
 
-  def __init__(self, pipeline_proto, device="cuda:0", model=None, **model_kwargs):
+  def __init__(self, pipeline_proto, device="cuda:0", model=None, use_graph=False,
+               **model_kwargs):
     pipeline_proto = unwrap(pipeline_proto)
     if not isinstance(pipeline_proto, pipeline_pb2.Pipeline):
       raise ValueError('pipeline_proto has to be an instance of Pipeline.')
@@ -97,6 +98,11 @@ class Trainer(object):
       raise ValueError("no trainable variables")
     self.bucket = (min(s[0] for s in segs), max(s[1] for s in segs))
     self.rank, self.world_size = data_parallel.world_info()
+    # hipGraph replay of the (static) step: removes the ~6 us host gap after each of the ~240
+    # launches.  Inputs are staged into fixed device buffers; the dropout seed lives in HBM.
+    self.use_graph = bool(use_graph)
+    self._graphs = None
+    self._static = None
 
   def learning_rate(self):
     tc = self.train_config
@@ -106,24 +112,82 @@ class Trainer(object):
       lr = exponential_decay(lr, self.global_step, d.decay_steps, d.decay_rate, d.staircase)
     return lr
 
-  def train_step(self, examples, **kwargs):
-    """One synchronous step; returns {loss name: 0-d device tensor} (+ 'total_loss',
-    'regularization_loss').  No host synchronisation happens inside."""
+  def _forward_backward(self, examples, **kwargs):
     model, store = self.model, self.model.store
     lo, hi = self.bucket
     store.grads[lo:hi].zero_()
     predictions = model.build_prediction(examples, **kwargs)
     losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
-    reg = model.regularization_loss()
+    losses['regularization_loss'] = model.regularization_loss()
     model.backward()
-    scale = data_parallel.allreduce_bucket(store.grads[lo:hi])
-    lr = self.learning_rate()
+    return predictions, losses
+
+  def _apply_gradients(self, scale, lr):
+    store = self.model.store
     for off, end, m, l2 in self.segments:
       ops.adagrad_step(store.values[off:end], store.grads[off:end], store.accum[off:end], lr, l2,
                        m, scale)
-    model.refresh(only_trainable=True)
+    self.model.refresh(only_trainable=True)
+
+  def train_step(self, examples, **kwargs):
+    """One synchronous step; returns {loss name: 0-d device tensor} (+ 'total_loss',
+    'regularization_loss').  No host synchronisation happens inside."""
+    if self.use_graph and "dropout_mask" not in kwargs:
+      return self._graph_step(examples, **kwargs)
+    store = self.model.store
+    lo, hi = self.bucket
+    predictions, losses = self._forward_backward(examples, **kwargs)
+    scale = data_parallel.allreduce_bucket(store.grads[lo:hi])
+    self._apply_gradients(scale, self.learning_rate())
     self.global_step += 1
-    losses['regularization_loss'] = reg
-    losses['total_loss'] = model._losses.sum()
+    losses['total_loss'] = self.model._losses.sum()
     self.predictions = predictions
     return losses
+
+  # -- hipGraph path ------------------------------------------------------------------
+  def _graph_step(self, examples, dropout_seed=None, **kwargs):
+    from cap2det_amd.core.standard_fields import InputDataFields as F
+    model, store = self.model, self.model.store
+    lo, hi = self.bucket
+    lr = self.learning_rate()
+    labels = model.label_extractor.extract_labels(examples)      # host lookup + small kernel
+    key = (tuple(examples[F.image].shape), tuple(examples[F.proposals].shape), lr)
+    if self._graphs is None or self._graphs["key"] != key:
+      # eager warm-up on this shape (allocates every buffer), then capture
+      st = {F.image: examples[F.image].clone(), F.proposals: examples[F.proposals].clone(),
+            F.num_proposals: examples[F.num_proposals].clone(), "labels": labels.clone(),
+            "seed": torch.zeros(1, dtype=torch.int64, device=self.device)}
+      ex = {F.image: st[F.image], F.proposals: st[F.proposals],
+            F.num_proposals: st[F.num_proposals]}
+      state = (store.values.clone(), store.accum.clone())
+      self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
+      self._apply_gradients(1.0 / self.world_size, lr)
+      torch.cuda.synchronize()
+      store.values.copy_(state[0]); store.accum.copy_(state[1])   # undo the warm-up update
+      self.model.refresh(only_trainable=True)
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+      with torch.cuda.stream(side):
+        with torch.cuda.graph(g_fb, stream=side):
+          predictions, losses = self._forward_backward(ex, labels=st["labels"],
+                                                       dropout_seed=st["seed"])
+        with torch.cuda.graph(g_opt, stream=side):
+          self._apply_gradients(1.0 / self.world_size, lr)
+          total = self.model._losses.sum()
+      torch.cuda.current_stream().wait_stream(side)
+      losses['total_loss'] = total
+      self._graphs = dict(key=key, fb=g_fb, opt=g_opt, predictions=predictions, losses=losses)
+      self._static = st
+    st = self._static
+    st[F.image].copy_(examples[F.image], non_blocking=True)
+    st[F.proposals].copy_(examples[F.proposals], non_blocking=True)
+    st[F.num_proposals].copy_(examples[F.num_proposals], non_blocking=True)
+    st["labels"].copy_(labels, non_blocking=True)
+    st["seed"].fill_(int(dropout_seed) if dropout_seed is not None else self.global_step)
+    self._graphs["fb"].replay()
+    data_parallel.allreduce_bucket(store.grads[lo:hi])
+    self._graphs["opt"].replay()
+    self.global_step += 1
+    self.predictions = self._graphs["predictions"]
+    return self._graphs["losses"]

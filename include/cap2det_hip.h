@@ -147,6 +147,10 @@ int c2d_spatial_mean_dropout_bwd(const float* dy, int lddy, int dyoff, float* dx
 /* Counter-based keep mask: mask[i] = u(seed, i) < keep_prob. */
 int c2d_dropout_mask(uint8_t* mask, long long n, unsigned long long seed, float keep_prob,
                      void* stream);
+/* Same with the seed read from device memory (seed_dev[0]) at execution time, so that a
+ * captured hipGraph of the step draws a fresh mask on every replay. */
+int c2d_dropout_mask_dev(uint8_t* mask, long long n, const long long* seed_dev, float keep_prob,
+                         void* stream);
 
 /* FasterRCNN preprocess (2/255)*x - 1 [third party, models/utils.py:127] fused with a pad of
  * the RGB image to 4 channels: image [pixels][3] -> out [pixels][4]. */
