@@ -119,8 +119,11 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+// Second __launch_bounds__ argument = waves per SIMD the register allocator must leave room
+// for: the 128x128 config sits right at the 168-register step (3 waves/SIMD); losing it cost
+// 25-35 % on the layers with three n-tiles.
 template <int MODE, int WM, int WN, int MT, int NT, int BKT>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_nt_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_nt_kernel(IgemmArgs a) {
   // BKT = floats of K per slab: 32 for the big tiles; 128 for the 64x64 small-problem tile, whose
   // grids (16-126 workgroups) leave one block per CU, so a deeper slab is the only way to keep
   // enough bytes in flight to cover the global-load latency (measured ~1 us per 32-deep slab).
