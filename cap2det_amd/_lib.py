@@ -43,10 +43,11 @@ def header_signatures():
   with open(HEADER_PATH) as f:
     text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
   sigs = {}
-  for m in re.finditer(r"(const char\*|int)\s+(c2d_\w+)\s*\(([^)]*)\)\s*;", text):
+  for m in re.finditer(r"(const char\*|long long|int)\s+(c2d_\w+)\s*\(([^)]*)\)\s*;", text):
     ret, name, params = m.group(1), m.group(2), m.group(3).strip()
     args = [] if params in ("void", "") else [_ctype(p) for p in params.split(",")]
-    sigs[name] = (ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int, args)
+    restype = {"int": ctypes.c_int, "long long": ctypes.c_longlong}.get(ret, ctypes.c_char_p)
+    sigs[name] = (restype, args)
   _SIGS = sigs
   return sigs
 

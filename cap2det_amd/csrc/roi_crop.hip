@@ -245,6 +245,191 @@ __global__ __launch_bounds__(512) void roi_crop_pool_bwd_lds_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Atomic-free, bitwise-reproducible backward ("row owner" form).
+//   1. roi_axes_kernel      : the 2*crop sampling descriptors of every box -> workspace tables.
+//   2. roi_bin_rows_kernel  : for every feature-map row y, the ORDERED list of pooled cells
+//                             (roi, py, px) that can touch row y (a stable compaction, so the
+//                             summation order below is fixed).
+//   3. roi_bwd_rows_kernel  : one workgroup per (row y, 16-channel chunk, image) walks its list;
+//                             its 16 lane groups accumulate into private [wf][16] LDS strips with
+//                             plain read-modify-writes (a strip is touched by one 16-lane group,
+//                             one lane per channel), then the strips are summed in a fixed order
+//                             and the row is written with plain stores.
+// LDS float atomics (the privatised kernel above) retire ~1.4 lane-adds per clock per CU and
+// global float atomics are at the chip-wide atomic rate already; this form has neither.
+// ---------------------------------------------------------------------------------------------
+struct AxisRec { int lo, hi; float lerp; int pad; };
+
+__global__ __launch_bounds__(256) void roi_axes_kernel(const float* __restrict__ boxes,
+                                                       AxisRec* __restrict__ ys,
+                                                       AxisRec* __restrict__ xs, int num_boxes,
+                                                       int hf, int wf, int crop) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_boxes * crop) return;
+  const int roi = i / crop, c = i - roi * crop;
+  const float y1 = boxes[roi * 4 + 0], x1 = boxes[roi * 4 + 1];
+  const float y2 = boxes[roi * 4 + 2], x2 = boxes[roi * 4 + 3];
+  const SampleAxis sy = sample_axis(y1, y2, hf, crop, c);
+  const SampleAxis sx = sample_axis(x1, x2, wf, crop, c);
+  ys[i] = {sy.lo, sy.hi, sy.lerp, 0};
+  xs[i] = {sx.lo, sx.hi, sx.lerp, 0};
+}
+
+constexpr int kBinSegs = 8;   // cell-range segments per row list (parallelism of the binning)
+
+// One list entry = everything about (cell, row y) that does not depend on the channel: the row
+// weight of either vertical sample of the 2x2 pooling window and the column taps of either
+// horizontal sample.  Computed once by the binning kernel instead of 576 times per cell.
+struct RowEntry {
+  int id;            // roi << 8 | py << 4 | px
+  float wy0, wy1;    // weight of row y if the argmax sample is the upper / lower one
+  int x0;            // lo | hi << 16 of the left sample (lo < 0: outside the map)
+  float lx0;
+  int x1;
+  float lx1;
+  int pad;
+};
+
+__device__ __forceinline__ float row_weight(const AxisRec& r, int y) {
+  if (r.lo < 0) return 0.0f;
+  float w = 0.0f;
+  if (r.lo == y) w += 1.0f - r.lerp;   // TF: dtop = (1-ly)*g goes to row lo
+  if (r.hi == y) w += r.lerp;          //     dbottom = ly*g to row hi
+  return w;
+}
+
+// grid (hf, kBinSegs, batch): stable compaction of the cells of one segment whose 2x2 pooling
+// window has a sample on row y (pool_k == 2).
+__global__ __launch_bounds__(256) void roi_bin_rows_kernel(
+    const AxisRec* __restrict__ ys, const AxisRec* __restrict__ xs,
+    const int32_t* __restrict__ box_ind, RowEntry* __restrict__ lists,
+    int32_t* __restrict__ counts, int num_boxes, int hf, int ps, int pout, int crop, int cap) {
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  const int y = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
+  const int p2 = pout * pout;
+  const int total = num_boxes * p2;
+  const int per = ((total + kBinSegs - 1) / kBinSegs + 255) / 256 * 256;
+  const int beg = seg * per, end = min(total, beg + per);
+  RowEntry* list = lists + (((size_t)b * hf + y) * kBinSegs + seg) * cap;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = beg; base < end; base += 256) {
+    const int cell = base + threadIdx.x;
+    bool hit = false;
+    RowEntry e;
+    e.pad = 0;
+    if (cell < end) {
+      const int roi = cell / p2;
+      if (box_ind[roi] == b) {
+        const int c = cell - roi * p2;
+        const int py = c / pout, px = c - py * pout;
+        e.id = (roi << 8) | (py << 4) | px;
+        e.wy0 = row_weight(ys[roi * crop + py * ps], y);
+        e.wy1 = row_weight(ys[roi * crop + py * ps + 1], y);
+        hit = e.wy0 != 0.0f || e.wy1 != 0.0f;
+        if (hit) {
+          const AxisRec a0 = xs[roi * crop + px * ps], a1 = xs[roi * crop + px * ps + 1];
+          e.x0 = a0.lo < 0 ? -1 : (a0.lo | (a0.hi << 16)); e.lx0 = a0.lerp;
+          e.x1 = a1.lo < 0 ? -1 : (a1.lo | (a1.hi << 16)); e.lx1 = a1.lerp;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = running;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[((size_t)b * hf + y) * kBinSegs + seg] = running;
+}
+
+constexpr int kRowParts = 4;  // workgroups sharing one (row, chunk): finer grains -> better balance
+
+// grid (hf, depth/CH, batch*kRowParts), block 256 = (256/CH) lane groups x CH channels.  Part q
+// walks segments [q*kBinSegs/kRowParts, ...) of the row list and writes its partial row into
+// part[q] (plain stores); roi_bwd_sum_parts_kernel then adds the parts in a fixed order.
+template <int CH>
+__global__ __launch_bounds__(256) void roi_bwd_rows_kernel(
+    const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
+    const RowEntry* __restrict__ lists, const int32_t* __restrict__ counts,
+    float* __restrict__ parts, int batch, int hf, int wf, int depth, int pout, int cap) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [NG groups][wf][CH]
+  constexpr int NG = 256 / CH;
+  const int y = blockIdx.x, c0 = blockIdx.y * CH;
+  const int b = blockIdx.z / kRowParts, part = blockIdx.z % kRowParts;
+  const int ch = threadIdx.x % CH, grp = threadIdx.x / CH;
+  for (int i = threadIdx.x; i < NG * wf * CH; i += 256) acc[i] = 0.0f;
+  __syncthreads();
+  const int p2 = pout * pout;
+  float* mine = acc + (size_t)grp * wf * CH + ch;
+  constexpr int U = 4;   // list entries per trip: their loads are issued together
+  constexpr int SEGS = kBinSegs / kRowParts;
+  for (int seg = part * SEGS; seg < (part + 1) * SEGS; ++seg) {   // fixed summation order
+    const size_t lrow = ((size_t)b * hf + y) * kBinSegs + seg;
+    const RowEntry* list = lists + lrow * cap;
+    const int count = counts[lrow];
+    for (int i0 = grp; i0 < count; i0 += NG * U) {
+      RowEntry e[U];
+      float g[U];
+      int k[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + NG * u;
+        const bool in = i < count;
+        e[u] = list[in ? i : (count - 1)];
+        const int roi = e[u].id >> 8, py = (e[u].id >> 4) & 15, px = e[u].id & 15;
+        const size_t o = ((size_t)roi * p2 + py * pout + px) * depth + c0 + ch;
+        g[u] = in ? dout[o] : 0.0f;
+        k[u] = argmax[o];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float wy = (k[u] >> 1) ? e[u].wy1 : e[u].wy0;
+        const int xp = (k[u] & 1) ? e[u].x1 : e[u].x0;
+        const float lx = (k[u] & 1) ? e[u].lx1 : e[u].lx0;
+        const float v = wy * g[u];
+        if (v == 0.0f || xp < 0) continue;
+        mine[(xp & 0xffff) * CH] += (1.0f - lx) * v;
+        mine[(xp >> 16) * CH] += lx * v;
+      }
+    }
+  }
+  __syncthreads();
+  float* drow = parts + ((((size_t)part * batch + b) * hf + y) * wf) * depth + c0;
+  for (int i = threadIdx.x; i < wf * CH; i += 256) {
+    float s = 0.0f;
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) s += acc[(size_t)gq * wf * CH + i];
+    drow[(size_t)(i / CH) * depth + (i % CH)] = s;
+  }
+}
+
+// dfeat += part[0] + part[1] + ... (fixed order), float4 per lane.
+__global__ __launch_bounds__(256) void roi_bwd_sum_parts_kernel(const float4* __restrict__ parts,
+                                                                float4* __restrict__ dfeat,
+                                                                long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 s = parts[i];
+#pragma unroll
+    for (int q = 1; q < kRowParts; ++q) {
+      const float4 v = parts[(size_t)q * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4 d = dfeat[i];
+    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+    dfeat[i] = d;
+  }
+}
+
 }  // namespace
 
 extern "C" int c2d_crop_and_resize_fwd(const float* feat, const float* boxes,
@@ -314,5 +499,66 @@ extern "C" int c2d_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax,
   hipLaunchKernelGGL(roi_crop_pool_bwd_kernel, dim3(num_boxes), dim3(256), 0,
                      (hipStream_t)stream, dout, argmax, boxes, box_ind, dfeat, batch, hf, wf,
                      depth, crop, pool_k, pool_s, pout);
+  return c2d_launch_status();
+}
+
+extern "C" long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, int wf, int depth,
+                                                           int num_boxes, int crop, int pool_k,
+                                                           int pool_s) {
+  if (batch <= 0 || hf <= 0 || wf <= 0 || depth <= 0 || num_boxes < 0 || crop <= 0 ||
+      pool_k <= 0 || pool_s <= 0)
+    return -1;
+  const long long pout = (crop - pool_k) / pool_s + 1;
+  const long long cells = (long long)num_boxes * pout * pout;
+  const long long seg_cap = ((cells + kBinSegs - 1) / kBinSegs + 255) / 256 * 256;
+  return 2ll * num_boxes * crop * (long long)sizeof(AxisRec) + 256 +
+         (long long)batch * hf * kBinSegs * 4 + 256 +
+         (long long)batch * hf * kBinSegs * seg_cap * (long long)sizeof(RowEntry) + 256 +
+         (long long)kRowParts * batch * hf * wf * depth * 4;
+}
+
+extern "C" int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax,
+                                        const float* boxes, const int32_t* box_ind, float* dfeat,
+                                        int batch, int hf, int wf, int depth, int num_boxes,
+                                        int crop, int pool_k, int pool_s, void* workspace,
+                                        long long workspace_bytes, void* stream) {
+  C2D_CHECK_ARG(dout && argmax && boxes && box_ind && dfeat && workspace);
+  C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 16 == 0);
+  C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0 && pool_s > 0);
+  if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) || wf > 64)
+    return C2D_ERR_UNSUPPORTED;
+  if (num_boxes == 0) return C2D_OK;
+  if (workspace_bytes <
+      c2d_roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes, crop, pool_k,
+                                            pool_s))
+    return C2D_ERR_WORKSPACE;
+  const int pout = (crop - pool_k) / pool_s + 1;
+  const int cap = ((num_boxes * pout * pout + kBinSegs - 1) / kBinSegs + 255) / 256 * 256;
+  char* w = (char*)workspace;
+  AxisRec* ys = (AxisRec*)w;
+  AxisRec* xs = ys + (size_t)num_boxes * crop;
+  size_t off = ((2 * (size_t)num_boxes * crop * sizeof(AxisRec)) + 255) / 256 * 256;
+  int32_t* counts = (int32_t*)(w + off);
+  off = (off + (size_t)batch * hf * kBinSegs * 4 + 255) / 256 * 256;
+  RowEntry* lists = (RowEntry*)(w + off);
+  off = (off + (size_t)batch * hf * kBinSegs * cap * sizeof(RowEntry) + 255) / 256 * 256;
+  float* parts = (float*)(w + off);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(roi_axes_kernel, dim3(c2d_ceil_div((long long)num_boxes * crop, 256)),
+                     dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
+  hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
+                     box_ind, lists, counts, num_boxes, hf, pool_s, pout, crop, cap);
+  const int chsel = 16;   // measured: 16-channel chunks 447 us, 32: 492, 64: ~1000 (N=2000, 32x32x576)
+#define C2D_ROWS(CHV)                                                                          \
+  hipLaunchKernelGGL((roi_bwd_rows_kernel<CHV>), dim3(hf, depth / CHV, batch * kRowParts),        \
+                     dim3(256), (size_t)256 * wf * sizeof(float), st, dout, argmax, lists, counts, \
+                     parts, batch, hf, wf, depth, pout, cap)
+  if (depth % 64 == 0 && chsel == 64) { C2D_ROWS(64); }
+  else if (depth % 32 == 0 && chsel == 32) { C2D_ROWS(32); }
+  else { C2D_ROWS(16); }
+#undef C2D_ROWS
+  const long long n4 = (long long)batch * hf * wf * depth / 4;
+  hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, st,
+                     (const float4*)parts, (float4*)dfeat, n4);
   return c2d_launch_status();
 }

@@ -58,6 +58,20 @@ def roi_crop_pool_bwd(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool_s)
   return dfeat
 
 
+def roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes, crop, pool_k, pool_s):
+  return int(_lib.load().c2d_roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes,
+                                                               crop, pool_k, pool_s))
+
+
+def roi_crop_pool_bwd_ws(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool_s, workspace):
+  """Atomic-free, bitwise-reproducible ROI-crop backward (workspace: uint8 device tensor)."""
+  b, hf, wf, d = dfeat.shape
+  _lib.call("c2d_roi_crop_pool_bwd_ws", _p(dout), _p(argmax), _p(boxes), _p(box_ind), _p(dfeat), b,
+            hf, wf, d, boxes.shape[0], crop, pool_k, pool_s, _p(workspace), workspace.numel(),
+            _stream())
+  return dfeat
+
+
 # -- convolution ------------------------------------------------------------------------
 
 def conv_fwd(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride,

@@ -605,8 +605,18 @@ class FrcnnEngine(object):
       gfeat = self.first.out_grad(plan1, self.first_trainable_idx)
       gfeat.t.zero_()
       d = self.first.cout
-      ops.roi_crop_pool_bwd(dpooled.t.view(b * n, bufs["p"], bufs["p"], d),
-                            bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], d), ctx["boxes"],
-                            bufs["box_ind"], gfeat.t.view(b, bufs["fh"], bufs["fw"], d), self.crop,
-                            self.pool_k, self.pool_s)
+      dp4 = dpooled.t.view(b * n, bufs["p"], bufs["p"], d)
+      arg4 = bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], d)
+      gf4 = gfeat.t.view(b, bufs["fh"], bufs["fw"], d)
+      if self.pool_k == 2 and bufs["p"] <= 16 and bufs["fw"] <= 64 and d % 16 == 0:
+        # atomic-free, bitwise reproducible row-owner form (needs a workspace)
+        if "crop_ws" not in bufs:
+          nbytes = ops.roi_crop_pool_bwd_workspace_bytes(b, bufs["fh"], bufs["fw"], d, b * n,
+                                                         self.crop, self.pool_k, self.pool_s)
+          bufs["crop_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        ops.roi_crop_pool_bwd_ws(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
+                                 self.pool_k, self.pool_s, bufs["crop_ws"])
+      else:
+        ops.roi_crop_pool_bwd(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
+                              self.pool_k, self.pool_s)
       self.first.backward(plan1, bufs["stem"], self.first_trainable_idx, None)

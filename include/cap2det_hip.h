@@ -224,6 +224,18 @@ int c2d_adagrad_step(float* w, const float* g, float* acc, long long n, float lr
 /* *out += 0.5*weight*sum(w^2)  (slim l2_regularizer). */
 int c2d_l2_loss(const float* w, long long n, float weight, float* out, void* stream);
 
+/* Atomic-free, bitwise-reproducible form of c2d_roi_crop_pool_bwd (same semantics: adds into
+ * dfeat).  Needs a caller-owned device workspace of at least
+ * c2d_roi_crop_pool_bwd_workspace_bytes(...) bytes (sampling tables + per-row cell lists);
+ * returns C2D_ERR_WORKSPACE if it is too small, C2D_ERR_UNSUPPORTED unless pool_k == 2, the
+ * pooled map is at most 16x16 and wf <= 64 (use c2d_roi_crop_pool_bwd then). */
+long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, int wf, int depth,
+                                                int num_boxes, int crop, int pool_k, int pool_s);
+int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax, const float* boxes,
+                             const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
+                             int depth, int num_boxes, int crop, int pool_k, int pool_s,
+                             void* workspace, long long workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

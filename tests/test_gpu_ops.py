@@ -70,6 +70,32 @@ def test_roi_crop_pool_fwd_bwd_matches_oracle(ops):
   np.testing.assert_allclose(_n(dfeat), want_df, rtol=1e-4, atol=1e-4)
 
 
+def test_roi_crop_pool_bwd_workspace_form_is_exact_and_deterministic(ops):
+  rng = np.random.default_rng(8)
+  hf, wf, d, n = 13, 9, 32, 70
+  feat = np.maximum(rng.standard_normal((2, hf, wf, d)), 0).astype(np.float32)
+  boxes = _edge_boxes(rng, n)
+  ind = rng.integers(0, 2, n).astype(np.int32)
+  crop = ref_ops.crop_and_resize(feat, boxes, ind, 14)
+  pooled, arg = ref_ops.max_pool(crop, 2, 2, "VALID")
+  dout = rng.standard_normal(pooled.shape).astype(np.float32)
+  dcrop = ref_ops.max_pool_backward(crop.shape, arg, dout, 2, 2, "VALID")
+  want = ref_ops.crop_and_resize_grad_image(dcrop.astype(np.float64), boxes, ind, feat.shape)
+  ws = torch.empty(ops.roi_crop_pool_bwd_workspace_bytes(2, hf, wf, d, n, 14, 2, 2), dtype=torch.uint8,
+                   device=DEV)
+  outs = []
+  for _ in range(2):
+    dfeat = torch.full(feat.shape, 0.25, device=DEV)       # adds into the existing gradient
+    ops.roi_crop_pool_bwd_ws(_t(dout), _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2, ws)
+    outs.append(_n(dfeat))
+  np.testing.assert_allclose(outs[0] - 0.25, want, rtol=1e-4, atol=1e-5)
+  np.testing.assert_array_equal(outs[0], outs[1])          # no atomics: bitwise reproducible
+  small = torch.empty(16, dtype=torch.uint8, device=DEV)
+  from cap2det_amd._lib import Cap2DetHipError
+  with pytest.raises(Cap2DetHipError):
+    ops.roi_crop_pool_bwd_ws(_t(dout), _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2, small)
+
+
 CONV_CASES = [
     # n, ih, iw, cin, cout, k, stride
     (3, 7, 7, 32, 64, 1, 1),

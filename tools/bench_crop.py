@@ -16,5 +16,12 @@ def t(fn,it=20):
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b)/it
 tf=t(lambda: ops.roi_crop_pool_fwd(feat,boxes,ind,14,2,2,out=out,argmax=arg))
 tb=t(lambda: ops.roi_crop_pool_bwd(dout,arg,boxes,ind,dfeat,14,2,2))
+ws=torch.empty(ops.roi_crop_pool_bwd_workspace_bytes(1,hf,wf,D,N,14,2,2),dtype=torch.uint8,device=dev)
+d1=torch.zeros_like(feat); ops.roi_crop_pool_bwd(dout,arg,boxes,ind,d1,14,2,2)
+d2=torch.zeros_like(feat); ops.roi_crop_pool_bwd_ws(dout,arg,boxes,ind,d2,14,2,2,ws)
+d3=torch.zeros_like(feat); ops.roi_crop_pool_bwd_ws(dout,arg,boxes,ind,d3,14,2,2,ws)
+print("ws vs atomic maxdiff %.3e (scale %.3e); ws deterministic: %s" % ((d1-d2).abs().max().item(), d1.abs().max().item(), bool((d2==d3).all())))
+tw=t(lambda: ops.roi_crop_pool_bwd_ws(dout,arg,boxes,ind,dfeat,14,2,2,ws))
+print("bwd_ws %.1f us" % (tw*1e3))
 byts=4.0*(N*49*D+feat.numel()+boxes.numel())
 print("fwd %.1f us %.0f GB/s | bwd %.1f us" % (tf*1e3, byts/tf/1e6, tb*1e3))
