@@ -123,7 +123,7 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
 // for: the 128x128 config sits right at the 168-register step (3 waves/SIMD); losing it cost
 // 25-35 % on the layers with three n-tiles.
 template <int MODE, int WM, int WN, int MT, int NT, int BKT>
-__global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_nt_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3)) void igemm_nt_kernel(IgemmArgs a) {
   // BKT = floats of K per slab: 32 for the big tiles; 128 for the 64x64 small-problem tile, whose
   // grids (16-126 workgroups) leave one block per CU, so a deeper slab is the only way to keep
   // enough bytes in flight to cover the global-load latency (measured ~1 us per 32-deep slab).
@@ -672,11 +672,11 @@ int run_igemm(const IgemmArgs& a, hipStream_t s) {
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
   if (big_blocks < 256) {
     launch_igemm<2, 2, 1, 1, 32>(a, s);          // small problems (first stage): 64x64 tiles
-  } else if (a.N % 128 != 0 && a.N % 128 <= 64 && a.M >= 65536) {
-    // last 128-wide n-tile at most half full and plenty of rows: 256x64 tiles with the 4 waves
-    // stacked along M, so a partial n-tile shortens every wave equally (measured: 576->192
-    // at 98k rows 272 -> 250 us; loses at 32k rows where 256-row tiles leave CUs idle).
-    launch_igemm<4, 1, 2, 2, 32>(a, s);
+  } else if (a.N % 128 != 0 && a.N % 128 <= 64) {
+    // N = 192, 320, 576, 160 ...: 128x64 tiles (waves 2x2, each 64x32) waste at most half a
+    // 64-wide tile instead of half a 128-wide one, and the smaller accumulator file leaves room
+    // for a fourth wave per SIMD (576->192 at 98k rows: 252 -> 221 us; 192<-256 dgrad 934 -> 786).
+    launch_igemm<2, 2, 2, 1, 32>(a, s);
   } else {
     launch_igemm<2, 2, 2, 2, 32>(a, s);          // 128x128, waves 2x2
   }

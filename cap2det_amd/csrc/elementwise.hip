@@ -161,7 +161,28 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
                        ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f);
     }
     if (active) {
-      for (int r = r0 + ty; r < r1; r += TY) {
+      // 4 rows per trip: 8 independent 16-B loads in flight per lane
+      int r = r0 + ty;
+      for (; r + 3 * TY < r1; r += 4 * TY) {
+        float4 g[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          g[u] = *reinterpret_cast<const float4*>(dy + (size_t)(r + u * TY) * lddy + dyoff + c);
+          v[u] = *reinterpret_cast<const float4*>(y + (size_t)(r + u * TY) * ldy + yoff + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float4 dz;
+          dz.x = v[u].x > 0.f ? g[u].x : 0.f; dz.y = v[u].y > 0.f ? g[u].y : 0.f;
+          dz.z = v[u].z > 0.f ? g[u].z : 0.f; dz.w = v[u].w > 0.f ? g[u].w : 0.f;
+          sb.x += dz.x; sb.y += dz.y; sb.z += dz.z; sb.w += dz.w;
+          sg.x += dz.x * (v[u].x - be.x) * ig.x; sg.y += dz.y * (v[u].y - be.y) * ig.y;
+          sg.z += dz.z * (v[u].z - be.z) * ig.z; sg.w += dz.w * (v[u].w - be.w) * ig.w;
+          *reinterpret_cast<float4*>(dc + (size_t)(r + u * TY) * c4n * 4 + c) =
+              make_float4(dz.x * sc.x, dz.y * sc.y, dz.z * sc.z, dz.w * sc.w);
+        }
+      }
+      for (; r < r1; r += TY) {
         const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + dyoff + c);
         const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * ldy + yoff + c);
         float4 dz;
