@@ -341,6 +341,113 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3))
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-problem kernel (first stage: one image, 32x32 .. 125x125 maps => 1k-16k rows).
+// A 64x64-tile launch gives only 16-126 workgroups and every wave owns one 32x32 tile for the
+// whole K loop: K*taps/2 dependent MFMAs (15 us for a 3x3x128 conv) whatever the chip size.
+// Here a block owns ONE 32x32 output tile and its 4 waves split the K loop 4 ways; each lane
+// loads its MFMA operands straight from global memory (lane (i,h) needs A[i][16h..16h+15] = four
+// 16-B loads of its own row: no LDS, no barrier in the loop), the next slab is prefetched into a
+// second register set, and the 4 partial tiles are summed through LDS before the epilogue.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void igemm_small_kernel(IgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / a.n_tiles) * 32, n0 = (tile % a.n_tiles) * 32;
+  const RowPos pos = decompose(m0 + li, a.M, a.g);
+  const int ncol = min(n0 + li, a.N - 1);
+  const int kslabs = (a.K + 31) / 32;
+  const int total = a.g.nky * a.g.nkx * kslabs;
+  const int sbeg = (int)((long long)total * wave / 4), send = (int)((long long)total * (wave + 1) / 4);
+  const size_t tap_stride = (size_t)a.N * a.K;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  f32x4 fa[2][4], fb[2][4];
+  unsigned okm[2] = {0u, 0u};
+  // slab index -> (tap, kc)
+#define C2D_SM_LOAD(SLAB, SET)                                                                 \
+  {                                                                                            \
+    const int tp = (SLAB) / kslabs;                                                            \
+    const int kc = ((SLAB) - tp * kslabs) * 32 + lh * 16;                                      \
+    const int ty_ = tp / a.g.nkx, tx_ = tp - ty_ * a.g.nkx;                                    \
+    const int ky = a.g.ky0 + ty_ * a.g.kstep, kx = a.g.kx0 + tx_ * a.g.kstep;                  \
+    const int sr = src_row<MODE>(a.g, pos, ky, kx);                                            \
+    const float* ap = a.A + (size_t)max(sr, 0) * a.lda + a.a_off;                              \
+    const float* bp = a.Bt + (size_t)(ky * a.g.kw + kx) * tap_stride + (size_t)ncol * a.K;     \
+    okm[SET] = 0;                                                                              \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                            \
+      const int k = kc + 4 * v;                                                                \
+      const int kk = min(k, a.K - 4);                                                          \
+      okm[SET] |= ((sr >= 0 && k < a.K) ? 1u : 0u) << v;                                       \
+      fa[SET][v] = *reinterpret_cast<const f32x4*>(ap + kk);                                   \
+      fb[SET][v] = *reinterpret_cast<const f32x4*>(bp + kk);                                   \
+    }                                                                                          \
+  }
+#define C2D_SM_MMA(SET)                                                                        \
+  {                                                                                            \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                            \
+      const f32x4 av = mask4(fa[SET][v], (okm[SET] >> v) & 1u);                                \
+      const f32x4 bv = fb[SET][v];                                                             \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);                    \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);                    \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);                    \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);                    \
+    }                                                                                          \
+  }
+
+  if (sbeg < send) C2D_SM_LOAD(sbeg, 0);
+  for (int sl = sbeg; sl < send; sl += 2) {
+    if (sl + 1 < send) C2D_SM_LOAD(sl + 1, 1);
+    C2D_SM_MMA(0);
+    if (sl + 1 < send) {
+      if (sl + 2 < send) C2D_SM_LOAD(sl + 2, 0);
+      C2D_SM_MMA(1);
+    }
+  }
+#undef C2D_SM_LOAD
+#undef C2D_SM_MMA
+
+  // sum the 4 partial tiles; C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    red[wave * (32 * 33) + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+  __syncthreads();
+  // 256 threads: row = tid/8, 4 consecutive columns at (tid%8)*4
+  const int er = tid >> 3, ec = (tid & 7) * 4;
+  const int m = m0 + er, n = n0 + ec;
+  if (m < a.M && n < a.N) {
+    f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int o = er * 33 + ec + c;
+      v[c] = red[o] + red[32 * 33 + o] + red[2 * 32 * 33 + o] + red[3 * 32 * 33 + o];
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+    if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+    v = v * sc + sh;
+    if (a.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    int drow = m;
+    if (MODE == 1 && a.g.sub > 1) {
+      const RowPos p = decompose(m, a.M, a.g);
+      drow = (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw + p.x * a.g.sub + a.g.x0;
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + n);
+    if (a.accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
 struct WgradArgs {
   const float* A; int lda; int a_off;   // activations x (rows of the conv input)
   const float* G; int ldg; int g_off;   // dC rows (conv output rows)
@@ -670,8 +777,16 @@ int run_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return C2D_OK;
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
-  if (big_blocks < 256) {
-    launch_igemm<2, 2, 1, 1, 32>(a, s);          // small problems (first stage): 64x64 tiles
+  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384) {
+    // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
+    IgemmArgs b = a;
+    b.m_tiles = c2d_ceil_div(a.M, 32);
+    b.n_tiles = c2d_ceil_div(a.N, 32);
+    const dim3 grid(b.m_tiles * b.n_tiles), block(256);
+    if (a.g.mode == 0) hipLaunchKernelGGL(igemm_small_kernel<0>, grid, block, 0, s, b);
+    else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, block, 0, s, b);
+  } else if (big_blocks < 256) {
+    launch_igemm<2, 2, 1, 1, 32>(a, s);          // 64x64 tiles
   } else if (a.N % 128 != 0 && a.N % 128 <= 64) {
     // N = 192, 320, 576, 160 ...: 128x64 tiles (waves 2x2, each 64x32) waste at most half a
     // 64-wide tile instead of half a 128-wide one, and the smaller accumulator file leaves room

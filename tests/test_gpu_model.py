@@ -88,7 +88,12 @@ def test_train_step_matches_oracle(dm, hw, n, nums):
   state = model.state_dict()
   for name in P:
     if name in want["applied"]:
-      _close(state[name], P[name], 5e-5, "updated " + name)
+      # Adagrad step w -= lr*g/sqrt(acc), acc >= 0.1: a gradient error dg (<= 5e-4 of the
+      # gradient scale, checked above) moves the update by at most lr*dg/sqrt(0.1).
+      gscale = np.abs(want["applied"][name]).max()
+      bound = 0.01 / np.sqrt(0.1) * (5e-4 * gscale + 3e-7) + 1e-6 * np.abs(P[name]).max()
+      err = np.abs(state[name].astype(np.float64) - P[name]).max()
+      assert err <= bound, "updated %s: err %.3e > bound %.3e" % (name, err, bound)
     else:
       np.testing.assert_array_equal(state[name], P32[name], err_msg="frozen " + name)
   assert "first_stage_feature_extraction/InceptionV2/Mixed_4e/Branch_0/Conv2d_0a_1x1/weights" \
