@@ -398,6 +398,61 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
   shift[i] = beta[i] - mean[i] * s;
 }
 
+// Batched "refresh" of the per-layer kernel operands after an optimiser step: one launch
+// transposes the weights of every trainable layer, one folds every BatchNorm (instead of two
+// 4-us launches per layer).  Descriptors live in device memory (built once by the caller):
+//   transpose: {src_off, dst_off, taps, rows, cols, tile_begin} in floats / 32x32 tiles
+//   bn_fold  : {gamma_off (or -1), beta_off, mean_off, var_off, scale_off, shift_off, c, begin}
+struct TransDesc { long long src_off, dst_off; int taps, rows, cols, tile_begin; };
+struct FoldDesc { long long gamma, beta, mean, var, scale, shift; int c, begin; };
+
+__global__ __launch_bounds__(256) void transpose_taps_batched_kernel(
+    const TransDesc* __restrict__ desc, int num, const float* __restrict__ src_base,
+    float* __restrict__ dst_base) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = num - 1;          // last descriptor with tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TransDesc d = desc[lo];
+  int t = blockIdx.x - d.tile_begin;
+  const int tj = (d.cols + 31) / 32, ti = (d.rows + 31) / 32;
+  const int tap = t / (ti * tj);
+  t -= tap * ti * tj;
+  const int i0 = (t / tj) * 32, j0 = (t % tj) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = src_base + d.src_off + (size_t)tap * d.rows * d.cols;
+  float* dst = dst_base + d.dst_off + (size_t)tap * d.rows * d.cols;
+  for (int k = ty; k < 32; k += 8) {
+    const int i = i0 + k, j = j0 + tx;
+    tile[k][tx] = (i < d.rows && j < d.cols) ? src[(size_t)i * d.cols + j] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int j = j0 + k, i = i0 + tx;
+    if (i < d.rows && j < d.cols) dst[(size_t)j * d.rows + i] = tile[tx][k];
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_fold_batched_kernel(
+    const FoldDesc* __restrict__ desc, int num, int total, const float* __restrict__ vars,
+    const float* __restrict__ stats, float eps, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = num - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].begin <= i) lo = mid; else hi = mid - 1;
+  }
+  const FoldDesc d = desc[lo];
+  const int c = i - d.begin;
+  const float g = d.gamma >= 0 ? vars[d.gamma + c] : 1.0f;
+  const float s = g / sqrtf(stats[d.var + c] + eps);
+  out[d.scale + c] = s;
+  out[d.shift + c] = vars[d.beta + c] - stats[d.mean + c] * s;
+}
+
 inline int grid_for(long long total) {
   long long b = (total + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -564,5 +619,24 @@ extern "C" int c2d_bn_fold(const float* gamma, const float* beta, const float* m
   C2D_CHECK_ARG(beta && mean && var && scale && shift && c > 0);
   hipLaunchKernelGGL(bn_fold_kernel, dim3(c2d_ceil_div(c, 256)), dim3(256), 0,
                      (hipStream_t)stream, gamma, beta, mean, var, eps, scale, shift, c);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_transpose_taps_batched(const void* desc, int num, int total_tiles,
+                                          const float* src_base, float* dst_base,
+                                          void* stream) {
+  C2D_CHECK_ARG(desc && src_base && dst_base && num > 0 && total_tiles > 0);
+  hipLaunchKernelGGL(transpose_taps_batched_kernel, dim3(total_tiles), dim3(256), 0,
+                     (hipStream_t)stream, (const TransDesc*)desc, num, src_base, dst_base);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_bn_fold_batched(const void* desc, int num, int total_channels,
+                                   const float* vars, const float* stats, float eps, float* out,
+                                   void* stream) {
+  C2D_CHECK_ARG(desc && vars && stats && out && num > 0 && total_channels > 0);
+  hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(c2d_ceil_div(total_channels, 256)), dim3(256),
+                     0, (hipStream_t)stream, (const FoldDesc*)desc, num, total_channels, vars,
+                     stats, eps, out);
   return c2d_launch_status();
 }

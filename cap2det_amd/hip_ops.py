@@ -105,6 +105,16 @@ def transpose_taps(w, wt, taps, rows, cols):
   _lib.call("c2d_transpose_taps", _p(w), _p(wt), taps, rows, cols, _stream())
 
 
+def transpose_taps_batched(desc, num, total_tiles, src_base, dst_base):
+  _lib.call("c2d_transpose_taps_batched", _p(desc), num, total_tiles, _p(src_base), _p(dst_base),
+            _stream())
+
+
+def bn_fold_batched(desc, num, total_channels, vars_base, stats_base, eps, out_base):
+  _lib.call("c2d_bn_fold_batched", _p(desc), num, total_channels, _p(vars_base), _p(stats_base),
+            float(eps), _p(out_base), _stream())
+
+
 def bn_fold(gamma, beta, mean, var, eps, scale, shift):
   _lib.call("c2d_bn_fold", _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(scale),
             _p(shift), beta.numel(), _stream())

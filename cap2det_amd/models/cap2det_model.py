@@ -57,7 +57,8 @@ class Model(ModelBase):
     self.store.declare(HEADS_W, (d, self._npad))
     self.store.declare(HEADS_B, (self._npad,))
     self.store.finalize()
-    self._heads_wt = torch.empty(1, self._npad, d, device=self._device)
+    self.engine.finalize(extra_transposes=[(HEADS_W, "heads/wt", 1, d, self._npad)])
+    self._heads_wt = self.engine.stats.derived["heads/wt"]
     self._l2_weight = 0.0
     reg = options.fc_hyperparams.regularizer
     if reg.WhichOneof('regularizer_oneof') == 'l2_regularizer':
@@ -184,9 +185,7 @@ class Model(ModelBase):
 
   def refresh(self, only_trainable=False):
     """Re-derives kernel operands (transposed weights, folded BN) from the variables."""
-    self.engine.refresh(only_trainable)
-    ops.transpose_taps(self.store.var[HEADS_W], self._heads_wt, 1, self.engine.feature_dims,
-                       self._npad)
+    self.engine.refresh(only_trainable)     # (the fused heads operand rides in the same launch)
 
   def set_trainable(self, trainable_names):
     self.engine.set_trainable(set(trainable_names))

@@ -131,6 +131,54 @@ class VariableStore(object):
     return lo, hi
 
 
+class DerivedStore(object):
+  """Flat buffers for (a) BatchNorm moving statistics and (b) operands derived from the
+  variables; dict-like over the statistics so existing `stats[name]` call sites keep working."""
+
+  def __init__(self, device):
+    self.device = device
+    self._stat_specs, self._der_specs = [], []
+    self._stat_size = self._der_size = 0
+    self.stat_flat = self.der_flat = None
+    self._stats, self.derived = {}, {}
+    self.stat_off, self.der_off = {}, {}
+
+  def declare(self, name, shape, fill):
+    n = int(math.prod(shape))
+    self._stat_specs.append((name, tuple(shape), self._stat_size, n, fill))
+    self._stat_size += -(-n // 4) * 4
+
+  def declare_derived(self, name, shape):
+    n = int(math.prod(shape))
+    self._der_specs.append((name, tuple(shape), self._der_size, n))
+    self._der_size += -(-n // 4) * 4
+
+  def finalize(self):
+    self.stat_flat = torch.zeros(max(self._stat_size, 4), device=self.device)
+    self.der_flat = torch.zeros(max(self._der_size, 4), device=self.device)
+    for name, shape, off, n, fill in self._stat_specs:
+      v = self.stat_flat[off:off + n].view(shape)
+      v.fill_(fill)
+      self._stats[name] = v
+      self.stat_off[name] = off
+    for name, shape, off, n in self._der_specs:
+      self.derived[name] = self.der_flat[off:off + n].view(shape)
+      self.der_off[name] = off
+
+  # dict protocol over the moving statistics
+  def __getitem__(self, k):
+    return self._stats[k]
+
+  def __contains__(self, k):
+    return k in self._stats
+
+  def __iter__(self):
+    return iter(self._stats)
+
+  def keys(self):
+    return self._stats.keys()
+
+
 class ConvBN(object):
   """conv (SAME, no bias) + inference BatchNorm + ReLU; owns its variables and folded forms."""
 
@@ -142,12 +190,27 @@ class ConvBN(object):
     if bn_scale:
       store.declare(name + "/BatchNorm/gamma", (cout,))
     store.declare(name + "/BatchNorm/beta", (cout,))
-    stats[name + "/BatchNorm/moving_mean"] = torch.zeros(cout, device=store.device)
-    stats[name + "/BatchNorm/moving_variance"] = torch.ones(cout, device=store.device)
-    self.wt = torch.empty(k * k, cout, cin, device=store.device)
-    self.scale = torch.empty(cout, device=store.device)
-    self.shift = torch.empty(cout, device=store.device)
+    # moving statistics and the derived kernel operands (per-tap transposed weights, folded
+    # BN affine) are views into flat buffers owned by the engine (see DerivedStore), so that
+    # ONE batched launch can refresh all layers.
+    stats.declare(name + "/BatchNorm/moving_mean", (cout,), 0.0)
+    stats.declare(name + "/BatchNorm/moving_variance", (cout,), 1.0)
+    stats.declare_derived(name + "/wt", (k * k, cout, cin))
+    stats.declare_derived(name + "/scale", (cout,))
+    stats.declare_derived(name + "/shift", (cout,))
     self.trainable = False
+
+  @property
+  def wt(self):
+    return self.stats.derived[self.name + "/wt"]
+
+  @property
+  def scale(self):
+    return self.stats.derived[self.name + "/scale"]
+
+  @property
+  def shift(self):
+    return self.stats.derived[self.name + "/shift"]
 
   def var_names(self):
     n = [self.name + "/weights", self.name + "/BatchNorm/beta"]
@@ -459,7 +522,7 @@ class FrcnnEngine(object):
     if options.dropout_on_feature_map:
       # true only by proto default; every shipped config sets it false (configs/*.pbtxt:55)
       raise NotImplementedError("dropout_on_feature_map is not supported on the HIP path")
-    self.stats = {}
+    self.stats = DerivedStore(self.device)
     dm = depth_multiplier
     self.stem_cout = max(int(64 * dm), 16)
     self.stem_mult = min(int(self.stem_cout / 3), 8)
@@ -488,11 +551,67 @@ class FrcnnEngine(object):
     self.first_trainable_idx = None
 
   # -- variables --------------------------------------------------------------------
+  def finalize(self, extra_transposes=()):
+    """Call after VariableStore.finalize(): allocates the flat statistics / derived buffers and
+    prepares the batched-refresh descriptor tables.  extra_transposes: (var_name, derived_name,
+    taps, rows, cols) operands that the owner wants refreshed in the same launch."""
+    for _, dname, taps, rows, cols in extra_transposes:
+      self.stats.declare_derived(dname, (taps, cols, rows))
+    self.stats.finalize()
+    self._extra_transposes = list(extra_transposes)
+    self._tables = {}
+
+  def _layers(self, only_trainable):
+    out = []
+    for net in (self.first, self.second):
+      for L in net.layers.values():
+        if L.trainable or not only_trainable:
+          out.append(L)
+    return out
+
+  def _build_tables(self, only_trainable):
+    import numpy as np
+    layers = self._layers(only_trainable)
+    tdt = np.dtype([("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("rows", "<i4"),
+                    ("cols", "<i4"), ("begin", "<i4")])
+    fdt = np.dtype([("gamma", "<i8"), ("beta", "<i8"), ("mean", "<i8"), ("var", "<i8"),
+                    ("scale", "<i8"), ("shift", "<i8"), ("c", "<i4"), ("begin", "<i4")])
+    trans, folds, tiles, chans = [], [], 0, 0
+    voff, soff, doff = self.store.offset, self.stats.stat_off, self.stats.der_off
+    items = [(voff[L.name + "/weights"][0], doff[L.name + "/wt"], L.k * L.k, L.cin, L.cout)
+             for L in layers]
+    items += [(voff[v][0], doff[dn], taps, rows, cols)
+              for v, dn, taps, rows, cols in self._extra_transposes]
+    for src, dst, taps, rows, cols in items:
+      trans.append((src, dst, taps, rows, cols, tiles))
+      tiles += taps * (-(-rows // 32)) * (-(-cols // 32))
+    for L in layers:
+      g = voff[L.name + "/BatchNorm/gamma"][0] if L.bn_scale else -1
+      folds.append((g, voff[L.name + "/BatchNorm/beta"][0],
+                    soff[L.name + "/BatchNorm/moving_mean"],
+                    soff[L.name + "/BatchNorm/moving_variance"], doff[L.name + "/scale"],
+                    doff[L.name + "/shift"], L.cout, chans))
+      chans += L.cout
+    def dev(arr):
+      return torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+    return dict(trans=dev(np.array(trans, dtype=tdt)), ntrans=len(trans), tiles=tiles,
+                folds=dev(np.array(folds, dtype=fdt)) if folds else None, nfolds=len(folds),
+                chans=chans)
+
   def refresh(self, only_trainable=False):
+    """Re-derives every (trainable) layer's kernel operands with two batched launches."""
     if not only_trainable:
       self._refresh_stem()
-    self.first.refresh(only_trainable)
-    self.second.refresh(only_trainable)
+    key = (bool(only_trainable), tuple(L.name for L in self._layers(only_trainable)))
+    if self._tables.get("key") != key:
+      self._tables = dict(key=key, t=self._build_tables(only_trainable))
+    t = self._tables["t"]
+    if t["ntrans"]:
+      ops.transpose_taps_batched(t["trans"], t["ntrans"], t["tiles"], self.store.values,
+                                 self.stats.der_flat)
+    if t["nfolds"]:
+      ops.bn_fold_batched(t["folds"], t["nfolds"], t["chans"], self.store.values,
+                          self.stats.stat_flat, BN_EPS, self.stats.der_flat)
 
   def _refresh_stem(self):
     """Folds depthwise(7x7, x8) o pointwise(1x1) into one 7x7 kernel over the 4-channel padded

@@ -112,6 +112,17 @@ int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, 
 /* wt[t][j][i] = w[t][i][j] for t < taps (HWIO <-> per-tap transposed weights). */
 int c2d_transpose_taps(const float* w, float* wt, int taps, int rows, int cols, void* stream);
 
+/* Batched forms for the per-step refresh of every trainable layer in ONE launch each.  `desc`
+ * is a DEVICE array of `num` records sorted by their begin field:
+ *   transpose: struct { int64 src_off, dst_off; int32 taps, rows, cols, tile_begin; } — offsets
+ *              in floats from src_base / dst_base, tile_begin = running count of 32x32 tiles;
+ *   bn_fold  : struct { int64 gamma (or -1), beta, mean, var, scale, shift; int32 c, begin; } —
+ *              gamma/beta index `vars`, mean/var index `stats`, scale/shift index `out`. */
+int c2d_transpose_taps_batched(const void* desc, int num, int total_tiles, const float* src_base,
+                               float* dst_base, void* stream);
+int c2d_bn_fold_batched(const void* desc, int num, int total_channels, const float* vars,
+                        const float* stats, float eps, float* out, void* stream);
+
 /* Inference BatchNorm folded to an affine: scale = gamma*rsqrt(var+eps) (gamma NULL => 1),
  * shift = beta - mean*scale. */
 int c2d_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
