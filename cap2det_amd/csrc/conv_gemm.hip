@@ -455,85 +455,80 @@ struct WgradArgs {
   int M;                                // conv output rows (reduction length)
   int I, J;                             // cin, cout
   int rows_per_split;                   // multiple of WBK
-  int itiles, jtiles, tiles, splits;    // tiles = taps*itiles*jtiles
   ConvGeom g;                           // mode 0
 };
 
-constexpr int WBK = 32;             // rows of M per slab
+constexpr int WBK = 16;             // rows of M per slab
 constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
-constexpr int WG_LOADS = WBK / 8;   // float4 loads per thread per operand per slab
 
-// Block tile 128(i) x 128(j) = 16 MFMA tiles dealt to 4 waves.  1-D grid with the
-// XCD-aware order: all (tap, i-tile, j-tile) blocks of one row split are consecutive logical
-// ids on one XCD, so the x / dC rows of the split are fetched from HBM once and re-read by the
-// other taps / tiles from that XCD's L2.
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
+// Block tile 128(i) x 128(j); 4 waves as 2x2, each 64x64 (2x2 MFMA tiles); 3-D grid
+// (tap * i-tiles, j-tiles, row splits).  108 registers: 4 waves per SIMD.  (An XCD-remapped 1-D
+// grid with 32-row slabs and a dynamic deal of the valid tiles to the waves measured 10-25 %
+// SLOWER on the 1x1 / stride-2 layers this kernel still serves: it cost the fourth wave.)
+// NTJ = 32-column MFMA tiles per wave along j: 2 (block tile 128x128) or 1 (128x64, used when
+// the last 128-wide j-tile would be at most half full: J = 192, 160, 320 ...).
+template <int NTJ>
+__global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
+  constexpr int BJ = 2 * NTJ * 32;
   __shared__ __attribute__((aligned(16))) float As[WBK * WG_STRIDE];
   __shared__ __attribute__((aligned(16))) float Gs[WBK * WG_STRIDE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
-  const int split = logical / a.tiles;
-  int t = logical - split * a.tiles;
-  const int jt = t % a.jtiles; t /= a.jtiles;
-  const int it_ = t % a.itiles;
-  const int tap = t / a.itiles;
-  const int i0 = it_ * 128, j0 = jt * 128;
+  const int itiles = (a.I + 127) / 128;
+  const int tap = blockIdx.x / itiles;
+  const int i0 = (blockIdx.x - tap * itiles) * 128;
+  const int j0 = blockIdx.y * BJ;
   const int ky = tap / a.g.kw, kx = tap - ky * a.g.kw;
-  const int mbeg = split * a.rows_per_split;
+  const int mbeg = blockIdx.z * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
-  // loader: thread -> (k rows kr + 8u, float4 column c4); columns beyond I/J are clamped
+  // loader: thread -> (k row kr and kr+8, float4 column c4); columns beyond I/J are clamped
   // (their products land in dW rows/cols that are never stored).
   const int kr = tid >> 5;   // 0..7
   const int c4 = (tid & 31) * 4;
   const float* abase = a.A + a.a_off + min(i0 + c4, a.I - 4);
-  const float* gbase = a.G + a.g_off + min(j0 + c4, a.J - 4);
+  const bool gload = c4 < BJ;   // (BJ = 64: the upper half of each 32-lane row group idles)
+  const float* gbase = a.G + a.g_off + min(j0 + min(c4, BJ - 4), a.J - 4);
 
-  f32x16 acc[4];
+  f32x16 acc[2][NTJ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // Dynamic tile assignment: the valid 32x32 tiles of the block (I and J are multiples of 32
-  // but not of 128) are dealt round-robin to the 4 waves, so a partial block tile keeps every
-  // wave equally busy instead of idling the waves that own the out-of-range quadrant.
-  const int nvi = min(4, (a.I - i0 + 31) / 32), nvj = min(4, (a.J - j0 + 31) / 32);
-  const int nvalid = nvi * nvj;
-  int ti[4], tj[4];
-  bool on[4];
+  bool tile_on[2][NTJ];   // 32x32 tiles beyond I / J issue no MFMA
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int t = wave + 4 * q;
-    on[q] = t < nvalid;
-    const int tt = on[q] ? t : 0;
-    ti[q] = tt / nvj;
-    tj[q] = tt - ti[q] * nvj;
-  }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+      tile_on[i][j] = (i0 + wm * 64 + i * 32 < a.I) && (j0 + (wn * NTJ + j) * 32 < a.J);
 
-  f32x4 ra[WG_LOADS], rg[WG_LOADS];
-  unsigned vmask = 0;   // bit u: A row valid, bit 8+u: G row valid
+  f32x4 ra[2], rg[2];
+  unsigned vmask = 0;   // bit u: A row valid, bit 2+u: G row valid
   {
 #pragma unroll
-    for (int u = 0; u < WG_LOADS; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int m = mbeg + kr + u * 8;
       const RowPos p = decompose(m, mend, a.g);
       const int sr = src_row<0>(a.g, p, ky, kx);
       vmask |= (sr >= 0 ? 1u : 0u) << u;
-      vmask |= (p.valid ? 1u : 0u) << (8 + u);
+      vmask |= (p.valid ? 1u : 0u) << (2 + u);
       ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
       rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
     }
   }
   for (int mb = mbeg; mb < mend; mb += WBK) {
 #pragma unroll
-    for (int u = 0; u < WG_LOADS; ++u) {
+    for (int u = 0; u < 2; ++u) {
       *reinterpret_cast<f32x4*>(&As[(kr + u * 8) * WG_STRIDE + c4]) =
           mask4(ra[u], (vmask >> u) & 1u);
-      *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) =
-          mask4(rg[u], (vmask >> (8 + u)) & 1u);
+      if (gload)
+        *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) =
+            mask4(rg[u], (vmask >> (2 + u)) & 1u);
     }
     __syncthreads();
     {
@@ -541,52 +536,48 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgradArgs a) {
       const int nb = mb + WBK;
       vmask = 0;
 #pragma unroll
-      for (int u = 0; u < WG_LOADS; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const int m = nb + kr + u * 8;
         const RowPos p = decompose(m, mend, a.g);
         const int sr = src_row<0>(a.g, p, ky, kx);
         vmask |= (sr >= 0 ? 1u : 0u) << u;
-        vmask |= (p.valid ? 1u : 0u) << (8 + u);
+        vmask |= (p.valid ? 1u : 0u) << (2 + u);
         ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
         rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int part = 0; part < WBK / 8; ++part) {
-      // fragments of 4 k-steps first (32 independent ds_read_b32), then up to 16 MFMAs
-      float af[4][4], bf[4][4];
+    for (int s = 0; s < 8; ++s) {
+      const int k = lh * 8 + s;
+      float af[2], bf[NTJ];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int k = lh * (WBK / 2) + part * 4 + s;
+      for (int i = 0; i < 2; ++i) af[i] = As[k * WG_STRIDE + wm * 64 + i * 32 + li];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          af[q][s] = As[k * WG_STRIDE + ti[q] * 32 + li];
-          bf[q][s] = Gs[k * WG_STRIDE + tj[q] * 32 + li];
-        }
-      }
+      for (int j = 0; j < NTJ; ++j) bf[j] = Gs[k * WG_STRIDE + (wn * NTJ + j) * 32 + li];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (on[q])   // wave-uniform
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][s], bf[q][s], acc[q], 0, 0, 0);
+        for (int j = 0; j < NTJ; ++j)
+          if (tile_on[i][j])
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 
   float* dw = a.dW + (size_t)tap * a.I * a.J;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (!on[q]) continue;
-    const int jj = j0 + tj[q] * 32 + li;
+  for (int j = 0; j < NTJ; ++j) {
+    const int jj = j0 + (wn * NTJ + j) * 32 + li;
     if (jj >= a.J) continue;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ii = i0 + ti[q] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (ii >= a.I) continue;
-      atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ii >= a.I) continue;
+        atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
+      }
   }
 }
 
@@ -906,16 +897,17 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
   if (rc) return rc;
   a.A = x; a.lda = ldx; a.a_off = xoff; a.G = dc; a.ldg = ldc; a.g_off = coff; a.dW = dw;
   a.M = n * a.g.oh * a.g.ow; a.I = cin; a.J = cout;
-  a.itiles = c2d_ceil_div(cin, 128);
-  a.jtiles = c2d_ceil_div(cout, 128);
-  a.tiles = kh * kw * a.itiles * a.jtiles;
-  int splits = c2d_ceil_div(768, a.tiles);                // ~3 blocks per CU, one round
+  const bool narrow = cout % 128 != 0 && cout % 128 <= 64;   // 128x64 block tiles
+  const int bj = narrow ? 64 : 128;
+  const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, bj);
+  int splits = c2d_ceil_div(1024, tiles);                 // ~4 blocks per CU
   const int max_splits = c2d_ceil_div(a.M, 4 * WBK);      // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), WBK) * WBK;
-  a.splits = c2d_ceil_div(a.M, a.rows_per_split);
-  dim3 grid(a.tiles * a.splits);
-  hipLaunchKernelGGL(wgrad_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  splits = c2d_ceil_div(a.M, a.rows_per_split);
+  dim3 grid(kh * kw * c2d_ceil_div(cin, 128), c2d_ceil_div(cout, bj), splits);
+  if (narrow) hipLaunchKernelGGL(wgrad_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(wgrad_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return c2d_launch_status();
 }
