@@ -158,13 +158,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3))
     arow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
     apos[i] = decompose(m0 + arow_l[i], a.M, a.g);
   }
-  const float* bptr[B_LOADS];
-  int brow_l[B_LOADS];
+  int brow_l[B_LOADS], brow_off[B_LOADS];
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i) {
     brow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
-    const int n = min(n0 + brow_l[i], a.N - 1);   // columns >= N are never stored: clamp only
-    bptr[i] = a.Bt + (size_t)n * a.K + q4;
+    brow_off[i] = min(n0 + brow_l[i], a.N - 1);   // columns >= N are never stored: clamp only
   }
   const float* abase = a.A + a.a_off + q4;
   int lda = a.lda, Kc = a.K, sgi = 0;   // current segment (wave-uniform)
@@ -196,25 +194,42 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3))
   f32x4 ra[A_LOADS], rb[B_LOADS];
   unsigned amask = 0;       // bit i: A load i hit a real pixel (else SAME-padding zero)
   int ky = a.g.ky0, kx = a.g.kx0, kc = 0;   // wave-uniform slab cursor
-  int tap = ky * a.g.kw + kx;
+
+  // Row pointers of the current tap / segment.  They change only when the cursor moves to the
+  // next tap (every K/BKT slabs; never for a 1x1 convolution), so the per-slab address work is
+  // one add per load instead of the whole gather arithmetic.
+  int aoff[A_LOADS], boff[B_LOADS];   // 32-bit float offsets (operands are < 2^31 floats)
+  const float* bbase = a.Bt + q4;
+  unsigned rowok = 0;
+#define C2D_RETAP()                                                                            \
+  {                                                                                            \
+    rowok = 0;                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                      \
+      const int sr = src_row<MODE>(a.g, apos[i], ky, kx);                                      \
+      rowok |= (sr >= 0 ? 1u : 0u) << i;                                                       \
+      aoff[i] = max(sr, 0) * lda;                                                              \
+    }                                                                                          \
+    const int toff = (ky * a.g.kw + kx) * (int)tap_stride;                                     \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) boff[i] = brow_off[i] * Kc + toff;     \
+  }
+#define C2D_ISSUE()                                                                            \
+  {                                                                                            \
+    const int koff = min(kc, Kc - 4 - q4);                                                     \
+    amask = (kc + q4 < Kc) ? rowok : 0u;                                                       \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
+        ra[i] = *reinterpret_cast<const f32x4*>(abase + (aoff[i] + koff));                     \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
+        rb[i] = *reinterpret_cast<const f32x4*>(bbase + (boff[i] + koff));                     \
+  }
 
   // Prologue: loads of slab 0.  Inside the loop the loads of slab it+1 are issued
   // unconditionally right after the barrier (the last iteration harmlessly re-loads the last
   // slab) so that the loop body is straight-line code and the loads fly under the MFMAs.
-  // K is a multiple of 16, not necessarily of BK: lanes past the end of the last slab re-read
+  // K is a multiple of 16, not necessarily of BKT: lanes past the end of the last slab re-read
   // the row's last float4 (in bounds) and contribute zeros through the A mask.
   if (total > 0) {   // (a stride-2 parity class can have no tap at all: it just stores zeros)
-    const int koff = min(kc, Kc - 4 - q4);
-    const unsigned kok = (kc + q4 < Kc) ? 1u : 0u;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int sr = src_row<MODE>(a.g, apos[i], ky, kx);
-      amask |= ((sr >= 0 ? 1u : 0u) & kok) << i;
-      ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * lda + koff);
-    }
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i)
-      rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + tap * tap_stride + koff);
+    C2D_RETAP();
+    C2D_ISSUE();
   }
   for (int it = 0; it < total; ++it) {
 #pragma unroll
@@ -235,28 +250,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3))
             ++sgi;
             lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
             abase = a.segA[sgi] + a.seg_off[sgi] + q4;
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i)
-              bptr[i] = a.segB[sgi] + (size_t)min(n0 + brow_l[i], a.N - 1) * Kc + q4;
+            bbase = a.segB[sgi] + q4;
           } else {
             kx += a.g.kstep;
             if (kx >= a.g.kw) { kx = a.g.kx0; ky += a.g.kstep; }
-            tap = ky * a.g.kw + kx;
           }
+          C2D_RETAP();
         }
       }
-      const int koff = min(kc, Kc - 4 - q4);
-      const unsigned kok = (kc + q4 < Kc) ? 1u : 0u;
-      amask = 0;
-#pragma unroll
-      for (int i = 0; i < A_LOADS; ++i) {
-        const int sr = src_row<MODE>(a.g, apos[i], ky, kx);
-        amask |= ((sr >= 0 ? 1u : 0u) & kok) << i;
-        ra[i] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * lda + koff);
-      }
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
-        rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + tap * tap_stride + koff);
+      C2D_ISSUE();
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -292,6 +294,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3))
     __syncthreads();
   }
 
+#undef C2D_RETAP
+#undef C2D_ISSUE
   // Epilogue.  C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5),
   // i.e. 4 B per lane per store.  Each wave transposes 32-row strips through its private slice
   // of the (now idle) staging LDS so that the global stores are 16 B per lane on contiguous
