@@ -93,6 +93,11 @@ class KernelTimer(object):
         return r
       return inner
 
+    def multi_work(args):
+      # conv1x1_dgrad_multi(dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin, accumulate)
+      return 2.0 * args[8] * args[9] * sum(args[4])
+
+    ops.conv1x1_dgrad_multi = timed(ops.conv1x1_dgrad_multi, "igemm_nt", multi_work)
     ops.conv_fwd = timed(ops.conv_fwd, "igemm_nt", conv_work("fwd"))
     ops.conv_dgrad = timed(ops.conv_dgrad, "igemm_nt", conv_work("dgrad"))
     ops.conv_wgrad = timed(ops.conv_wgrad, "wgrad_tn", wgrad_work)
@@ -235,34 +240,46 @@ def main():
                    "launch": "hipGraph replay" if args.graph else "eager"},
         "final_total_loss": total_loss,
     }
+    # HBM traffic per step of each kernel family from the committed rocprofv3 PMC passes
+    # (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for 16-B/lane streaming reads,
+    # + WRITE_SIZE); null when the summary file is absent.  See profiles/README.md.
+    traffic = {}
+    try:
+      with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        traffic = {k: v["hbm_bytes_per_step"] for k, v in json.load(f)["families"].items()}
+    except Exception:
+      traffic = {}
     if not args.no_kernel_timing:
       summ = timer.summary()
       ig = summ.get("igemm_nt")
       if ig:
         tf = ig["work"] / (ig["ms"] * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "igemm_nt_kernel (conv fwd + dgrad, fp32 MFMA 32x32x2)",
+            "kernel": "igemm_nt_kernel<*> + igemm_small_kernel<*> (implicit-GEMM conv fwd + dgrad "
+                      "+ heads GEMM, fp32 MFMA 32x32x2; a stride-2 dgrad call = 4 launches)",
             "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "launches_per_step": ig["launches"],
-            "avg_launch_ms": ig["ms"] / ig["launches"],
+            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("igemm"),
+            "calls_per_step": ig["launches"],
+            "avg_call_ms": ig["ms"] / ig["launches"],
+            "family_ms_per_step": ig["ms"],
             "algorithmic_gflop_per_step": ig["work"] / 1e9,
             "timed_with": "HIP events around every launch of the last timed step"}
       wg = summ.get("wgrad_tn")
       if wg:
         tf = wg["work"] / (wg["ms"] * 1e-3) / 1e12
         result["roofline_wgrad"] = {
-            "kernel": "wgrad_tn_kernel (conv filter gradient, fp32 MFMA)", "bound": "mfma",
+            "kernel": "wgrad_tn_kernel<*> + wgrad3x3_kernel<*> (conv filter gradient, fp32 MFMA)",
+            "bound": "mfma",
             "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "avg_launch_ms": wg["ms"] / wg["launches"]}
+            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("wgrad"),
+            "family_ms_per_step": wg["ms"], "calls_per_step": wg["launches"]}
       rc = summ.get("roi_crop_pool_fwd")
       if rc:
         gbs = rc["work"] / (rc["ms"] * 1e-3) / 1e9
         result["roofline_roi_crop"] = {
             "kernel": "roi_crop_pool_fwd_kernel (crop_and_resize 14x14 fused with 2x2 max-pool)",
             "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-            "frac": gbs / PEAK_HBM_GBPS, "traffic": None,
+            "frac": gbs / PEAK_HBM_GBPS, "traffic": traffic.get("roi_crop_pool_fwd"),
             "avg_launch_ms": rc["ms"] / rc["launches"],
             "algorithmic_bytes_per_launch": rc["work"] / rc["launches"]}
     if not args.no_cpu_baseline and world == 1:

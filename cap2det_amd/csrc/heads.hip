@@ -8,6 +8,7 @@
 //   c2d_oicr_loss_fwd_bwd       models/utils.py:64-103, models/cap2det_model.py:314-328
 //   c2d_labels_from_ids         models/label_extractor.py:15-39,183-207
 //   c2d_text_classifier_fwd     models/label_extractor.py:353-421,442-472
+//   c2d_word_vector_match_fwd   models/label_extractor.py:232-328
 #include "c2d_common.h"
 
 namespace {
@@ -315,6 +316,77 @@ __global__ __launch_bounds__(256) void text_labels_merge_kernel(const float* __r
   }
 }
 
+
+// WordVectorMatchExtractor (models/label_extractor.py:232-328): cosine similarity between every
+// caption token and every class name in GloVe space, masked max-pool over the non-OOV tokens
+// (core/utils.py:63-79 formula), one-hot of the best class; overridden by the exact match.
+// One block per caption; sim[T][C] lives in LDS.
+__global__ __launch_bounds__(256) void word_vector_match_kernel(
+    const int32_t* __restrict__ ids, int T, const float* __restrict__ emb, int vocab, int E,
+    const int32_t* __restrict__ class_ids, int C, const float* __restrict__ exact,
+    float* __restrict__ labels) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sim = smem;                 // [T][C]
+  float* tinv = smem + T * C;        // [T] 1/||token||
+  float* cinv = tinv + T;            // [C] 1/||class||
+  float* pooled = cinv + C;          // [C]
+  __shared__ int any_token, any_exact, best_c;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) { any_token = 0; any_exact = 0; }
+  __syncthreads();
+  // tf.nn.l2_normalize: x * rsqrt(max(sum(x^2), 1e-12))
+  for (int i = threadIdx.x; i < T + C; i += blockDim.x) {
+    int id = i < T ? ids[b * T + i] : class_ids[i - T];
+    if (id < 0 || id > vocab) id = vocab;
+    const float* v = emb + (size_t)id * E;
+    float ss = 0.f;
+    for (int e = 0; e < E; ++e) ss += v[e] * v[e];
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    if (i < T) { tinv[i] = inv; if (id != vocab) any_token = 1; }
+    else cinv[i - T] = inv;
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    if (exact[b * C + c] > 0.f) any_exact = 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * C; i += blockDim.x) {
+    const int t = i / C, c = i - t * C;
+    int id = ids[b * T + t];
+    if (id < 0 || id > vocab) id = vocab;
+    int cid = class_ids[c];
+    if (cid < 0 || cid > vocab) cid = vocab;
+    const float* tv = emb + (size_t)id * E;
+    const float* cv = emb + (size_t)cid * E;
+    float d = 0.f;
+    for (int e = 0; e < E; ++e) d += (tv[e] * tinv[t]) * (cv[e] * cinv[c]);
+    sim[i] = d;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mn = INFINITY;
+    for (int t = 0; t < T; ++t) mn = fminf(mn, sim[t * C + c]);
+    float best = -INFINITY;
+    for (int t = 0; t < T; ++t) {
+      int id = ids[b * T + t];
+      const float m = (id >= 0 && id < vocab) ? 1.0f : 0.0f;
+      best = fmaxf(best, (sim[t * C + c] - mn) * m);
+    }
+    pooled[c] = best + mn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int bc = 0;
+    float bv = pooled[0];
+    for (int c = 1; c < C; ++c)
+      if (pooled[c] > bv) { bv = pooled[c]; bc = c; }   // tf.argmax: first maximum
+    best_c = bc;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float ms = (any_token && c == best_c) ? 1.0f : 0.0f;
+    labels[b * C + c] = any_exact ? exact[b * C + c] : ms;
+  }
+}
+
 }  // namespace
 
 extern "C" int c2d_midn_fwd(const float* logits, int ld, int off_r, int off_c,
@@ -402,5 +474,21 @@ extern "C" int c2d_text_classifier_fwd(const int32_t* ids, int batch, int num_to
   if (labels)
     hipLaunchKernelGGL(text_labels_merge_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream,
                        logits, exact_labels, label_threshold, num_classes, labels);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_word_vector_match_fwd(const int32_t* ids, int batch, int num_tokens,
+                                         const float* embedding, int vocab_size, int emb_dims,
+                                         const int32_t* class_ids, int num_classes,
+                                         const float* exact_labels, float* labels,
+                                         void* stream) {
+  C2D_CHECK_ARG(ids && embedding && class_ids && exact_labels && labels);
+  C2D_CHECK_ARG(batch > 0 && num_tokens > 0 && vocab_size > 0 && emb_dims > 0 && num_classes > 0);
+  const size_t smem =
+      ((size_t)num_tokens * num_classes + num_tokens + 2 * (size_t)num_classes) * sizeof(float);
+  if (smem > 64 * 1024) return C2D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(word_vector_match_kernel, dim3(batch), dim3(256), smem, (hipStream_t)stream,
+                     ids, num_tokens, embedding, vocab_size, emb_dims, class_ids, num_classes,
+                     exact_labels, labels);
   return c2d_launch_status();
 }

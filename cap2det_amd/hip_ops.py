@@ -212,6 +212,13 @@ def text_classifier_fwd(ids, embedding, w1, b1, w2, b2, exact_labels, label_thre
             _p(exact_labels), float(label_threshold), _p(logits), _p(labels), _stream())
 
 
+def word_vector_match_fwd(ids, embedding, class_ids, exact_labels, labels):
+  batch, t = ids.shape
+  _lib.call("c2d_word_vector_match_fwd", _p(ids), batch, t, _p(embedding), embedding.shape[0] - 1,
+            embedding.shape[1], _p(class_ids), class_ids.numel(), _p(exact_labels), _p(labels),
+            _stream())
+
+
 # -- optimiser --------------------------------------------------------------------------
 
 def adagrad_step(w, g, acc, lr, l2, mult, grad_scale=1.0):

@@ -153,6 +153,30 @@ class _OpenVocabularyExtractor(LabelExtractor):
     self._embedding = torch.from_numpy(full.astype(np.float32)).to(self._device).contiguous()
 
 
+class WordVectorMatchExtractor(_OpenVocabularyExtractor):
+  """models/label_extractor.py:210-328."""
+
+  def __init__(self, options, device="cuda:0"):
+    super(WordVectorMatchExtractor, self).__init__(options, device)
+    self._classes_to_match = _replace_class_names(self._classes)
+    # "Check if all classes appear in the open-vocabulary" (models/label_extractor.py:263-266)
+    for class_name in self._classes_to_match:
+      if class_name not in self._vocab_table:
+        raise ValueError('Class %s has no vector representation.' % class_name)
+    self._match_table = {name: i for i, name in enumerate(self._classes_to_match)}
+    self._class_ids = torch.tensor([self._vocab_table[c] for c in self._classes_to_match],
+                                   dtype=torch.int32, device=self._device)
+
+  def extract_labels(self, examples):
+    texts = examples[InputDataFields.concat_caption_string]
+    ids = tokens_to_ids(texts, self._vocab_table, len(self._open_vocabulary_list), self._device,
+                        min_tokens=1)
+    exact = _match_labels(texts, self._match_table, self._num_classes, self._device)
+    labels = torch.empty_like(exact)
+    ops.word_vector_match_fwd(ids, self._embedding, self._class_ids, exact, labels)
+    return labels
+
+
 class TextClassifierMatchExtractor(_OpenVocabularyExtractor):
   """models/label_extractor.py:331-472."""
 
@@ -219,8 +243,7 @@ def build_label_extractor(config, device="cuda:0"):
   elif 'extend_match_extractor' == oneof:
     return ExtendMatchExtractor(config.extend_match_extractor, device)
   elif 'word_vector_match_extractor' == oneof:
-    raise NotImplementedError(
-        'word_vector_match_extractor is not on the MI355X hot path yet (SURVEY.md §8 A10)')
+    return WordVectorMatchExtractor(config.word_vector_match_extractor, device)
   elif 'text_classifier_match_extractor' == oneof:
     return TextClassifierMatchExtractor(config.text_classifier_match_extractor, device)
   raise ValueError('Invalid label extractor %s' % oneof)

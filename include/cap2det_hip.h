@@ -224,6 +224,16 @@ int c2d_text_classifier_fwd(const int32_t* ids, int batch, int num_tokens,
                             const float* b2, int num_classes, const float* exact_labels,
                             float label_threshold, float* logits, float* labels, void* stream);
 
+/* WordVectorMatchExtractor (models/label_extractor.py:251-328): cosine similarity of every
+ * token with every class name (class_ids = vocabulary ids of the class names) in the embedding
+ * table ([vocab_size+1][emb_dims], last row = OOV), masked max-pool over non-OOV tokens, one-hot
+ * of the best class (zeros when every token is OOV); rows with an exact match keep
+ * exact_labels.  num_tokens*num_classes floats must fit 64 KiB of LDS. */
+int c2d_word_vector_match_fwd(const int32_t* ids, int batch, int num_tokens,
+                              const float* embedding, int vocab_size, int emb_dims,
+                              const int32_t* class_ids, int num_classes,
+                              const float* exact_labels, float* labels, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Optimiser  (train/trainer.py:55-61,104-146; core/training_utils.py:45-50)
  * ------------------------------------------------------------------------------------- */
