@@ -240,13 +240,14 @@ def main():
                    "launch": "hipGraph replay" if args.graph else "eager"},
         "final_total_loss": total_loss,
     }
-    # HBM traffic per step of each kernel family from the committed rocprofv3 PMC passes
-    # (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for 16-B/lane streaming reads,
-    # + WRITE_SIZE); null when the summary file is absent.  See profiles/README.md.
+    # HBM traffic (bytes per kernel launch, averaged over the family) from the committed
+    # rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950,
+    # + WRITE_SIZE, separate passes; tools/summarize_pmc.py); null when the summary file is
+    # absent.  See profiles/README.md.
     traffic = {}
     try:
       with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-        traffic = {k: v["hbm_bytes_per_step"] for k, v in json.load(f)["families"].items()}
+        traffic = json.load(f)["families"]
     except Exception:
       traffic = {}
     if not args.no_kernel_timing:
@@ -258,7 +259,8 @@ def main():
             "kernel": "igemm_nt_kernel<*> + igemm_small_kernel<*> (implicit-GEMM conv fwd + dgrad "
                       "+ heads GEMM, fp32 MFMA 32x32x2; a stride-2 dgrad call = 4 launches)",
             "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("igemm"),
+            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("igemm", {}).get("hbm_bytes_per_launch"),
+            "traffic_bytes_per_step": traffic.get("igemm", {}).get("hbm_bytes_per_step"),
             "calls_per_step": ig["launches"],
             "avg_call_ms": ig["ms"] / ig["launches"],
             "family_ms_per_step": ig["ms"],
@@ -271,7 +273,8 @@ def main():
             "kernel": "wgrad_tn_kernel<*> + wgrad3x3_kernel<*> (conv filter gradient, fp32 MFMA)",
             "bound": "mfma",
             "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("wgrad"),
+            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("wgrad", {}).get("hbm_bytes_per_launch"),
+            "traffic_bytes_per_step": traffic.get("wgrad", {}).get("hbm_bytes_per_step"),
             "family_ms_per_step": wg["ms"], "calls_per_step": wg["launches"]}
       rc = summ.get("roi_crop_pool_fwd")
       if rc:
@@ -279,7 +282,7 @@ def main():
         result["roofline_roi_crop"] = {
             "kernel": "roi_crop_pool_fwd_kernel (crop_and_resize 14x14 fused with 2x2 max-pool)",
             "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-            "frac": gbs / PEAK_HBM_GBPS, "traffic": traffic.get("roi_crop_pool_fwd"),
+            "frac": gbs / PEAK_HBM_GBPS, "traffic": traffic.get("roi_crop_pool_fwd", {}).get("hbm_bytes_per_launch"),
             "avg_launch_ms": rc["ms"] / rc["launches"],
             "algorithmic_bytes_per_launch": rc["work"] / rc["launches"]}
     if not args.no_cpu_baseline and world == 1:

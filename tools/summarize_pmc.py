@@ -1,0 +1,100 @@
+"""Turns rocprofv3 PMC passes of `bench.py` into the per-kernel-family HBM traffic summary that
+bench.py reads back as `roofline.traffic` (profiles/rNN_traffic.json).
+
+  python tools/summarize_pmc.py OUT.json FETCH_DIR WRITE_DIR [STATS_DIR]
+
+FETCH_DIR / WRITE_DIR are the output directories of two SEPARATE passes
+(`rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR -- python3 bench.py ...`
+and the same with WRITE_SIZE: the two counters do not fit one pass on gfx950).  Units and
+corrections follow MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950 FETCH_SIZE
+tallies 128-B requests at 64 B, so it is DOUBLED; WRITE_SIZE is exact for 16-B/lane stores and
+float atomics.  Steps are counted by the launches of `midn_fwd_kernel` (exactly one per training
+step)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
+    ("igemm", "igemm_nt_kernel"),
+    ("igemm", "igemm_small_kernel"),
+    ("wgrad", "wgrad_tn_kernel"),
+    ("wgrad", "wgrad3x3_kernel"),
+    ("roi_crop_pool_fwd", "roi_crop_pool_fwd_kernel"),
+    ("roi_crop_pool_bwd", "roi_bwd_"),
+    ("roi_crop_pool_bwd", "roi_bin_rows_kernel"),
+    ("roi_crop_pool_bwd", "roi_axes_kernel"),
+    ("bn_relu_bwd", "bn_relu_bwd_kernel"),
+    ("pool3x3", "pool3x3_"),
+    ("adagrad", "adagrad_kernel"),
+]
+
+
+def family_of(name):
+  for fam, sub in FAMILIES:
+    if sub in name:
+      return fam
+  return None
+
+
+def read_counter(directory, counter):
+  """-> ({family: [sum_KiB, launches]}, steps)"""
+  out = collections.defaultdict(lambda: [0.0, 0])
+  steps = 0
+  files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+  if not files:
+    raise SystemExit("no counter_collection.csv under " + directory)
+  for path in files:
+    with open(path) as f:
+      for row in csv.DictReader(f):
+        if row["Counter_Name"] != counter:
+          continue
+        name = row["Kernel_Name"]
+        if "midn_fwd_kernel" in name:
+          steps += 1
+        fam = family_of(name)
+        if fam:
+          out[fam][0] += float(row["Counter_Value"])
+          out[fam][1] += 1
+  return out, steps
+
+
+def main():
+  out_path, fetch_dir, write_dir = sys.argv[1:4]
+  fetch, fsteps = read_counter(fetch_dir, "FETCH_SIZE")
+  write, wsteps = read_counter(write_dir, "WRITE_SIZE")
+  fams = {}
+  for fam in sorted(set(fetch) | set(write)):
+    fk, fl = fetch.get(fam, [0.0, 0])
+    wk, wl = write.get(fam, [0.0, 0])
+    launches = fl / float(fsteps) if fsteps else 0.0
+    rd = 2.0 * fk * 1024.0 / max(fsteps, 1)          # gfx950: FETCH_SIZE reads 1/2 (doubled)
+    wr = wk * 1024.0 / max(wsteps, 1)
+    fams[fam] = {
+        "launches_per_step": launches,
+        "hbm_read_bytes_per_step": rd,
+        "hbm_write_bytes_per_step": wr,
+        "hbm_bytes_per_step": rd + wr,
+        "hbm_bytes_per_launch": (rd + wr) / launches if launches else None,
+        "raw_FETCH_SIZE_KiB_per_step": fk / max(fsteps, 1),
+        "raw_WRITE_SIZE_KiB_per_step": wk / max(wsteps, 1),
+    }
+  doc = {
+      "source": {"fetch_pass": fetch_dir, "write_pass": write_dir,
+                 "steps_in_fetch_pass": fsteps, "steps_in_write_pass": wsteps},
+      "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md §HBM); "
+                     "WRITE_SIZE as read",
+      "families": fams,
+  }
+  with open(out_path, "w") as f:
+    json.dump(doc, f, indent=1, sort_keys=True)
+  for fam, v in fams.items():
+    print("%-20s %6.1f launches/step  read %9.1f MB  write %9.1f MB per step"
+          % (fam, v["launches_per_step"], v["hbm_read_bytes_per_step"] / 1e6,
+             v["hbm_write_bytes_per_step"] / 1e6))
+
+
+if __name__ == "__main__":
+  main()
