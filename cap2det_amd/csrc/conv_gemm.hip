@@ -608,19 +608,24 @@ struct Wgrad3Args {
   int h, w;
 };
 
-// WC = compile-time (square) map width, IMGS = whole images per slab.  The x slab is staged in
-// ZERO-PADDED image coordinates (every image gets a one-pixel border of zeros in LDS), so tap
-// (ky,kx) of output pixel at padded index P is simply LDS row P + (ky-1)*(WC+2) + (kx-1): SAME
-// padding needs no predicate, and because a slab is a whole number of images every LDS row
-// index is a compile-time constant.  Wave v owns output columns [j0+32v, j0+32v+32), all taps.
+// WC = compile-time (square) map width, IMGS = whole images per slab (even).  The x slab is
+// staged in ZERO-PADDED image coordinates (every image gets a one-pixel border in LDS), so tap
+// (ky,kx) of the output pixel at padded index P is simply LDS row P + (ky-1)*(WC+2) + (kx-1) and
+// because a slab is a whole number of images every LDS row index is a compile-time constant.
+// One MFMA k-step (k = 2) pairs the SAME pixel of two images (lower half-wave: image 2i, upper:
+// image 2i+1), so whether tap (ky,kx) falls into the SAME padding is a compile-time property of
+// the step and those MFMAs are simply not issued: 100 of 144 (pixel, tap) pairs remain on a 4x4
+// map, 361 of 441 on 7x7 — no matrix-pipe time is spent multiplying padding zeros.
+// Wave v owns output columns [j0+32v, j0+32v+32), all taps.
 template <int WC, int IMGS>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
+  constexpr bool PAIR = IMGS % 2 == 0;       // else: a k-step takes rows 2s, 2s+1 (no skipping)
   constexpr int PW = WC + 2;
   constexpr int HW = WC * WC;
   constexpr int PIMG = PW * PW;              // padded pixels per image
   constexpr int R = IMGS * HW;               // output rows per slab
-  constexpr int STEPS = (R + 1) / 2;         // MFMA k-steps (2 rows each; odd R: one zero row)
-  constexpr int RP = STEPS * 2;
+  constexpr int STEPS = (R + 1) / 2;         // MFMA k-steps (PAIR: (image pair, pixel))
+  constexpr int RP = STEPS * 2;              // staged dC rows (odd R: one zero row)
   constexpr int AROWS = IMGS * PIMG;
   constexpr int A_LD = (AROWS + 31) / 32;    // x loads per thread (rows ar0 + 32u)
   constexpr int G_LD = (RP + 7) / 8;         // dC loads per thread (rows gkr + 8u)
@@ -680,6 +685,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
     }                                                                                          \
   }
 
+  // per-lane bases: the upper half-wave reads the odd image of each pair (PAIR) / the odd row
+  const float* const apl = &As[(PAIR ? lh * PIMG : 0) * W3_ASTR + li];
+  const float* const gpl = &Gs[(PAIR ? lh * HW : lh) * W3_GSTR + wave * 32 + li];
+
   C2D_W3_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += R) {
 #pragma unroll
@@ -696,20 +705,35 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
     C2D_W3_LOAD(mb + R);
     __builtin_amdgcn_sched_barrier(0);
     if (wave_on) {
-      const float* gcol = &Gs[lh * W3_GSTR + wave * 32 + li];
+      if constexpr (PAIR) {
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        // rows k = 2s (lower half-wave) and 2s+1 (upper); padded LDS row of pixel k
-        constexpr int dummy = 0; (void)dummy;
-        const int k0 = 2 * s, k1 = (2 * s + 1 < R) ? 2 * s + 1 : 2 * s;
-        const int p0 = (k0 / HW) * PIMG + ((k0 % HW) / WC + 1) * PW + (k0 % WC) + 1;
-        const int p1 = (k1 / HW) * PIMG + ((k1 % HW) / WC + 1) * PW + (k1 % WC) + 1;
-        const float* ap = &As[(lh ? p1 : p0) * W3_ASTR + li];
-        const float bv = gcol[2 * s * W3_GSTR];
+        for (int s = 0; s < STEPS; ++s) {
+          const int ip = s / HW, p = s % HW;     // image pair, pixel (compile-time after unroll)
+          const int y = p / WC, x = p % WC;
+          const float* ap = apl + ((2 * ip) * PIMG + (y + 1) * PW + (x + 1)) * W3_ASTR;
+          const float bv = gpl[((2 * ip) * HW + p) * W3_GSTR];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const int off = ((q / 3) - 1) * PW + ((q % 3) - 1);
-          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[off * W3_ASTR], bv, acc[q], 0, 0, 0);
+          for (int q = 0; q < 9; ++q) {
+            const int dy = q / 3 - 1, dx = q % 3 - 1;
+            if (y + dy < 0 || y + dy >= WC || x + dx < 0 || x + dx >= WC) continue;   // padding
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(dy * PW + dx) * W3_ASTR], bv,
+                                                          acc[q], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          // rows k = 2s (lower half-wave) and 2s+1 (upper); padded LDS row of pixel k
+          const int k0 = 2 * s, k1 = (2 * s + 1 < R) ? 2 * s + 1 : 2 * s;
+          const int p0 = (k0 / HW) * PIMG + ((k0 % HW) / WC + 1) * PW + (k0 % WC) + 1;
+          const int p1 = (k1 / HW) * PIMG + ((k1 % HW) / WC + 1) * PW + (k1 % WC) + 1;
+          const float* ap = apl + (lh ? p1 : p0) * W3_ASTR;
+          const float bv = gpl[2 * s * W3_GSTR];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const int off = ((q / 3) - 1) * PW + ((q % 3) - 1);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[off * W3_ASTR], bv, acc[q], 0, 0, 0);
+          }
         }
       }
     }

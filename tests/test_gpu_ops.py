@@ -159,10 +159,11 @@ def test_conv_dgrad_wgrad(ops, case):
 
 
 @pytest.mark.parametrize("mode,stride", [(0, 1), (0, 2), (1, 1)])
-@pytest.mark.parametrize("ih,iw", [(7, 7), (4, 4), (9, 5)])
-def test_pool3x3(ops, mode, stride, ih, iw):
+@pytest.mark.parametrize("ih,iw,n", [(7, 7, 6), (4, 4, 6), (9, 5, 6), (7, 7, 70), (4, 4, 70)])
+def test_pool3x3(ops, mode, stride, ih, iw, n):
+  """n = 70 takes the whole-map kernels of the per-ROI second-stage maps (n >= 64)."""
   rng = np.random.default_rng(17)
-  n, c = 6, 24
+  c = 24
   x = np.maximum(rng.standard_normal((n, ih, iw, c)), 0).astype(np.float32)  # ties at 0
   if mode == 0:
     want, want_arg = ref_ops.max_pool(x, 3, stride, "SAME")
@@ -182,6 +183,17 @@ def test_pool3x3(ops, mode, stride, ih, iw):
   dx = torch.zeros(n, ih, iw, c, device=DEV)
   ops.pool3x3_bwd(_t(dy), c, 0, arg, dx, c, 0, n, ih, iw, c, stride, mode, 0)
   np.testing.assert_allclose(_n(dx), want_dx, rtol=1e-5, atol=1e-6)
+  # channel slices of wider buffers (concat layout) + accumulate into an existing gradient
+  xw = torch.zeros(n, ih, iw, c + 8, device=DEV); xw[..., 4:4 + c] = _t(x)
+  yw = torch.full((n, oh, ow, c + 12), 7.0, device=DEV)
+  ops.pool3x3_fwd(xw, c + 8, 4, yw, c + 12, 8, arg, n, ih, iw, c, stride, mode)
+  np.testing.assert_allclose(_n(yw[..., 8:8 + c]), want, rtol=1e-6, atol=1e-6)
+  assert float(yw[..., :8].min()) == 7.0 and float(yw[..., 8 + c:].min()) == 7.0
+  dxw = torch.ones(n, ih, iw, c + 8, device=DEV)
+  dyw = torch.zeros(n, oh, ow, c + 12, device=DEV); dyw[..., 8:8 + c] = _t(dy)
+  ops.pool3x3_bwd(dyw, c + 12, 8, arg, dxw, c + 8, 4, n, ih, iw, c, stride, mode, 1)
+  np.testing.assert_allclose(_n(dxw[..., 4:4 + c]), want_dx + 1.0, rtol=1e-5, atol=1e-5)
+  assert float(dxw[..., :4].max()) == 1.0 and float(dxw[..., 4 + c:].min()) == 1.0
 
 
 def test_bn_relu_bwd(ops):
