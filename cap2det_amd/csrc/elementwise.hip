@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
     const float* __restrict__ dy, int lddy, int dyoff, const float* __restrict__ y, int ldy,
     int yoff, const float* __restrict__ scale, const float* __restrict__ beta,
     const float* __restrict__ gamma, float* __restrict__ dc, float* __restrict__ dbeta,
-    float* __restrict__ dgamma, int M, int c4n, int rows_per_block) {
+    float* __restrict__ dgamma, float* __restrict__ partials, int M, int c4n,
+    int rows_per_block) {
   constexpr int TY = 256 / TX;
   __shared__ float4 red[2][TY][TX];
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
     const float4 sc = *reinterpret_cast<const float4*>(scale + c);
     float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
     float4 be = make_float4(0.f, 0.f, 0.f, 0.f), ig = be;
-    if (dgamma) {
+    if (dgamma || (partials && gamma)) {
       be = *reinterpret_cast<const float4*>(beta + c);
       const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
       ig = make_float4(ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
@@ -362,6 +363,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
         const float4 b = red[0][k][tx], gq = red[1][k][tx];
         tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
         tg.x += gq.x; tg.y += gq.y; tg.z += gq.z; tg.w += gq.w;
+      }
+      if (partials) {
+        // [block][2][C]: summed in block order by bn_partials_reduce_batched (no atomics, so
+        // the beta/gamma gradients are bitwise reproducible)
+        float* pp = partials + (size_t)blockIdx.x * 2 * (c4n * 4) + c;
+        *reinterpret_cast<float4*>(pp) = tb;
+        *reinterpret_cast<float4*>(pp + c4n * 4) = tg;
       }
       if (dbeta) {
         atomicAdd(dbeta + c + 0, tb.x); atomicAdd(dbeta + c + 1, tb.y);
@@ -611,11 +619,81 @@ __global__ __launch_bounds__(256) void bn_fold_batched_kernel(
   out[d.shift + c] = vars[d.beta + c] - stats[d.mean + c] * s;
 }
 
+// Sums the per-block partial sums of bn_relu_bwd (partial form) into the flat gradient buffer.
+// One workgroup per (layer, 64-channel chunk): 16 float4 channel lanes x 16 block lanes.
+struct BnPartDesc { long long ws_off, dbeta_off, dgamma_off; int nblocks, c, begin, pad; };
+
+__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(
+    const BnPartDesc* __restrict__ desc, int num, const float* __restrict__ ws,
+    float* __restrict__ grads) {
+  __shared__ float4 red[2][16][16];
+  int lo = 0, hi = num - 1;          // last descriptor with begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const BnPartDesc d = desc[lo];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = ((blockIdx.x - d.begin) * 16 + tx) * 4;
+  const bool active = c < d.c;
+  float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+  if (active) {
+    const float* base = ws + d.ws_off + c;
+    const size_t bstride = (size_t)2 * d.c;
+    for (int b = ty; b < d.nblocks; b += 16) {
+      const float4 vb = *reinterpret_cast<const float4*>(base + b * bstride);
+      const float4 vg = *reinterpret_cast<const float4*>(base + b * bstride + d.c);
+      sb.x += vb.x; sb.y += vb.y; sb.z += vb.z; sb.w += vb.w;
+      sg.x += vg.x; sg.y += vg.y; sg.z += vg.z; sg.w += vg.w;
+    }
+  }
+  red[0][ty][tx] = sb;
+  red[1][ty][tx] = sg;
+  __syncthreads();
+  if (ty < 2 && active) {           // ty 0: beta, ty 1: gamma
+    const long long off = ty == 0 ? d.dbeta_off : d.dgamma_off;
+    if (off >= 0) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < 16; ++k) {
+        const float4 v = red[ty][k][tx];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      float* g = grads + off + c;
+      g[0] += t.x; g[1] += t.y; g[2] += t.z; g[3] += t.w;
+    }
+  }
+}
+
+inline int bn_rows_per_block(int rows) {
+  // ~1024 row blocks (4 per CU) with at least 32 rows each, a multiple of 32 rows
+  int rpb = (int)(((long long)rows + 1023) / 1024);
+  rpb = (rpb + 31) / 32 * 32;
+  return rpb < 32 ? 32 : rpb;
+}
+
 inline int grid_for(long long total) {
   long long b = (total + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+int launch_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ldy, int yoff,
+                       const float* scale, const float* beta, const float* gamma, float* dc,
+                       float* dbeta, float* dgamma, float* partials, int rows, int c,
+                       int rows_per_block, hipStream_t s) {
+  const int c4n = c / 4;
+  const int blocks = c2d_ceil_div(rows, rows_per_block);
+#define C2D_BNB(TX)                                                                          \
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<TX>), dim3(blocks), dim3(256), 0, s, dy, lddy, dyoff, \
+                     y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, partials, rows, c4n, \
+                     rows_per_block)
+  if (c4n <= 16) C2D_BNB(16);
+  else if (c4n <= 32) C2D_BNB(32);
+  else if (c4n <= 64) C2D_BNB(64);
+  else C2D_BNB(128);
+#undef C2D_BNB
+  return c2d_launch_status();
 }
 
 }  // namespace
@@ -680,19 +758,32 @@ extern "C" int c2d_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float
   C2D_CHECK_ARG(dy && y && scale && dc && rows > 0 && c > 0 && c % 4 == 0);
   C2D_CHECK_ARG(!dgamma || (beta && gamma));
   C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
-  const int c4n = c / 4;
-  const int rows_per_block = 128;
-  const int blocks = c2d_ceil_div(rows, rows_per_block);
-  hipStream_t s = (hipStream_t)stream;
-#define C2D_BNB(TX)                                                                          \
-  hipLaunchKernelGGL((bn_relu_bwd_kernel<TX>), dim3(blocks), dim3(256), 0, s, dy, lddy, dyoff, \
-                     y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, rows, c4n,        \
-                     rows_per_block)
-  if (c4n <= 16) C2D_BNB(16);
-  else if (c4n <= 32) C2D_BNB(32);
-  else if (c4n <= 64) C2D_BNB(64);
-  else C2D_BNB(128);
-#undef C2D_BNB
+  return launch_bn_relu_bwd(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma,
+                            nullptr, rows, c, 128, (hipStream_t)stream);
+}
+
+extern "C" int c2d_bn_relu_bwd_partial_blocks(int rows, int c) {
+  (void)c;
+  return rows > 0 ? c2d_ceil_div(rows, bn_rows_per_block(rows)) : 0;
+}
+
+extern "C" int c2d_bn_relu_bwd_partial(const float* dy, int lddy, int dyoff, const float* y,
+                                       int ldy, int yoff, const float* scale, const float* beta,
+                                       const float* gamma, float* dc, float* partials, int rows,
+                                       int c, void* stream) {
+  C2D_CHECK_ARG(dy && y && scale && dc && partials && rows > 0 && c > 0 && c % 4 == 0);
+  C2D_CHECK_ARG(!gamma || beta);
+  C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
+  return launch_bn_relu_bwd(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, nullptr,
+                            nullptr, partials, rows, c, bn_rows_per_block(rows),
+                            (hipStream_t)stream);
+}
+
+extern "C" int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks,
+                                              const float* ws, float* grads, void* stream) {
+  C2D_CHECK_ARG(desc && ws && grads && num > 0 && total_chunks > 0);
+  hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(total_chunks), dim3(256), 0,
+                     (hipStream_t)stream, (const BnPartDesc*)desc, num, ws, grads);
   return c2d_launch_status();
 }
 

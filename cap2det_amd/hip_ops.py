@@ -125,6 +125,20 @@ def bn_relu_bwd(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dg
             _p(gamma), _p(dc), _p(dbeta), _p(dgamma), rows, c, _stream())
 
 
+def bn_relu_bwd_partial_blocks(rows, c):
+  return int(_lib.load().c2d_bn_relu_bwd_partial_blocks(rows, c))
+
+
+def bn_relu_bwd_partial(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, partials, rows, c):
+  _lib.call("c2d_bn_relu_bwd_partial", _p(dy), lddy, dyoff, _p(y), ldy, yoff, _p(scale),
+            _p(beta), _p(gamma), _p(dc), _p(partials), rows, c, _stream())
+
+
+def bn_partials_reduce_batched(desc, num, total_chunks, ws, grads):
+  _lib.call("c2d_bn_partials_reduce_batched", _p(desc), num, total_chunks, _p(ws), _p(grads),
+            _stream())
+
+
 def col_sum(x, ldx, xoff, out, rows, ncols):
   _lib.call("c2d_col_sum", _p(x), ldx, xoff, _p(out), rows, ncols, _stream())
 

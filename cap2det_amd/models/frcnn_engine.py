@@ -415,6 +415,36 @@ class Net(object):
               brow = bst["n"] * bst["oh"] * bst["ow"]
               bst["gy"] = Ref(torch.empty(brow, bst["y"].c, device=dev), bst["y"].c, 0,
                               bst["y"].c)
+    # BatchNorm beta/gamma gradients: every trainable conv's bn_relu_bwd stores per-row-block
+    # partial sums into one workspace; one batched launch at the end of backward() adds them
+    # into the flat gradient buffer (atomic-free, bitwise reproducible).
+    import numpy as np
+    convs = []
+    for i in range(first_idx, len(steps)):
+      st = steps[i]
+      if st["kind"] == "conv":
+        convs.append(st)
+      elif st["kind"] == "block":
+        convs.extend(b for bsteps in st["branches"] for b in bsteps if b["kind"] == "conv")
+    ddt = np.dtype([("ws", "<i8"), ("dbeta", "<i8"), ("dgamma", "<i8"), ("nblocks", "<i4"),
+                    ("c", "<i4"), ("begin", "<i4"), ("pad", "<i4")])
+    recs, ws_size, chunks = [], 0, 0
+    voff = self.store.offset
+    for st in convs:
+      L = st["layer"]
+      if not L.trainable:
+        continue
+      rows = st["n"] * st["oh"] * st["ow"]
+      nb = ops.bn_relu_bwd_partial_blocks(rows, L.cout)
+      st["bn_part"] = (ws_size, nb * 2 * L.cout)
+      g = voff[L.name + "/BatchNorm/gamma"][0] if L.bn_scale else -1
+      recs.append((ws_size, voff[L.name + "/BatchNorm/beta"][0], g, nb, L.cout, chunks, 0))
+      ws_size += nb * 2 * L.cout
+      chunks += -(-L.cout // 64)
+    plan["bn_ws"] = torch.empty(max(ws_size, 4), device=dev)
+    plan["bn_desc"] = (torch.from_numpy(np.array(recs, dtype=ddt).view(np.uint8).copy()).to(dev)
+                       if recs else None)
+    plan["bn_num"], plan["bn_chunks"] = len(recs), chunks
     plan["bwd_ready"] = True
     plan["first_idx"] = first_idx
 
@@ -437,6 +467,9 @@ class Net(object):
         gx = dx_in
       x = st["x"] if st["x"] is not None else x_in
       self._bwd_step(plan, st, x, gx, False)
+    if plan["bn_num"]:
+      ops.bn_partials_reduce_batched(plan["bn_desc"], plan["bn_num"], plan["bn_chunks"],
+                                     plan["bn_ws"], self.store.grads)
 
   def _conv_bwd(self, plan, st, x, gx, accumulate, dc=None):
     """BN/ReLU backward -> dc, filter gradient, and (when gx is given) the input gradient."""
@@ -449,10 +482,15 @@ class Net(object):
     gamma = self.store.var.get(L.name + "/BatchNorm/gamma")
     beta = self.store.var[L.name + "/BatchNorm/beta"]
     tr = L.trainable
-    ops.bn_relu_bwd(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
-                    g[L.name + "/BatchNorm/beta"] if tr else None,
-                    g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
-                    rows, L.cout)
+    if tr and "bn_part" in st:
+      off, size = st["bn_part"]
+      ops.bn_relu_bwd_partial(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
+                              plan["bn_ws"][off:off + size], rows, L.cout)
+    else:
+      ops.bn_relu_bwd(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
+                      g[L.name + "/BatchNorm/beta"] if tr else None,
+                      g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
+                      rows, L.cout)
     if tr:
       ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
                      st["iw"], L.cin, L.cout, L.k, L.k, L.stride)

@@ -134,6 +134,22 @@ int c2d_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ld
                     const float* scale, const float* beta, const float* gamma, float* dc,
                     float* dbeta, float* dgamma, int rows, int c, void* stream);
 
+/* Atomic-free form of c2d_bn_relu_bwd for the training step: the same dc, but every row block
+ * stores its partial sums to partials[block][2][c] (beta sums, then gamma sums; the gamma half is
+ * zero when gamma is NULL) and ONE c2d_bn_partials_reduce_batched launch at the end of the
+ * backward pass adds them, in block order, into the flat gradient buffer — the BatchNorm
+ * gradients become bitwise reproducible and the kernel keeps >= 1000 row blocks in flight.
+ * c2d_bn_relu_bwd_partial_blocks(rows, c) = number of row blocks (size the workspace with it).
+ * desc: DEVICE array of struct { int64 ws_off, dbeta_off, dgamma_off (-1: none); int32 nblocks,
+ * c, chunk_begin, pad; } sorted by chunk_begin = running count of ceil(c/64) channel chunks;
+ * ws_off indexes `ws`, dbeta_off/dgamma_off index `grads` (floats). */
+int c2d_bn_relu_bwd_partial_blocks(int rows, int c);
+int c2d_bn_relu_bwd_partial(const float* dy, int lddy, int dyoff, const float* y, int ldy,
+                            int yoff, const float* scale, const float* beta, const float* gamma,
+                            float* dc, float* partials, int rows, int c, void* stream);
+int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks, const float* ws,
+                                   float* grads, void* stream);
+
 /* out[j] += sum_rows x[row][xoff+j]  (bias gradients). */
 int c2d_col_sum(const float* x, int ldx, int xoff, float* out, int rows, int ncols,
                 void* stream);

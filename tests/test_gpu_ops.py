@@ -216,6 +216,49 @@ def test_bn_relu_bwd(ops):
                              rtol=1e-4, atol=1e-3)
 
 
+
+@pytest.mark.parametrize("rows,c,with_gamma", [(1000, 96, True), (70001, 352, True), (3136, 128, False)])
+def test_bn_relu_bwd_partial_form_is_reproducible(ops, rows, c, with_gamma):
+  """Atomic-free form used by the training step: per-row-block partial sums + ONE batched
+  reduce into the flat gradient buffer (two layers share the launch here)."""
+  rng = np.random.default_rng(23)
+  y = np.maximum(rng.standard_normal((rows, c)), 0).astype(np.float32)
+  dy = rng.standard_normal((rows, c)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+  scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  dz = (dy * (y > 0)).astype(np.float64)
+  nb = ops.bn_relu_bwd_partial_blocks(rows, c)
+  assert nb >= 1 and (rows < 32 * 1024 or nb >= 512)
+  ddt = np.dtype([("ws", "<i8"), ("dbeta", "<i8"), ("dgamma", "<i8"), ("nblocks", "<i4"),
+                  ("c", "<i4"), ("begin", "<i4"), ("pad", "<i4")])
+  chunks = -(-c // 64)
+  # layer 0 and layer 1 are the same tensors: grads = [dbeta0 | dgamma0 | dbeta1 | dgamma1]
+  recs = np.array([(0, 0, c if with_gamma else -1, nb, c, 0, 0),
+                   (nb * 2 * c, 2 * c, 3 * c if with_gamma else -1, nb, c, chunks, 0)], dtype=ddt)
+  desc = torch.from_numpy(recs.view(np.uint8).copy()).to(DEV)
+  outs = []
+  for _ in range(2):
+    ws = torch.full((2 * nb * 2 * c,), float("nan"), device=DEV)
+    grads = torch.ones(4 * c, device=DEV)          # the reduce ACCUMULATES into the gradients
+    dc = torch.empty(rows, c, device=DEV)
+    for layer in range(2):
+      ops.bn_relu_bwd_partial(_t(dy), c, 0, _t(y), c, 0, _t(scale), _t(beta),
+                              _t(gamma) if with_gamma else None, dc,
+                              ws[layer * nb * 2 * c:(layer + 1) * nb * 2 * c], rows, c)
+    ops.bn_partials_reduce_batched(desc, 2, 2 * chunks, ws, grads)
+    outs.append(_n(grads))
+    np.testing.assert_allclose(_n(dc), (dz * scale).astype(np.float32), rtol=1e-6, atol=1e-6)
+  np.testing.assert_array_equal(outs[0], outs[1])              # bitwise reproducible
+  tol = dict(rtol=1e-4, atol=1e-5 * np.sqrt(rows) + 1e-4)
+  for layer in range(2):
+    np.testing.assert_allclose(outs[0][2 * layer * c:(2 * layer + 1) * c] - 1.0, dz.sum(0), **tol)
+    if with_gamma:
+      np.testing.assert_allclose(outs[0][(2 * layer + 1) * c:(2 * layer + 2) * c] - 1.0,
+                                 (dz * (y - beta) / gamma).sum(0), **tol)
+    else:
+      np.testing.assert_array_equal(outs[0][(2 * layer + 1) * c:(2 * layer + 2) * c], 1.0)
+
 def test_spatial_mean_dropout(ops):
   rng = np.random.default_rng(23)
   rows, sp, c = 50, 16, 64
