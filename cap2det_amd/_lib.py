@@ -13,7 +13,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcap2det_hip.so")
+# C2D_LIB: tools-only override (the diagnostic trace build); the product always loads the in-tree
+# library.
+LIB_PATH = os.environ.get("C2D_LIB") or os.path.join(_HERE, "csrc", "libcap2det_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cap2det_hip.h")
 
 _lib = None

@@ -18,6 +18,7 @@
 // lets each lane fetch its 16 k-values with four ds_read_b128).  fp32 in, fp32 accumulate:
 // bit-for-bit an fmaf chain, no reduced precision anywhere.
 #include "c2d_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,6 +43,8 @@ struct ConvGeom {
   int sub, y0, x0; // mode 1 only: stride-2 dgrad is split into the 4 parity classes of the
                    // input pixel, each of which sees only the taps of matching parity
   int ky0, kx0, kstep, nky, nkx;  // tap subset: ky = ky0 + kstep*t, t < nky (same for kx)
+  int nimg;        // images (ROIs) in the batch
+  int pm;          // 1: PIXEL-MAJOR row order (small maps, see decompose<true>)
 };
 
 // Row m of the iteration space -> (image, y, x).  Exact for m * d < 2^40 (always here).
@@ -50,8 +53,24 @@ struct RowPos {
   bool valid;
 };
 
+// PM (pixel-major, used for the 3x3 convolutions over the tiny per-ROI maps): rows are ordered
+// (group of 32 images, pixel, image in group), m = ((grp * rh*rw) + pixel) * 32 + r, so every
+// aligned 32-row MFMA tile holds ONE pixel position of 32 images.  Whether a tap falls into the
+// SAME padding is then uniform over the tile and its MFMAs are skipped instead of multiplying
+// zeros (4x4 map: 100 of 144 (pixel, tap) pairs are real; 7x7: 361 of 441).
+template <bool PM = false>
 __device__ __forceinline__ RowPos decompose(int m, int M, const ConvGeom& g) {
   RowPos p;
+  if (PM) {
+    const unsigned t = (unsigned)m >> 5, r = (unsigned)m & 31u;
+    const unsigned grp = (unsigned)(((unsigned long long)t * g.magic_hw) >> 40);
+    const unsigned px = t - grp * (unsigned)(g.rh * g.rw);
+    p.img = (int)(grp * 32u + r);
+    p.valid = m < M && p.img < g.nimg;
+    p.y = (int)(((unsigned long long)px * g.magic_w) >> 40);
+    p.x = (int)px - p.y * g.rw;
+    return p;
+  }
   p.valid = m < M;
   const unsigned mm = p.valid ? (unsigned)m : 0u;
   p.img = (int)(((unsigned long long)mm * g.magic_hw) >> 40);
@@ -84,6 +103,40 @@ __device__ __forceinline__ int src_row(const ConvGeom& g, const RowPos& p, int k
   }
 }
 
+// Does tap (ky,kx) of a row at pixel (y,x) of the row space read a real pixel?  (the image-
+// independent part of src_row)
+template <int MODE>
+__host__ __device__ __forceinline__ bool tap_ok(const ConvGeom& g, int y, int x, int ky, int kx) {
+  if (MODE == 0) {
+    const int iy = y * g.stride - g.pad_t + ky;
+    const int ix = x * g.stride - g.pad_l + kx;
+    return iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+  } else {
+    const int ty = y * g.sub + g.y0 + g.pad_t - ky;
+    const int tx = x * g.sub + g.x0 + g.pad_l - kx;
+    const int sh = g.stride - 1;
+    return ty >= 0 && tx >= 0 && ((ty | tx) & sh) == 0 && (ty >> sh) < g.oh && (tx >> sh) < g.ow;
+  }
+}
+
+// Raw buffer descriptor over [p, p + bytes) built from wave-uniform inputs (readfirstlane makes
+// that provable to the compiler: no waterfall loop around the loads, cdna_hip_programming.md T20).
+constexpr unsigned OOB_OFFSET = 0x7FFFFF00u;   // >= any buffer size here: the load returns zeros
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long long bytes) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  const unsigned nb = __builtin_amdgcn_readfirstlane(
+      (unsigned)(bytes < (long long)OOB_OFFSET ? bytes : (long long)OOB_OFFSET));
+  return __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
 __device__ __forceinline__ f32x4 mask4(f32x4 v, bool keep) {
   v.x = keep ? v.x : 0.0f; v.y = keep ? v.y : 0.0f;
   v.z = keep ? v.z : 0.0f; v.w = keep ? v.w : 0.0f;
@@ -92,6 +145,7 @@ __device__ __forceinline__ f32x4 mask4(f32x4 v, bool keep) {
 
 struct IgemmArgs {
   const float* A; int lda; int a_off;
+  long long a_rows;         // rows of the A operand's buffer (for the buffer-load range check)
   const float* Bt;          // [taps][N][K]
   float* C; int ldc; int c_off;
   const float* scale;       // [N] or null (=1)
@@ -105,10 +159,17 @@ struct IgemmArgs {
   // Inception block whose branches all start with a 1x1 convolution of the same input.
   int nseg;
   const float* segA[4]; const float* segB[4];
-  int seg_lda[4], seg_off[4], segK[4];
+  int seg_lda[4], seg_off[4], segK[4];   // (every segment's A has a_rows rows)
   int total_slabs;
   ConvGeom g;
+#ifdef C2D_TRACE
+  unsigned long long* trace;   // diagnostic build only: 8 x u64 per block (tools/trace_igemm.py)
+#endif
 };
+
+#ifdef C2D_TRACE
+unsigned long long* g_trace = nullptr;
+#endif
 
 // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): consecutive logical tiles
 // run on one XCD, and the n-tiles of one m-tile are consecutive, so the A rows they share are
@@ -119,14 +180,41 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+// Stream-K plan (host-computed, passed by value).  The iteration space of a launch is the
+// concatenation, in tile order (m-tile major, n-tile minor), of every tile's slab iterations
+// (cost = visited taps x K slabs; PM tiles on the map border visit fewer taps).  `grid`
+// persistent workgroups each take `share` consecutive iterations, so all of them finish together
+// whatever the tile count is: no partial last round of tiles, no idle CUs at the end (the
+// per-block timeline of the one-tile-per-block form showed 25-35 % of a launch spent in such a
+// tail).  A tile cut by a share boundary is finished by whichever of its pieces arrives last
+// (cdna_hip_programming.md §5, in-launch split-K recipe): every piece stores its fp32
+// accumulators to its own slab, releases, and draws a ticket on the tile's counter; the piece
+// that draws the last ticket acquires, sums all slabs IN PIECE ORDER (bitwise reproducible) and
+// runs the epilogue.  Nobody ever waits, so no residency or dispatch-order assumption is made.
+constexpr int SK_MAX_PERIOD = 64;
+struct SkPlan {
+  int enabled;
+  int period;                       // block rows after which the tile costs repeat
+  int cost[SK_MAX_PERIOD];          // slab iterations of a tile in block row r (mod period)
+  int prefix[SK_MAX_PERIOD + 1];    // prefix[r] = sum_{q<r} cost[q]; prefix[period] = period sum
+  int total;                        // all iterations of the launch
+  int share;                        // ceil(total / grid)
+  float* partials;                  // [grid][2][BM*BN]: slot 0 = piece that starts inside a
+                                    // tile, slot 1 = piece that starts a tile it does not finish
+  int* counters;                    // [tiles]: zero on entry, re-zeroed by the reducing piece
+};
+
+struct IgemmSkArgs {
+  IgemmArgs a;
+  SkPlan sk;
+};
+
 // Second __launch_bounds__ argument = waves per SIMD the register allocator must leave room
 // for: the 128x128 config sits right at the 168-register step (3 waves/SIMD); losing it cost
 // 25-35 % on the layers with three n-tiles.
-template <int MODE, int WM, int WN, int MT, int NT, int BKT>
-__global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3)) void igemm_nt_kernel(IgemmArgs a) {
-  // BKT = floats of K per slab: 32 for the big tiles; 128 for the 64x64 small-problem tile, whose
-  // grids (16-126 workgroups) leave one block per CU, so a deeper slab is the only way to keep
-  // enough bytes in flight to cover the global-load latency (measured ~1 us per 32-deep slab).
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM, bool SK>
+__device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk) {
+  // BKT = floats of K per slab (one 128-B line per row at 32).
   constexpr int LDS_STRIDE = BKT + 4;
   constexpr int LPR = BKT / 4;                  // lanes per row (float4 each)
   constexpr int BM = WM * MT * 32;
@@ -142,207 +230,451 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3))
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int tile = xcd_remap(blockIdx.x, a.m_tiles * a.n_tiles);
-  const int m0 = (tile / a.n_tiles) * BM;
-  const int n0 = (tile % a.n_tiles) * BN;
-
-  // loader coordinates
   const int q4 = (tid % LPR) * 4;  // float offset inside the k slab
-  RowPos apos[A_LOADS];
-  int arow_l[A_LOADS];
-#pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) {
-    arow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
-    apos[i] = decompose(m0 + arow_l[i], a.M, a.g);
-  }
-  int brow_l[B_LOADS], brow_off[B_LOADS];
-#pragma unroll
-  for (int i = 0; i < B_LOADS; ++i) {
-    brow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
-    brow_off[i] = min(n0 + brow_l[i], a.N - 1);   // columns >= N are never stored: clamp only
-  }
-  const float* abase = a.A + a.a_off + q4;
-  int lda = a.lda, Kc = a.K, sgi = 0;   // current segment (wave-uniform)
+#ifdef C2D_TRACE
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime();
+  int tr_iters = 0;
+  unsigned long long tr_seg[5] = {0, 0, 0, 0, 0}, tr_a, tr_b;
+#define C2D_STAMP(v)                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");            \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define C2D_STAMP(v)
+#endif
 
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  bool tile_on[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-      tile_on[i][j] = (m0 + (wm * MT + i) * 32 < a.M) && (n0 + (wn * NT + j) * 32 < a.N);
+  // ---- work range of this workgroup ---------------------------------------------------------
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);   // logical block: consecutive ones share an XCD
+  int mt, nt, s0 = 0, remaining = 1;
+  if (SK) {
+    const int lo = min(lb * sk.share, sk.total);
+    remaining = min(lo + sk.share, sk.total) - lo;
+    const int perlen = a.n_tiles * sk.prefix[sk.period];
+    const int per = lo / perlen;
+    int rem = lo - per * perlen;
+    int r = 0;
+    while (r + 1 < sk.period && a.n_tiles * sk.prefix[r + 1] <= rem) ++r;
+    rem -= a.n_tiles * sk.prefix[r];
+    nt = rem / sk.cost[r];
+    s0 = rem - nt * sk.cost[r];
+    mt = per * sk.period + r;
+  } else {
+    mt = lb / a.n_tiles;
+    nt = lb - mt * a.n_tiles;
+  }
 
   const int ntaps = a.g.nky * a.g.nkx;
-  int total = ntaps * ((a.K + BKT - 1) / BKT);
-  if (a.nseg > 1) {
-    total = 0;
-    for (int sg = 0; sg < a.nseg; ++sg) total += (a.segK[sg] + BKT - 1) / BKT;
-  }
+  const int kslabs = (a.K + BKT - 1) / BKT;
   const size_t tap_stride = (size_t)a.N * a.K;
-  (void)ntaps;
 
-  f32x4 ra[A_LOADS], rb[B_LOADS];
-  unsigned amask = 0;       // bit i: A load i hit a real pixel (else SAME-padding zero)
-  int ky = a.g.ky0, kx = a.g.kx0, kc = 0;   // wave-uniform slab cursor
+  while (remaining > 0) {
+    const int m0 = mt * BM, n0 = nt * BN;
 
-  // Row pointers of the current tap / segment.  They change only when the cursor moves to the
-  // next tap (every K/BKT slabs; never for a 1x1 convolution), so the per-slab address work is
-  // one add per load instead of the whole gather arithmetic.
-  int aoff[A_LOADS], boff[B_LOADS];   // 32-bit float offsets (operands are < 2^31 floats)
-  const float* bbase = a.Bt + q4;
-  unsigned rowok = 0;
+    // loader coordinates
+    RowPos apos[A_LOADS];
+    int arow_l[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      arow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
+      apos[i] = decompose<PM>(m0 + arow_l[i], a.M, a.g);
+    }
+    int brow_l[B_LOADS], brow_off[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      brow_l[i] = (tid / LPR) + i * ROWS_PER_PASS;
+      brow_off[i] = min(n0 + brow_l[i], a.N - 1);   // columns >= N are never stored: clamp only
+    }
+    // Operands are read with raw buffer loads: the address is descriptor base (SGPRs) + a per-lane
+    // byte offset that changes only with the tap + a scalar byte offset that walks K, so a slab
+    // costs NO vector ALU work for addresses, and SAME-padding rows / lanes past the end of K
+    // simply carry an out-of-range offset for which the hardware returns 0.0 (no v_cndmask).
+    // That matters: the SIMD issues vector ALU instructions of co-resident waves very slowly
+    // while fp32 MFMAs (64 cycles each) occupy it — the address + mask work of the flat-load
+    // form took as long as the MFMAs themselves (per-phase stamps, tools/trace_igemm.py).
+    int lda = a.lda, Kc = a.K, sgi = 0;   // current segment (wave-uniform)
+    __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a.a_off, (a.a_rows * a.lda - a.a_off) * 4);
+    __amdgpu_buffer_rsrc_t rsB = make_rsrc(
+        a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 4);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // bit i*NT+j: 32x32 tile (i,j) of this wave lies inside M x N (scalar: all inputs uniform)
+    unsigned tile_bits = 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if ((m0 + (wm * MT + i) * 32 < a.M) && (n0 + (wn * NT + j) * 32 < a.N))
+          tile_bits |= 1u << (i * NT + j);
+    tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
+
+    // Taps this tile iterates over (bit t <-> ky = ky0 + kstep*(t / nkx), kx = kx0 + kstep*(t %
+    // nkx)).  PM: a tap that is SAME padding for every 32-row tile of the block is not visited at
+    // all (no loads, no barriers), and within a visited tap each wave skips the MFMAs of its
+    // padding tiles.
+    unsigned long long tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1ull);
+    int wy[MT], wx[MT];   // PM: pixel of the wave's i-th row tile
+    if (PM) {
+      tapmask = 0;
+      const int hw = a.g.rh * a.g.rw;
+#pragma unroll
+      for (int tb = 0; tb < BM / 32; ++tb) {
+        const unsigned t = (unsigned)(m0 >> 5) + tb;
+        const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
+        const unsigned px = t - grp * (unsigned)hw;
+        const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
+        const int x = (int)px - y * a.g.rw;
+        if (tb / MT == wm) { wy[tb % MT] = y; wx[tb % MT] = x; }
+        for (int tp = 0; tp < ntaps; ++tp) {
+          const int ty_ = tp / a.g.nkx;
+          if (tap_ok<MODE>(a.g, y, x, a.g.ky0 + a.g.kstep * ty_,
+                           a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx)))
+            tapmask |= 1ull << tp;
+        }
+      }
+    }
+    int cost = __builtin_popcountll(tapmask) * kslabs;   // slab iterations of the whole tile
+    if (a.nseg > 1) cost = a.total_slabs;
+    const int cnt = SK ? min(cost - s0, remaining) : cost;   // ... of this piece
+    const bool whole = !SK || cnt == cost;
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    int ky = a.g.ky0, kx = a.g.kx0, kc = 0;   // wave-uniform slab cursor
+    unsigned long long taps_left = tapmask;
+    // bit i: the tap of the slab being LOADED (tv_load) / being MULTIPLIED (tv_mma, one slab
+    // behind) is real for row tile i of this wave
+    unsigned tv_load = ~0u, tv_mma = ~0u;
+    if (SK && s0 > 0) {       // the piece starts inside the tile: move the cursor to slab s0
+      if (a.nseg > 1) {
+        int sl = s0;
+        while (sl >= (a.segK[sgi] + BKT - 1) / BKT) { sl -= (a.segK[sgi] + BKT - 1) / BKT; ++sgi; }
+        kc = sl * BKT;
+        lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
+        rsA = make_rsrc(a.segA[sgi] + a.seg_off[sgi], (a.a_rows * lda - a.seg_off[sgi]) * 4);
+        rsB = make_rsrc(a.segB[sgi], (long long)a.N * Kc * 4);
+      } else {
+        const int tskip = s0 / kslabs;
+        kc = (s0 - tskip * kslabs) * BKT;
+        for (int q = 0; q < tskip; ++q) taps_left &= taps_left - 1ull;
+      }
+    }
+
+    // Row pointers of the current tap / segment.  They change only when the cursor moves to the
+    // next tap (every K/BKT slabs; never for a 1x1 convolution), so the per-slab address work is
+    // one add per load instead of the whole gather arithmetic.
+    unsigned aoff[A_LOADS], boff[B_LOADS];   // per-lane BYTE offsets (operands are < 2 GB)
 #define C2D_RETAP()                                                                            \
   {                                                                                            \
-    rowok = 0;                                                                                 \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                      \
       const int sr = src_row<MODE>(a.g, apos[i], ky, kx);                                      \
-      rowok |= (sr >= 0 ? 1u : 0u) << i;                                                       \
-      aoff[i] = max(sr, 0) * lda;                                                              \
+      aoff[i] = sr >= 0 ? (unsigned)(sr * lda + q4) * 4u : OOB_OFFSET;                         \
     }                                                                                          \
     const int toff = (ky * a.g.kw + kx) * (int)tap_stride;                                     \
-    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) boff[i] = brow_off[i] * Kc + toff;     \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
+        boff[i] = (unsigned)(brow_off[i] * Kc + toff + q4) * 4u;                               \
+    if (PM) {                                                                                  \
+      tv_load = 0;                                                                             \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
+          tv_load |= (tap_ok<MODE>(a.g, wy[i], wx[i], ky, kx) ? 1u : 0u) << i;                 \
+    }                                                                                          \
+  }
+#define C2D_TAP_FROM_MASK()                                                                    \
+  {                                                                                            \
+    const int tp = taps_left ? __builtin_ctzll(taps_left) : 0;                                 \
+    const int ty_ = tp / a.g.nkx;                                                              \
+    ky = a.g.ky0 + a.g.kstep * ty_;                                                            \
+    kx = a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx);                                           \
   }
 #define C2D_ISSUE()                                                                            \
   {                                                                                            \
-    const int koff = min(kc, Kc - 4 - q4);                                                     \
-    amask = (kc + q4 < Kc) ? rowok : 0u;                                                       \
-    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
-        ra[i] = *reinterpret_cast<const f32x4*>(abase + (aoff[i] + koff));                     \
-    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        rb[i] = *reinterpret_cast<const f32x4*>(bbase + (boff[i] + koff));                     \
+    const int soff = kc * 4;                                                                   \
+    if (kc + BKT <= Kc) {      /* whole slab inside K: offsets as they stand */                \
+      _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) ra[i] = buf_load4(rsA, aoff[i], soff); \
+      _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) rb[i] = buf_load4(rsB, boff[i], soff); \
+    } else {                   /* last slab of a K that is not a multiple of BKT */            \
+      const bool in = kc + q4 < Kc;                                                            \
+      _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                      \
+          ra[i] = buf_load4(rsA, in ? aoff[i] : OOB_OFFSET, soff);                             \
+      _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                      \
+          rb[i] = buf_load4(rsB, in ? boff[i] : OOB_OFFSET, soff);                             \
+    }                                                                                          \
   }
 
-  // Prologue: loads of slab 0.  Inside the loop the loads of slab it+1 are issued
-  // unconditionally right after the barrier (the last iteration harmlessly re-loads the last
-  // slab) so that the loop body is straight-line code and the loads fly under the MFMAs.
-  // K is a multiple of 16, not necessarily of BKT: lanes past the end of the last slab re-read
-  // the row's last float4 (in bounds) and contribute zeros through the A mask.
-  if (total > 0) {   // (a stride-2 parity class can have no tap at all: it just stores zeros)
-    C2D_RETAP();
-    C2D_ISSUE();
-  }
-  for (int it = 0; it < total; ++it) {
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i)
-      *reinterpret_cast<f32x4*>(&As[arow_l[i] * LDS_STRIDE + q4]) =
-          mask4(ra[i], (amask >> i) & 1u);
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i)
-      *reinterpret_cast<f32x4*>(&Bs[brow_l[i] * LDS_STRIDE + q4]) = rb[i];
-    __syncthreads();
-    {
-      // advance the wave-uniform cursor (saturating at the last slab)
-      if (it + 1 < total) {
-        kc += BKT;
-        if (kc >= Kc) {
-          kc = 0;
-          if (a.nseg > 1) {          // next (A, Bt) segment of a multi-segment 1x1 GEMM
-            ++sgi;
-            lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
-            abase = a.segA[sgi] + a.seg_off[sgi] + q4;
-            bbase = a.segB[sgi] + q4;
-          } else {
-            kx += a.g.kstep;
-            if (kx >= a.g.kw) { kx = a.g.kx0; ky += a.g.kstep; }
-          }
-          C2D_RETAP();
-        }
-      }
+    // Prologue: loads of the first slab.  Inside the loop the loads of slab it+1 are issued
+    // unconditionally right after the barrier (the last iteration harmlessly re-loads the last
+    // slab) so that the loop body is straight-line code and the loads fly under the MFMAs.
+    // K is a multiple of 16, not necessarily of BKT: lanes past the end of the last slab re-read
+    // the row's last float4 (in bounds) and contribute zeros through the A mask.
+    if (cnt > 0) {   // (a stride-2 parity class can have no tap at all: it just stores zeros)
+      C2D_TAP_FROM_MASK();
+      C2D_RETAP();
       C2D_ISSUE();
     }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < cnt; ++it) {
+      if (SK) {
+        // The SIMD arbitrates its matrix pipe by priority, then AGE: with static priorities the
+        // oldest of the co-resident workgroups runs at full speed and the youngest starves, so
+        // equal shares finish up to 70 % apart (per-block timeline).  Rotating the priority
+        // with the slab index gives every co-resident workgroup the same share of the pipe.
+        switch (((blockIdx.x >> 8) + it) & 3) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
+      }
+      C2D_STAMP(tr_a)
+      tv_mma = tv_load;   // validity of the slab now in registers (to be staged + multiplied)
+      // tiles beyond M / N or (PM) in the SAME padding of this tap cost no MFMA time
+      unsigned onbits = tile_bits;
+      if (PM) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          if (!((tv_mma >> i) & 1u)) onbits &= ~(((1u << NT) - 1u) << (i * NT));
+        onbits = __builtin_amdgcn_readfirstlane(onbits);
+      }
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+        *reinterpret_cast<f32x4*>(&As[arow_l[i] * LDS_STRIDE + q4]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i)
+        *reinterpret_cast<f32x4*>(&Bs[brow_l[i] * LDS_STRIDE + q4]) = rb[i];
+#ifdef C2D_TRACE
+      C2D_STAMP(tr_b) tr_seg[0] += tr_b - tr_a;    // wait for the loads + LDS stores
+#endif
+      __syncthreads();
+#ifdef C2D_TRACE
+      C2D_STAMP(tr_a) tr_seg[1] += tr_a - tr_b;    // barrier 1
+#endif
+      {
+        // advance the wave-uniform cursor (saturating at the last slab)
+        if (it + 1 < cnt) {
+          kc += BKT;
+          if (kc >= Kc) {
+            kc = 0;
+            if (a.nseg > 1) {          // next (A, Bt) segment of a multi-segment 1x1 GEMM
+              ++sgi;
+              lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
+              rsA = make_rsrc(a.segA[sgi] + a.seg_off[sgi], (a.a_rows * lda - a.seg_off[sgi]) * 4);
+              rsB = make_rsrc(a.segB[sgi], (long long)a.N * Kc * 4);
+            } else {
+              taps_left &= taps_left - 1ull;   // next tap that is real for some tile of the block
+              C2D_TAP_FROM_MASK();
+            }
+            C2D_RETAP();
+          }
+        }
+        C2D_ISSUE();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef C2D_TRACE
+      C2D_STAMP(tr_b) tr_seg[2] += tr_b - tr_a;    // cursor + issue of the next slab's loads
+#endif
 
 #pragma unroll
-    for (int half = 0; half < BKT / 16; ++half) {
-      float af[MT][8], bf[NT][8];
+      for (int half = 0; half < BKT / 16; ++half) {
+        float af[MT][8], bf[NT][8];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
-        af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
-        af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
-      }
+        for (int i = 0; i < MT; ++i) {
+          const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
+          af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+          af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+        }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
-        bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
-        bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
+        for (int j = 0; j < NT; ++j) {
+          const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
+          bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
+          bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+        }
+        // one scalar branch per 32x32 tile (8 chained MFMAs each: the dependent-accumulator
+        // latency of v_mfma_f32_32x32x2_f32 equals its issue interval, so a chain does not stall)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            if (tile_on[i][j])   // wave-uniform: 32x32 tiles beyond M / N cost no MFMA time
-              acc[i][j] =
-                  __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            if ((onbits >> (i * NT + j)) & 1u) {
+#pragma unroll
+              for (int s = 0; s < 8; ++s)
+                acc[i][j] =
+                    __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
+      }
+#ifdef C2D_TRACE
+      C2D_STAMP(tr_a) tr_seg[3] += tr_a - tr_b;    // fragment reads + MFMA issue
+#endif
+      __syncthreads();
+#ifdef C2D_TRACE
+      C2D_STAMP(tr_b) tr_seg[4] += tr_b - tr_a;    // barrier 2
+#endif
     }
-    __syncthreads();
-  }
-
 #undef C2D_RETAP
 #undef C2D_ISSUE
-  // Epilogue.  C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5),
-  // i.e. 4 B per lane per store.  Each wave transposes 32-row strips through its private slice
-  // of the (now idle) staging LDS so that the global stores are 16 B per lane on contiguous
-  // 128*NT-byte row segments (4x fewer store instructions, cdna_hip_programming.md T21).
-  constexpr int SCOLS = NT * 32;
-  constexpr int SSTR = SCOLS + 4;
-  static_assert(WM * WN * 32 * SSTR <= (BM + BN) * LDS_STRIDE, "epilogue staging exceeds LDS");
-  float* stage = smem + wave * (32 * SSTR);   // (the K loop ended with a block barrier)
-  constexpr int C4 = SCOLS / 4;          // float4 per strip row
-  constexpr int RPP = 64 / C4;           // rows per pass over the strip
-  const int ec4 = lane % C4, er = lane / C4;
-  const int ncol = n0 + wn * SCOLS + ec4 * 4;
-  f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
-  const bool ncol_ok = ncol < a.N;       // N is a multiple of 4
-  if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
-  if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+#undef C2D_TAP_FROM_MASK
+#ifdef C2D_TRACE
+    tr_iters += cnt;
+#endif
+
+    bool finish = true;   // does this workgroup run the tile's epilogue?
+    if (SK && !whole) {
+      // ---- a piece of a tile: publish the accumulators, the last arriver reduces --------------
+      const int per = mt / sk.period, r = mt - per * sk.period;
+      const int tbeg = a.n_tiles * (per * sk.prefix[sk.period] + sk.prefix[r]) + nt * sk.cost[r];
+      const int first_b = tbeg / sk.share;
+      const int pieces = (tbeg + cost - 1) / sk.share - first_b + 1;
+      float* mine = sk.partials + ((size_t)lb * 2 + (s0 > 0 ? 0 : 1)) * (size_t)(BM * BN);
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int pass = 0; pass < 32 / RPP; ++pass) {
-      const int row = pass * RPP + er;
-      const int m = m0 + (wm * MT + i) * 32 + row;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
-      if (m < a.M && ncol_ok) {
-        v = v * esc + esh;
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          for (int rq = 0; rq < 4; ++rq) {
+            f32x4 v = {acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2],
+                       acc[i][j][4 * rq + 3]};
+            *reinterpret_cast<f32x4*>(mine + ((size_t)(((i * NT + j) * 4 + rq) * NTHREADS + tid)) * 4) = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* cntp = sk.counters + (mt * a.n_tiles + nt);
+        const int old = __hip_atomic_fetch_add(cntp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == pieces - 1;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(cntp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
         }
-        int drow = m;
-        if (MODE == 1 && a.g.sub > 1) {   // scattered rows of a parity class
-          const RowPos p = decompose(m, a.M, a.g);
-          drow = (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw + p.x * a.g.sub + a.g.x0;
+        reinterpret_cast<volatile int*>(smem)[0] = last;
+      }
+      __syncthreads();
+      finish = reinterpret_cast<volatile int*>(smem)[0] != 0;
+      __syncthreads();   // smem is reused below / by the next piece
+      if (finish) {
+        // sum every piece's slab in piece order (own one included: fixed order, reproducible)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) acc[i][j][r2] = 0.0f;
+        for (int pc = 0; pc < pieces; ++pc) {
+          const float* src = sk.partials + ((size_t)(first_b + pc) * 2 + (pc == 0 ? 1 : 0)) * (size_t)(BM * BN);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(
+                    src + ((size_t)(((i * NT + j) * 4 + rq) * NTHREADS + tid)) * 4);
+                acc[i][j][4 * rq] += v.x; acc[i][j][4 * rq + 1] += v.y;
+                acc[i][j][4 * rq + 2] += v.z; acc[i][j][4 * rq + 3] += v.w;
+              }
         }
-        f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
-        if (a.accumulate) v += *dst;
-        *dst = v;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+
+    if (finish) {
+      // Epilogue.  C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5),
+      // i.e. 4 B per lane per store.  Each wave transposes 32-row strips through its private
+      // slice of the (now idle) staging LDS so that the global stores are 16 B per lane on
+      // contiguous 128*NT-byte row segments (4x fewer store instructions, T21).
+      constexpr int SCOLS = NT * 32;
+      constexpr int SSTR = SCOLS + 4;
+      static_assert(WM * WN * 32 * SSTR <= (BM + BN) * LDS_STRIDE, "epilogue staging exceeds LDS");
+      float* stage = smem + wave * (32 * SSTR);   // (the K loop ended with a block barrier)
+      constexpr int C4 = SCOLS / 4;          // float4 per strip row
+      constexpr int RPP = 64 / C4;           // rows per pass over the strip
+      const int ec4 = lane % C4, er = lane / C4;
+      const int ncol = n0 + wn * SCOLS + ec4 * 4;
+      f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+      const bool ncol_ok = ncol < a.N;       // N is a multiple of 4
+      if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
+      if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; ++pass) {
+          const int row = pass * RPP + er;
+          const int m = m0 + (wm * MT + i) * 32 + row;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
+          bool row_ok = m < a.M;
+          int drow = m;
+          if (PM || (MODE == 1 && a.g.sub > 1)) {   // permuted rows / rows of a parity class
+            const RowPos p = decompose<PM>(m, a.M, a.g);
+            row_ok = p.valid;
+            drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
+                             : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
+                                   p.x * a.g.sub + a.g.x0;
+          }
+          if (row_ok && ncol_ok) {
+            v = v * esc + esh;
+            if (a.relu) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
+            if (a.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+
+    if (!SK) break;
+    __syncthreads();      // the epilogue's LDS strips must be drained before the next piece stages
+    remaining -= cnt;
+    s0 = 0;
+    if (++nt == a.n_tiles) { nt = 0; ++mt; }
   }
+#ifdef C2D_TRACE
+  if (a.trace && tid == 0) {
+    unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
+    t[0] = tr_t0; t[1] = __builtin_amdgcn_s_memrealtime();
+    t[2] = tr_c0; t[3] = __builtin_amdgcn_s_memtime();
+    t[4] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |   // HW_REG_XCC_ID
+           (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));                         // HW_REG_HW_ID
+    t[5] = (unsigned long long)lb; t[6] = (unsigned long long)tr_iters; t[7] = 0;
+  }
+  if (a.trace && lane == 0) {   // per-wave phase sums (shader cycles) behind the block records
+    unsigned long long* t = a.trace + (size_t)(8192 + blockIdx.x * 4 + wave) * 8;
+    for (int q = 0; q < 5; ++q) t[q] = tr_seg[q];
+    t[5] = (unsigned long long)tr_iters;
+  }
+#endif
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM>
+__global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3)) void igemm_nt_kernel(IgemmArgs a) {
+  SkPlan none;
+  igemm_body<MODE, WM, WN, MT, NT, BKT, PM, false>(a, none);
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM>
+__global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel(IgemmSkArgs p) {
+  igemm_body<MODE, WM, WN, MT, NT, BKT, PM, true>(p.a, p.sk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -770,6 +1102,7 @@ int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode)
   g->rw = mode == 0 ? g->ow : iw;
   g->sub = 1; g->y0 = 0; g->x0 = 0;
   g->ky0 = 0; g->kx0 = 0; g->kstep = 1; g->nky = kh; g->nkx = kw;
+  g->nimg = 0; g->pm = 0;
   set_magic(g);
   return C2D_OK;
 }
@@ -780,20 +1113,140 @@ void set_magic(ConvGeom* g) {
   g->magic_w = (one + (unsigned long long)g->rw - 1) / (unsigned long long)g->rw;
 }
 
-template <int WM, int WN, int MT, int NT, int BKT>
-void launch_igemm(IgemmArgs a, hipStream_t s) {
+struct IgemmWs {
+  void* ptr;
+  long long bytes;
+};
+
+int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
+
+// Fills the stream-K plan for tile BM x BN; returns false when the launch should use the
+// one-tile-per-block form instead (no workspace, degenerate costs, ...).
+template <int MODE, int BM, int BN, int BKT, bool PM>
+bool make_sk_plan(const IgemmArgs& a, int slots, const IgemmWs& ws, SkPlan* sk, int* err) {
+  *err = C2D_OK;
+  if (!ws.ptr || slots <= 0) return false;
+  const int kslabs = c2d_ceil_div(a.K, BKT);
+  const int ntaps = a.g.nky * a.g.nkx;
+  sk->enabled = 1;
+  if (PM) {
+    const int hw = a.g.rh * a.g.rw, tb = BM / 32;
+    sk->period = hw / gcd_int(hw, tb);
+    if (sk->period > SK_MAX_PERIOD) return false;
+    for (int r = 0; r < sk->period; ++r) {
+      unsigned long long mask = 0;
+      for (int t = 0; t < tb; ++t) {
+        const int px = (r * tb + t) % hw, y = px / a.g.rw, x = px % a.g.rw;
+        for (int tp = 0; tp < ntaps; ++tp) {
+          const int ty = tp / a.g.nkx;
+          if (tap_ok<MODE>(a.g, y, x, a.g.ky0 + a.g.kstep * ty,
+                           a.g.kx0 + a.g.kstep * (tp - ty * a.g.nkx)))
+            mask |= 1ull << tp;
+        }
+      }
+      sk->cost[r] = __builtin_popcountll(mask) * kslabs;
+    }
+  } else {
+    sk->period = 1;
+    sk->cost[0] = a.nseg > 1 ? a.total_slabs : ntaps * kslabs;
+  }
+  sk->prefix[0] = 0;
+  for (int r = 0; r < sk->period; ++r) {
+    if (sk->cost[r] <= 0) return false;
+    sk->prefix[r + 1] = sk->prefix[r] + sk->cost[r];
+  }
+  const long long rows = (long long)(a.m_tiles / sk->period) * sk->prefix[sk->period] +
+                         sk->prefix[a.m_tiles % sk->period];
+  const long long total = rows * a.n_tiles;
+  if (total <= 0 || total >= (1ll << 30)) return false;
+  sk->total = (int)total;
+  int grid = slots < sk->total ? slots : sk->total;
+  sk->share = (sk->total + grid - 1) / grid;
+  const long long tiles = (long long)a.m_tiles * a.n_tiles;
+  const long long part_bytes = (long long)grid * 2 * BM * BN * 4;
+  if (part_bytes + tiles * 4 > ws.bytes) { *err = C2D_ERR_WORKSPACE; return false; }
+  sk->partials = (float*)ws.ptr;
+  sk->counters = (int*)((char*)ws.ptr + part_bytes);
+  return true;
+}
+
+bool sk_disabled_by_env() {
+  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  if (!tune) return false;
+  const char* e = getenv("C2D_IGEMM_SK");
+  return e && e[0] == '0';
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM>
+int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   a.m_tiles = c2d_ceil_div(a.M, BM);
   a.n_tiles = c2d_ceil_div(a.N, BN);
-  const dim3 grid(a.m_tiles * a.n_tiles), block(WM * WN * 64);
-  if (a.g.mode == 0)
-    hipLaunchKernelGGL((igemm_nt_kernel<0, WM, WN, MT, NT, BKT>), grid, block, 0, s, a);
-  else
-    hipLaunchKernelGGL((igemm_nt_kernel<1, WM, WN, MT, NT, BKT>), grid, block, 0, s, a);
+#ifdef C2D_TRACE
+  a.trace = g_trace;
+#endif
+  const dim3 block(WM * WN * 64);
+  if (ws.ptr && !sk_disabled_by_env()) {
+    // resident workgroups of the persistent kernel = its occupancy x the CU count (queried once)
+    static int slots = -1;
+    if (slots < 0) {
+      int occ = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &occ, igemm_sk_kernel<MODE, WM, WN, MT, NT, BKT, PM>, WM * WN * 64, 0) == hipSuccess &&
+          hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        slots = occ * prop.multiProcessorCount;
+      else
+        slots = 0;
+    }
+    IgemmSkArgs p;
+    p.a = a;
+    int err = C2D_OK;
+    if (make_sk_plan<MODE, BM, BN, BKT, PM>(a, slots, ws, &p.sk, &err)) {
+      const int grid = c2d_ceil_div(p.sk.total, p.sk.share);
+      hipLaunchKernelGGL((igemm_sk_kernel<MODE, WM, WN, MT, NT, BKT, PM>), dim3(grid), block, 0, s, p);
+      return c2d_launch_status();
+    }
+    if (err) return err;
+  }
+  const dim3 grid(a.m_tiles * a.n_tiles);
+  hipLaunchKernelGGL((igemm_nt_kernel<MODE, WM, WN, MT, NT, BKT, PM>), grid, block, 0, s, a);
+  return c2d_launch_status();
 }
 
-int run_igemm(const IgemmArgs& a, hipStream_t s) {
+template <int WM, int WN, int MT, int NT, int BKT, bool PM = false>
+int launch_igemm(const IgemmArgs& a, hipStream_t s, const IgemmWs& ws) {
+  if (a.g.mode == 0) return launch_igemm_mode<0, WM, WN, MT, NT, BKT, PM>(a, s, ws);
+  return launch_igemm_mode<1, WM, WN, MT, NT, BKT, PM>(a, s, ws);
+}
+
+int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{nullptr, 0}) {
+  IgemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return C2D_OK;
+  // Pixel-major rows for multi-tap convolutions over small per-ROI maps (see decompose<true>).
+  const int hw = a.g.rh * a.g.rw;
+  // Tuning hooks for tools/sweep_igemm.py (read only when C2D_TUNE is set at load time):
+  // C2D_IGEMM_ROW_MAJOR=1 disables the pixel-major order, C2D_IGEMM_CFG=2|3 forces the 128x64 /
+  // 128x128 tile, C2D_IGEMM_SK=0 the one-tile-per-block form.
+  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  bool row_major_only = false;
+  int force = 0;
+  if (tune) {
+    const char* e = getenv("C2D_IGEMM_ROW_MAJOR");
+    row_major_only = e && e[0] == '1';
+    e = getenv("C2D_IGEMM_CFG");
+    force = e ? atoi(e) : 0;
+  }
+  const bool narrow = force ? force == 2 : (a.N % 128 != 0 && a.N % 128 <= 64);
+  if (!row_major_only && a.nseg == 1 && a.g.kh * a.g.kw > 1 && hw <= 64 && a.g.nimg >= 64 &&
+      a.N % 4 == 0 && a.g.sub == 1) {
+    a.g.pm = 1;
+    a.M = c2d_ceil_div(a.g.nimg, 32) * 32 * hw;
+    // 128x64 tiles (4 waves per SIMD) measured best or within 3 % of best on every 3x3 layer of
+    // the second stage (tools/sweep_igemm.py); 128x128 only when forced by the tuning hook.
+    if (force != 3) return launch_igemm<2, 2, 2, 1, 32, true>(a, s, ws);
+    return launch_igemm<2, 2, 2, 2, 32, true>(a, s, ws);
+  }
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
   if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384) {
@@ -804,25 +1257,34 @@ int run_igemm(const IgemmArgs& a, hipStream_t s) {
     const dim3 grid(b.m_tiles * b.n_tiles), block(256);
     if (a.g.mode == 0) hipLaunchKernelGGL(igemm_small_kernel<0>, grid, block, 0, s, b);
     else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, block, 0, s, b);
+    return c2d_launch_status();
   } else if (big_blocks < 256) {
-    launch_igemm<2, 2, 1, 1, 32>(a, s);          // 64x64 tiles
-  } else if (a.N % 128 != 0 && a.N % 128 <= 64) {
+    return launch_igemm<2, 2, 1, 1, 32>(a, s, IgemmWs{nullptr, 0});          // 64x64 tiles
+  } else if (narrow) {
     // N = 192, 320, 576, 160 ...: 128x64 tiles (waves 2x2, each 64x32) waste at most half a
     // 64-wide tile instead of half a 128-wide one, and the smaller accumulator file leaves room
-    // for a fourth wave per SIMD (576->192 at 98k rows: 252 -> 221 us; 192<-256 dgrad 934 -> 786).
-    launch_igemm<2, 2, 2, 1, 32>(a, s);
-  } else {
-    launch_igemm<2, 2, 2, 2, 32>(a, s);          // 128x128, waves 2x2
+    // for a fourth wave per SIMD.
+    return launch_igemm<2, 2, 2, 1, 32>(a, s, ws);
   }
-  return c2d_launch_status();
+  return launch_igemm<2, 2, 2, 2, 32>(a, s, ws);          // 128x128, waves 2x2
 }
 
 }  // namespace
 
-extern "C" int c2d_conv_fwd(const float* x, int ldx, int xoff, const float* wt,
-                            const float* scale, const float* shift, float* y, int ldy,
-                            int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
-                            int stride, int relu, void* stream) {
+#ifdef C2D_TRACE
+// Diagnostic build only (make trace): per-block timeline buffer, 8 x u64 per block.
+extern "C" int c2d_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; return C2D_OK; }
+#endif
+
+extern "C" long long c2d_conv_workspace_bytes(void) {
+  // <= 1024 resident workgroups x 2 slabs of a 128x128 fp32 tile + the tile counters
+  return 1024ll * 2 * 128 * 128 * 4 + (4ll << 20);
+}
+
+static int conv_fwd_impl(const float* x, int ldx, int xoff, const float* wt,
+                         const float* scale, const float* shift, float* y, int ldy,
+                         int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                         int stride, int relu, IgemmWs ws, void* stream) {
   C2D_CHECK_ARG(x && wt && y && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 16 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   IgemmArgs a;
@@ -830,13 +1292,34 @@ extern "C" int c2d_conv_fwd(const float* x, int ldx, int xoff, const float* wt,
   if (rc) return rc;
   a.A = x; a.lda = ldx; a.a_off = xoff; a.Bt = wt; a.C = y; a.ldc = ldy; a.c_off = yoff;
   a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = 0; a.nseg = 1;
-  a.M = n * a.g.oh * a.g.ow; a.N = cout; a.K = cin;
-  return run_igemm(a, (hipStream_t)stream);
+  a.M = n * a.g.oh * a.g.ow; a.N = cout; a.K = cin; a.g.nimg = n;
+  a.a_rows = (long long)n * ih * iw;
+  C2D_CHECK_ARG(kh * kw <= 64);
+  C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)kh * kw * cin * cout * 4 < (long long)OOB_OFFSET);
+  return run_igemm(a, (hipStream_t)stream, ws);
 }
 
-extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w, float* dx,
-                              int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
-                              int kh, int kw, int stride, int accumulate, void* stream) {
+extern "C" int c2d_conv_fwd(const float* x, int ldx, int xoff, const float* wt,
+                            const float* scale, const float* shift, float* y, int ldy,
+                            int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                            int stride, int relu, void* stream) {
+  return conv_fwd_impl(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw,
+                       stride, relu, IgemmWs{nullptr, 0}, stream);
+}
+
+extern "C" int c2d_conv_fwd_ws(const float* x, int ldx, int xoff, const float* wt,
+                               const float* scale, const float* shift, float* y, int ldy,
+                               int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                               int stride, int relu, void* workspace, long long workspace_bytes,
+                               void* stream) {
+  C2D_CHECK_ARG(workspace && workspace_bytes > 0);
+  return conv_fwd_impl(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw,
+                       stride, relu, IgemmWs{workspace, workspace_bytes}, stream);
+}
+
+static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, float* dx,
+                           int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
+                           int kh, int kw, int stride, int accumulate, IgemmWs ws, void* stream) {
   C2D_CHECK_ARG(dc && w && dx && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cout % 16 == 0 && ldc % 4 == 0 && coff % 4 == 0);
   IgemmArgs a;
@@ -844,10 +1327,13 @@ extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w
   if (rc) return rc;
   a.A = dc; a.lda = ldc; a.a_off = coff; a.Bt = w; a.C = dx; a.ldc = lddx; a.c_off = dxoff;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate; a.nseg = 1;
-  a.N = cin; a.K = cout;
+  a.N = cin; a.K = cout; a.g.nimg = n;
+  a.a_rows = (long long)n * a.g.oh * a.g.ow;
+  C2D_CHECK_ARG(kh * kw <= 64);
+  C2D_CHECK_ARG(a.a_rows * ldc * 4 < (long long)OOB_OFFSET && (long long)kh * kw * cin * cout * 4 < (long long)OOB_OFFSET);
   if (stride == 1) {
     a.M = n * ih * iw;
-    return run_igemm(a, (hipStream_t)stream);
+    return run_igemm(a, (hipStream_t)stream, ws);
   }
   // stride 2: one launch per parity class (py, px) of the input pixel; a pixel of the class
   // only meets the taps with ky = (py + pad_t) mod 2 (+2, ...), i.e. 2.25 taps per pixel on
@@ -865,16 +1351,32 @@ extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w
       if (b.g.nky == 0 || b.g.nkx == 0) { b.g.nky = 0; b.g.nkx = 0; }
       set_magic(&b.g);
       b.M = n * b.g.rh * b.g.rw;
-      rc = run_igemm(b, (hipStream_t)stream);
-      if (rc) return rc;
+      rc = run_igemm(b, (hipStream_t)stream, ws);   // (launches of one stream run in order: the
+      if (rc) return rc;                             //  four classes share the workspace)
     }
   return C2D_OK;
 }
 
-extern "C" int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs,
-                                       const int* coffs, const float* const* ws,
-                                       const int* couts, float* dx, int lddx, int dxoff,
-                                       int rows, int cin, int accumulate, void* stream) {
+extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w, float* dx,
+                              int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
+                              int kh, int kw, int stride, int accumulate, void* stream) {
+  return conv_dgrad_impl(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
+                         accumulate, IgemmWs{nullptr, 0}, stream);
+}
+
+extern "C" int c2d_conv_dgrad_ws(const float* dc, int ldc, int coff, const float* w, float* dx,
+                                 int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
+                                 int kh, int kw, int stride, int accumulate, void* workspace,
+                                 long long workspace_bytes, void* stream) {
+  C2D_CHECK_ARG(workspace && workspace_bytes > 0);
+  return conv_dgrad_impl(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
+                         accumulate, IgemmWs{workspace, workspace_bytes}, stream);
+}
+
+static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
+                            const int* coffs, const float* const* ws,
+                            const int* couts, float* dx, int lddx, int dxoff,
+                            int rows, int cin, int accumulate, IgemmWs wsp, void* stream) {
   C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && dcs && ldcs && coffs && ws && couts && dx);
   C2D_CHECK_ARG(rows > 0 && cin > 0 && cin % 4 == 0 && lddx % 4 == 0 && dxoff % 4 == 0);
   IgemmArgs a;
@@ -887,13 +1389,33 @@ extern "C" int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const 
     a.segA[i] = dcs[i]; a.segB[i] = ws[i]; a.seg_lda[i] = ldcs[i]; a.seg_off[i] = coffs[i];
     a.segK[i] = couts[i];
     a.total_slabs += (couts[i] + BK - 1) / BK;
+    C2D_CHECK_ARG((long long)rows * ldcs[i] * 4 < (long long)OOB_OFFSET);
   }
+  a.a_rows = rows;
   a.nseg = nseg;
   a.A = dcs[0]; a.lda = ldcs[0]; a.a_off = coffs[0]; a.Bt = ws[0]; a.K = couts[0];
   a.C = dx; a.ldc = lddx; a.c_off = dxoff;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate;
   a.M = rows; a.N = cin;
-  return run_igemm(a, (hipStream_t)stream);
+  return run_igemm(a, (hipStream_t)stream, wsp);
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs,
+                                       const int* coffs, const float* const* ws,
+                                       const int* couts, float* dx, int lddx, int dxoff,
+                                       int rows, int cin, int accumulate, void* stream) {
+  return dgrad_multi_impl(nseg, dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
+                          accumulate, IgemmWs{nullptr, 0}, stream);
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi_ws(int nseg, const float* const* dcs, const int* ldcs,
+                                          const int* coffs, const float* const* ws,
+                                          const int* couts, float* dx, int lddx, int dxoff,
+                                          int rows, int cin, int accumulate, void* workspace,
+                                          long long workspace_bytes, void* stream) {
+  C2D_CHECK_ARG(workspace && workspace_bytes > 0);
+  return dgrad_multi_impl(nseg, dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
+                          accumulate, IgemmWs{workspace, workspace_bytes}, stream);
 }
 
 extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc,

@@ -74,14 +74,41 @@ def roi_crop_pool_bwd_ws(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool
 
 # -- convolution ------------------------------------------------------------------------
 
+_conv_ws = None   # (tensor, nbytes): workspace of the balanced (stream-K) convolution forms
+
+
+def conv_workspace_bytes():
+  return int(_lib.load().c2d_conv_workspace_bytes())
+
+
+def set_conv_workspace(ws):
+  """ws: ZERO-filled uint8 device tensor of >= conv_workspace_bytes() bytes (or None to go back
+  to the one-tile-per-block launches).  One workspace serves all convolutions of one stream."""
+  global _conv_ws
+  if ws is None:
+    _conv_ws = None
+    return
+  assert ws.is_cuda and ws.dtype == torch.uint8 and ws.numel() >= conv_workspace_bytes()
+  _conv_ws = (ws, ws.numel())
+
+
 def conv_fwd(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride,
              relu):
+  if _conv_ws is not None:
+    _lib.call("c2d_conv_fwd_ws", _p(x), ldx, xoff, _p(wt), _p(scale), _p(shift), _p(y), ldy, yoff,
+              n, ih, iw, cin, cout, kh, kw, stride, int(relu), _p(_conv_ws[0]), _conv_ws[1],
+              _stream())
+    return
   _lib.call("c2d_conv_fwd", _p(x), ldx, xoff, _p(wt), _p(scale), _p(shift), _p(y), ldy, yoff, n,
             ih, iw, cin, cout, kh, kw, stride, int(relu), _stream())
 
 
 def conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
                accumulate):
+  if _conv_ws is not None:
+    _lib.call("c2d_conv_dgrad_ws", _p(dc), ldc, coff, _p(w), _p(dx), lddx, dxoff, n, ih, iw, cin,
+              cout, kh, kw, stride, int(accumulate), _p(_conv_ws[0]), _conv_ws[1], _stream())
+    return
   _lib.call("c2d_conv_dgrad", _p(dc), ldc, coff, _p(w), _p(dx), lddx, dxoff, n, ih, iw, cin, cout,
             kh, kw, stride, int(accumulate), _stream())
 
@@ -91,6 +118,11 @@ def conv1x1_dgrad_multi(dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
   n = len(dcs)
   ptrs = ctypes.c_void_p * n
   ints = ctypes.c_int * n
+  if _conv_ws is not None:
+    _lib.call("c2d_conv1x1_dgrad_multi_ws", n, ptrs(*[_p(t) for t in dcs]), ints(*ldcs),
+              ints(*coffs), ptrs(*[_p(t) for t in ws]), ints(*couts), _p(dx), lddx, dxoff, rows,
+              cin, int(accumulate), _p(_conv_ws[0]), _conv_ws[1], _stream())
+    return
   _lib.call("c2d_conv1x1_dgrad_multi", n, ptrs(*[_p(t) for t in dcs]), ints(*ldcs), ints(*coffs),
             ptrs(*[_p(t) for t in ws]), ints(*couts), _p(dx), lddx, dxoff, rows, cin,
             int(accumulate), _stream())

@@ -103,6 +103,28 @@ int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs, 
                             const float* const* ws, const int* couts, float* dx, int lddx,
                             int dxoff, int rows, int cin, int accumulate, void* stream);
 
+/* Balanced ("stream-K") forms of the three calls above.  `workspace` is a caller-owned device
+ * buffer of at least c2d_conv_workspace_bytes() bytes that is ZERO when first used (the kernels
+ * leave its counters zero again) and is not shared by launches that may run concurrently.
+ * The launch then runs as one persistent workgroup per resident slot, each taking an equal share
+ * of the (tile, K-slab) iterations; a tile cut by a share boundary is reduced, in a fixed order,
+ * by whichever of its pieces finishes last, so results are bitwise reproducible and no CU idles
+ * in a partial last round of tiles.  Same results as the plain forms up to fp32 summation order.
+ * Returns C2D_ERR_WORKSPACE if the buffer is too small. */
+long long c2d_conv_workspace_bytes(void);
+int c2d_conv_fwd_ws(const float* x, int ldx, int xoff, const float* wt, const float* scale,
+                    const float* shift, float* y, int ldy, int yoff, int n, int ih, int iw,
+                    int cin, int cout, int kh, int kw, int stride, int relu, void* workspace,
+                    long long workspace_bytes, void* stream);
+int c2d_conv_dgrad_ws(const float* dc, int ldc, int coff, const float* w, float* dx, int lddx,
+                      int dxoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                      int stride, int accumulate, void* workspace, long long workspace_bytes,
+                      void* stream);
+int c2d_conv1x1_dgrad_multi_ws(int nseg, const float* const* dcs, const int* ldcs,
+                               const int* coffs, const float* const* ws, const int* couts,
+                               float* dx, int lddx, int dxoff, int rows, int cin, int accumulate,
+                               void* workspace, long long workspace_bytes, void* stream);
+
 /* dw[kh*kw][cin][cout] += Conv2DBackpropFilter(x, dc)  (fp32 atomics over row splits; the
  * caller zero-fills dw once per step). */
 int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, int coff,

@@ -103,7 +103,12 @@ CONV_CASES = [
     (5, 7, 7, 32, 64, 3, 2),
     (2, 4, 4, 64, 352, 3, 1),
     (1, 13, 9, 16, 32, 3, 2),
-    (300, 7, 7, 64, 160, 3, 1),   # M large enough for the 128x128 tile path
+    (300, 7, 7, 64, 160, 3, 1),   # M large enough for the 128x128 tile path; pixel-major rows
+    (70, 4, 4, 48, 96, 3, 1),     # pixel-major rows (n >= 64), ragged last group of 32 images
+    (100, 7, 7, 32, 64, 3, 2),    # pixel-major stride-2 forward + parity-class dgrad
+    (65, 4, 4, 32, 192, 3, 1),    # pixel-major, 128x64 tile variant (N % 128 == 64)
+    (700, 4, 4, 96, 224, 3, 1),   # enough tiles for stream-K shares that cut tiles (K = 9 x 3 slabs)
+    (900, 7, 7, 64, 96, 1, 1),    # 1x1, row-major stream-K
 ]
 
 
@@ -113,8 +118,25 @@ def _conv_inputs(rng, n, ih, iw, cin, cout, k):
   return x, w
 
 
+@pytest.fixture(params=["tile_per_block", "stream_k"])
+def conv_mode(request, ops):
+  """Runs a test with the plain launches and with the balanced (stream-K) workspace forms."""
+  if request.param == "stream_k":
+    ws = torch.zeros(ops.conv_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    ops.set_conv_workspace(ws)
+    yield ws
+    ops.set_conv_workspace(None)
+    torch.cuda.synchronize()
+    # the kernels must leave every tile counter zero for the next launch
+    part = 1024 * 2 * 128 * 128 * 4
+    assert int(ws[part:].to(torch.int32).abs().sum()) == 0 or int(ws[part:].max()) == 0
+  else:
+    ops.set_conv_workspace(None)
+    yield None
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_bn_relu(ops, case):
+def test_conv_fwd_bn_relu(ops, case, conv_mode):
   n, ih, iw, cin, cout, k, s = case
   rng = np.random.default_rng(11)
   x, w = _conv_inputs(rng, n, ih, iw, cin, cout, k)
@@ -141,7 +163,7 @@ def test_conv_fwd_bn_relu(ops, case):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_dgrad_wgrad(ops, case):
+def test_conv_dgrad_wgrad(ops, case, conv_mode):
   n, ih, iw, cin, cout, k, s = case
   rng = np.random.default_rng(13)
   x, w = _conv_inputs(rng, n, ih, iw, cin, cout, k)
