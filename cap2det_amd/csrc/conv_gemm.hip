@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(IgemmArgs a) {
 
 struct WgradArgs {
   const float* A; int lda; int a_off;   // activations x (rows of the conv input)
+  long long a_rows;                     // rows of x
   const float* G; int ldg; int g_off;   // dC rows (conv output rows)
   float* dW;                            // [taps][I][J], pre-zeroed or accumulated into
   int M;                                // conv output rows (reduction length)
@@ -803,13 +804,14 @@ constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
 // SLOWER on the 1x1 / stride-2 layers this kernel still serves: it cost the fourth wave.)
 // NTJ = 32-column MFMA tiles per wave along j: 2 (block tile 128x128) or 1 (128x64, used when
 // the last 128-wide j-tile would be at most half full: J = 192, 160, 320 ...).
-template <int NTJ>
+// PLAIN = 1x1 / stride 1 (source row = output row): the loader's offsets are slab-invariant.
+template <int NTJ, bool PLAIN>
 __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   constexpr int BJ = 2 * NTJ * 32;
   __shared__ __attribute__((aligned(16))) float As[WBK * WG_STRIDE];
   __shared__ __attribute__((aligned(16))) float Gs[WBK * WG_STRIDE];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int itiles = (a.I + 127) / 128;
@@ -824,9 +826,13 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   // (their products land in dW rows/cols that are never stored).
   const int kr = tid >> 5;   // 0..7
   const int c4 = (tid & 31) * 4;
-  const float* abase = a.A + a.a_off + min(i0 + c4, a.I - 4);
   const bool gload = c4 < BJ;   // (BJ = 64: the upper half of each 32-lane row group idles)
-  const float* gbase = a.G + a.g_off + min(j0 + min(c4, BJ - 4), a.J - 4);
+  // raw buffer loads (see igemm_body): descriptors end at the operands' last row, masked rows
+  // carry an out-of-range offset and come back as zeros
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a.a_off, (a.a_rows * a.lda - a.a_off) * 4);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(a.G + a.g_off, ((long long)a.M * a.ldg - a.g_off) * 4);
+  const unsigned acol = (unsigned)min(i0 + c4, a.I - 4) * 4u;
+  const unsigned gcol = (unsigned)min(j0 + min(c4, BJ - 4), a.J - 4) * 4u;
 
   f32x16 acc[2][NTJ];
 #pragma unroll
@@ -836,71 +842,78 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  bool tile_on[2][NTJ];   // 32x32 tiles beyond I / J issue no MFMA
+  unsigned tile_bits = 0;   // bit i*NTJ+j: 32x32 tile inside I x J (others issue no MFMA); scalar
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NTJ; ++j)
-      tile_on[i][j] = (i0 + wm * 64 + i * 32 < a.I) && (j0 + (wn * NTJ + j) * 32 < a.J);
+      if ((i0 + wm * 64 + i * 32 < a.I) && (j0 + (wn * NTJ + j) * 32 < a.J))
+        tile_bits |= 1u << (i * NTJ + j);
+  tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
 
   f32x4 ra[2], rg[2];
-  unsigned vmask = 0;   // bit u: A row valid, bit 2+u: G row valid
-  {
+  // PLAIN: splits are whole slabs except the last one, whose rows >= M fall outside the
+  // descriptors, so the offsets never change and the slab's first row is the scalar offset.
+  unsigned aoffs[2], goffs[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int m = mbeg + kr + u * 8;
-      const RowPos p = decompose(m, mend, a.g);
-      const int sr = src_row<0>(a.g, p, ky, kx);
-      vmask |= (sr >= 0 ? 1u : 0u) << u;
-      vmask |= (p.valid ? 1u : 0u) << (2 + u);
-      ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
-      rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
-    }
+  for (int u = 0; u < 2; ++u) {
+    aoffs[u] = (unsigned)((kr + u * 8) * a.lda) * 4u + acol;
+    goffs[u] = (unsigned)((kr + u * 8) * a.ldg) * 4u + gcol;
   }
+#define C2D_WG_LOAD(MB)                                                                        \
+  {                                                                                            \
+    if (PLAIN) {                                                                               \
+      const int sa = (MB) * a.lda * 4, sg = (MB) * a.ldg * 4;                                  \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
+        ra[u] = buf_load4(rsA, aoffs[u], sa);                                                  \
+        rg[u] = buf_load4(rsG, goffs[u], sg);                                                  \
+      }                                                                                        \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
+        const int m = (MB) + kr + u * 8;                                                       \
+        const RowPos p = decompose(m, mend, a.g);                                              \
+        const int sr = src_row<0>(a.g, p, ky, kx);                                             \
+        ra[u] = buf_load4(rsA, sr >= 0 ? (unsigned)(sr * a.lda) * 4u + acol : OOB_OFFSET, 0);  \
+        rg[u] = buf_load4(rsG, p.valid ? (unsigned)(m * a.ldg) * 4u + gcol : OOB_OFFSET, 0);   \
+      }                                                                                        \
+    }                                                                                          \
+  }
+  C2D_WG_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += WBK) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      *reinterpret_cast<f32x4*>(&As[(kr + u * 8) * WG_STRIDE + c4]) =
-          mask4(ra[u], (vmask >> u) & 1u);
-      if (gload)
-        *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) =
-            mask4(rg[u], (vmask >> (2 + u)) & 1u);
+      *reinterpret_cast<f32x4*>(&As[(kr + u * 8) * WG_STRIDE + c4]) = ra[u];
+      if (gload) *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) = rg[u];
     }
     __syncthreads();
-    {
-      // loads of the next slab (rows past `mend` are masked; addresses stay in bounds)
-      const int nb = mb + WBK;
-      vmask = 0;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int m = nb + kr + u * 8;
-        const RowPos p = decompose(m, mend, a.g);
-        const int sr = src_row<0>(a.g, p, ky, kx);
-        vmask |= (sr >= 0 ? 1u : 0u) << u;
-        vmask |= (p.valid ? 1u : 0u) << (2 + u);
-        ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)max(sr, 0) * a.lda);
-        rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);
-      }
-    }
+    C2D_WG_LOAD(mb + WBK);   // next slab (rows past `mend` come back as zeros / are never used)
     __builtin_amdgcn_sched_barrier(0);
+    {
+      // all fragments of the slab first, then ONE scalar branch per 32x32 tile around its 8
+      // chained MFMAs (per-MFMA conditions make hipcc shuffle whole accumulators through copies)
+      float af[2][8], bf[NTJ][8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int k = lh * 8 + s;
-      float af[2], bf[NTJ];
+      for (int s = 0; s < 8; ++s) {
+        const int k = lh * 8 + s;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = As[k * WG_STRIDE + wm * 64 + i * 32 + li];
+        for (int i = 0; i < 2; ++i) af[i][s] = As[k * WG_STRIDE + wm * 64 + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < NTJ; ++j) bf[j] = Gs[k * WG_STRIDE + (wn * NTJ + j) * 32 + li];
+        for (int j = 0; j < NTJ; ++j) bf[j][s] = Gs[k * WG_STRIDE + (wn * NTJ + j) * 32 + li];
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NTJ; ++j)
-          if (tile_on[i][j])
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          if ((tile_bits >> (i * NTJ + j)) & 1u) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+          }
     }
     __syncthreads();
   }
 
+#undef C2D_WG_LOAD
   float* dw = a.dW + (size_t)tap * a.I * a.J;
 #pragma unroll
   for (int j = 0; j < NTJ; ++j) {
@@ -983,38 +996,36 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
   // loaders: everything about WHERE a staged row comes from is slab-invariant
+  // Raw buffer loads (see igemm_body): per-lane byte offsets are slab-invariant, the slab's first
+  // row goes into the scalar offset, rows of the zero border carry an out-of-range offset, and
+  // rows past M (only the last slab can have them: splits are whole slabs) fall outside the
+  // descriptors, which end at row M — the loader needs no vector ALU work per slab.
   const int gkr = tid >> 5, gc4 = (tid & 31) * 4;       // dC: rows gkr + 8u, float4 column gc4
-  const float* gbase = a.G + a.g_off + min(j0 + gc4, a.J - 4);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(a.G + a.g_off, ((long long)a.M * a.ldg - a.g_off) * 4);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a.a_off, ((long long)a.M * a.lda - a.a_off) * 4);
   const int aq4 = (tid & 7) * 4, ar0 = tid >> 3;        // x: LDS rows ar0 + 32u, float4 col aq4
-  const float* abase = a.A + a.a_off + i0 + aq4;
-  int apix[A_LD];                                       // pixel offset inside the slab, or -1
+  unsigned goffs[G_LD], aoffs[A_LD];
+#pragma unroll
+  for (int u = 0; u < G_LD; ++u) {
+    const int k = gkr + u * 8;
+    goffs[u] = k < R ? (unsigned)(k * a.ldg + min(j0 + gc4, a.J - 4)) * 4u : OOB_OFFSET;
+  }
 #pragma unroll
   for (int u = 0; u < A_LD; ++u) {
     const int r = ar0 + u * 32;
     const int im = r / PIMG, rr = r - im * PIMG;
     const int yp = rr / PW, xp = rr - yp * PW;
     const bool real = r < AROWS && yp >= 1 && yp <= WC && xp >= 1 && xp <= WC;
-    apix[u] = real ? im * HW + (yp - 1) * WC + (xp - 1) : -1;
+    const int apix = im * HW + (yp - 1) * WC + (xp - 1);   // pixel offset inside the slab
+    aoffs[u] = real ? (unsigned)(apix * a.lda + i0 + aq4) * 4u : OOB_OFFSET;
   }
   f32x4 rg[G_LD], ra[A_LD];
-  unsigned amask = 0, gmask = 0;
 
 #define C2D_W3_LOAD(MB)                                                                        \
   {                                                                                            \
-    gmask = 0;                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < G_LD; ++u) {                                         \
-      const int k = gkr + u * 8;                                                               \
-      const int m = (MB) + k;                                                                  \
-      gmask |= ((k < R && m < mend) ? 1u : 0u) << u;                                           \
-      rg[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)min(m, a.M - 1) * a.ldg);        \
-    }                                                                                          \
-    amask = 0;                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < A_LD; ++u) {                                         \
-      const int gm = (MB) + apix[u];                                                           \
-      const bool ok = apix[u] >= 0 && gm < mend;                                               \
-      amask |= (ok ? 1u : 0u) << u;                                                            \
-      ra[u] = *reinterpret_cast<const f32x4*>(abase + (size_t)(ok ? gm : 0) * a.lda);          \
-    }                                                                                          \
+    const int sg = (MB) * a.ldg * 4, sa = (MB) * a.lda * 4;                                    \
+    _Pragma("unroll") for (int u = 0; u < G_LD; ++u) rg[u] = buf_load4(rsG, goffs[u], sg);     \
+    _Pragma("unroll") for (int u = 0; u < A_LD; ++u) ra[u] = buf_load4(rsA, aoffs[u], sa);     \
   }
 
   // per-lane bases: the upper half-wave reads the odd image of each pair (PAIR) / the odd row
@@ -1026,13 +1037,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
 #pragma unroll
     for (int u = 0; u < G_LD; ++u)
       if (gkr + u * 8 < RP)
-        *reinterpret_cast<f32x4*>(&Gs[(gkr + u * 8) * W3_GSTR + gc4]) =
-            mask4(rg[u], (gmask >> u) & 1u);
+        *reinterpret_cast<f32x4*>(&Gs[(gkr + u * 8) * W3_GSTR + gc4]) = rg[u];
 #pragma unroll
     for (int u = 0; u < A_LD; ++u)
       if (ar0 + u * 32 < AROWS)
-        *reinterpret_cast<f32x4*>(&As[(ar0 + u * 32) * W3_ASTR + aq4]) =
-            mask4(ra[u], (amask >> u) & 1u);
+        *reinterpret_cast<f32x4*>(&As[(ar0 + u * 32) * W3_ASTR + aq4]) = ra[u];
     __syncthreads();
     C2D_W3_LOAD(mb + R);
     __builtin_amdgcn_sched_barrier(0);
@@ -1430,6 +1439,7 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
     b.A = x; b.lda = ldx; b.a_off = xoff; b.G = dc; b.ldg = ldc; b.g_off = coff; b.dW = dw;
     b.M = n * ih * iw; b.I = cin; b.J = cout; b.h = ih; b.w = iw;
     b.itiles = cin / 32; b.jtiles = c2d_ceil_div(cout, 128); b.tiles = b.itiles * b.jtiles;
+    C2D_CHECK_ARG((long long)b.M * ldx * 4 < (long long)OOB_OFFSET && (long long)b.M * ldc * 4 < (long long)OOB_OFFSET);
     const int slab = iw == 4 ? 32 : 49;                    // whole images per slab
     const int nslabs = c2d_ceil_div(b.M, slab);
     int splits = c2d_ceil_div(512, b.tiles);               // 2 blocks per CU, one round
@@ -1457,7 +1467,13 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
   a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), WBK) * WBK;
   splits = c2d_ceil_div(a.M, a.rows_per_split);
   dim3 grid(kh * kw * c2d_ceil_div(cin, 128), c2d_ceil_div(cout, bj), splits);
-  if (narrow) hipLaunchKernelGGL(wgrad_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(wgrad_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  a.a_rows = (long long)n * ih * iw;
+  C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)a.M * ldc * 4 < (long long)OOB_OFFSET);
+  const bool plain = kh == 1 && kw == 1 && stride == 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true>), grid, dim3(256), 0, st, a);
+  else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false>), grid, dim3(256), 0, st, a);
+  else if (plain) hipLaunchKernelGGL((wgrad_tn_kernel<2, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_tn_kernel<2, false>), grid, dim3(256), 0, st, a);
   return c2d_launch_status();
 }
