@@ -265,6 +265,51 @@ def word_vector_match_fwd(ids, embedding, class_ids, exact_labels, labels):
             _stream())
 
 
+# -- inference post-processing ------------------------------------------------------------
+
+def multiclass_nms(boxes, scores, ld, off, num_classes, score_thresh, iou_thresh,
+                   max_size_per_class, max_total_size, workspace=None):
+  """boxes [B,N,4]; scores: [B,N,ld] tensor whose class columns start at `off`.  Returns
+  (num_detections int32 [B], boxes [B,T,4], scores [B,T], classes [B,T] 1-based)."""
+  b, n = boxes.shape[0], boxes.shape[1]
+  _f32(boxes, scores)
+  dev = boxes.device
+  mpc = min(max_size_per_class, n)
+  need = int(_lib.load().c2d_multiclass_nms_workspace_bytes(b, n, num_classes, mpc))
+  if workspace is None or workspace.numel() < need:
+    workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+  num = torch.empty(b, dtype=torch.int32, device=dev)
+  ob = torch.empty(b, max_total_size, 4, device=dev)
+  osc = torch.empty(b, max_total_size, device=dev)
+  ocl = torch.empty(b, max_total_size, device=dev)
+  _lib.call("c2d_multiclass_nms", _p(boxes), _p(scores), ld, off, b, n, num_classes,
+            float(score_thresh), float(iou_thresh), max_size_per_class, max_total_size, _p(num),
+            _p(ob), _p(osc), _p(ocl), _p(workspace), workspace.numel(), _stream())
+  return num, ob, osc, ocl
+
+
+def softmax_drop_background(logits, ld, off, rows, c1, out):
+  _lib.call("c2d_softmax_drop_background", _p(logits), ld, off, rows, c1, _p(out), _stream())
+
+
+def scores_accumulate(dst, src, ld, off, rows, cols, init):
+  _lib.call("c2d_scores_accumulate", _p(dst), _p(src), ld, off, rows, cols, int(init), _stream())
+
+
+def scores_divide(x, divisor):
+  _lib.call("c2d_scores_divide", _p(x), x.numel(), float(divisor), _stream())
+
+
+def resize_bilinear(image, oh, ow, out=None):
+  """image [H,W,C] fp32 -> [oh,ow,C] (TF1 legacy bilinear, align_corners=False)."""
+  ih, iw, c = image.shape
+  _f32(image)
+  if out is None:
+    out = torch.empty(oh, ow, c, device=image.device, dtype=torch.float32)
+  _lib.call("c2d_resize_bilinear", _p(image), ih, iw, c, _p(out), oh, ow, _stream())
+  return out
+
+
 # -- optimiser --------------------------------------------------------------------------
 
 def adagrad_step(w, g, acc, lr, l2, mult, grad_scale=1.0):

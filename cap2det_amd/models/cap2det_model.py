@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from cap2det_amd import hip_ops as ops
+from cap2det_amd.core import builder as function_builder
 from cap2det_amd.core.standard_fields import (Cap2DetPredictions, DetectionResultFields,
                                               InputDataFields)
 from cap2det_amd.models.frcnn_engine import FrcnnEngine, VariableStore
@@ -39,6 +40,8 @@ class Model(ModelBase):
     if fe_type != 'faster_rcnn_inception_v2':
       raise ValueError('Unknown Faster R-CNN feature_extractor: {}'.format(fe_type))
     self._device = torch.device(device)
+    self._midn_postprocess_fn = function_builder.build_post_processor(options.midn_post_processor)
+    self._oicr_postprocess_fn = function_builder.build_post_processor(options.oicr_post_processor)
     self._label_extractor = build_label_extractor(options.label_extractor, self._device)
     self._num_classes = self._label_extractor.num_classes
     self._oicr_iterations = options.oicr_iterations
@@ -242,16 +245,76 @@ class Model(ModelBase):
                      num_proposals=num_proposals, proposals=proposals)
     return predictions
 
+  def _postprocess(self, inputs, predictions):
+    """models/cap2det_model.py:111-150: per-class NMS of the MIDN proposal scores (iteration 0)
+    and of softmax(OICR scores)[..., 1:] (iterations 1..K)."""
+    results = {}
+    k, c = self._oicr_iterations, self._num_classes
+    proposals = predictions[DetectionResultFields.proposal_boxes]
+    b, n = proposals.shape[0], proposals.shape[1]
+    for i in range(1 + k):
+      scores = predictions[Cap2DetPredictions.oicr_proposal_scores + '_at_{}'.format(i)]
+      post_process_fn = self._midn_postprocess_fn
+      if i > 0:
+        post_process_fn = self._oicr_postprocess_fn
+        base = scores._base if scores._base is not None else scores
+        ld = base.shape[-1]
+        off = scores.storage_offset() - base.storage_offset()   # column slice of a wider buffer
+        probs = torch.empty(b, n, c, device=self._device)
+        ops.softmax_drop_background(base, ld, off, b * n, c + 1, probs)
+        scores = probs
+      num, boxes, sc, classes, _ = post_process_fn(proposals, scores.contiguous())
+      results[DetectionResultFields.num_detections + '_at_{}'.format(i)] = num
+      results[DetectionResultFields.detection_boxes + '_at_{}'.format(i)] = boxes
+      results[DetectionResultFields.detection_scores + '_at_{}'.format(i)] = sc
+      results[DetectionResultFields.detection_classes + '_at_{}'.format(i)] = classes
+    return results
+
   def build_prediction(self, examples, **kwargs):
-    """models/cap2det_model.py:218-272.  Training mode / no eval_min_dimension: one pass.
-    (Multi-scale inference + NMS post-processing are SURVEY.md §8f rows, not the train step.)"""
+    """models/cap2det_model.py:218-272.  Training mode / no eval_min_dimension: one pass (the
+    training step skips the NMS outputs, which `train_op` never consumes: pass
+    postprocess=True to get them).  Evaluation with `eval_min_dimension`: one forward per
+    resolution (TF1 legacy-bilinear resize of the single image to the given minimum side,
+    core/imgproc.py:300-353), the proposal scores of every OICR iteration averaged over the
+    resolutions, then the post-processing."""
     options = self._model_proto
     if self._is_training or len(options.eval_min_dimension) == 0 or kwargs.get("single_scale"):
-      return self._build_prediction(examples, kwargs.get("dropout_seed"),
-                                    kwargs.get("dropout_mask"))
-    raise NotImplementedError(
-        "multi-scale inference (eval_min_dimension) is outside the training hot path; pass "
-        "single_scale=True for a single-resolution forward")
+      predictions = self._build_prediction(examples, kwargs.get("dropout_seed"),
+                                           kwargs.get("dropout_mask"))
+      if kwargs.get("postprocess", not self._is_training):
+        predictions.update(self._postprocess(examples, predictions))
+      return predictions
+
+    inputs = examples[InputDataFields.image]
+    assert inputs.shape[0] == 1
+    k, c = self._oicr_iterations, self._num_classes
+    b, n = examples[InputDataFields.proposals].shape[:2]
+    key = ("ms", b, n)
+    if key not in self._cache:
+      self._cache[key] = [torch.empty(b, n, c if i == 0 else c + 1, device=self._device)
+                          for i in range(1 + k)]
+    sums = self._cache[key]
+    examples = dict(examples)
+    dims = list(options.eval_min_dimension)
+    predictions = None
+    for si, min_dimension in enumerate(dims):
+      h, w = int(inputs.shape[1]), int(inputs.shape[2])
+      oh, ow = resize_to_min_dimension_size(h, w, min_dimension)
+      resized = ops.resize_bilinear(inputs[0].contiguous(), oh, ow)
+      examples[InputDataFields.image] = resized.unsqueeze(0)
+      predictions = self._build_prediction(examples)
+      for i in range(1 + k):
+        sc = predictions[Cap2DetPredictions.oicr_proposal_scores + '_at_{}'.format(i)]
+        base = sc._base if sc._base is not None else sc
+        ops.scores_accumulate(sums[i], base, base.shape[-1],
+                              sc.storage_offset() - base.storage_offset(), b * n, sc.shape[-1],
+                              si == 0)
+    predictions_aggregated = dict(predictions)
+    for i in range(1 + k):
+      ops.scores_divide(sums[i], float(len(dims)))
+      predictions_aggregated[Cap2DetPredictions.oicr_proposal_scores + '_at_{}'.format(i)] = sums[i]
+    predictions_aggregated.update(self._postprocess(inputs, predictions_aggregated))
+    return predictions_aggregated
 
   def build_loss(self, predictions, examples=None, **kwargs):
     """models/cap2det_model.py:274-330.  Also leaves d(loss)/d(head logits) in the step
@@ -315,6 +378,12 @@ class Model(ModelBase):
   def build_evaluation(self, predictions, examples=None, **kwargs):
     """models/cap2det_model.py:332-343 returns {} in the reference."""
     return {}
+
+
+def resize_to_min_dimension_size(height, width, min_dimension):
+  """core/imgproc.py:329-343 `_compute_new_dynamic_size`: fp32 scale, tf.round (half to even)."""
+  scale = np.float32(min_dimension) / np.float32(min(height, width))
+  return (int(np.round(np.float32(height) * scale)), int(np.round(np.float32(width) * scale)))
 
 
 register_model_class(cap2det_model_pb2.Cap2DetModel.ext, Model)

@@ -295,6 +295,44 @@ int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax, const flo
                              int depth, int num_boxes, int crop, int pool_k, int pool_s,
                              void* workspace, long long workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Inference post-processing
+ * ------------------------------------------------------------------------------------- */
+
+/* Multi-class non-max suppression over SHARED boxes: replaces
+ * object_detection.core.post_processing.batch_multiclass_non_max_suppression as called by
+ * core/builder.py:57-65 from models/cap2det_model.py:137-140.  boxes [batch][n][4]
+ * (ymin,xmin,ymax,xmax), scores [batch][n][ld] with the class columns at [off, off+num_classes).
+ * Per class: candidates with score > score_thresh by decreasing score (ties: lower index), a
+ * candidate is dropped when its IoU with a kept box is > iou_thresh, at most max_size_per_class
+ * kept; all classes merged by decreasing score (ties: class order, then selection order), first
+ * max_total_size written, rest zero padded.  out_classes is 1-based (float), as the reference
+ * returns `nmsed_classes + 1`.  n <= 8192.  Workspace from the query below. */
+long long c2d_multiclass_nms_workspace_bytes(int batch, int n, int num_classes,
+                                             int max_size_per_class);
+int c2d_multiclass_nms(const float* boxes, const float* scores, int ld, int off, int batch, int n,
+                       int num_classes, float score_thresh, float iou_thresh,
+                       int max_size_per_class, int max_total_size, int32_t* num_detections,
+                       float* out_boxes, float* out_scores, float* out_classes, void* workspace,
+                       long long workspace_bytes, void* stream);
+
+/* out[rows][c1-1] = softmax(logits[r][off .. off+c1))[1:]  (tf.nn.softmax(...)[:, :, 1:],
+ * models/cap2det_model.py:135). */
+int c2d_softmax_drop_background(const float* logits, int ld, int off, int rows,
+                                int num_classes_plus_one, float* out, void* stream);
+
+/* Running mean over the evaluation scales (tf.stack + tf.reduce_mean,
+ * models/cap2det_model.py:262-267): dst[rows][cols] (dense) = init ? src : dst + src, with src
+ * rows of stride ld at column off; then dst /= count. */
+int c2d_scores_accumulate(float* dst, const float* src, int ld, int off, int rows, int cols,
+                          int init, void* stream);
+int c2d_scores_divide(float* x, long long n, float divisor, void* stream);
+
+/* tf.image.resize_images(BILINEAR, align_corners=False) of TF1 (legacy scaler, no half-pixel
+ * offset) on one NHWC fp32 image: core/imgproc.py:348-351, and the reader's resizer (f1). */
+int c2d_resize_bilinear(const float* in, int ih, int iw, int channels, float* out, int oh, int ow,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif
