@@ -34,7 +34,7 @@ def _ctype(decl):
   base = base.replace("const", "").strip()
   return {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,
           "unsigned long long": ctypes.c_ulonglong, "int32_t": ctypes.c_int32,
-          "void": None}[base]
+          "unsigned int": ctypes.c_uint, "void": None}[base]
 
 
 def header_signatures():
@@ -45,10 +45,13 @@ def header_signatures():
   with open(HEADER_PATH) as f:
     text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
   sigs = {}
-  for m in re.finditer(r"(const char\*|long long|int)\s+(c2d_\w+)\s*\(([^)]*)\)\s*;", text):
+  for m in re.finditer(r"(const char\*|unsigned long long|unsigned int|long long|int)\s+(c2d_\w+)"
+                       r"\s*\(([^)]*)\)\s*;", text):
     ret, name, params = m.group(1), m.group(2), m.group(3).strip()
     args = [] if params in ("void", "") else [_ctype(p) for p in params.split(",")]
-    restype = {"int": ctypes.c_int, "long long": ctypes.c_longlong}.get(ret, ctypes.c_char_p)
+    restype = {"int": ctypes.c_int, "long long": ctypes.c_longlong,
+               "unsigned int": ctypes.c_uint,
+               "unsigned long long": ctypes.c_ulonglong}.get(ret, ctypes.c_char_p)
     sigs[name] = (restype, args)
   _SIGS = sigs
   return sigs

@@ -2,6 +2,28 @@
 core/standard_fields.py:67-132; only the fields the hot path touches)."""
 
 
+class TFExampleDataFields(object):
+  """Feature names of the tf.Example records (core/standard_fields.py:35-65)."""
+  image_id = "image/source_id"
+  image_encoded = "image/encoded"
+  caption_string = "image/caption/string"
+  caption_offset = "image/caption/offset"
+  caption_length = "image/caption/length"
+  number_of_proposals = "image/proposal/num_proposals"
+  proposal_box = "image/proposal/bbox"
+  proposal_box_ymin = "image/proposal/bbox/ymin"
+  proposal_box_xmin = "image/proposal/bbox/xmin"
+  proposal_box_ymax = "image/proposal/bbox/ymax"
+  proposal_box_xmax = "image/proposal/bbox/xmax"
+  object_box = "image/object/bbox"
+  object_text = "image/object/class/text"
+  object_label = "image/object/class/label"
+  object_box_ymin = "image/object/bbox/ymin"
+  object_box_xmin = "image/object/bbox/xmin"
+  object_box_ymax = "image/object/bbox/ymax"
+  object_box_xmax = "image/object/bbox/xmax"
+
+
 class InputDataFields(object):
   """core/standard_fields.py:67-96."""
   image = "image"

@@ -10,6 +10,7 @@ extern "C" const char* c2d_error_string(int code) {
     case C2D_ERR_UNSUPPORTED: return "unsupported configuration";
     case C2D_ERR_LAUNCH: return "kernel launch failed";
     case C2D_ERR_WORKSPACE: return "workspace too small";
+    case C2D_ERR_DATA: return "malformed input data";
     default: return "unknown error";
   }
 }

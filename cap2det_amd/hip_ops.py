@@ -310,6 +310,17 @@ def resize_bilinear(image, oh, ow, out=None):
   return out
 
 
+# -- input pipeline (GPU side) ----------------------------------------------------------
+
+def image_resize_pad_u8(image_u8, flip, canvas, oh, ow):
+  """image_u8 [ih,iw,3] uint8 device tensor -> canvas [ph,pw,3] fp32 (top-left oh x ow)."""
+  ih, iw, _ = image_u8.shape
+  ph, pw, _ = canvas.shape
+  assert image_u8.dtype == torch.uint8 and canvas.dtype == torch.float32
+  _lib.call("c2d_image_resize_pad_u8", _p(image_u8), ih, iw, int(bool(flip)), _p(canvas), oh, ow,
+            ph, pw, _stream())
+
+
 # -- optimiser --------------------------------------------------------------------------
 
 def adagrad_step(w, g, acc, lr, l2, mult, grad_scale=1.0):

@@ -30,6 +30,7 @@ extern "C" {
 #define C2D_ERR_UNSUPPORTED (-2)
 #define C2D_ERR_LAUNCH (-3)
 #define C2D_ERR_WORKSPACE (-4)
+#define C2D_ERR_DATA (-5)        /* malformed input data (record framing, protobuf, JPEG stream) */
 
 /* ABI version: major*10000 + minor*100 + patch. */
 int c2d_version(void);
@@ -332,6 +333,48 @@ int c2d_scores_divide(float* x, long long n, float divisor, void* stream);
  * offset) on one NHWC fp32 image: core/imgproc.py:348-351, and the reader's resizer (f1). */
 int c2d_resize_bilinear(const float* in, int ih, int iw, int channels, float* out, int oh, int ow,
                         void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Input pipeline: host-side record / proto / JPEG decoding
+ * (io_native.cpp, plain C++: entropy decoding is serial) and GPU-side pixel work.
+ * All pointers in this block are HOST pointers unless stated otherwise.
+ * ------------------------------------------------------------------------------------- */
+
+/* CRC-32C and TFRecord's masked form rotr(crc, 15) + 0xa282ead8. */
+unsigned int c2d_crc32c(const void* data, long long n);
+unsigned int c2d_masked_crc32c(const void* data, long long n);
+/* Next record of a TFRecord byte buffer (what tf.data.TFRecordDataset yields,
+ * readers/cap2det_reader.py:217-218): returns the position after the record, 0 at a clean end,
+ * C2D_ERR_DATA on truncation / CRC mismatch (verify_crc != 0). */
+long long c2d_tfrecord_next(const uint8_t* buf, long long size, long long pos,
+                            long long* payload_off, long long* payload_len, int verify_crc);
+/* Frames one payload (n + 16 bytes written); used to write fixtures. */
+long long c2d_tfrecord_frame(const uint8_t* payload, long long n, uint8_t* out);
+/* tf.parse_single_example (readers/cap2det_reader.py:40-59) of one serialized tf.Example for
+ * `nkeys` feature names: kinds[k] = 0 absent, 1 bytes, 2 float, 3 int64; counts[k] values
+ * starting at starts[k] in the arena of that kind; bytes values are (offset, length) pairs into
+ * `rec`.  C2D_ERR_WORKSPACE when an arena is too small. */
+int c2d_example_parse(const uint8_t* rec, long long len, const char* const* keys, int nkeys,
+                      int* kinds, long long* counts, long long* starts, float* floats,
+                      long long float_cap, long long* ints, long long int_cap, long long* spans,
+                      long long span_cap);
+/* TensorFlow's Hash64 (seed 0xDECAFCAFFE): tf.strings.to_hash_bucket(s, k) = hash % k, the
+ * shard filter of readers/cap2det_reader.py:201-211. */
+unsigned long long c2d_tf_hash64(const void* data, long long n);
+/* Baseline / extended-sequential JPEG -> RGB u8 [height][width][3] with libjpeg's default
+ * decompression choices (islow IDCT, fancy upsampling), i.e. tf.image.decode_jpeg(channels=3)
+ * (readers/cap2det_reader.py:91-92).  Progressive streams: C2D_ERR_UNSUPPORTED. */
+int c2d_jpeg_info(const uint8_t* data, long long n, int* height, int* width, int* components);
+long long c2d_jpeg_workspace_bytes(int height, int width);
+int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* out, int height, int width,
+                        void* workspace, long long workspace_bytes);
+
+/* DEVICE pointers: one decoded RGB u8 image [ih][iw][3] -> optional tf.image.flip_left_right
+ * (core/preprocess.py:48-52) -> TF1 legacy-bilinear resize to oh x ow (core/builder.py:70-128
+ * resizers) -> written into the top-left corner of a ph x pw fp32 canvas, zeros elsewhere (the
+ * zero padding of `padded_batch`, readers/cap2det_reader.py:220-247). */
+int c2d_image_resize_pad_u8(const uint8_t* image, int ih, int iw, int flip_left_right,
+                            float* canvas, int oh, int ow, int ph, int pw, void* stream);
 
 #ifdef __cplusplus
 }
