@@ -166,11 +166,17 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  # C2D_BENCH_SAME_DEVICE=1 (validation of the multi-rank code path on a 1-GPU box only): every
+  # rank uses cuda:0 and the process group runs over gloo; the reported number is meaningless.
+  same_device = os.environ.get("C2D_BENCH_SAME_DEVICE") == "1"
+  if same_device:
+    local_rank = 0
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dist.init_process_group(backend="gloo" if same_device else "nccl", rank=rank,
+                            world_size=world)
   elif args.gpus > 1:
     raise SystemExit("launch with torch.distributed.run for --gpus > 1")
   device = "cuda:%d" % local_rank
