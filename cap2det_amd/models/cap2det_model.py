@@ -360,9 +360,11 @@ class Model(ModelBase):
       ops.l2_loss(self.store.var[HEADS_W], self._l2_weight, out)
     return self._losses[-1]
 
-  def backward(self):
+  def backward(self, after_second_stage=None):
     """Gradients of sum(losses) w.r.t. every trainable variable, accumulated into
-    `self.store.grads` (caller zeroes it once per step)."""
+    `self.store.grads` (caller zeroes it once per step).  after_second_stage: callable invoked
+    once the head and second-stage gradients are final (the data-parallel reducer starts its
+    big all-reduce there, under the ROI-crop / first-stage backward)."""
     ctx = self._ctx
     bufs, b, n = ctx["bufs"], ctx["b"], ctx["n"]
     d = self.engine.feature_dims
@@ -373,7 +375,7 @@ class Model(ModelBase):
     ops.col_sum(bufs["dlogits"], self._npad, 0, g[HEADS_B], b * n, self._npad)
     ops.conv_dgrad(bufs["dlogits"], self._npad, 0, self.store.var[HEADS_W], bufs["dfeatures"], d, 0,
                    b * n, 1, 1, d, self._npad, 1, 1, 1, False)
-    self.engine.backward(bufs["dfeatures"], d, 0, ctx["fctx"])
+    self.engine.backward(bufs["dfeatures"], d, 0, ctx["fctx"], after_second_stage)
 
   def build_evaluation(self, predictions, examples=None, **kwargs):
     """models/cap2det_model.py:332-343 returns {} in the reference."""

@@ -741,7 +741,7 @@ class FrcnnEngine(object):
     ctx = dict(bufs=bufs, b=b, n=n, boxes=boxes, mask=mask, feat4=feat4)
     return bufs["features"], ctx
 
-  def backward(self, dfeatures, lddf, dfoff, ctx):
+  def backward(self, dfeatures, lddf, dfoff, ctx, after_second_stage=None):
     """dfeatures: [B*N][lddf] buffer holding d(loss)/d(features) at columns [dfoff, dfoff+D)."""
     bufs, b, n = ctx["bufs"], ctx["b"], ctx["n"]
     plan2 = bufs["plan2"]
@@ -757,6 +757,8 @@ class FrcnnEngine(object):
                               bufs["pooled"].c)
       dpooled = bufs["dpooled"]
     self.second.backward(plan2, bufs["pooled"], 0, dpooled)
+    if after_second_stage is not None:
+      after_second_stage()
     if need_first:
       plan1 = bufs["plan1"]
       gfeat = self.first.out_grad(plan1, self.first_trainable_idx)

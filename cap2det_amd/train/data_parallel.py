@@ -33,3 +33,35 @@ def allreduce_bucket(flat, group=None):
       raise ValueError("gradient bucket must be contiguous")
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
   return 1.0 / world
+
+
+class OverlappedReducer(object):
+  """Two-bucket reduction of the flat gradient buffer, the big one under the tail of backward.
+
+  The flat gradient bucket is laid out [first-stage trainable part | second stage | heads].
+  Everything from the second stage on is final as soon as the second-stage backward has run,
+  while the ROI-crop backward and the first-stage layers (Mixed_4e in the shipped configs)
+  still have ~1 ms of kernels to go: `start_tail()` launches the all-reduce of that suffix
+  (>= 85 % of the bytes) asynchronously — RCCL runs it on its own stream after the gradient
+  kernels already enqueued — and `finish()` reduces the small prefix and waits for both.
+  With one rank both are no-ops."""
+
+  def __init__(self, flat, split, group=None):
+    self.flat, self.split, self.group = flat, int(split), group
+    self._work = None
+    _, self.world = world_info()
+
+  def start_tail(self):
+    if self.world > 1 and self.split < self.flat.numel():
+      self._work = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, group=self.group,
+                                   async_op=True)
+
+  def finish(self):
+    if self.world > 1:
+      head = self.flat[:self.split] if self._work is not None else self.flat
+      if head.numel():
+        dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
+      if self._work is not None:
+        self._work.wait()
+        self._work = None
+    return 1.0 / self.world

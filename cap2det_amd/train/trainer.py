@@ -98,6 +98,12 @@ class Trainer(object):
       raise ValueError("no trainable variables")
     self.bucket = (min(s[0] for s in segs), max(s[1] for s in segs))
     self.rank, self.world_size = data_parallel.world_info()
+    # first flat offset of the second stage: everything from there on (second stage + heads) is
+    # final before the ROI-crop / first-stage backward starts (data_parallel.OverlappedReducer)
+    second = [store.offset[n][0] for n in store.names()
+              if n.startswith("second_stage_feature_extraction")]
+    lo = self.bucket[0]
+    self._tail_split = (min(second) - lo) if second and min(second) > lo else 0
     # hipGraph replay of the (static) step: removes the ~6 us host gap after each of the ~240
     # launches.  Inputs are staged into fixed device buffers; the dropout seed lives in HBM.
     self.use_graph = bool(use_graph)
@@ -112,14 +118,14 @@ class Trainer(object):
       lr = exponential_decay(lr, self.global_step, d.decay_steps, d.decay_rate, d.staircase)
     return lr
 
-  def _forward_backward(self, examples, **kwargs):
+  def _forward_backward(self, examples, after_second_stage=None, **kwargs):
     model, store = self.model, self.model.store
     lo, hi = self.bucket
     store.grads[lo:hi].zero_()
     predictions = model.build_prediction(examples, **kwargs)
     losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
     losses['regularization_loss'] = model.regularization_loss()
-    model.backward()
+    model.backward(after_second_stage)
     return predictions, losses
 
   def _apply_gradients(self, scale, lr):
@@ -136,8 +142,9 @@ class Trainer(object):
       return self._graph_step(examples, **kwargs)
     store = self.model.store
     lo, hi = self.bucket
-    predictions, losses = self._forward_backward(examples, **kwargs)
-    scale = data_parallel.allreduce_bucket(store.grads[lo:hi])
+    reducer = data_parallel.OverlappedReducer(store.grads[lo:hi], self._tail_split)
+    predictions, losses = self._forward_backward(examples, reducer.start_tail, **kwargs)
+    scale = reducer.finish()
     self._apply_gradients(scale, self.learning_rate())
     self.global_step += 1
     losses['total_loss'] = self.model._losses.sum()

@@ -85,3 +85,34 @@ def test_single_process_bucket_is_identity():
   t = torch.arange(8, dtype=torch.float32)
   assert data_parallel.allreduce_bucket(t) == 1.0
   assert t.tolist() == list(range(8))
+
+
+def _overlap_worker(rank, world, port, out_path):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    flat = torch.arange(1000, dtype=torch.float64) * (rank + 1)
+    red = data_parallel.OverlappedReducer(flat, 137)
+    red.start_tail()                      # big suffix, asynchronous
+    flat[:137] += 0.5                     # "first-stage backward" still writes the prefix
+    scale = red.finish()
+    if rank == 0:
+      np.save(out_path, flat.numpy() * scale)
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_overlapped_two_bucket_reducer(tmp_path):
+  out_path = str(tmp_path / "ov.npy")
+  mp.spawn(_overlap_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+  got = np.load(out_path)
+  want = np.arange(1000, dtype=np.float64) * 1.5       # mean of x and 2x
+  want[:137] += 0.5
+  np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+  # single process: both calls are no-ops
+  t = torch.arange(8, dtype=torch.float32)
+  r = data_parallel.OverlappedReducer(t, 3)
+  r.start_tail()
+  assert r.finish() == 1.0 and t.tolist() == list(range(8))
