@@ -110,6 +110,28 @@ class Trainer(object):
     self._graphs = None
     self._static = None
 
+  # -- checkpoint / resume (reference: tf.estimator saves `model.ckpt-<step>` in model_dir,
+  #    train/trainer.py:174-208; here one .npz per step under the reference variable names) ----
+  def save_checkpoint(self, model_dir):
+    import os
+    import numpy as np
+    os.makedirs(model_dir, exist_ok=True)
+    path = os.path.join(model_dir, "model.ckpt-%d" % self.global_step)
+    state = self.model.state_dict()
+    store = self.model.store
+    np.savez(path + ".npz", __global_step=np.int64(self.global_step),
+             __adagrad_accumulators=store.accum.detach().cpu().numpy(), **state)
+    return path
+
+  def load_checkpoint(self, path):
+    import numpy as np
+    arrays = dict(np.load(path if path.endswith(".npz") else path + ".npz"))
+    self.global_step = int(arrays.pop("__global_step"))
+    accum = arrays.pop("__adagrad_accumulators")
+    self.model.load_state_dict(arrays)
+    self.model.store.accum.copy_(torch.from_numpy(accum).to(self.device))
+    self._graphs = None
+
   def learning_rate(self):
     tc = self.train_config
     lr = tc.learning_rate

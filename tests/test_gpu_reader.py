@@ -140,3 +140,61 @@ def test_reader_feeds_the_model(tmp_path):
   trainer = Trainer(util_model.load_pipeline(), device=DEV, depth_multiplier=0.5)
   losses = trainer.train_step(batch, dropout_seed=0)
   assert np.isfinite(float(losses["total_loss"].item()))
+
+
+def test_evaluation_loop_and_checkpoint_round_trip(tmp_path):
+  """TFRecords -> reader (eval mode) -> multi-scale inference + NMS -> PASCAL evaluator
+  (train/predict.py:328-420), and trainer checkpoints (save, keep-best, resume bit-exactly)."""
+  from cap2det_amd.models import builder
+  from cap2det_amd.readers import cap2det_reader
+  from cap2det_amd.train import evaluation as ev
+  from cap2det_amd.train.trainer import Trainer
+  from tests import util_model
+  rng = np.random.default_rng(41)
+  recs = [_example(rng, "%06d" % i, 50 + 4 * i, 64 - 3 * i, 9, 2, ["a", "b"]) for i in range(3)]
+  T.write_records(str(tmp_path / "e.record"), recs)
+  opt = _reader_options(str(tmp_path / "e.record"), False, 1)
+  pipeline = util_model.load_pipeline()
+  model = builder.build(pipeline.model, is_training=False, device=DEV, depth_multiplier=0.5)
+  m = model._model_proto
+  del m.eval_min_dimension[:]
+  m.eval_min_dimension.extend([48, 40])
+  classes = model.label_extractor.classes
+  cats = [{'id': i + 1, 'name': c} for i, c in enumerate(classes)]
+  cat2id = {c['name']: c['id'] for c in cats}
+
+  def batches():
+    for b in cap2det_reader.get_input_fn(opt, device=DEV)():
+      # the fixture's object texts are cls0..2: rename them to real class names
+      b["object_texts"] = [[classes[int(t[3:])] if t else "" for t in row] for row in b["object_texts"]]
+      yield b
+
+  evaluators = [ev.PascalDetectionEvaluator(cats) for _ in range(4)]
+  metrics = ev.run_evaluation(model, batches(), evaluators, cat2id)
+  assert len(metrics) == 4
+  for mt in metrics:
+    v = mt['PascalBoxes_Precision/mAP@0.5IOU']
+    assert 0.0 <= v <= 1.0
+    assert 0.0 <= mt['PascalBoxes_Precision/meanCorLoc@0.5IOU'] <= 1.0
+  # checkpoints: train 2 steps, save, train 1 more; resume from the save and repeat the step
+  tr = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=3)
+  ex = util_model.make_examples(rng, 1, 48, 48, 6, [6], classes)
+  dev = dict(ex)
+  for k in ("image", "proposals"):
+    dev[k] = torch.from_numpy(ex[k]).to(DEV)
+  dev["number_of_proposals"] = torch.from_numpy(ex["number_of_proposals"]).to(DEV)
+  for i in range(2):
+    tr.train_step(dev, dropout_seed=i)
+  path = tr.save_checkpoint(str(tmp_path / "model_dir"))
+  assert path.endswith("model.ckpt-2")
+  l3 = float(tr.train_step(dev, dropout_seed=2)["total_loss"].item())
+  w3 = tr.model.store.values.clone()
+  tr2 = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=99)     # different init
+  tr2.load_checkpoint(path)
+  assert tr2.global_step == 2
+  l3b = float(tr2.train_step(dev, dropout_seed=2)["total_loss"].item())
+  np.testing.assert_allclose(l3b, l3, rtol=1e-5)
+  np.testing.assert_allclose(tr2.model.store.values.cpu().numpy(), w3.cpu().numpy(), rtol=1e-4, atol=1e-6)
+  step_best, metric_best = ev.save_model_if_it_is_better(2, 0.5, path, str(tmp_path / "best"))
+  assert (step_best, metric_best) == (2, 0.5)
+  assert ev.get_best_model_checkpoint(str(tmp_path / "best")).endswith("model.ckpt-2")
