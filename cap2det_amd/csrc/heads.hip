@@ -298,6 +298,97 @@ __global__ __launch_bounds__(256) void text_classifier_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Text-classifier TRAINING (models/text_model.py:31-129 through
+// models/label_extractor.py:353-421 with is_training=True).  The two FC layers run on the MFMA
+// GEMM kernels (c2d_conv_fwd / dgrad / wgrad with 1x1 geometry); these kernels do the rest.
+// ---------------------------------------------------------------------------------------------
+
+// x[b*T + t][0..ld) = embedding[id] zero-padded from E to ld columns (ld % 16 == 0 for the GEMM).
+__global__ __launch_bounds__(256) void embedding_gather_kernel(const int32_t* __restrict__ ids,
+                                                               long long rows,
+                                                               const float* __restrict__ emb,
+                                                               int vocab, int E, int ld,
+                                                               float* __restrict__ x) {
+  const long long total = rows * ld;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / ld;
+    const int e = (int)(i - r * ld);
+    int id = ids[r];
+    if (id < 0 || id > vocab) id = vocab;
+    x[i] = e < E ? emb[(size_t)id * E + e] : 0.0f;
+  }
+}
+
+// hidden[b][h] = dropout(relu(masked_maximum_t(pre[b][t][h]))) with masked_maximum =
+// max_t((pre - min_t pre) * mask_t) + min_t pre, mask_t = (id_t != OOV) (core/utils.py:63-79),
+// dropout = x * keepmask / keep_prob (slim.dropout; keepmask NULL = no dropout).
+__global__ __launch_bounds__(256) void text_pool_fwd_kernel(
+    const float* __restrict__ pre, const int32_t* __restrict__ ids, int T, int H, int vocab,
+    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ hidden) {
+  const int b = blockIdx.y;
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const float* p = pre + (size_t)b * T * H + h;
+  float mn = INFINITY;
+  for (int t = 0; t < T; ++t) mn = fminf(mn, p[(size_t)t * H]);
+  float best = -INFINITY;
+  for (int t = 0; t < T; ++t) {
+    const int id = ids[b * T + t];
+    const float m = (id >= 0 && id < vocab) ? 1.0f : 0.0f;
+    best = fmaxf(best, (p[(size_t)t * H] - mn) * m);
+  }
+  float y = fmaxf(best + mn, 0.0f);
+  if (keepmask) y = keepmask[(size_t)b * H + h] ? y * inv_keep : 0.0f;
+  hidden[(size_t)b * H + h] = y;
+}
+
+// Gradient of the above w.r.t. pre, with TensorFlow's tie rules (reduce_max / reduce_min split
+// the gradient equally among tied extrema): with z_t = (x_t - m) mu_t, y = max_t z_t + m,
+//   dy/dx_s = mu_s [z_s == max z] / n_max + ([x_s == m] / n_min) (1 - sum_t mu_t [z_t == max z] / n_max)
+__global__ __launch_bounds__(256) void text_pool_bwd_kernel(
+    const float* __restrict__ dhidden, const float* __restrict__ pre,
+    const int32_t* __restrict__ ids, int T, int H, int vocab, const uint8_t* __restrict__ keepmask,
+    float inv_keep, float* __restrict__ dpre) {
+  const int b = blockIdx.y;
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const float* p = pre + (size_t)b * T * H + h;
+  float* d = dpre + (size_t)b * T * H + h;
+  float mn = INFINITY;
+  for (int t = 0; t < T; ++t) mn = fminf(mn, p[(size_t)t * H]);
+  float zmax = -INFINITY;
+  int nmin = 0;
+  for (int t = 0; t < T; ++t) {
+    const int id = ids[b * T + t];
+    const float m = (id >= 0 && id < vocab) ? 1.0f : 0.0f;
+    const float x = p[(size_t)t * H];
+    zmax = fmaxf(zmax, (x - mn) * m);
+    nmin += x == mn ? 1 : 0;
+  }
+  int nmax = 0;
+  float smu = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const int id = ids[b * T + t];
+    const float m = (id >= 0 && id < vocab) ? 1.0f : 0.0f;
+    if ((p[(size_t)t * H] - mn) * m == zmax) { ++nmax; smu += m; }
+  }
+  float g = dhidden[(size_t)b * H + h];
+  if (keepmask) g = keepmask[(size_t)b * H + h] ? g * inv_keep : 0.0f;
+  if (!(zmax + mn > 0.0f)) g = 0.0f;                       // relu'(y): y > 0
+  const float via_min = g * (1.0f - smu / (float)nmax) / (float)nmin;
+  for (int t = 0; t < T; ++t) {
+    const int id = ids[b * T + t];
+    const float m = (id >= 0 && id < vocab) ? 1.0f : 0.0f;
+    const float x = p[(size_t)t * H];
+    float v = 0.f;
+    if ((x - mn) * m == zmax) v += g * m / (float)nmax;
+    if (x == mn) v += via_min;
+    d[(size_t)t * H] = v;
+  }
+}
+
 // labels = any(exact > 0) ? exact : (sigmoid(logits) > thr)
 __global__ __launch_bounds__(256) void text_labels_merge_kernel(const float* __restrict__ logits,
                                                                 const float* __restrict__ exact,
@@ -490,5 +581,39 @@ extern "C" int c2d_word_vector_match_fwd(const int32_t* ids, int batch, int num_
   hipLaunchKernelGGL(word_vector_match_kernel, dim3(batch), dim3(256), smem, (hipStream_t)stream,
                      ids, num_tokens, embedding, vocab_size, emb_dims, class_ids, num_classes,
                      exact_labels, labels);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_embedding_gather(const int32_t* ids, long long rows, const float* embedding,
+                                    int vocab_size, int emb_dims, int ld, float* x, void* stream) {
+  C2D_CHECK_ARG(ids && embedding && x && rows > 0 && vocab_size > 0 && emb_dims > 0 &&
+                ld >= emb_dims);
+  long long blocks = (rows * ld + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(embedding_gather_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                     ids, rows, embedding, vocab_size, emb_dims, ld, x);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_text_pool_fwd(const float* pre, const int32_t* ids, int batch, int num_tokens,
+                                 int hidden_units, int vocab_size, const uint8_t* keep_mask,
+                                 float keep_prob, float* hidden, void* stream) {
+  C2D_CHECK_ARG(pre && ids && hidden && batch > 0 && num_tokens > 0 && hidden_units > 0);
+  C2D_CHECK_ARG(vocab_size > 0 && keep_prob > 0.0f);
+  hipLaunchKernelGGL(text_pool_fwd_kernel, dim3(c2d_ceil_div(hidden_units, 256), batch), dim3(256),
+                     0, (hipStream_t)stream, pre, ids, num_tokens, hidden_units, vocab_size,
+                     keep_mask, 1.0f / keep_prob, hidden);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_text_pool_bwd(const float* dhidden, const float* pre, const int32_t* ids,
+                                 int batch, int num_tokens, int hidden_units, int vocab_size,
+                                 const uint8_t* keep_mask, float keep_prob, float* dpre,
+                                 void* stream) {
+  C2D_CHECK_ARG(dhidden && pre && ids && dpre && batch > 0 && num_tokens > 0 && hidden_units > 0);
+  C2D_CHECK_ARG(vocab_size > 0 && keep_prob > 0.0f);
+  hipLaunchKernelGGL(text_pool_bwd_kernel, dim3(c2d_ceil_div(hidden_units, 256), batch), dim3(256),
+                     0, (hipStream_t)stream, dhidden, pre, ids, num_tokens, hidden_units,
+                     vocab_size, keep_mask, 1.0f / keep_prob, dpre);
   return c2d_launch_status();
 }

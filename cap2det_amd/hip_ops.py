@@ -321,6 +321,25 @@ def image_resize_pad_u8(image_u8, flip, canvas, oh, ow):
             ph, pw, _stream())
 
 
+# -- text-classifier training -----------------------------------------------------------
+
+def embedding_gather(ids, embedding, ld, x):
+  _lib.call("c2d_embedding_gather", _p(ids), ids.numel(), _p(embedding), embedding.shape[0] - 1,
+            embedding.shape[1], ld, _p(x), _stream())
+
+
+def text_pool_fwd(pre, ids, hidden_units, vocab_size, keep_mask, keep_prob, hidden):
+  b, t = ids.shape
+  _lib.call("c2d_text_pool_fwd", _p(pre), _p(ids), b, t, hidden_units, vocab_size, _p(keep_mask),
+            float(keep_prob), _p(hidden), _stream())
+
+
+def text_pool_bwd(dhidden, pre, ids, hidden_units, vocab_size, keep_mask, keep_prob, dpre):
+  b, t = ids.shape
+  _lib.call("c2d_text_pool_bwd", _p(dhidden), _p(pre), _p(ids), b, t, hidden_units, vocab_size,
+            _p(keep_mask), float(keep_prob), _p(dpre), _stream())
+
+
 # -- optimiser --------------------------------------------------------------------------
 
 def adagrad_step(w, g, acc, lr, l2, mult, grad_scale=1.0):

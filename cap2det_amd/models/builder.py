@@ -5,6 +5,7 @@ from cap2det_amd.protos.message import unwrap
 from cap2det_amd.models.registry import get_registered_model_classes
 
 import cap2det_amd.models.cap2det_model  # noqa: F401  (registration side effect, builder.py:9-10)
+import cap2det_amd.models.text_model     # noqa: F401
 
 
 def build(options, is_training=False, **kwargs):

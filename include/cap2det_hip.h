@@ -376,6 +376,26 @@ int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* out, int heig
 int c2d_image_resize_pad_u8(const uint8_t* image, int ih, int iw, int flip_left_right,
                             float* canvas, int oh, int ow, int ph, int pw, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Text-classifier training (models/text_model.py:31-129 over
+ * models/label_extractor.py:353-421 with is_training = True).  The two fully connected layers
+ * run on c2d_conv_fwd / c2d_conv_dgrad / c2d_conv_wgrad (1x1 geometry); these do the rest.
+ * ------------------------------------------------------------------------------------- */
+
+/* x[rows][ld] = embedding[ids[r]] (ids outside [0, vocab_size) -> the OOV row vocab_size),
+ * zero padded from emb_dims to ld columns: tf.nn.embedding_lookup, :384-390. */
+int c2d_embedding_gather(const int32_t* ids, long long rows, const float* embedding,
+                         int vocab_size, int emb_dims, int ld, float* x, void* stream);
+/* hidden[b][h] = dropout(relu(masked_maximum_t(pre[b][t][h]; id_t != OOV))) (:397-410,
+ * core/utils.py:63-79; keep_mask NULL = evaluation) and its gradient w.r.t. pre with
+ * TensorFlow's tie rules (reduce_max / reduce_min share the gradient among tied extrema). */
+int c2d_text_pool_fwd(const float* pre, const int32_t* ids, int batch, int num_tokens,
+                      int hidden_units, int vocab_size, const uint8_t* keep_mask, float keep_prob,
+                      float* hidden, void* stream);
+int c2d_text_pool_bwd(const float* dhidden, const float* pre, const int32_t* ids, int batch,
+                      int num_tokens, int hidden_units, int vocab_size, const uint8_t* keep_mask,
+                      float keep_prob, float* dpre, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

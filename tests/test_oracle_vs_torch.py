@@ -228,3 +228,38 @@ def test_midn_oicr_loss_gradients_match_autograd():
   np.testing.assert_allclose(dfeat, xt.grad.numpy(), rtol=1e-8, atol=1e-12)
   for kk, g in grads.items():
     np.testing.assert_allclose(g, Pt[kk].grad.numpy(), rtol=1e-8, atol=1e-12, err_msg=kk)
+
+
+def test_text_training_oracle_matches_torch_autograd():
+  """oracle/ref_text.py backward (TF tie rules of reduce_max / reduce_min) vs torch autograd:
+  amax / amin distribute the gradient evenly among ties, as TensorFlow does."""
+  from oracle import ref_text
+  rng = np.random.default_rng(77)
+  B, T, E, H, C, V = 4, 6, 10, 7, 5, 9
+  emb = rng.standard_normal((V + 1, E))
+  ids = rng.integers(0, V + 1, (B, T))
+  ids[1] = V                                   # all-OOV caption: the max falls back to the min
+  ids[2, 1:] = V                               # a single real token
+  w1 = rng.standard_normal((E, H)) * 0.5; b1 = rng.standard_normal(H) * 0.1
+  w2 = rng.standard_normal((H, C)) * 0.5; b2 = rng.standard_normal(C) * 0.1
+  emb[ids[3, 0]] = emb[ids[3, 1]]              # two identical tokens: exact ties in max and min
+  keep = (rng.uniform(size=(B, H)) < 0.6).astype(np.float64)
+  labels = (rng.uniform(size=(B, C)) < 0.3).astype(np.float64)
+  logits, tape = ref_text.forward(ids, emb, w1, b1, w2, b2, keep, 0.6)
+  loss, dlogits = ref_text.sigmoid_ce_mean(logits, labels)
+  grads, _ = ref_text.backward(dlogits, tape, w2)
+
+  tw1, tb1, tw2, tb2 = [torch.tensor(a, requires_grad=True) for a in (w1, b1, w2, b2)]
+  x = torch.tensor(emb)[torch.tensor(ids)]
+  mu = torch.tensor((ids != V).astype(np.float64))[..., None]
+  pre = x @ tw1 + tb1
+  m = pre.amin(dim=1, keepdim=True)
+  y = ((pre - m) * mu).amax(dim=1) + m[:, 0]
+  h = torch.relu(y) * torch.tensor(keep) / 0.6
+  lg = h @ tw2 + tb2
+  tl = torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.tensor(labels))
+  tl.backward()
+  np.testing.assert_allclose(logits, lg.detach().numpy(), rtol=1e-12, atol=1e-12)
+  np.testing.assert_allclose(loss, tl.item(), rtol=1e-12)
+  for k, t in (("w1", tw1), ("b1", tb1), ("w2", tw2), ("b2", tb2)):
+    np.testing.assert_allclose(grads[k], t.grad.numpy(), rtol=1e-9, atol=1e-12, err_msg=k)
