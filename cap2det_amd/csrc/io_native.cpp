@@ -361,72 +361,80 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+inline int clampc(long long v) { return (int)(v > (1 << 20) ? (1 << 20) : (v < -(1 << 20) ? -(1 << 20) : v)); }
 
 // jidctint.c (jpeg_idct_islow): LL&M integer IDCT, CONST_BITS = 13, PASS1_BITS = 2.
+// Intermediates are 64-bit: identical results on valid streams (libjpeg's 32-bit arithmetic
+// never overflows there) and no signed overflow on corrupted ones (coefficients are clamped to
+// +-2^20 by the caller).
+typedef long long idct_t;
+inline uint8_t clamp8l(idct_t v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 void idct_islow(const int* coef /* dequantized, natural order */, uint8_t* out, int stride) {
   const int CB = 13, P1 = 2;
-  const int F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633,
+  const idct_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633,
             F1501 = 12299, F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
-  int ws[64];
+  idct_t ws[64];
   for (int c = 0; c < 8; ++c) {
     const int* in = coef + c;
-    int* w = ws + c;
+    idct_t* w = ws + c;
     if (in[8] == 0 && in[16] == 0 && in[24] == 0 && in[32] == 0 && in[40] == 0 && in[48] == 0 &&
         in[56] == 0) {
-      const int dc = in[0] * (1 << P1);
+      const idct_t dc = (idct_t)in[0] * (1 << P1);
       for (int r = 0; r < 8; ++r) w[8 * r] = dc;
       continue;
     }
-    int z2 = in[16], z3 = in[48];
-    int z1 = (z2 + z3) * F0541;
-    int tmp2 = z1 + z3 * (-F1847);
-    int tmp3 = z1 + z2 * F0765;
+    idct_t z2 = in[16], z3 = in[48];
+    idct_t z1 = (z2 + z3) * F0541;
+    idct_t tmp2 = z1 + z3 * (-F1847);
+    idct_t tmp3 = z1 + z2 * F0765;
     z2 = in[0]; z3 = in[32];
-    int tmp0 = (z2 + z3) * (1 << CB);
-    int tmp1 = (z2 - z3) * (1 << CB);
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    idct_t tmp0 = (z2 + z3) * (1 << CB);
+    idct_t tmp1 = (z2 - z3) * (1 << CB);
+    const idct_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
     z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-    int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * F1175;
+    idct_t z4 = tmp1 + tmp3;
+    const idct_t z5 = (z3 + z4) * F1175;
     tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
     z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    const int sh = CB - P1, rnd = 1 << (sh - 1);
+    const int sh = CB - P1;
+    const idct_t rnd = 1 << (sh - 1);
     w[0] = (tmp10 + tmp3 + rnd) >> sh;  w[56] = (tmp10 - tmp3 + rnd) >> sh;
     w[8] = (tmp11 + tmp2 + rnd) >> sh;  w[48] = (tmp11 - tmp2 + rnd) >> sh;
     w[16] = (tmp12 + tmp1 + rnd) >> sh; w[40] = (tmp12 - tmp1 + rnd) >> sh;
     w[24] = (tmp13 + tmp0 + rnd) >> sh; w[32] = (tmp13 - tmp0 + rnd) >> sh;
   }
-  const int sh = CB + P1 + 3, rnd = 1 << (sh - 1);
+  const int sh = CB + P1 + 3;
+  const idct_t rnd = 1 << (sh - 1);
   for (int r = 0; r < 8; ++r) {
-    const int* w = ws + 8 * r;
+    const idct_t* w = ws + 8 * r;
     uint8_t* o = out + r * stride;
     if (w[1] == 0 && w[2] == 0 && w[3] == 0 && w[4] == 0 && w[5] == 0 && w[6] == 0 && w[7] == 0) {
-      const uint8_t dc = clamp8(((w[0] + (1 << (P1 + 2))) >> (P1 + 3)) + 128);
+      const uint8_t dc = clamp8l(((w[0] + (1 << (P1 + 2))) >> (P1 + 3)) + 128);
       for (int c = 0; c < 8; ++c) o[c] = dc;
       continue;
     }
-    int z2 = w[2], z3 = w[6];
-    int z1 = (z2 + z3) * F0541;
-    int tmp2 = z1 + z3 * (-F1847);
-    int tmp3 = z1 + z2 * F0765;
-    int tmp0 = (w[0] + w[4]) * (1 << CB);
-    int tmp1 = (w[0] - w[4]) * (1 << CB);
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    idct_t z2 = w[2], z3 = w[6];
+    idct_t z1 = (z2 + z3) * F0541;
+    idct_t tmp2 = z1 + z3 * (-F1847);
+    idct_t tmp3 = z1 + z2 * F0765;
+    idct_t tmp0 = (w[0] + w[4]) * (1 << CB);
+    idct_t tmp1 = (w[0] - w[4]) * (1 << CB);
+    const idct_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
     z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-    int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * F1175;
+    idct_t z4 = tmp1 + tmp3;
+    const idct_t z5 = (z3 + z4) * F1175;
     tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
     z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    o[0] = clamp8(((tmp10 + tmp3 + rnd) >> sh) + 128); o[7] = clamp8(((tmp10 - tmp3 + rnd) >> sh) + 128);
-    o[1] = clamp8(((tmp11 + tmp2 + rnd) >> sh) + 128); o[6] = clamp8(((tmp11 - tmp2 + rnd) >> sh) + 128);
-    o[2] = clamp8(((tmp12 + tmp1 + rnd) >> sh) + 128); o[5] = clamp8(((tmp12 - tmp1 + rnd) >> sh) + 128);
-    o[3] = clamp8(((tmp13 + tmp0 + rnd) >> sh) + 128); o[4] = clamp8(((tmp13 - tmp0 + rnd) >> sh) + 128);
+    o[0] = clamp8l(((tmp10 + tmp3 + rnd) >> sh) + 128); o[7] = clamp8l(((tmp10 - tmp3 + rnd) >> sh) + 128);
+    o[1] = clamp8l(((tmp11 + tmp2 + rnd) >> sh) + 128); o[6] = clamp8l(((tmp11 - tmp2 + rnd) >> sh) + 128);
+    o[2] = clamp8l(((tmp12 + tmp1 + rnd) >> sh) + 128); o[5] = clamp8l(((tmp12 - tmp1 + rnd) >> sh) + 128);
+    o[3] = clamp8l(((tmp13 + tmp0 + rnd) >> sh) + 128); o[4] = clamp8l(((tmp13 - tmp0 + rnd) >> sh) + 128);
   }
 }
 
@@ -611,7 +619,9 @@ extern "C" int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* ou
             if (t < 0 || t > 11) return C2D_ERR_DATA;
             int diff = t ? extend(get_bits(br, t), t) : 0;
             c.dc_pred += diff;
-            coef[0] = c.dc_pred * q[0];
+            if (c.dc_pred > (1 << 20)) c.dc_pred = 1 << 20;       // (only corrupted streams get here)
+            if (c.dc_pred < -(1 << 20)) c.dc_pred = -(1 << 20);
+            coef[0] = clampc((long long)c.dc_pred * q[0]);
             for (int k = 1; k < 64;) {
               const int rs = decode_sym(br, hd.ac[c.ta]);
               if (rs < 0) return C2D_ERR_DATA;
@@ -623,7 +633,7 @@ extern "C" int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* ou
               k += r;
               if (k > 63) return C2D_ERR_DATA;
               const int z = kZigzag[k];
-              coef[z] = extend(get_bits(br, s), s) * q[z];
+              coef[z] = clampc((long long)extend(get_bits(br, s), s) * q[z]);
               ++k;
             }
             uint8_t* dst = c.plane + (size_t)((my * c.v + by) * 8) * c.pw + (mx * c.h + bx) * 8;
