@@ -131,6 +131,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long
   return __builtin_amdgcn_make_buffer_rsrc(
       (void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
 }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_b(const void* p, long long bytes) {
+  return make_rsrc((const float*)p, bytes);
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0);
@@ -161,6 +166,7 @@ struct IgemmArgs {
   const float* segA[4]; const float* segB[4];
   int seg_lda[4], seg_off[4], segK[4];   // (every segment's A has a_rows rows)
   int total_slabs;
+  int es;                   // operand / output element size: 4 (fp32) or 2 (bf16)
   ConvGeom g;
 #ifdef C2D_TRACE
   unsigned long long* trace;   // diagnostic build only: 8 x u64 per block (tools/trace_igemm.py)
@@ -212,11 +218,18 @@ struct IgemmSkArgs {
 // Second __launch_bounds__ argument = waves per SIMD the register allocator must leave room
 // for: the 128x128 config sits right at the 168-register step (3 waves/SIMD); losing it cost
 // 25-35 % on the layers with three n-tiles.
-template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM, bool SK>
+// ES = operand element size: 4 = fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32), 2 = bf16
+// operands / bf16 output on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE
+// configs[2] / [4]: "bf16 storage / fp32 accumulate").  Both stage 128-B row slabs (32 floats or
+// 64 bf16) with the same 16-B loads, LDS image and tile masks; only the fragment reads, the MFMA
+// and the epilogue's store width differ.
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM, bool SK, int ES = 4>
 __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk) {
-  // BKT = floats of K per slab (one 128-B line per row at 32).
-  constexpr int LDS_STRIDE = BKT + 4;
-  constexpr int LPR = BKT / 4;                  // lanes per row (float4 each)
+  // BKT = elements of K per slab (one 128-B line per row: 32 floats / 64 bf16).
+  static_assert(BKT * ES == 128, "a slab row is one 128-B line");
+  constexpr int LDS_STRIDE = 32 + 4;            // floats (144 B) per staged row
+  constexpr int EPL = 16 / ES;                  // elements per 16-B lane load
+  constexpr int LPR = 8;                        // lanes per row (16 B each)
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
   constexpr int NTHREADS = WM * WN * 64;
@@ -233,7 +246,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int q4 = (tid % LPR) * 4;  // float offset inside the k slab
+  const int q4 = (tid % LPR) * EPL;  // element offset inside the k slab
+  const int q4f = (tid % LPR) * 4;   // float (4-B) offset of the lane's 16 B inside a staged row
 #ifdef C2D_TRACE
   const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime();
@@ -296,9 +310,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     // while fp32 MFMAs (64 cycles each) occupy it — the address + mask work of the flat-load
     // form took as long as the MFMAs themselves (per-phase stamps, tools/trace_igemm.py).
     int lda = a.lda, Kc = a.K, sgi = 0;   // current segment (wave-uniform)
-    __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a.a_off, (a.a_rows * a.lda - a.a_off) * 4);
-    __amdgpu_buffer_rsrc_t rsB = make_rsrc(
-        a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 4);
+    __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * ES,
+                                             (a.a_rows * a.lda - a.a_off) * ES);
+    __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
+        a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * ES);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -360,8 +375,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
         while (sl >= (a.segK[sgi] + BKT - 1) / BKT) { sl -= (a.segK[sgi] + BKT - 1) / BKT; ++sgi; }
         kc = sl * BKT;
         lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
-        rsA = make_rsrc(a.segA[sgi] + a.seg_off[sgi], (a.a_rows * lda - a.seg_off[sgi]) * 4);
-        rsB = make_rsrc(a.segB[sgi], (long long)a.N * Kc * 4);
+        rsA = make_rsrc_b((const char*)a.segA[sgi] + (size_t)a.seg_off[sgi] * ES,
+                          (a.a_rows * lda - a.seg_off[sgi]) * ES);
+        rsB = make_rsrc_b(a.segB[sgi], (long long)a.N * Kc * ES);
       } else {
         const int tskip = s0 / kslabs;
         kc = (s0 - tskip * kslabs) * BKT;
@@ -377,11 +393,11 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
   {                                                                                            \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                      \
       const int sr = src_row<MODE>(a.g, apos[i], ky, kx);                                      \
-      aoff[i] = sr >= 0 ? (unsigned)(sr * lda + q4) * 4u : OOB_OFFSET;                         \
+      aoff[i] = sr >= 0 ? (unsigned)(sr * lda + q4) * (unsigned)ES : OOB_OFFSET;               \
     }                                                                                          \
     const int toff = (ky * a.g.kw + kx) * (int)tap_stride;                                     \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        boff[i] = (unsigned)(brow_off[i] * Kc + toff + q4) * 4u;                               \
+        boff[i] = (unsigned)(brow_off[i] * Kc + toff + q4) * (unsigned)ES;                     \
     if (PM) {                                                                                  \
       tv_load = 0;                                                                             \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
@@ -397,7 +413,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
   }
 #define C2D_ISSUE()                                                                            \
   {                                                                                            \
-    const int soff = kc * 4;                                                                   \
+    const int soff = kc * ES;                                                                  \
     if (kc + BKT <= Kc) {      /* whole slab inside K: offsets as they stand */                \
       _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) ra[i] = buf_load4(rsA, aoff[i], soff); \
       _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) rb[i] = buf_load4(rsB, boff[i], soff); \
@@ -445,10 +461,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
       }
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i)
-        *reinterpret_cast<f32x4*>(&As[arow_l[i] * LDS_STRIDE + q4]) = ra[i];
+        *reinterpret_cast<f32x4*>(&As[arow_l[i] * LDS_STRIDE + q4f]) = ra[i];
 #pragma unroll
       for (int i = 0; i < B_LOADS; ++i)
-        *reinterpret_cast<f32x4*>(&Bs[brow_l[i] * LDS_STRIDE + q4]) = rb[i];
+        *reinterpret_cast<f32x4*>(&Bs[brow_l[i] * LDS_STRIDE + q4f]) = rb[i];
 #ifdef C2D_TRACE
       C2D_STAMP(tr_b) tr_seg[0] += tr_b - tr_a;    // wait for the loads + LDS stores
 #endif
@@ -465,8 +481,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
             if (a.nseg > 1) {          // next (A, Bt) segment of a multi-segment 1x1 GEMM
               ++sgi;
               lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
-              rsA = make_rsrc(a.segA[sgi] + a.seg_off[sgi], (a.a_rows * lda - a.seg_off[sgi]) * 4);
-              rsB = make_rsrc(a.segB[sgi], (long long)a.N * Kc * 4);
+              rsA = make_rsrc_b((const char*)a.segA[sgi] + (size_t)a.seg_off[sgi] * ES,
+                                (a.a_rows * lda - a.seg_off[sgi]) * ES);
+              rsB = make_rsrc_b(a.segB[sgi], (long long)a.N * Kc * ES);
             } else {
               taps_left &= taps_left - 1ull;   // next tap that is real for some tile of the block
               C2D_TAP_FROM_MASK();
@@ -481,12 +498,13 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
       C2D_STAMP(tr_b) tr_seg[2] += tr_b - tr_a;    // cursor + issue of the next slab's loads
 #endif
 
+      if constexpr (ES == 4) {
 #pragma unroll
-      for (int half = 0; half < BKT / 16; ++half) {
+      for (int half = 0; half < 2; ++half) {   // (32 floats per slab row)
         float af[MT][8], bf[NT][8];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
+          const float* p = &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + lh * 16 + half * 8];
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
           af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
@@ -494,7 +512,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * (BKT / 2) + half * 8];
+          const float* p = &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + lh * 16 + half * 8];
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + 4);
           bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
@@ -511,6 +529,33 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
               for (int s = 0; s < 8; ++s)
                 acc[i][j] =
                     __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
+      }
+      } else {
+        // bf16: lane (li, lh) feeds k = 16*st + 8*lh .. +8 of row li to each 32x32x16 MFMA:
+        // one ds_read_b128 per fragment; all fragments of the slab first, then one scalar
+        // branch per 32x32 tile around its 4 chained MFMAs.
+        bf16x8 af[MT][4], bf[NT][4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            af[i][st] = *reinterpret_cast<const bf16x8*>(
+                &As[(wm * MT * 32 + i * 32 + li) * LDS_STRIDE + st * 8 + lh * 4]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            bf[j][st] = *reinterpret_cast<const bf16x8*>(
+                &Bs[(wn * NT * 32 + j * 32 + li) * LDS_STRIDE + st * 8 + lh * 4]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            if ((onbits >> (i * NT + j)) & 1u) {
+#pragma unroll
+              for (int st = 0; st < 4; ++st)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][st], bf[j][st], acc[i][j],
+                                                                    0, 0, 0);
             }
       }
 #ifdef C2D_TRACE
@@ -634,9 +679,21 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
             if (a.relu) {
               v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
-            if (a.accumulate) v += *dst;
-            *dst = v;
+            if constexpr (ES == 4) {
+              f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
+              if (a.accumulate) v += *dst;
+              *dst = v;
+            } else {                                  // 4 bf16 = 8 B per lane
+              bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
+                                                      (size_t)drow * a.ldc + a.c_off + ncol);
+              if (a.accumulate) {
+                const bf16x4 o = *dst;
+                v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+              }
+              bf16x4 o;
+              o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+              *dst = o;
+            }
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -666,15 +723,15 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
 #endif
 }
 
-template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM>
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM, int ES = 4>
 __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : (MT * NT == 2 ? 4 : 3)) void igemm_nt_kernel(IgemmArgs a) {
   SkPlan none;
-  igemm_body<MODE, WM, WN, MT, NT, BKT, PM, false>(a, none);
+  igemm_body<MODE, WM, WN, MT, NT, BKT, PM, false, ES>(a, none);
 }
 
-template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM>
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM, int ES = 4>
 __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel(IgemmSkArgs p) {
-  igemm_body<MODE, WM, WN, MT, NT, BKT, PM, true>(p.a, p.sk);
+  igemm_body<MODE, WM, WN, MT, NT, BKT, PM, true, ES>(p.a, p.sk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1186,11 +1243,15 @@ bool sk_disabled_by_env() {
   return e && e[0] == '0';
 }
 
-template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM>
+template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM, int ES>
 int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   a.m_tiles = c2d_ceil_div(a.M, BM);
   a.n_tiles = c2d_ceil_div(a.N, BN);
+  if (a.nseg > 1) {
+    a.total_slabs = 0;
+    for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], BKT);
+  }
 #ifdef C2D_TRACE
   a.trace = g_trace;
 #endif
@@ -1202,7 +1263,7 @@ int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
       int occ = 0, dev = 0;
       hipDeviceProp_t prop;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-              &occ, igemm_sk_kernel<MODE, WM, WN, MT, NT, BKT, PM>, WM * WN * 64, 0) == hipSuccess &&
+              &occ, igemm_sk_kernel<MODE, WM, WN, MT, NT, BKT, PM, ES>, WM * WN * 64, 0) == hipSuccess &&
           hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         slots = occ * prop.multiProcessorCount;
       else
@@ -1213,20 +1274,24 @@ int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
     int err = C2D_OK;
     if (make_sk_plan<MODE, BM, BN, BKT, PM>(a, slots, ws, &p.sk, &err)) {
       const int grid = c2d_ceil_div(p.sk.total, p.sk.share);
-      hipLaunchKernelGGL((igemm_sk_kernel<MODE, WM, WN, MT, NT, BKT, PM>), dim3(grid), block, 0, s, p);
+      hipLaunchKernelGGL((igemm_sk_kernel<MODE, WM, WN, MT, NT, BKT, PM, ES>), dim3(grid), block, 0, s, p);
       return c2d_launch_status();
     }
     if (err) return err;
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
-  hipLaunchKernelGGL((igemm_nt_kernel<MODE, WM, WN, MT, NT, BKT, PM>), grid, block, 0, s, a);
+  hipLaunchKernelGGL((igemm_nt_kernel<MODE, WM, WN, MT, NT, BKT, PM, ES>), grid, block, 0, s, a);
   return c2d_launch_status();
 }
 
 template <int WM, int WN, int MT, int NT, int BKT, bool PM = false>
 int launch_igemm(const IgemmArgs& a, hipStream_t s, const IgemmWs& ws) {
-  if (a.g.mode == 0) return launch_igemm_mode<0, WM, WN, MT, NT, BKT, PM>(a, s, ws);
-  return launch_igemm_mode<1, WM, WN, MT, NT, BKT, PM>(a, s, ws);
+  if (a.es == 2) {   // bf16 operands: 64 elements per 128-B slab row
+    if (a.g.mode == 0) return launch_igemm_mode<0, WM, WN, MT, NT, 2 * BKT, PM, 2>(a, s, ws);
+    return launch_igemm_mode<1, WM, WN, MT, NT, 2 * BKT, PM, 2>(a, s, ws);
+  }
+  if (a.g.mode == 0) return launch_igemm_mode<0, WM, WN, MT, NT, BKT, PM, 4>(a, s, ws);
+  return launch_igemm_mode<1, WM, WN, MT, NT, BKT, PM, 4>(a, s, ws);
 }
 
 int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{nullptr, 0}) {
@@ -1258,7 +1323,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   }
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
-  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384) {
+  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && a.es == 4) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);
@@ -1293,7 +1358,7 @@ extern "C" long long c2d_conv_workspace_bytes(void) {
 static int conv_fwd_impl(const float* x, int ldx, int xoff, const float* wt,
                          const float* scale, const float* shift, float* y, int ldy,
                          int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
-                         int stride, int relu, IgemmWs ws, void* stream) {
+                         int stride, int relu, IgemmWs ws, void* stream, int es = 4) {
   C2D_CHECK_ARG(x && wt && y && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 16 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   IgemmArgs a;
@@ -1301,9 +1366,9 @@ static int conv_fwd_impl(const float* x, int ldx, int xoff, const float* wt,
   if (rc) return rc;
   a.A = x; a.lda = ldx; a.a_off = xoff; a.Bt = wt; a.C = y; a.ldc = ldy; a.c_off = yoff;
   a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = 0; a.nseg = 1;
-  a.M = n * a.g.oh * a.g.ow; a.N = cout; a.K = cin; a.g.nimg = n;
+  a.M = n * a.g.oh * a.g.ow; a.N = cout; a.K = cin; a.g.nimg = n; a.es = es;
   a.a_rows = (long long)n * ih * iw;
-  C2D_CHECK_ARG(kh * kw <= 64);
+  C2D_CHECK_ARG(kh * kw <= 64 && (es == 4 || (ldx % 8 == 0 && xoff % 8 == 0 && ldy % 4 == 0 && yoff % 4 == 0)));
   C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)kh * kw * cin * cout * 4 < (long long)OOB_OFFSET);
   return run_igemm(a, (hipStream_t)stream, ws);
 }
@@ -1328,7 +1393,8 @@ extern "C" int c2d_conv_fwd_ws(const float* x, int ldx, int xoff, const float* w
 
 static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, float* dx,
                            int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
-                           int kh, int kw, int stride, int accumulate, IgemmWs ws, void* stream) {
+                           int kh, int kw, int stride, int accumulate, IgemmWs ws, void* stream,
+                           int es = 4) {
   C2D_CHECK_ARG(dc && w && dx && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cout % 16 == 0 && ldc % 4 == 0 && coff % 4 == 0);
   IgemmArgs a;
@@ -1336,9 +1402,9 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
   if (rc) return rc;
   a.A = dc; a.lda = ldc; a.a_off = coff; a.Bt = w; a.C = dx; a.ldc = lddx; a.c_off = dxoff;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate; a.nseg = 1;
-  a.N = cin; a.K = cout; a.g.nimg = n;
+  a.N = cin; a.K = cout; a.g.nimg = n; a.es = es;
   a.a_rows = (long long)n * a.g.oh * a.g.ow;
-  C2D_CHECK_ARG(kh * kw <= 64);
+  C2D_CHECK_ARG(kh * kw <= 64 && (es == 4 || (ldc % 8 == 0 && coff % 8 == 0)));
   C2D_CHECK_ARG(a.a_rows * ldc * 4 < (long long)OOB_OFFSET && (long long)kh * kw * cin * cout * 4 < (long long)OOB_OFFSET);
   if (stride == 1) {
     a.M = n * ih * iw;
@@ -1385,7 +1451,8 @@ extern "C" int c2d_conv_dgrad_ws(const float* dc, int ldc, int coff, const float
 static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
                             const int* coffs, const float* const* ws,
                             const int* couts, float* dx, int lddx, int dxoff,
-                            int rows, int cin, int accumulate, IgemmWs wsp, void* stream) {
+                            int rows, int cin, int accumulate, IgemmWs wsp, void* stream,
+                            int es = 4) {
   C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && dcs && ldcs && coffs && ws && couts && dx);
   C2D_CHECK_ARG(rows > 0 && cin > 0 && cin % 4 == 0 && lddx % 4 == 0 && dxoff % 4 == 0);
   IgemmArgs a;
@@ -1401,7 +1468,8 @@ static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
     C2D_CHECK_ARG((long long)rows * ldcs[i] * 4 < (long long)OOB_OFFSET);
   }
   a.a_rows = rows;
-  a.nseg = nseg;
+  a.nseg = nseg; a.es = es;
+  for (int i = 0; i < nseg && es == 2; ++i) C2D_CHECK_ARG(ldcs[i] % 8 == 0 && coffs[i] % 8 == 0);
   a.A = dcs[0]; a.lda = ldcs[0]; a.a_off = coffs[0]; a.Bt = ws[0]; a.K = couts[0];
   a.C = dx; a.ldc = lddx; a.c_off = dxoff;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate;
@@ -1425,6 +1493,35 @@ extern "C" int c2d_conv1x1_dgrad_multi_ws(int nseg, const float* const* dcs, con
   C2D_CHECK_ARG(workspace && workspace_bytes > 0);
   return dgrad_multi_impl(nseg, dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
                           accumulate, IgemmWs{workspace, workspace_bytes}, stream);
+}
+
+// ---- bf16 storage / fp32 accumulate forms (BASELINE configs[2] / [4]) -------------------------
+// Same arguments as the fp32 calls; x / wt / y (dc / w / dx) are bf16 (uint16 storage),
+// scale / shift stay fp32.  Strides and offsets are in ELEMENTS; ld % 8 == 0, off % 8 == 0.
+extern "C" int c2d_conv_fwd_bf16(const void* x, int ldx, int xoff, const void* wt,
+                                 const float* scale, const float* shift, void* y, int ldy,
+                                 int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                                 int stride, int relu, void* stream) {
+  return conv_fwd_impl((const float*)x, ldx, xoff, (const float*)wt, scale, shift, (float*)y, ldy,
+                       yoff, n, ih, iw, cin, cout, kh, kw, stride, relu, IgemmWs{nullptr, 0}, stream,
+                       2);
+}
+
+extern "C" int c2d_conv_dgrad_bf16(const void* dc, int ldc, int coff, const void* w, void* dx,
+                                   int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
+                                   int kh, int kw, int stride, int accumulate, void* stream) {
+  return conv_dgrad_impl((const float*)dc, ldc, coff, (const float*)w, (float*)dx, lddx, dxoff, n,
+                         ih, iw, cin, cout, kh, kw, stride, accumulate, IgemmWs{nullptr, 0}, stream,
+                         2);
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi_bf16(int nseg, const void* const* dcs, const int* ldcs,
+                                            const int* coffs, const void* const* ws,
+                                            const int* couts, void* dx, int lddx, int dxoff,
+                                            int rows, int cin, int accumulate, void* stream) {
+  return dgrad_multi_impl(nseg, (const float* const*)dcs, ldcs, coffs, (const float* const*)ws,
+                          couts, (float*)dx, lddx, dxoff, rows, cin, accumulate,
+                          IgemmWs{nullptr, 0}, stream, 2);
 }
 
 extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc,

@@ -94,6 +94,11 @@ def set_conv_workspace(ws):
 
 def conv_fwd(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride,
              relu):
+  if x.dtype == torch.bfloat16:
+    assert wt.dtype == torch.bfloat16 and y.dtype == torch.bfloat16
+    _lib.call("c2d_conv_fwd_bf16", _p(x), ldx, xoff, _p(wt), _p(scale), _p(shift), _p(y), ldy,
+              yoff, n, ih, iw, cin, cout, kh, kw, stride, int(relu), _stream())
+    return
   if _conv_ws is not None:
     _lib.call("c2d_conv_fwd_ws", _p(x), ldx, xoff, _p(wt), _p(scale), _p(shift), _p(y), ldy, yoff,
               n, ih, iw, cin, cout, kh, kw, stride, int(relu), _p(_conv_ws[0]), _conv_ws[1],
@@ -105,6 +110,11 @@ def conv_fwd(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout,
 
 def conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
                accumulate):
+  if dc.dtype == torch.bfloat16:
+    assert w.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16
+    _lib.call("c2d_conv_dgrad_bf16", _p(dc), ldc, coff, _p(w), _p(dx), lddx, dxoff, n, ih, iw, cin,
+              cout, kh, kw, stride, int(accumulate), _stream())
+    return
   if _conv_ws is not None:
     _lib.call("c2d_conv_dgrad_ws", _p(dc), ldc, coff, _p(w), _p(dx), lddx, dxoff, n, ih, iw, cin,
               cout, kh, kw, stride, int(accumulate), _p(_conv_ws[0]), _conv_ws[1], _stream())
@@ -118,6 +128,11 @@ def conv1x1_dgrad_multi(dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
   n = len(dcs)
   ptrs = ctypes.c_void_p * n
   ints = ctypes.c_int * n
+  if dcs[0].dtype == torch.bfloat16:
+    _lib.call("c2d_conv1x1_dgrad_multi_bf16", n, ptrs(*[_p(t) for t in dcs]), ints(*ldcs),
+              ints(*coffs), ptrs(*[_p(t) for t in ws]), ints(*couts), _p(dx), lddx, dxoff, rows,
+              cin, int(accumulate), _stream())
+    return
   if _conv_ws is not None:
     _lib.call("c2d_conv1x1_dgrad_multi_ws", n, ptrs(*[_p(t) for t in dcs]), ints(*ldcs),
               ints(*coffs), ptrs(*[_p(t) for t in ws]), ints(*couts), _p(dx), lddx, dxoff, rows,

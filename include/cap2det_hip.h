@@ -126,6 +126,23 @@ int c2d_conv1x1_dgrad_multi_ws(int nseg, const float* const* dcs, const int* ldc
                                float* dx, int lddx, int dxoff, int rows, int cin, int accumulate,
                                void* workspace, long long workspace_bytes, void* stream);
 
+/* bf16 storage / fp32 accumulate forms of the three convolution calls (BASELINE.json configs[2]
+ * and [4]): activations, weights and outputs are bf16 (uint16 storage; leading dimensions and
+ * offsets in ELEMENTS, multiples of 8), BatchNorm scale / shift stay fp32, products are
+ * accumulated in fp32 on v_mfma_f32_32x32x16_bf16 and rounded to bf16 (nearest even) once, in
+ * the epilogue.  The reference has no reduced-precision mode; tolerances are stated in
+ * tests/test_gpu_bf16.py. */
+int c2d_conv_fwd_bf16(const void* x, int ldx, int xoff, const void* wt, const float* scale,
+                      const float* shift, void* y, int ldy, int yoff, int n, int ih, int iw,
+                      int cin, int cout, int kh, int kw, int stride, int relu, void* stream);
+int c2d_conv_dgrad_bf16(const void* dc, int ldc, int coff, const void* w, void* dx, int lddx,
+                        int dxoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                        int stride, int accumulate, void* stream);
+int c2d_conv1x1_dgrad_multi_bf16(int nseg, const void* const* dcs, const int* ldcs,
+                                 const int* coffs, const void* const* ws, const int* couts,
+                                 void* dx, int lddx, int dxoff, int rows, int cin, int accumulate,
+                                 void* stream);
+
 /* dw[kh*kw][cin][cout] += Conv2DBackpropFilter(x, dc)  (fp32 atomics over row splits; the
  * caller zero-fills dw once per step). */
 int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, int coff,

@@ -1,0 +1,34 @@
+"""bf16 igemm (fwd / dgrad) on the second-stage conv shapes, next to the fp32 kernels."""
+import sys, torch
+sys.path.insert(0, ".")
+from cap2det_amd import hip_ops as ops
+dev = "cuda:0"
+SHAPES = [(2000, 7, 576, 128, 1, 1), (2000, 7, 576, 192, 1, 1), (2000, 7, 192, 256, 3, 1),
+          (2000, 7, 256, 256, 3, 2), (2000, 4, 1024, 352, 1, 1), (2000, 4, 1024, 192, 1, 1),
+          (2000, 4, 192, 320, 3, 1), (2000, 4, 224, 224, 3, 1), (2000, 4, 1024, 128, 1, 1)]
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+tot = {}
+for (n, ih, cin, cout, k, st) in SHAPES:
+    oh = -(-ih // st)
+    fl = 2.0 * n * oh * oh * cin * cout * k * k
+    res = []
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(n * ih * ih, cin, device=dev).to(dt)
+        w = (torch.randn(k * k, cin, cout, device=dev) / (k * k * cin) ** 0.5).to(dt)
+        wt = w.permute(0, 2, 1).contiguous()
+        y = torch.empty(n * oh * oh, cout, device=dev, dtype=dt); dy = torch.randn(n * oh * oh, cout, device=dev).to(dt)
+        dx = torch.empty_like(x)
+        sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
+        tf_ = timeit(lambda: ops.conv_fwd(x, cin, 0, wt, sc, sh, y, cout, 0, n, ih, ih, cin, cout, k, k, st, True))
+        td = timeit(lambda: ops.conv_dgrad(dy, cout, 0, w, dx, cin, 0, n, ih, ih, cin, cout, k, k, st, False))
+        name = "f32" if dt == torch.float32 else "bf16"
+        res.append("%s fwd %6.1f us %6.1f TF dgrad %6.1f us %6.1f TF" % (name, tf_ * 1e3, fl / tf_ / 1e9, td * 1e3, fl / td / 1e9))
+        tot[name] = tot.get(name, 0) + tf_ + td
+    print("n=%4d %dx%d cin=%4d cout=%3d k=%d s=%d | %s" % (n, ih, ih, cin, cout, k, st, " | ".join(res)))
+print("sum ms:", {k: round(v, 3) for k, v in tot.items()})
