@@ -31,3 +31,20 @@ __device__ __forceinline__ float c2d_wave_min(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---- element access for the two activation storage types (fp32 / bf16): 4 channels per lane ----
+typedef __bf16 c2d_bf16;
+typedef __bf16 c2d_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 c2d_ld4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ float4 c2d_ld4(const c2d_bf16* p) {
+  const c2d_bf16x4 v = *reinterpret_cast<const c2d_bf16x4*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void c2d_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void c2d_st4(c2d_bf16* p, float4 v) {
+  c2d_bf16x4 o;
+  o[0] = (c2d_bf16)v.x; o[1] = (c2d_bf16)v.y; o[2] = (c2d_bf16)v.z; o[3] = (c2d_bf16)v.w;
+  *reinterpret_cast<c2d_bf16x4*>(p) = o;
+}

@@ -142,6 +142,21 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned v
   return __builtin_bit_cast(f32x4, v);
 }
 
+// four consecutive operand elements (fp32: one 16-B load; bf16: one 8-B load, widened) as fp32
+template <int ES>
+__device__ __forceinline__ f32x4 buf_load_elems4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  if constexpr (ES == 4) {
+    return buf_load4(rs, voff, soff);
+  } else {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0);
+    f32x4 o;   // bf16 -> fp32 = the 16 bits moved to the top half
+    o.x = __uint_as_float(v.x << 16); o.y = __uint_as_float(v.x & 0xffff0000u);
+    o.z = __uint_as_float(v.y << 16); o.w = __uint_as_float(v.y & 0xffff0000u);
+    return o;
+  }
+}
+
 __device__ __forceinline__ f32x4 mask4(f32x4 v, bool keep) {
   v.x = keep ? v.x : 0.0f; v.y = keep ? v.y : 0.0f;
   v.z = keep ? v.z : 0.0f; v.w = keep ? v.w : 0.0f;
@@ -862,7 +877,7 @@ constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
 // NTJ = 32-column MFMA tiles per wave along j: 2 (block tile 128x128) or 1 (128x64, used when
 // the last 128-wide j-tile would be at most half full: J = 192, 160, 320 ...).
 // PLAIN = 1x1 / stride 1 (source row = output row): the loader's offsets are slab-invariant.
-template <int NTJ, bool PLAIN>
+template <int NTJ, bool PLAIN, int ES>
 __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   constexpr int BJ = 2 * NTJ * 32;
   __shared__ __attribute__((aligned(16))) float As[WBK * WG_STRIDE];
@@ -886,10 +901,12 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   const bool gload = c4 < BJ;   // (BJ = 64: the upper half of each 32-lane row group idles)
   // raw buffer loads (see igemm_body): descriptors end at the operands' last row, masked rows
   // carry an out-of-range offset and come back as zeros
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a.a_off, (a.a_rows * a.lda - a.a_off) * 4);
-  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(a.G + a.g_off, ((long long)a.M * a.ldg - a.g_off) * 4);
-  const unsigned acol = (unsigned)min(i0 + c4, a.I - 4) * 4u;
-  const unsigned gcol = (unsigned)min(j0 + min(c4, BJ - 4), a.J - 4) * 4u;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * ES,
+                                                 (a.a_rows * a.lda - a.a_off) * ES);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * ES,
+                                                 ((long long)a.M * a.ldg - a.g_off) * ES);
+  const unsigned acol = (unsigned)min(i0 + c4, a.I - 4) * (unsigned)ES;
+  const unsigned gcol = (unsigned)min(j0 + min(c4, BJ - 4), a.J - 4) * (unsigned)ES;
 
   f32x16 acc[2][NTJ];
 #pragma unroll
@@ -914,24 +931,26 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   unsigned aoffs[2], goffs[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    aoffs[u] = (unsigned)((kr + u * 8) * a.lda) * 4u + acol;
-    goffs[u] = (unsigned)((kr + u * 8) * a.ldg) * 4u + gcol;
+    aoffs[u] = (unsigned)((kr + u * 8) * a.lda) * (unsigned)ES + acol;
+    goffs[u] = (unsigned)((kr + u * 8) * a.ldg) * (unsigned)ES + gcol;
   }
 #define C2D_WG_LOAD(MB)                                                                        \
   {                                                                                            \
     if (PLAIN) {                                                                               \
-      const int sa = (MB) * a.lda * 4, sg = (MB) * a.ldg * 4;                                  \
+      const int sa = (MB) * a.lda * ES, sg = (MB) * a.ldg * ES;                                \
       _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
-        ra[u] = buf_load4(rsA, aoffs[u], sa);                                                  \
-        rg[u] = buf_load4(rsG, goffs[u], sg);                                                  \
+        ra[u] = buf_load_elems4<ES>(rsA, aoffs[u], sa);                                        \
+        rg[u] = buf_load_elems4<ES>(rsG, goffs[u], sg);                                        \
       }                                                                                        \
     } else {                                                                                   \
       _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
         const int m = (MB) + kr + u * 8;                                                       \
         const RowPos p = decompose(m, mend, a.g);                                              \
         const int sr = src_row<0>(a.g, p, ky, kx);                                             \
-        ra[u] = buf_load4(rsA, sr >= 0 ? (unsigned)(sr * a.lda) * 4u + acol : OOB_OFFSET, 0);  \
-        rg[u] = buf_load4(rsG, p.valid ? (unsigned)(m * a.ldg) * 4u + gcol : OOB_OFFSET, 0);   \
+        ra[u] = buf_load_elems4<ES>(                                                           \
+            rsA, sr >= 0 ? (unsigned)(sr * a.lda) * (unsigned)ES + acol : OOB_OFFSET, 0);      \
+        rg[u] = buf_load_elems4<ES>(                                                           \
+            rsG, p.valid ? (unsigned)(m * a.ldg) * (unsigned)ES + gcol : OOB_OFFSET, 0);       \
       }                                                                                        \
     }                                                                                          \
   }
@@ -1019,7 +1038,7 @@ struct Wgrad3Args {
 // the step and those MFMAs are simply not issued: 100 of 144 (pixel, tap) pairs remain on a 4x4
 // map, 361 of 441 on 7x7 — no matrix-pipe time is spent multiplying padding zeros.
 // Wave v owns output columns [j0+32v, j0+32v+32), all taps.
-template <int WC, int IMGS>
+template <int WC, int IMGS, int ES>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
   constexpr bool PAIR = IMGS % 2 == 0;       // else: a k-step takes rows 2s, 2s+1 (no skipping)
   constexpr int PW = WC + 2;
@@ -1058,14 +1077,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
   // rows past M (only the last slab can have them: splits are whole slabs) fall outside the
   // descriptors, which end at row M — the loader needs no vector ALU work per slab.
   const int gkr = tid >> 5, gc4 = (tid & 31) * 4;       // dC: rows gkr + 8u, float4 column gc4
-  const __amdgpu_buffer_rsrc_t rsG = make_rsrc(a.G + a.g_off, ((long long)a.M * a.ldg - a.g_off) * 4);
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A + a.a_off, ((long long)a.M * a.lda - a.a_off) * 4);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * ES,
+                                                 ((long long)a.M * a.ldg - a.g_off) * ES);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * ES,
+                                                 ((long long)a.M * a.lda - a.a_off) * ES);
   const int aq4 = (tid & 7) * 4, ar0 = tid >> 3;        // x: LDS rows ar0 + 32u, float4 col aq4
   unsigned goffs[G_LD], aoffs[A_LD];
 #pragma unroll
   for (int u = 0; u < G_LD; ++u) {
     const int k = gkr + u * 8;
-    goffs[u] = k < R ? (unsigned)(k * a.ldg + min(j0 + gc4, a.J - 4)) * 4u : OOB_OFFSET;
+    goffs[u] = k < R ? (unsigned)(k * a.ldg + min(j0 + gc4, a.J - 4)) * (unsigned)ES : OOB_OFFSET;
   }
 #pragma unroll
   for (int u = 0; u < A_LD; ++u) {
@@ -1074,15 +1095,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
     const int yp = rr / PW, xp = rr - yp * PW;
     const bool real = r < AROWS && yp >= 1 && yp <= WC && xp >= 1 && xp <= WC;
     const int apix = im * HW + (yp - 1) * WC + (xp - 1);   // pixel offset inside the slab
-    aoffs[u] = real ? (unsigned)(apix * a.lda + i0 + aq4) * 4u : OOB_OFFSET;
+    aoffs[u] = real ? (unsigned)(apix * a.lda + i0 + aq4) * (unsigned)ES : OOB_OFFSET;
   }
   f32x4 rg[G_LD], ra[A_LD];
 
 #define C2D_W3_LOAD(MB)                                                                        \
   {                                                                                            \
-    const int sg = (MB) * a.ldg * 4, sa = (MB) * a.lda * 4;                                    \
-    _Pragma("unroll") for (int u = 0; u < G_LD; ++u) rg[u] = buf_load4(rsG, goffs[u], sg);     \
-    _Pragma("unroll") for (int u = 0; u < A_LD; ++u) ra[u] = buf_load4(rsA, aoffs[u], sa);     \
+    const int sg = (MB) * a.ldg * ES, sa = (MB) * a.lda * ES;                                  \
+    _Pragma("unroll") for (int u = 0; u < G_LD; ++u)                                           \
+        rg[u] = buf_load_elems4<ES>(rsG, goffs[u], sg);                                        \
+    _Pragma("unroll") for (int u = 0; u < A_LD; ++u)                                           \
+        ra[u] = buf_load_elems4<ES>(rsA, aoffs[u], sa);                                        \
   }
 
   // per-lane bases: the upper half-wave reads the odd image of each pair (PAIR) / the odd row
@@ -1524,9 +1547,10 @@ extern "C" int c2d_conv1x1_dgrad_multi_bf16(int nseg, const void* const* dcs, co
                           IgemmWs{nullptr, 0}, stream, 2);
 }
 
-extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc,
-                              int coff, float* dw, int n, int ih, int iw, int cin, int cout,
-                              int kh, int kw, int stride, void* stream) {
+template <int ES>
+static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, int ldc,
+                           int coff, float* dw, int n, int ih, int iw, int cin, int cout,
+                           int kh, int kw, int stride, void* stream) {
   C2D_CHECK_ARG(x && dc && dw && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   C2D_CHECK_ARG(ldc % 4 == 0 && coff % 4 == 0);
@@ -1545,8 +1569,8 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
-    if (iw == 4) hipLaunchKernelGGL((wgrad3x3_kernel<4, 2>), grid, dim3(256), 0, st, b);
-    else hipLaunchKernelGGL((wgrad3x3_kernel<7, 1>), grid, dim3(256), 0, st, b);
+    if (iw == 4) hipLaunchKernelGGL((wgrad3x3_kernel<4, 2, ES>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((wgrad3x3_kernel<7, 1, ES>), grid, dim3(256), 0, st, b);
     return c2d_launch_status();
   }
   WgradArgs a;
@@ -1568,9 +1592,25 @@ extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc
   C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)a.M * ldc * 4 < (long long)OOB_OFFSET);
   const bool plain = kh == 1 && kw == 1 && stride == 1;
   hipStream_t st = (hipStream_t)stream;
-  if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true>), grid, dim3(256), 0, st, a);
-  else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false>), grid, dim3(256), 0, st, a);
-  else if (plain) hipLaunchKernelGGL((wgrad_tn_kernel<2, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad_tn_kernel<2, false>), grid, dim3(256), 0, st, a);
+  if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true, ES>), grid, dim3(256), 0, st, a);
+  else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false, ES>), grid, dim3(256), 0, st, a);
+  else if (plain) hipLaunchKernelGGL((wgrad_tn_kernel<2, true, ES>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_tn_kernel<2, false, ES>), grid, dim3(256), 0, st, a);
   return c2d_launch_status();
+}
+
+extern "C" int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc,
+                              int coff, float* dw, int n, int ih, int iw, int cin, int cout,
+                              int kh, int kw, int stride, void* stream) {
+  return conv_wgrad_impl<4>(x, ldx, xoff, dc, ldc, coff, dw, n, ih, iw, cin, cout, kh, kw, stride,
+                            stream);
+}
+
+// bf16 activations / gradients in, fp32 filter gradient out (the operands are widened to fp32 as
+// they are staged: same fp32 MFMA accumulation as the fp32 call).
+extern "C" int c2d_conv_wgrad_bf16(const void* x, int ldx, int xoff, const void* dc, int ldc,
+                                   int coff, float* dw, int n, int ih, int iw, int cin, int cout,
+                                   int kh, int kw, int stride, void* stream) {
+  return conv_wgrad_impl<2>((const float*)x, ldx, xoff, (const float*)dc, ldc, coff, dw, n, ih, iw,
+                            cin, cout, kh, kw, stride, stream);
 }

@@ -27,8 +27,9 @@ __host__ __device__ inline PoolGeom make_pool_geom(int ih, int iw, int stride) {
 }
 
 // mode 0: max (writes uint8 argmax = ky*3+kx of the first maximum), mode 1: avg over valid cells.
+template <typename T>
 __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(
-    const float* __restrict__ x, int ldx, int xoff, float* __restrict__ y, int ldy, int yoff,
+    const T* __restrict__ x, int ldx, int xoff, T* __restrict__ y, int ldy, int yoff,
     uint8_t* __restrict__ arg, int n, int c4n, PoolGeom g, int mode) {
   const long long total = (long long)n * g.oh * g.ow * c4n;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -51,8 +52,7 @@ __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * g.stride - g.pad_l + kx;
         if (ix < 0 || ix >= g.iw) continue;
-        const float4 v = *reinterpret_cast<const float4*>(
-            x + ((size_t)(img * g.ih + iy) * g.iw + ix) * ldx + xoff + c4 * 4);
+        const float4 v = c2d_ld4(x + ((size_t)(img * g.ih + iy) * g.iw + ix) * ldx + xoff + c4 * 4);
         const unsigned char k = (unsigned char)(ky * 3 + kx);
         if (first) {
           best = v; am = make_uchar4(k, k, k, k); first = false;
@@ -74,15 +74,16 @@ __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(
       const float d = (float)cnt;
       out = make_float4(sum.x / d, sum.y / d, sum.z / d, sum.w / d);
     }
-    *reinterpret_cast<float4*>(y + (size_t)row * ldy + yoff + c4 * 4) = out;
+    c2d_st4(y + (size_t)row * ldy + yoff + c4 * 4, out);
   }
 }
 
 // Gather form of the pool gradient: one lane per INPUT element loops over the <= 9 outputs
 // whose window contains it (no atomics, deterministic).
+template <typename T>
 __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(
-    const float* __restrict__ dy, int lddy, int dyoff, const uint8_t* __restrict__ arg,
-    float* __restrict__ dx, int lddx, int dxoff, int n, int c4n, PoolGeom g, int mode,
+    const T* __restrict__ dy, int lddy, int dyoff, const uint8_t* __restrict__ arg,
+    T* __restrict__ dx, int lddx, int dxoff, int n, int c4n, PoolGeom g, int mode,
     int accumulate) {
   const long long total = (long long)n * g.ih * g.iw * c4n;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(
         const int ox = tx / g.stride;
         if (ox >= g.ow) continue;
         const size_t orow = (size_t)(img * g.oh + oy) * g.ow + ox;
-        const float4 gy = *reinterpret_cast<const float4*>(dy + orow * lddy + dyoff + c4 * 4);
+        const float4 gy = c2d_ld4(dy + orow * lddy + dyoff + c4 * 4);
         if (mode == 0) {
           const uchar4 am = *reinterpret_cast<const uchar4*>(arg + orow * c4n * 4 + c4 * 4);
           const unsigned char k = (unsigned char)(ky * 3 + kx);
@@ -124,12 +125,12 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(
         }
       }
     }
-    float4* dst = reinterpret_cast<float4*>(dx + (size_t)row * lddx + dxoff + c4 * 4);
+    T* dst = dx + (size_t)row * lddx + dxoff + c4 * 4;
     if (accumulate) {
-      const float4 o = *dst;
+      const float4 o = c2d_ld4(dst);
       acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
     }
-    *dst = acc;
+    c2d_st4(dst, acc);
   }
 }
 
@@ -141,9 +142,9 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(
 // the fabric: PMC showed 4.7 GB fetched for 0.9 GB of tensors).  Arithmetic order (scan order of
 // the taps, first-maximum tie rule, sum then divide) is that of the generic kernels.
 // ---------------------------------------------------------------------------------------------
-template <int IH, int STRIDE, int MODE>
+template <int IH, int STRIDE, int MODE, typename T>
 __global__ __launch_bounds__(256) void pool3x3_map_fwd_kernel(
-    const float* __restrict__ x, int ldx, int xoff, float* __restrict__ y, int ldy, int yoff,
+    const T* __restrict__ x, int ldx, int xoff, T* __restrict__ y, int ldy, int yoff,
     uint8_t* __restrict__ arg, int n, int c4n) {
   constexpr int IW = IH;
   constexpr int OH = (IH + STRIDE - 1) / STRIDE, OW = OH;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(256) void pool3x3_map_fwd_kernel(
        idx += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % c4n);
     const long long img = idx / c4n;
-    const float* xp = x + (size_t)img * (IH * IW) * ldx + xoff + c4 * 4;
-    float* yp = y + (size_t)img * (OH * OW) * ldy + yoff + c4 * 4;
+    const T* xp = x + (size_t)img * (IH * IW) * ldx + xoff + c4 * 4;
+    T* yp = y + (size_t)img * (OH * OW) * ldy + yoff + c4 * 4;
     uint8_t* ap = arg ? arg + ((size_t)img * (OH * OW) * c4n + c4) * 4 : nullptr;
     float4 rows[3][IW];   // the three input rows of the current output row
 #pragma unroll
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void pool3x3_map_fwd_kernel(
         }
 #pragma unroll
         for (int ix = 0; ix < IW; ++ix)
-          rows[ky][ix] = *reinterpret_cast<const float4*>(xp + (size_t)(iy * IW + ix) * ldx);
+          rows[ky][ix] = c2d_ld4(xp + (size_t)(iy * IW + ix) * ldx);
       }
 #pragma unroll
       for (int ox = 0; ox < OW; ++ox) {
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void pool3x3_map_fwd_kernel(
           const float d = (float)cnt;
           out = make_float4(sum.x / d, sum.y / d, sum.z / d, sum.w / d);
         }
-        *reinterpret_cast<float4*>(yp + (size_t)(oy * OW + ox) * ldy) = out;
+        c2d_st4(yp + (size_t)(oy * OW + ox) * ldy, out);
       }
     }
   }
@@ -225,10 +226,10 @@ __global__ __launch_bounds__(256) void pool3x3_map_fwd_kernel(
 // Gradient: the lane keeps the whole dy map (and arg-max map) of its ROI in registers and emits
 // each input pixel's gradient from the <= 9 outputs whose window holds it, in the generic
 // kernel's (ky, kx) order.
-template <int IH, int STRIDE, int MODE>
+template <int IH, int STRIDE, int MODE, typename T>
 __global__ __launch_bounds__(256) void pool3x3_map_bwd_kernel(
-    const float* __restrict__ dy, int lddy, int dyoff, const uint8_t* __restrict__ arg,
-    float* __restrict__ dx, int lddx, int dxoff, int n, int c4n, int accumulate) {
+    const T* __restrict__ dy, int lddy, int dyoff, const uint8_t* __restrict__ arg,
+    T* __restrict__ dx, int lddx, int dxoff, int n, int c4n, int accumulate) {
   constexpr int IW = IH;
   constexpr int OH = (IH + STRIDE - 1) / STRIDE, OW = OH;
   constexpr int PT = ((OH - 1) * STRIDE + 3 - IH) > 0 ? ((OH - 1) * STRIDE + 3 - IH) / 2 : 0;
@@ -237,13 +238,13 @@ __global__ __launch_bounds__(256) void pool3x3_map_bwd_kernel(
        idx += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % c4n);
     const long long img = idx / c4n;
-    const float* gp = dy + (size_t)img * (OH * OW) * lddy + dyoff + c4 * 4;
-    float* dp = dx + (size_t)img * (IH * IW) * lddx + dxoff + c4 * 4;
+    const T* gp = dy + (size_t)img * (OH * OW) * lddy + dyoff + c4 * 4;
+    T* dp = dx + (size_t)img * (IH * IW) * lddx + dxoff + c4 * 4;
     float4 g[OH * OW];
     uchar4 am[OH * OW];
 #pragma unroll
     for (int o = 0; o < OH * OW; ++o) {
-      g[o] = *reinterpret_cast<const float4*>(gp + (size_t)o * lddy);
+      g[o] = c2d_ld4(gp + (size_t)o * lddy);
       if (MODE == 0)
         am[o] = *reinterpret_cast<const uchar4*>(arg + ((size_t)img * (OH * OW) + o) * c4n * 4 +
                                                  c4 * 4);
@@ -280,12 +281,12 @@ __global__ __launch_bounds__(256) void pool3x3_map_bwd_kernel(
             }
           }
         }
-        float4* dst = reinterpret_cast<float4*>(dp + (size_t)(iy * IW + ix) * lddx);
+        T* dst = dp + (size_t)(iy * IW + ix) * lddx;
         if (accumulate) {
-          const float4 o = *dst;
+          const float4 o = c2d_ld4(dst);
           acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
         }
-        *dst = acc;
+        c2d_st4(dst, acc);
       }
     }
   }
@@ -294,11 +295,11 @@ __global__ __launch_bounds__(256) void pool3x3_map_bwd_kernel(
 // dc = dy * (y > 0) * scale[c];  dbeta[c] += sum dz;  dgamma[c] += sum dz * (y - beta)/gamma
 // where dz = dy * (y > 0).  (y = gamma*xhat + beta wherever y > 0, so xhat = (y-beta)/gamma.)
 // Block: TX lanes over float4 channel groups x TY row lanes; LDS reduce over TY.
-template <int TX>
+template <int TX, typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
-    const float* __restrict__ dy, int lddy, int dyoff, const float* __restrict__ y, int ldy,
+    const T* __restrict__ dy, int lddy, int dyoff, const T* __restrict__ y, int ldy,
     int yoff, const float* __restrict__ scale, const float* __restrict__ beta,
-    const float* __restrict__ gamma, float* __restrict__ dc, float* __restrict__ dbeta,
+    const float* __restrict__ gamma, T* __restrict__ dc, float* __restrict__ dbeta,
     float* __restrict__ dgamma, float* __restrict__ partials, int M, int c4n,
     int rows_per_block) {
   constexpr int TY = 256 / TX;
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
         float4 g[4], v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          g[u] = *reinterpret_cast<const float4*>(dy + (size_t)(r + u * TY) * lddy + dyoff + c);
-          v[u] = *reinterpret_cast<const float4*>(y + (size_t)(r + u * TY) * ldy + yoff + c);
+          g[u] = c2d_ld4(dy + (size_t)(r + u * TY) * lddy + dyoff + c);
+          v[u] = c2d_ld4(y + (size_t)(r + u * TY) * ldy + yoff + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -337,21 +338,21 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
           sb.x += dz.x; sb.y += dz.y; sb.z += dz.z; sb.w += dz.w;
           sg.x += dz.x * (v[u].x - be.x) * ig.x; sg.y += dz.y * (v[u].y - be.y) * ig.y;
           sg.z += dz.z * (v[u].z - be.z) * ig.z; sg.w += dz.w * (v[u].w - be.w) * ig.w;
-          *reinterpret_cast<float4*>(dc + (size_t)(r + u * TY) * c4n * 4 + c) =
-              make_float4(dz.x * sc.x, dz.y * sc.y, dz.z * sc.z, dz.w * sc.w);
+          c2d_st4(dc + (size_t)(r + u * TY) * c4n * 4 + c,
+                  make_float4(dz.x * sc.x, dz.y * sc.y, dz.z * sc.z, dz.w * sc.w));
         }
       }
       for (; r < r1; r += TY) {
-        const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * lddy + dyoff + c);
-        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)r * ldy + yoff + c);
+        const float4 g = c2d_ld4(dy + (size_t)r * lddy + dyoff + c);
+        const float4 v = c2d_ld4(y + (size_t)r * ldy + yoff + c);
         float4 dz;
         dz.x = v.x > 0.f ? g.x : 0.f; dz.y = v.y > 0.f ? g.y : 0.f;
         dz.z = v.z > 0.f ? g.z : 0.f; dz.w = v.w > 0.f ? g.w : 0.f;
         sb.x += dz.x; sb.y += dz.y; sb.z += dz.z; sb.w += dz.w;
         sg.x += dz.x * (v.x - be.x) * ig.x; sg.y += dz.y * (v.y - be.y) * ig.y;
         sg.z += dz.z * (v.z - be.z) * ig.z; sg.w += dz.w * (v.w - be.w) * ig.w;
-        *reinterpret_cast<float4*>(dc + (size_t)r * c4n * 4 + c) =
-            make_float4(dz.x * sc.x, dz.y * sc.y, dz.z * sc.z, dz.w * sc.w);
+        c2d_st4(dc + (size_t)r * c4n * 4 + c,
+                make_float4(dz.x * sc.x, dz.y * sc.y, dz.z * sc.z, dz.w * sc.w));
       }
     }
     red[0][ty][tx] = sb;
@@ -404,8 +405,9 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
 }
 
 // y[r][c] = mean_s x[r][s][c] * (mask ? mask[r][c] * inv_keep : 1)
+template <typename T>
 __global__ __launch_bounds__(256) void spatial_mean_dropout_fwd_kernel(
-    const float* __restrict__ x, float* __restrict__ y, const uint8_t* __restrict__ mask,
+    const T* __restrict__ x, float* __restrict__ y, const uint8_t* __restrict__ mask,
     int rows, int spatial, int c4n, float inv_keep) {
   const long long total = (long long)rows * c4n;
   const float inv_s = 1.0f / (float)spatial;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void spatial_mean_dropout_fwd_kernel(
     const long long r = idx / c4n;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < spatial; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)r * spatial + k) * c4n * 4 + c4 * 4);
+      const float4 v = c2d_ld4(x + ((size_t)r * spatial + k) * c4n * 4 + c4 * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     s.x *= inv_s; s.y *= inv_s; s.z *= inv_s; s.w *= inv_s;
@@ -428,8 +430,9 @@ __global__ __launch_bounds__(256) void spatial_mean_dropout_fwd_kernel(
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void spatial_mean_dropout_bwd_kernel(
-    const float* __restrict__ dy, int lddy, int dyoff, float* __restrict__ dx,
+    const float* __restrict__ dy, int lddy, int dyoff, T* __restrict__ dx,
     const uint8_t* __restrict__ mask, int rows, int spatial, int c4n, float inv_keep) {
   const long long total = (long long)rows * spatial * c4n;
   const float inv_s = 1.0f / (float)spatial;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256) void spatial_mean_dropout_bwd_kernel(
       g.z = g.z * inv_keep * (float)m.z; g.w = g.w * inv_keep * (float)m.w;
     }
     g.x *= inv_s; g.y *= inv_s; g.z *= inv_s; g.w *= inv_s;
-    *reinterpret_cast<float4*>(dx + (size_t)idx * 4) = g;
+    c2d_st4(dx + (size_t)idx * 4, g);
   }
 }
 
@@ -678,14 +681,15 @@ inline int grid_for(long long total) {
   return (int)b;
 }
 
-int launch_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ldy, int yoff,
-                       const float* scale, const float* beta, const float* gamma, float* dc,
+template <typename T>
+int launch_bn_relu_bwd(const T* dy, int lddy, int dyoff, const T* y, int ldy, int yoff,
+                       const float* scale, const float* beta, const float* gamma, T* dc,
                        float* dbeta, float* dgamma, float* partials, int rows, int c,
                        int rows_per_block, hipStream_t s) {
   const int c4n = c / 4;
   const int blocks = c2d_ceil_div(rows, rows_per_block);
 #define C2D_BNB(TX)                                                                          \
-  hipLaunchKernelGGL((bn_relu_bwd_kernel<TX>), dim3(blocks), dim3(256), 0, s, dy, lddy, dyoff, \
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<TX, T>), dim3(blocks), dim3(256), 0, s, dy, lddy, dyoff, \
                      y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, partials, rows, c4n, \
                      rows_per_block)
   if (c4n <= 16) C2D_BNB(16);
@@ -698,9 +702,9 @@ int launch_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int
 
 }  // namespace
 
-extern "C" int c2d_pool3x3_fwd(const float* x, int ldx, int xoff, float* y, int ldy, int yoff,
-                               uint8_t* argmax, int n, int ih, int iw, int c, int stride,
-                               int mode, void* stream) {
+template <typename T>
+int pool3x3_fwd_impl(const T* x, int ldx, int xoff, T* y, int ldy, int yoff, uint8_t* argmax, int n,
+                     int ih, int iw, int c, int stride, int mode, void* stream) {
   C2D_CHECK_ARG(x && y && n > 0 && ih > 0 && iw > 0 && c > 0 && c % 4 == 0);
   C2D_CHECK_ARG((stride == 1 || stride == 2) && (mode == 0 || mode == 1));
   C2D_CHECK_ARG(ldx % 4 == 0 && xoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
@@ -710,8 +714,8 @@ extern "C" int c2d_pool3x3_fwd(const float* x, int ldx, int xoff, float* y, int 
     // per-ROI maps of the second stage: whole-map kernel, every input element fetched once
     const dim3 grid(grid_for((long long)n * (c / 4))), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define C2D_POOL_F(IH, S, MD)                                                                 \
-  hipLaunchKernelGGL((pool3x3_map_fwd_kernel<IH, S, MD>), grid, block, 0, st, x, ldx, xoff, y, \
+#define C2D_POOL_F(IH, S, MD)                                                                    \
+  hipLaunchKernelGGL((pool3x3_map_fwd_kernel<IH, S, MD, T>), grid, block, 0, st, x, ldx, xoff, y, \
                      ldy, yoff, argmax, n, c / 4)
     if (ih == 4 && mode == 0) C2D_POOL_F(4, 1, 0);
     else if (ih == 4) C2D_POOL_F(4, 1, 1);
@@ -719,14 +723,15 @@ extern "C" int c2d_pool3x3_fwd(const float* x, int ldx, int xoff, float* y, int 
 #undef C2D_POOL_F
     return c2d_launch_status();
   }
-  hipLaunchKernelGGL(pool3x3_fwd_kernel, dim3(grid_for(total)), dim3(256), 0,
+  hipLaunchKernelGGL(pool3x3_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
                      (hipStream_t)stream, x, ldx, xoff, y, ldy, yoff, argmax, n, c / 4, g, mode);
   return c2d_launch_status();
 }
 
-extern "C" int c2d_pool3x3_bwd(const float* dy, int lddy, int dyoff, const uint8_t* argmax,
-                               float* dx, int lddx, int dxoff, int n, int ih, int iw, int c,
-                               int stride, int mode, int accumulate, void* stream) {
+template <typename T>
+int pool3x3_bwd_impl(const T* dy, int lddy, int dyoff, const uint8_t* argmax, T* dx, int lddx,
+                     int dxoff, int n, int ih, int iw, int c, int stride, int mode, int accumulate,
+                     void* stream) {
   C2D_CHECK_ARG(dy && dx && n > 0 && ih > 0 && iw > 0 && c > 0 && c % 4 == 0);
   C2D_CHECK_ARG((stride == 1 || stride == 2) && (mode == 0 || mode == 1));
   C2D_CHECK_ARG(mode == 1 || argmax);
@@ -736,8 +741,8 @@ extern "C" int c2d_pool3x3_bwd(const float* dy, int lddy, int dyoff, const uint8
   if (n >= 64 && ih == iw && ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
     const dim3 grid(grid_for((long long)n * (c / 4))), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define C2D_POOL_B(IH, S, MD)                                                                  \
-  hipLaunchKernelGGL((pool3x3_map_bwd_kernel<IH, S, MD>), grid, block, 0, st, dy, lddy, dyoff,  \
+#define C2D_POOL_B(IH, S, MD)                                                                     \
+  hipLaunchKernelGGL((pool3x3_map_bwd_kernel<IH, S, MD, T>), grid, block, 0, st, dy, lddy, dyoff,  \
                      argmax, dx, lddx, dxoff, n, c / 4, accumulate)
     if (ih == 4 && mode == 0) C2D_POOL_B(4, 1, 0);
     else if (ih == 4) C2D_POOL_B(4, 1, 1);
@@ -745,10 +750,38 @@ extern "C" int c2d_pool3x3_bwd(const float* dy, int lddy, int dyoff, const uint8
 #undef C2D_POOL_B
     return c2d_launch_status();
   }
-  hipLaunchKernelGGL(pool3x3_bwd_kernel, dim3(grid_for(total)), dim3(256), 0,
+  hipLaunchKernelGGL(pool3x3_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
                      (hipStream_t)stream, dy, lddy, dyoff, argmax, dx, lddx, dxoff, n, c / 4, g,
                      mode, accumulate);
   return c2d_launch_status();
+}
+
+extern "C" int c2d_pool3x3_fwd(const float* x, int ldx, int xoff, float* y, int ldy, int yoff,
+                               uint8_t* argmax, int n, int ih, int iw, int c, int stride,
+                               int mode, void* stream) {
+  return pool3x3_fwd_impl<float>(x, ldx, xoff, y, ldy, yoff, argmax, n, ih, iw, c, stride, mode,
+                                 stream);
+}
+
+extern "C" int c2d_pool3x3_fwd_bf16(const void* x, int ldx, int xoff, void* y, int ldy, int yoff,
+                                    uint8_t* argmax, int n, int ih, int iw, int c, int stride,
+                                    int mode, void* stream) {
+  return pool3x3_fwd_impl<c2d_bf16>((const c2d_bf16*)x, ldx, xoff, (c2d_bf16*)y, ldy, yoff, argmax,
+                                    n, ih, iw, c, stride, mode, stream);
+}
+
+extern "C" int c2d_pool3x3_bwd(const float* dy, int lddy, int dyoff, const uint8_t* argmax,
+                               float* dx, int lddx, int dxoff, int n, int ih, int iw, int c,
+                               int stride, int mode, int accumulate, void* stream) {
+  return pool3x3_bwd_impl<float>(dy, lddy, dyoff, argmax, dx, lddx, dxoff, n, ih, iw, c, stride,
+                                 mode, accumulate, stream);
+}
+
+extern "C" int c2d_pool3x3_bwd_bf16(const void* dy, int lddy, int dyoff, const uint8_t* argmax,
+                                    void* dx, int lddx, int dxoff, int n, int ih, int iw, int c,
+                                    int stride, int mode, int accumulate, void* stream) {
+  return pool3x3_bwd_impl<c2d_bf16>((const c2d_bf16*)dy, lddy, dyoff, argmax, (c2d_bf16*)dx, lddx,
+                                    dxoff, n, ih, iw, c, stride, mode, accumulate, stream);
 }
 
 extern "C" int c2d_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ldy,
@@ -779,6 +812,19 @@ extern "C" int c2d_bn_relu_bwd_partial(const float* dy, int lddy, int dyoff, con
                             (hipStream_t)stream);
 }
 
+extern "C" int c2d_bn_relu_bwd_partial_bf16(const void* dy, int lddy, int dyoff, const void* y,
+                                            int ldy, int yoff, const float* scale,
+                                            const float* beta, const float* gamma, void* dc,
+                                            float* partials, int rows, int c, void* stream) {
+  C2D_CHECK_ARG(dy && y && scale && dc && partials && rows > 0 && c > 0 && c % 4 == 0);
+  C2D_CHECK_ARG(!gamma || beta);
+  C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
+  return launch_bn_relu_bwd<c2d_bf16>((const c2d_bf16*)dy, lddy, dyoff, (const c2d_bf16*)y, ldy,
+                                      yoff, scale, beta, gamma, (c2d_bf16*)dc, nullptr, nullptr,
+                                      partials, rows, c, bn_rows_per_block(rows),
+                                      (hipStream_t)stream);
+}
+
 extern "C" int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks,
                                               const float* ws, float* grads, void* stream) {
   C2D_CHECK_ARG(desc && ws && grads && num > 0 && total_chunks > 0);
@@ -800,9 +846,19 @@ extern "C" int c2d_spatial_mean_dropout_fwd(const float* x, float* y, const uint
                                             int rows, int spatial, int c, float keep_prob,
                                             void* stream) {
   C2D_CHECK_ARG(x && y && rows > 0 && spatial > 0 && c > 0 && c % 4 == 0 && keep_prob > 0.f);
-  hipLaunchKernelGGL(spatial_mean_dropout_fwd_kernel, dim3(grid_for((long long)rows * c / 4)),
-                     dim3(256), 0, (hipStream_t)stream, x, y, mask, rows, spatial, c / 4,
-                     1.0f / keep_prob);
+  hipLaunchKernelGGL(spatial_mean_dropout_fwd_kernel<float>,
+                     dim3(grid_for((long long)rows * c / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, mask, rows, spatial, c / 4, 1.0f / keep_prob);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_spatial_mean_dropout_fwd_bf16(const void* x, float* y, const uint8_t* mask,
+                                                 int rows, int spatial, int c, float keep_prob,
+                                                 void* stream) {
+  C2D_CHECK_ARG(x && y && rows > 0 && spatial > 0 && c > 0 && c % 4 == 0 && keep_prob > 0.f);
+  hipLaunchKernelGGL(spatial_mean_dropout_fwd_kernel<c2d_bf16>,
+                     dim3(grid_for((long long)rows * c / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const c2d_bf16*)x, y, mask, rows, spatial, c / 4, 1.0f / keep_prob);
   return c2d_launch_status();
 }
 
@@ -811,9 +867,21 @@ extern "C" int c2d_spatial_mean_dropout_bwd(const float* dy, int lddy, int dyoff
                                             float keep_prob, void* stream) {
   C2D_CHECK_ARG(dy && dx && rows > 0 && spatial > 0 && c > 0 && c % 4 == 0 && keep_prob > 0.f);
   C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0);
-  hipLaunchKernelGGL(spatial_mean_dropout_bwd_kernel,
+  hipLaunchKernelGGL(spatial_mean_dropout_bwd_kernel<float>,
                      dim3(grid_for((long long)rows * spatial * c / 4)), dim3(256), 0,
                      (hipStream_t)stream, dy, lddy, dyoff, dx, mask, rows, spatial, c / 4,
+                     1.0f / keep_prob);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_spatial_mean_dropout_bwd_bf16(const float* dy, int lddy, int dyoff, void* dx,
+                                                 const uint8_t* mask, int rows, int spatial, int c,
+                                                 float keep_prob, void* stream) {
+  C2D_CHECK_ARG(dy && dx && rows > 0 && spatial > 0 && c > 0 && c % 4 == 0 && keep_prob > 0.f);
+  C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0);
+  hipLaunchKernelGGL(spatial_mean_dropout_bwd_kernel<c2d_bf16>,
+                     dim3(grid_for((long long)rows * spatial * c / 4)), dim3(256), 0,
+                     (hipStream_t)stream, dy, lddy, dyoff, (c2d_bf16*)dx, mask, rows, spatial, c / 4,
                      1.0f / keep_prob);
   return c2d_launch_status();
 }
@@ -912,5 +980,22 @@ extern "C" int c2d_bn_fold_batched(const void* desc, int num, int total_channels
   hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(c2d_ceil_div(total_channels, 256)), dim3(256),
                      0, (hipStream_t)stream, (const FoldDesc*)desc, num, total_channels, vars,
                      stats, eps, out);
+  return c2d_launch_status();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src,
+                                                        c2d_bf16* __restrict__ dst, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x)
+    c2d_st4(dst + i * 4, c2d_ld4(src + i * 4));
+}
+}  // namespace
+
+extern "C" int c2d_cast_bf16(const float* src, void* dst, long long n, void* stream) {
+  C2D_CHECK_ARG(src && dst && n >= 0 && n % 4 == 0);
+  if (n == 0) return C2D_OK;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src,
+                     (c2d_bf16*)dst, n / 4);
   return c2d_launch_status();
 }

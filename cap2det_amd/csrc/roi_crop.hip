@@ -100,9 +100,10 @@ __global__ __launch_bounds__(256) void crop_and_resize_fwd_kernel(
   }
 }
 
+template <typename TO>   // pooled output storage: float or bf16 (rounded once, at the store)
 __global__ __launch_bounds__(256) void roi_crop_pool_fwd_kernel(
     const float4* __restrict__ feat, const float* __restrict__ boxes,
-    const int32_t* __restrict__ box_ind, float4* __restrict__ out,
+    const int32_t* __restrict__ box_ind, TO* __restrict__ out,
     uchar4* __restrict__ argmax, int batch, int hf, int wf, int d4n, int crop, int pk, int ps,
     int pout) {
   __shared__ SampleAxis ys[kMaxCrop], xs[kMaxCrop];
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void roi_crop_pool_fwd_kernel(
         }
       }
     }
-    out[obase + idx] = best;
+    c2d_st4(out + (obase + idx) * 4, best);
     if (argmax) argmax[obase + idx] = arg;
   }
 }
@@ -356,9 +357,9 @@ constexpr int kRowParts = 4;  // workgroups sharing one (row, chunk): finer grai
 // grid (hf, depth/CH, batch*kRowParts), block 256 = (256/CH) lane groups x CH channels.  Part q
 // walks segments [q*kBinSegs/kRowParts, ...) of the row list and writes its partial row into
 // part[q] (plain stores); roi_bwd_sum_parts_kernel then adds the parts in a fixed order.
-template <int CH>
+template <int CH, typename TG>
 __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(
-    const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
+    const TG* __restrict__ dout, const uint8_t* __restrict__ argmax,
     const RowEntry* __restrict__ lists, const int32_t* __restrict__ counts,
     float* __restrict__ parts, int batch, int hf, int wf, int depth, int pout, int cap) {
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [NG groups][wf][CH]
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(
         e[u] = list[in ? i : (count - 1)];
         const int roi = e[u].id >> 8, py = (e[u].id >> 4) & 15, px = e[u].id & 15;
         const size_t o = ((size_t)roi * p2 + py * pout + px) * depth + c0 + ch;
-        g[u] = in ? dout[o] : 0.0f;
+        g[u] = in ? (float)dout[o] : 0.0f;
         k[u] = argmax[o];
       }
 #pragma unroll
@@ -456,8 +457,24 @@ extern "C" int c2d_roi_crop_pool_fwd(const float* feat, const float* boxes,
   C2D_CHECK_ARG(pool_k > 0 && pool_s > 0 && pool_k <= crop && pool_k * pool_k <= 255);
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
-  hipLaunchKernelGGL(roi_crop_pool_fwd_kernel, dim3(num_boxes), dim3(256), 0,
-                     (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (float4*)out,
+  hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<float>, dim3(num_boxes), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
+                     (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pool_k, pool_s, pout);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_roi_crop_pool_fwd_bf16(const float* feat, const float* boxes,
+                                          const int32_t* box_ind, void* out, uint8_t* argmax,
+                                          int batch, int hf, int wf, int depth, int num_boxes,
+                                          int crop, int pool_k, int pool_s, void* stream) {
+  C2D_CHECK_ARG(feat && boxes && box_ind && out);
+  C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 4 == 0);
+  C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0);
+  C2D_CHECK_ARG(pool_k > 0 && pool_s > 0 && pool_k <= crop && pool_k * pool_k <= 255);
+  if (num_boxes == 0) return C2D_OK;
+  const int pout = (crop - pool_k) / pool_s + 1;
+  hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<c2d_bf16>, dim3(num_boxes), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,
                      (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pool_k, pool_s, pout);
   return c2d_launch_status();
 }
@@ -517,11 +534,11 @@ extern "C" long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, in
          (long long)kRowParts * batch * hf * wf * depth * 4;
 }
 
-extern "C" int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax,
-                                        const float* boxes, const int32_t* box_ind, float* dfeat,
-                                        int batch, int hf, int wf, int depth, int num_boxes,
-                                        int crop, int pool_k, int pool_s, void* workspace,
-                                        long long workspace_bytes, void* stream) {
+template <typename TG>
+static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, const float* boxes,
+                                     const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
+                                     int depth, int num_boxes, int crop, int pool_k, int pool_s,
+                                     void* workspace, long long workspace_bytes, void* stream) {
   C2D_CHECK_ARG(dout && argmax && boxes && box_ind && dfeat && workspace);
   C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 16 == 0);
   C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0 && pool_s > 0);
@@ -550,7 +567,7 @@ extern "C" int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax
                      box_ind, lists, counts, num_boxes, hf, pool_s, pout, crop, cap);
   const int chsel = 16;   // measured: 16-channel chunks 447 us, 32: 492, 64: ~1000 (N=2000, 32x32x576)
 #define C2D_ROWS(CHV)                                                                          \
-  hipLaunchKernelGGL((roi_bwd_rows_kernel<CHV>), dim3(hf, depth / CHV, batch * kRowParts),        \
+  hipLaunchKernelGGL((roi_bwd_rows_kernel<CHV, TG>), dim3(hf, depth / CHV, batch * kRowParts),    \
                      dim3(256), (size_t)256 * wf * sizeof(float), st, dout, argmax, lists, counts, \
                      parts, batch, hf, wf, depth, pout, cap)
   if (depth % 64 == 0 && chsel == 64) { C2D_ROWS(64); }
@@ -561,4 +578,25 @@ extern "C" int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax
   hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, st,
                      (const float4*)parts, (float4*)dfeat, n4);
   return c2d_launch_status();
+}
+
+extern "C" int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax,
+                                        const float* boxes, const int32_t* box_ind, float* dfeat,
+                                        int batch, int hf, int wf, int depth, int num_boxes,
+                                        int crop, int pool_k, int pool_s, void* workspace,
+                                        long long workspace_bytes, void* stream) {
+  return roi_crop_pool_bwd_ws_impl<float>(dout, argmax, boxes, box_ind, dfeat, batch, hf, wf, depth,
+                                          num_boxes, crop, pool_k, pool_s, workspace,
+                                          workspace_bytes, stream);
+}
+
+extern "C" int c2d_roi_crop_pool_bwd_ws_bf16(const void* dout, const uint8_t* argmax,
+                                             const float* boxes, const int32_t* box_ind,
+                                             float* dfeat, int batch, int hf, int wf, int depth,
+                                             int num_boxes, int crop, int pool_k, int pool_s,
+                                             void* workspace, long long workspace_bytes,
+                                             void* stream) {
+  return roi_crop_pool_bwd_ws_impl<c2d_bf16>((const c2d_bf16*)dout, argmax, boxes, box_ind, dfeat,
+                                             batch, hf, wf, depth, num_boxes, crop, pool_k, pool_s,
+                                             workspace, workspace_bytes, stream);
 }

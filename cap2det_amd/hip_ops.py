@@ -46,8 +46,9 @@ def roi_crop_pool_fwd(feat, boxes, box_ind, crop, pool_k, pool_s, out=None, argm
     out = torch.zeros(r, p, p, d, device=feat.device, dtype=torch.float32)
   if argmax is None and want_argmax:
     argmax = torch.zeros(r, p, p, d, device=feat.device, dtype=torch.uint8)
-  _lib.call("c2d_roi_crop_pool_fwd", _p(feat), _p(boxes), _p(box_ind), _p(out), _p(argmax), b, hf,
-            wf, d, r, crop, pool_k, pool_s, _stream())
+  fn = "c2d_roi_crop_pool_fwd_bf16" if out.dtype == torch.bfloat16 else "c2d_roi_crop_pool_fwd"
+  _lib.call(fn, _p(feat), _p(boxes), _p(box_ind), _p(out), _p(argmax), b, hf, wf, d, r, crop,
+            pool_k, pool_s, _stream())
   return out, argmax
 
 
@@ -66,9 +67,9 @@ def roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes, crop, poo
 def roi_crop_pool_bwd_ws(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool_s, workspace):
   """Atomic-free, bitwise-reproducible ROI-crop backward (workspace: uint8 device tensor)."""
   b, hf, wf, d = dfeat.shape
-  _lib.call("c2d_roi_crop_pool_bwd_ws", _p(dout), _p(argmax), _p(boxes), _p(box_ind), _p(dfeat), b,
-            hf, wf, d, boxes.shape[0], crop, pool_k, pool_s, _p(workspace), workspace.numel(),
-            _stream())
+  fn = "c2d_roi_crop_pool_bwd_ws_bf16" if dout.dtype == torch.bfloat16 else "c2d_roi_crop_pool_bwd_ws"
+  _lib.call(fn, _p(dout), _p(argmax), _p(boxes), _p(box_ind), _p(dfeat), b, hf, wf, d,
+            boxes.shape[0], crop, pool_k, pool_s, _p(workspace), workspace.numel(), _stream())
   return dfeat
 
 
@@ -144,8 +145,10 @@ def conv1x1_dgrad_multi(dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
 
 
 def conv_wgrad(x, ldx, xoff, dc, ldc, coff, dw, n, ih, iw, cin, cout, kh, kw, stride):
-  _lib.call("c2d_conv_wgrad", _p(x), ldx, xoff, _p(dc), ldc, coff, _p(dw), n, ih, iw, cin, cout,
-            kh, kw, stride, _stream())
+  fn = "c2d_conv_wgrad_bf16" if x.dtype == torch.bfloat16 else "c2d_conv_wgrad"
+  assert x.dtype == dc.dtype and dw.dtype == torch.float32
+  _lib.call(fn, _p(x), ldx, xoff, _p(dc), ldc, coff, _p(dw), n, ih, iw, cin, cout, kh, kw, stride,
+            _stream())
 
 
 def transpose_taps(w, wt, taps, rows, cols):
@@ -177,8 +180,10 @@ def bn_relu_bwd_partial_blocks(rows, c):
 
 
 def bn_relu_bwd_partial(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, partials, rows, c):
-  _lib.call("c2d_bn_relu_bwd_partial", _p(dy), lddy, dyoff, _p(y), ldy, yoff, _p(scale),
-            _p(beta), _p(gamma), _p(dc), _p(partials), rows, c, _stream())
+  fn = "c2d_bn_relu_bwd_partial_bf16" if dy.dtype == torch.bfloat16 else "c2d_bn_relu_bwd_partial"
+  assert dy.dtype == y.dtype == dc.dtype
+  _lib.call(fn, _p(dy), lddy, dyoff, _p(y), ldy, yoff, _p(scale), _p(beta), _p(gamma), _p(dc),
+            _p(partials), rows, c, _stream())
 
 
 def bn_partials_reduce_batched(desc, num, total_chunks, ws, grads):
@@ -186,28 +191,40 @@ def bn_partials_reduce_batched(desc, num, total_chunks, ws, grads):
             _stream())
 
 
+def cast_bf16(src, dst):
+  assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+  _lib.call("c2d_cast_bf16", _p(src), _p(dst), src.numel(), _stream())
+
+
 def col_sum(x, ldx, xoff, out, rows, ncols):
   _lib.call("c2d_col_sum", _p(x), ldx, xoff, _p(out), rows, ncols, _stream())
 
 
 def pool3x3_fwd(x, ldx, xoff, y, ldy, yoff, argmax, n, ih, iw, c, stride, mode):
-  _lib.call("c2d_pool3x3_fwd", _p(x), ldx, xoff, _p(y), ldy, yoff, _p(argmax), n, ih, iw, c,
-            stride, mode, _stream())
+  fn = "c2d_pool3x3_fwd_bf16" if x.dtype == torch.bfloat16 else "c2d_pool3x3_fwd"
+  assert x.dtype == y.dtype
+  _lib.call(fn, _p(x), ldx, xoff, _p(y), ldy, yoff, _p(argmax), n, ih, iw, c, stride, mode,
+            _stream())
 
 
 def pool3x3_bwd(dy, lddy, dyoff, argmax, dx, lddx, dxoff, n, ih, iw, c, stride, mode, accumulate):
-  _lib.call("c2d_pool3x3_bwd", _p(dy), lddy, dyoff, _p(argmax), _p(dx), lddx, dxoff, n, ih, iw, c,
-            stride, mode, int(accumulate), _stream())
+  fn = "c2d_pool3x3_bwd_bf16" if dy.dtype == torch.bfloat16 else "c2d_pool3x3_bwd"
+  assert dy.dtype == dx.dtype
+  _lib.call(fn, _p(dy), lddy, dyoff, _p(argmax), _p(dx), lddx, dxoff, n, ih, iw, c, stride, mode,
+            int(accumulate), _stream())
 
 
 def spatial_mean_dropout_fwd(x, y, mask, rows, spatial, c, keep_prob):
-  _lib.call("c2d_spatial_mean_dropout_fwd", _p(x), _p(y), _p(mask), rows, spatial, c,
-            float(keep_prob), _stream())
+  fn = ("c2d_spatial_mean_dropout_fwd_bf16" if x.dtype == torch.bfloat16
+        else "c2d_spatial_mean_dropout_fwd")
+  _lib.call(fn, _p(x), _p(y), _p(mask), rows, spatial, c, float(keep_prob), _stream())
 
 
 def spatial_mean_dropout_bwd(dy, lddy, dyoff, dx, mask, rows, spatial, c, keep_prob):
-  _lib.call("c2d_spatial_mean_dropout_bwd", _p(dy), lddy, dyoff, _p(dx), _p(mask), rows, spatial,
-            c, float(keep_prob), _stream())
+  fn = ("c2d_spatial_mean_dropout_bwd_bf16" if dx.dtype == torch.bfloat16
+        else "c2d_spatial_mean_dropout_bwd")
+  _lib.call(fn, _p(dy), lddy, dyoff, _p(dx), _p(mask), rows, spatial, c, float(keep_prob),
+            _stream())
 
 
 def dropout_mask(mask, seed, keep_prob):

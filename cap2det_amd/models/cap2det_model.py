@@ -30,7 +30,10 @@ class Model(ModelBase):
   """Cap2Det model."""
 
   def __init__(self, model_proto, is_training=False, device="cuda:0", depth_multiplier=1.0,
-               bn_scale=True, seed=0):
+               bn_scale=True, seed=0, compute_dtype="fp32"):
+    """compute_dtype: "fp32" (BASELINE configs[0], [1], [3]: exact fp32 everywhere) or "bf16"
+    (configs[2], [4]: ROI crop output and second stage in bf16 storage with fp32 accumulation;
+    first stage, heads, losses, variables and optimiser stay fp32)."""
     model_proto = unwrap(model_proto)
     super(Model, self).__init__(model_proto, is_training)
     if not isinstance(model_proto, cap2det_model_pb2.Cap2DetModel):
@@ -47,7 +50,11 @@ class Model(ModelBase):
     self._oicr_iterations = options.oicr_iterations
 
     self.store = VariableStore(self._device)
-    self.engine = FrcnnEngine(self.store, options.frcnn_options, bn_scale, depth_multiplier)
+    if compute_dtype not in ("fp32", "bf16"):
+      raise ValueError("compute_dtype must be 'fp32' or 'bf16'")
+    self.compute_dtype = compute_dtype
+    self.engine = FrcnnEngine(self.store, options.frcnn_options, bn_scale, depth_multiplier,
+                              act_dtype=torch.bfloat16 if compute_dtype == "bf16" else torch.float32)
     # Five fully-connected heads fused into one [D, Npad] GEMM operand:
     # columns = [r|c (C), c|r (C), oicr_1 (C+1), ..., oicr_K (C+1)], zero padded to 16.
     c, k = self._num_classes, self._oicr_iterations

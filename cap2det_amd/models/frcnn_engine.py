@@ -124,6 +124,13 @@ class VariableStore(object):
   def names(self):
     return [s[0] for s in self._specs]
 
+  def low_precision_view(self, name):
+    """bf16 mirror of a variable (refreshed by FrcnnEngine.refresh for bf16 networks)."""
+    if getattr(self, "values_bf16", None) is None:
+      self.values_bf16 = torch.zeros(self.values.numel(), device=self.device, dtype=torch.bfloat16)
+    off, numel = self.offset[name]
+    return self.values_bf16[off:off + numel].view(self.var[name].shape)
+
   def span(self, names):
     """Smallest [lo, hi) flat range covering `names` (aligned ends)."""
     lo = min(self.offset[n][0] for n in names)
@@ -140,6 +147,7 @@ class DerivedStore(object):
     self._stat_specs, self._der_specs = [], []
     self._stat_size = self._der_size = 0
     self.stat_flat = self.der_flat = None
+    self.der_bf16 = None
     self._stats, self.derived = {}, {}
     self.stat_off, self.der_off = {}, {}
 
@@ -164,6 +172,13 @@ class DerivedStore(object):
     for name, shape, off, n in self._der_specs:
       self.derived[name] = self.der_flat[off:off + n].view(shape)
       self.der_off[name] = off
+
+  def low_precision_view(self, name):
+    if self.der_bf16 is None:
+      self.der_bf16 = torch.zeros(self.der_flat.numel(), device=self.device, dtype=torch.bfloat16)
+    off = self.der_off[name]
+    v = self.derived[name]
+    return self.der_bf16[off:off + v.numel()].view(v.shape)
 
   # dict protocol over the moving statistics
   def __getitem__(self, k):
@@ -203,6 +218,15 @@ class ConvBN(object):
   @property
   def wt(self):
     return self.stats.derived[self.name + "/wt"]
+
+  def wt_for(self, dtype):
+    """Forward operand [tap][cout][cin] in the network's storage type."""
+    return self.wt if dtype == torch.float32 else self.stats.low_precision_view(self.name + "/wt")
+
+  def w_for(self, dtype):
+    """HWIO weights (the dgrad operand) in the network's storage type."""
+    v = self.store.var[self.name + "/weights"]
+    return v if dtype == torch.float32 else self.store.low_precision_view(self.name + "/weights")
 
   @property
   def scale(self):
@@ -244,8 +268,12 @@ class Ref(object):
 class Net(object):
   """A stack of conv / pool / Inception-block ops with a static plan per input shape."""
 
-  def __init__(self, store, stats, spec, scope, cin, bn_scale, depth_multiplier=1.0):
+  def __init__(self, store, stats, spec, scope, cin, bn_scale, depth_multiplier=1.0,
+               dtype=torch.float32):
+    """dtype: storage type of the activations and their gradients (fp32, or bf16 with fp32
+    accumulation: BASELINE.json configs[2] / [4])."""
     self.store, self.stats, self.spec, self.scope = store, stats, spec, scope
+    self.dtype = dtype
     self.dm = depth_multiplier
     self.layers = {}      # name -> ConvBN
     self.order = []       # top-level op index -> [conv names]
@@ -290,8 +318,8 @@ class Net(object):
       self._plans[key] = self._build_plan(n, ih, iw, training)
     return self._plans[key]
 
-  def _new(self, rows, c, dtype=torch.float32):
-    return torch.empty(rows, c, device=self.store.device, dtype=dtype)
+  def _new(self, rows, c, dtype=None):
+    return torch.empty(rows, c, device=self.store.device, dtype=dtype or self.dtype)
 
   def _build_plan(self, n, ih, iw, training):
     steps = []
@@ -377,7 +405,7 @@ class Net(object):
     x = st["x"] if st["x"] is not None else x_in
     if kind == "conv":
       L = st["layer"]
-      ops.conv_fwd(x.t, x.ld, x.off, L.wt, L.scale, L.shift, st["y"].t, st["y"].ld, st["y"].off,
+      ops.conv_fwd(x.t, x.ld, x.off, L.wt_for(self.dtype), L.scale, L.shift, st["y"].t, st["y"].ld, st["y"].off,
                    st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, True)
     elif kind == "pool":
       ops.pool3x3_fwd(x.t, x.ld, x.off, st["y"].t, st["y"].ld, st["y"].off, st["arg"], st["n"],
@@ -393,28 +421,28 @@ class Net(object):
     if plan["bwd_ready"]:
       return
     dev = self.store.device
-    plan["dc"] = torch.empty(plan["scratch_elems"], device=dev)
+    plan["dc"] = torch.empty(plan["scratch_elems"], device=dev, dtype=self.dtype)
     steps = plan["steps"]
     for i in range(first_idx, len(steps)):
       st = steps[i]
       y = st["y"]
       rows = st["n"] * st["oh"] * st["ow"]
-      st["gy"] = Ref(torch.empty(rows, y.c, device=dev), y.c, 0, y.c)   # grad of the op output
+      st["gy"] = Ref(torch.empty(rows, y.c, device=dev, dtype=self.dtype), y.c, 0, y.c)   # grad of the op output
       if st["kind"] == "block":
         for bsteps in st["branches"]:
           b0 = bsteps[0]
           if (b0["kind"] == "conv" and b0["layer"].k == 1 and b0["layer"].stride == 1 and
               (i > first_idx or plan.get("need_input_grad", True))):
             b0["dc_entry"] = torch.empty(b0["n"] * b0["oh"] * b0["ow"], b0["layer"].cout,
-                                         device=dev)
+                                         device=dev, dtype=self.dtype)
           for j, bst in enumerate(bsteps):
             if j == len(bsteps) - 1:
               by = bst["y"]
               bst["gy"] = Ref(st["gy"].t, st["gy"].ld, by.off, by.c)
             else:
               brow = bst["n"] * bst["oh"] * bst["ow"]
-              bst["gy"] = Ref(torch.empty(brow, bst["y"].c, device=dev), bst["y"].c, 0,
-                              bst["y"].c)
+              bst["gy"] = Ref(torch.empty(brow, bst["y"].c, device=dev, dtype=self.dtype),
+                              bst["y"].c, 0, bst["y"].c)
     # BatchNorm beta/gamma gradients: every trainable conv's bn_relu_bwd stores per-row-block
     # partial sums into one workspace; one batched launch at the end of backward() adds them
     # into the flat gradient buffer (atomic-free, bitwise reproducible).
@@ -487,6 +515,9 @@ class Net(object):
       ops.bn_relu_bwd_partial(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
                               plan["bn_ws"][off:off + size], rows, L.cout)
     else:
+      if self.dtype != torch.float32:
+        raise NotImplementedError("bf16 networks are trained as a whole (frozen layers inside the "
+                                  "backward range are not supported)")
       ops.bn_relu_bwd(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
                       g[L.name + "/BatchNorm/beta"] if tr else None,
                       g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
@@ -495,7 +526,7 @@ class Net(object):
       ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
                      st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
     if gx is not None:
-      ops.conv_dgrad(dc, L.cout, 0, self.store.var[L.name + "/weights"], gx.t, gx.ld, gx.off,
+      ops.conv_dgrad(dc, L.cout, 0, L.w_for(self.dtype), gx.t, gx.ld, gx.off,
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
 
   def _bwd_step(self, plan, st, x, gx, accumulate):
@@ -526,7 +557,7 @@ class Net(object):
         rows = st["n"] * st["ih"] * st["iw"]
         ops.conv1x1_dgrad_multi(
             [b["dc_entry"] for b in fused], [b["layer"].cout for b in fused], [0] * len(fused),
-            [self.store.var[b["layer"].name + "/weights"] for b in fused],
+            [b["layer"].w_for(self.dtype) for b in fused],
             [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off, rows, st["cin"], False)
         written = True
       else:
@@ -548,9 +579,13 @@ class FrcnnEngine(object):
 
   STEM = FIRST_SCOPE + "Conv2d_1a_7x7"
 
-  def __init__(self, store, options, bn_scale=True, depth_multiplier=1.0):
-    """options: FRCNN proto (protos/frcnn.proto:4-33)."""
+  def __init__(self, store, options, bn_scale=True, depth_multiplier=1.0,
+               act_dtype=torch.float32):
+    """options: FRCNN proto (protos/frcnn.proto:4-33).  act_dtype: storage of the per-ROI
+    tensors (ROI crop output, second stage activations and gradients): fp32, or bf16 with fp32
+    accumulation; the first stage, the heads, all statistics and all variables stay fp32."""
     self.store = store
+    self.act_dtype = act_dtype
     self.device = store.device
     self.options = options
     self.crop = options.initial_crop_size
@@ -583,7 +618,8 @@ class FrcnnEngine(object):
     self.stem_shift = torch.empty(self.stem_cout, device=dev)
     self.first = Net(store, self.stats, FIRST_STAGE_AFTER_STEM, FIRST_SCOPE, self.stem_cout,
                      bn_scale, dm)
-    self.second = Net(store, self.stats, SECOND_STAGE, SECOND_SCOPE, self.first.cout, bn_scale, dm)
+    self.second = Net(store, self.stats, SECOND_STAGE, SECOND_SCOPE, self.first.cout, bn_scale, dm,
+                      dtype=act_dtype)
     self.feature_dims = self.second.cout
     self._shape_cache = {}
     self.first_trainable_idx = None
@@ -650,6 +686,12 @@ class FrcnnEngine(object):
     if t["nfolds"]:
       ops.bn_fold_batched(t["folds"], t["nfolds"], t["chans"], self.store.values,
                           self.stats.stat_flat, BN_EPS, self.stats.der_flat)
+    if self.act_dtype != torch.float32:
+      # bf16 mirrors of the variables (dgrad operand) and of the derived operands (forward)
+      any_layer = next(iter(self.second.layers.values()))
+      any_layer.w_for(self.act_dtype); any_layer.wt_for(self.act_dtype)     # (allocate once)
+      ops.cast_bf16(self.store.values, self.store.values_bf16)
+      ops.cast_bf16(self.stats.der_flat, self.stats.der_bf16)
 
   def _refresh_stem(self):
     """Folds depthwise(7x7, x8) o pointwise(1x1) into one 7x7 kernel over the 4-channel padded
@@ -697,7 +739,7 @@ class FrcnnEngine(object):
     p = (self.crop - self.pool_k) // self.pool_s + 1
     d = self.first.cout
     bufs.update(fh=fh, fw=fw, p=p,
-                pooled=Ref(torch.empty(b * n * p * p, d, device=dev), d, 0, d),
+                pooled=Ref(torch.empty(b * n * p * p, d, device=dev, dtype=self.act_dtype), d, 0, d),
                 pool_arg=torch.empty(b * n * p * p, d, dtype=torch.uint8, device=dev),
                 box_ind=torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(n)
                 .contiguous())

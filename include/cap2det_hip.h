@@ -314,6 +314,41 @@ int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax, const flo
                              void* workspace, long long workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * bf16 storage forms of the activation-side kernels (BASELINE.json configs[2] / [4]: "bf16
+ * storage / fp32 accumulate").  Same arguments and semantics as the fp32 calls of the same
+ * name; the tensors marked void* hold bf16 (uint16) elements, strides / offsets stay in
+ * ELEMENTS, all arithmetic is fp32 with ONE round-to-nearest-even at the store.  Statistics,
+ * BatchNorm vectors, filter gradients, the first-stage feature map and its gradient stay fp32.
+ * ------------------------------------------------------------------------------------- */
+int c2d_cast_bf16(const float* src, void* dst, long long n, void* stream);   /* n % 4 == 0 */
+int c2d_roi_crop_pool_fwd_bf16(const float* feat, const float* boxes, const int32_t* box_ind,
+                               void* out, uint8_t* argmax, int batch, int hf, int wf, int depth,
+                               int num_boxes, int crop, int pool_k, int pool_s, void* stream);
+int c2d_roi_crop_pool_bwd_ws_bf16(const void* dout, const uint8_t* argmax, const float* boxes,
+                                  const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
+                                  int depth, int num_boxes, int crop, int pool_k, int pool_s,
+                                  void* workspace, long long workspace_bytes, void* stream);
+int c2d_pool3x3_fwd_bf16(const void* x, int ldx, int xoff, void* y, int ldy, int yoff,
+                         uint8_t* argmax, int n, int ih, int iw, int c, int stride, int mode,
+                         void* stream);
+int c2d_pool3x3_bwd_bf16(const void* dy, int lddy, int dyoff, const uint8_t* argmax, void* dx,
+                         int lddx, int dxoff, int n, int ih, int iw, int c, int stride, int mode,
+                         int accumulate, void* stream);
+int c2d_bn_relu_bwd_partial_bf16(const void* dy, int lddy, int dyoff, const void* y, int ldy,
+                                 int yoff, const float* scale, const float* beta,
+                                 const float* gamma, void* dc, float* partials, int rows, int c,
+                                 void* stream);
+int c2d_spatial_mean_dropout_fwd_bf16(const void* x, float* y, const uint8_t* mask, int rows,
+                                      int spatial, int c, float keep_prob, void* stream);
+int c2d_spatial_mean_dropout_bwd_bf16(const float* dy, int lddy, int dyoff, void* dx,
+                                      const uint8_t* mask, int rows, int spatial, int c,
+                                      float keep_prob, void* stream);
+/* x, dc bf16 -> dw fp32 (operands widened as they are staged; fp32 MFMA accumulation). */
+int c2d_conv_wgrad_bf16(const void* x, int ldx, int xoff, const void* dc, int ldc, int coff,
+                        float* dw, int n, int ih, int iw, int cin, int cout, int kh, int kw,
+                        int stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Inference post-processing
  * ------------------------------------------------------------------------------------- */
 
