@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 IMAGE_HW = 500
 NUM_PROPOSALS = 2000
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -77,7 +78,9 @@ class KernelTimer(object):
       feat, boxes = args[0], args[1]
       crop, pk, ps = args[3:6]
       p = (crop - pk) // ps + 1
-      return 4.0 * (boxes.shape[0] * p * p * feat.shape[3] + feat.numel() + boxes.numel())
+      out = kwargs.get("out")
+      out_bytes = 2.0 if out is not None and out.dtype == t.torch.bfloat16 else 4.0
+      return out_bytes * boxes.shape[0] * p * p * feat.shape[3] + 4.0 * (feat.numel() + boxes.numel())
 
     def timed(fn, family, work_fn):
       def inner(*args, **kwargs):
@@ -89,7 +92,10 @@ class KernelTimer(object):
         r = fn(*args, **kwargs)
         e.record()
         w = work_fn(args, kwargs) if family == "roi_crop_pool_fwd" else work_fn(args)
-        t.records.append((family, w, s, e))
+        # families are kept per operand type: bf16 operands run on the bf16 MFMA kernels
+        first = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
+        low = family != "roi_crop_pool_fwd" and first.dtype == t.torch.bfloat16
+        t.records.append((family + ("_bf16" if low else ""), w, s, e))
         return r
       return inner
 
@@ -263,30 +269,44 @@ def main():
       traffic = {}
     if not args.no_kernel_timing:
       summ = timer.summary()
-      ig = summ.get("igemm_nt")
-      if ig:
-        tf = ig["work"] / (ig["ms"] * 1e-3) / 1e12
-        result["roofline"] = {
-            "kernel": "igemm_nt_kernel<*> + igemm_small_kernel<*> (implicit-GEMM conv fwd + dgrad "
-                      "+ heads GEMM, fp32 MFMA 32x32x2; a stride-2 dgrad call = 4 launches)",
-            "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("igemm", {}).get("hbm_bytes_per_launch"),
-            "traffic_bytes_per_step": traffic.get("igemm", {}).get("hbm_bytes_per_step"),
-            "calls_per_step": ig["launches"],
-            "avg_call_ms": ig["ms"] / ig["launches"],
-            "family_ms_per_step": ig["ms"],
-            "algorithmic_gflop_per_step": ig["work"] / 1e9,
-            "timed_with": "HIP events around every launch of the last timed step"}
-      wg = summ.get("wgrad_tn")
-      if wg:
-        tf = wg["work"] / (wg["ms"] * 1e-3) / 1e12
-        result["roofline_wgrad"] = {
-            "kernel": "wgrad_tn_kernel<*> + wgrad3x3_kernel<*> (conv filter gradient, fp32 MFMA)",
-            "bound": "mfma",
-            "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("wgrad", {}).get("hbm_bytes_per_launch"),
-            "traffic_bytes_per_step": traffic.get("wgrad", {}).get("hbm_bytes_per_step"),
-            "family_ms_per_step": wg["ms"], "calls_per_step": wg["launches"]}
+      low = args.dtype == "bf16"
+      if low:
+        traffic = {}      # the committed PMC passes are of the fp32 build (profiles/README.md)
+
+      def mfma_family(key, kernel, traffic_key, peak):
+        f = summ.get(key)
+        if not f:
+          return None
+        tf = f["work"] / (f["ms"] * 1e-3) / 1e12
+        return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                "frac": tf / peak,
+                "traffic": traffic.get(traffic_key, {}).get("hbm_bytes_per_launch"),
+                "traffic_bytes_per_step": traffic.get(traffic_key, {}).get("hbm_bytes_per_step"),
+                "calls_per_step": f["launches"], "avg_call_ms": f["ms"] / f["launches"],
+                "family_ms_per_step": f["ms"], "algorithmic_gflop_per_step": f["work"] / 1e9,
+                "timed_with": "HIP events around every launch of the last timed step"}
+
+      ig32 = mfma_family("igemm_nt", "igemm_nt_kernel<*> + igemm_small_kernel<*> (implicit-GEMM conv "
+                         "fwd + dgrad + heads GEMM, fp32 MFMA 32x32x2; a stride-2 dgrad call = 4 launches)",
+                         "igemm", PEAK_FP32_MFMA_TFLOPS)
+      wg32 = mfma_family("wgrad_tn", "wgrad_tn_kernel<*> + wgrad3x3_kernel<*> (conv filter gradient, "
+                         "fp32 MFMA)", "wgrad", PEAK_FP32_MFMA_TFLOPS)
+      if not low:
+        if ig32: result["roofline"] = ig32
+        if wg32: result["roofline_wgrad"] = wg32
+      else:
+        # second stage on bf16 operands (MFMA 32x32x16 bf16, fp32 accumulate); the frozen /
+        # Mixed_4e first stage and the heads stay on the fp32 kernels
+        ig16 = mfma_family("igemm_nt_bf16", "igemm_nt_kernel<*, ES=2> (implicit-GEMM conv fwd + dgrad of "
+                           "the second stage, bf16 MFMA 32x32x16, fp32 accumulate)", "igemm_bf16",
+                           PEAK_BF16_MFMA_TFLOPS)
+        wg16 = mfma_family("wgrad_tn_bf16", "wgrad_tn_bf16_kernel<*> + wgrad3x3_bf16_kernel<*> (conv "
+                           "filter gradient, bf16 MFMA 32x32x16 through ds_read_b64_tr_b16)",
+                           "wgrad_bf16", PEAK_BF16_MFMA_TFLOPS)
+        if ig16: result["roofline"] = ig16
+        if wg16: result["roofline_wgrad"] = wg16
+        if ig32: result["roofline_fp32_igemm"] = ig32
+        if wg32: result["roofline_fp32_wgrad"] = wg32
       rc = summ.get("roi_crop_pool_fwd")
       if rc:
         gbs = rc["work"] / (rc["ms"] * 1e-3) / 1e9

@@ -1176,6 +1176,304 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), BASELINE configs[2] / [4].
+//
+// A filter gradient contracts over ROWS: both MFMA operands need 8 consecutive k (= rows) of
+// ONE channel per lane, i.e. column reads of the row-major [row][channel] tiles.  gfx950's
+// ds_read_b64_tr_b16 does that transpose in the LDS read path (cdna_hip_programming.md T10): per
+// 16-lane group, lane 4q+p supplies the address of row q / columns 4p..4p+3 of a 4x16 block and
+// lane i receives column i of the four rows.  Group g = lane>>4 reads columns 16*(g&1).. of rows
+// 8*(g>>1) + 4t.. (t = 0,1: two reads = the 8 k of the lane's half), so lane l ends up with
+// channel l&31 and k = 8*(l>>5) + e in element e: the 32x32x16 A/B operand map.  Both operands
+// go through the same read, hence share the k order.  The tiles are staged as they lie in HBM
+// (16-B chunks of 8 channels): no register transposes, no per-element LDS writes.
+// A 32-lane half reads 4 rows x 64 B: conflict-free when the row stride is 64 B mod 256 B.
+// ---------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// the two transposed reads of one operand fragment: rows +0..3 at p, rows +4..7 at p + hi_off
+__device__ __forceinline__ bf16x8 tr_frag(const char* p, int hi_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + hi_off));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+constexpr int WB_KB = 32;          // rows of M per slab: two 16-row MFMA k-steps
+constexpr int WB_RS = 256 + 64;    // bytes per staged row (128 bf16 + pad: stride = 64 mod 256)
+
+// Per-tap filter gradient, bf16 operands: same tiling / grid / split-K atomics as wgrad_tn_kernel.
+template <int NTJ, bool PLAIN>
+__global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
+  constexpr int BJ = 2 * NTJ * 32;
+  __shared__ __attribute__((aligned(16))) char As[WB_KB * WB_RS];
+  __shared__ __attribute__((aligned(16))) char Gs[WB_KB * WB_RS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int itiles = (a.I + 127) / 128;
+  const int tap = blockIdx.x / itiles;
+  const int i0 = (blockIdx.x - tap * itiles) * 128;
+  const int j0 = blockIdx.y * BJ;
+  const int ky = tap / a.g.kw, kx = tap - ky * a.g.kw;
+  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+
+  // loader: thread -> rows kr, kr+16 of the slab, 16-B chunk (8 channels) c8; columns beyond
+  // I / J are clamped (their products land in dW rows / columns that are never stored)
+  const int kr = tid >> 4;
+  const int c8 = (tid & 15) * 8;
+  const bool gload = c8 < BJ;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
+                                                 (a.a_rows * a.lda - a.a_off) * 2);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * 2,
+                                                 ((long long)a.M * a.ldg - a.g_off) * 2);
+  const unsigned acol = (unsigned)min(i0 + c8, a.I - 8) * 2u;
+  const unsigned gcol = (unsigned)min(j0 + min(c8, BJ - 8), a.J - 8) * 2u;
+
+  f32x16 acc[2][NTJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  unsigned tile_bits = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+      if ((i0 + wm * 64 + i * 32 < a.I) && (j0 + (wn * NTJ + j) * 32 < a.J))
+        tile_bits |= 1u << (i * NTJ + j);
+  tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
+
+  f32x4 ra[2], rg[2];
+  unsigned aoffs[2], goffs[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    aoffs[u] = (unsigned)((kr + u * 16) * a.lda) * 2u + acol;
+    goffs[u] = (unsigned)((kr + u * 16) * a.ldg) * 2u + gcol;
+  }
+#define C2D_WB_LOAD(MB)                                                                        \
+  {                                                                                            \
+    if (PLAIN) {                                                                               \
+      const int sa = (MB) * a.lda * 2, sg = (MB) * a.ldg * 2;                                  \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
+        ra[u] = buf_load4(rsA, aoffs[u], sa);                                                  \
+        rg[u] = buf_load4(rsG, goffs[u], sg);                                                  \
+      }                                                                                        \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
+        const int m = (MB) + kr + u * 16;                                                      \
+        const RowPos p = decompose(m, mend, a.g);                                              \
+        const int sr = src_row<0>(a.g, p, ky, kx);                                             \
+        ra[u] = buf_load4(rsA, sr >= 0 ? (unsigned)(sr * a.lda) * 2u + acol : OOB_OFFSET, 0);  \
+        rg[u] = buf_load4(rsG, p.valid ? (unsigned)(m * a.ldg) * 2u + gcol : OOB_OFFSET, 0);   \
+      }                                                                                        \
+    }                                                                                          \
+  }
+  // transposed-read bases: row 8*lh + q, 16-column half (lane>>4)&1, 4-column slot p
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const char* const apl = As + (8 * lh + tq) * WB_RS + (wm * 64 + 16 * tg + 4 * tp) * 2;
+  const char* const gpl = Gs + (8 * lh + tq) * WB_RS + (wn * NTJ * 32 + 16 * tg + 4 * tp) * 2;
+
+  C2D_WB_LOAD(mbeg);
+  for (int mb = mbeg; mb < mend; mb += WB_KB) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *reinterpret_cast<f32x4*>(As + (kr + u * 16) * WB_RS + c8 * 2) = ra[u];
+      if (gload) *reinterpret_cast<f32x4*>(Gs + (kr + u * 16) * WB_RS + c8 * 2) = rg[u];
+    }
+    __syncthreads();
+    C2D_WB_LOAD(mb + WB_KB);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      bf16x8 af[2][2], bf[NTJ][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i][s] = tr_frag(apl + s * 16 * WB_RS + i * 64, 4 * WB_RS);
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) bf[j][s] = tr_frag(gpl + s * 16 * WB_RS + j * 64, 4 * WB_RS);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j)
+          if ((tile_bits >> (i * NTJ + j)) & 1u) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+          }
+    }
+    __syncthreads();
+  }
+#undef C2D_WB_LOAD
+
+  float* dw = a.dW + (size_t)tap * a.I * a.J;
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j) {
+    const int jj = j0 + (wn * NTJ + j) * 32 + li;
+    if (jj >= a.J) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ii >= a.I) continue;
+        atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
+      }
+  }
+}
+
+// 3x3 / stride-1 filter gradient, all nine taps per block, bf16 operands.  Same plan as
+// wgrad3x3_kernel (x staged once in zero-padded image coordinates so that tap (ky,kx) of the
+// output pixel at padded index P is LDS row P + (ky-1)*(WC+2) + (kx-1); dC staged once for all
+// taps), but a k-step is 16 CONSECUTIVE output rows (a whole 4x4 map) and the padding taps ride
+// along as zeros: skipping them would need 16 images per pixel in a step (a 16-image dC slab does
+// not fit beside the accumulators), and at bf16 rates the kernel is bound by staging, not MFMA.
+// WI = 32-channel i-groups per block (waves = 4*WI: wave -> (i-group, 32-column j-group)).
+constexpr int W3B_RSA = 64;         // 32 bf16 per x row: consecutive rows = 64 B apart
+constexpr int W3B_RSG = 256 + 64;   // 128 bf16 per dC row + pad
+
+template <int WC, int IMGS, int WI>
+__global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kernel(Wgrad3Args a) {
+  constexpr int NT = 256 * WI;
+  constexpr int PW = WC + 2;
+  constexpr int HW = WC * WC;
+  constexpr int PIMG = PW * PW;
+  constexpr int R = IMGS * HW;                // output rows per slab
+  constexpr int STEPS = (R + 15) / 16;        // MFMA k-steps
+  constexpr int RP = STEPS * 16;              // staged dC rows (rows >= R stay zero)
+  constexpr int AROWS = IMGS * PIMG;
+  constexpr int A_LD = (R * 4 + 255) / 256;   // 16-B x chunks per thread (per i-group: 256 thr)
+  constexpr int G_LD = (R * 16 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) char As[WI * AROWS * W3B_RSA];
+  __shared__ __attribute__((aligned(16))) char Gs[RP * W3B_RSG];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 2, wj = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+  const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
+  const int split = logical / a.tiles;
+  const int t = logical - split * a.tiles;
+  const int jt = t % a.jtiles, it_ = t / a.jtiles;
+  const int i0 = it_ * 32 * WI, j0 = jt * 128;
+  const int mbeg = split * a.rows_per_split;           // multiple of R
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+  const bool wave_on = (j0 + wj * 32 < a.J) && (i0 + wi * 32 < a.I);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+  // zero the border rows of x and the tail rows of dC once: the loaders only rewrite real rows
+  for (int e = tid; e < WI * AROWS * W3B_RSA / 16; e += NT)
+    reinterpret_cast<f32x4*>(As)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < RP * W3B_RSG / 16; e += NT)
+    reinterpret_cast<f32x4*>(Gs)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * 2,
+                                                 ((long long)a.M * a.ldg - a.g_off) * 2);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
+                                                 ((long long)a.M * a.lda - a.a_off) * 2);
+  // x: i-group ag = tid / 256 stages its own [AROWS][32] image; chunk e -> (row e>>2, 8 channels)
+  const int ag = tid >> 8, at = tid & 255;
+  unsigned aoffs[A_LD]; int adst[A_LD];
+#pragma unroll
+  for (int u = 0; u < A_LD; ++u) {
+    const int e = at + u * 256, k = e >> 2, c = e & 3;
+    const int im = k / HW, pix = k - im * HW, y = pix / WC, x = pix - y * WC;
+    const bool on = k < R && i0 + ag * 32 < a.I;
+    aoffs[u] = on ? (unsigned)(k * a.lda + i0 + ag * 32 + c * 8) * 2u : OOB_OFFSET;
+    adst[u] = on ? (ag * AROWS + im * PIMG + (y + 1) * PW + x + 1) * W3B_RSA + c * 16 : -1;
+  }
+  unsigned goffs[G_LD]; int gdst[G_LD];
+#pragma unroll
+  for (int u = 0; u < G_LD; ++u) {
+    const int e = tid + u * NT, k = e >> 4, c = e & 15;
+    const bool on = k < R;
+    goffs[u] = on ? (unsigned)(k * a.ldg + min(j0 + c * 8, a.J - 8)) * 2u : OOB_OFFSET;
+    gdst[u] = on ? k * W3B_RSG + c * 16 : -1;
+  }
+  f32x4 rg[G_LD], ra[A_LD];
+#define C2D_W3B_LOAD(MB)                                                                       \
+  {                                                                                            \
+    const int sg = (MB) * a.ldg * 2, sa = (MB) * a.lda * 2;                                    \
+    _Pragma("unroll") for (int u = 0; u < G_LD; ++u) rg[u] = buf_load4(rsG, goffs[u], sg);     \
+    _Pragma("unroll") for (int u = 0; u < A_LD; ++u) ra[u] = buf_load4(rsA, aoffs[u], sa);     \
+  }
+
+  // transposed-read addresses: k-step s, read t -> slab row k = 16s + 8*lh + 4t + q
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const char* const abase = As + wi * AROWS * W3B_RSA + (16 * tg + 4 * tp) * 2;
+  const char* const gbase = Gs + (8 * lh + tq) * W3B_RSG + (wj * 32 + 16 * tg + 4 * tp) * 2;
+  int arow[STEPS][2];      // padded x row of the lane's k (bytes); compile-time stride when HW == 16
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int k = 16 * s + 8 * lh + 4 * u + tq;
+      if (k >= R) k = 0;      // dC rows >= R are zero: any staged x row will do
+      const int im = k / HW, pix = k - im * HW, y = pix / WC, x = pix - y * WC;
+      arow[s][u] = (im * PIMG + (y + 1) * PW + x + 1) * W3B_RSA;
+    }
+
+  C2D_W3B_LOAD(mbeg);
+  __syncthreads();
+  for (int mb = mbeg; mb < mend; mb += R) {
+#pragma unroll
+    for (int u = 0; u < G_LD; ++u)
+      if (gdst[u] >= 0) *reinterpret_cast<f32x4*>(Gs + gdst[u]) = rg[u];
+#pragma unroll
+    for (int u = 0; u < A_LD; ++u)
+      if (adst[u] >= 0) *reinterpret_cast<f32x4*>(As + adst[u]) = ra[u];
+    __syncthreads();
+    C2D_W3B_LOAD(mb + R);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_on) {
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const bf16x8 bv = tr_frag(gbase + s * 16 * W3B_RSG, 4 * W3B_RSG);
+        const char* const a0 = abase + (HW == 16 ? arow[0][0] + s * PIMG * W3B_RSA : arow[s][0]);
+        const char* const a1 = abase + (HW == 16 ? arow[0][1] + s * PIMG * W3B_RSA : arow[s][1]);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int off = ((q / 3 - 1) * PW + (q % 3 - 1)) * W3B_RSA;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + off));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1 + off));
+          const bf16x8 av = __builtin_bit_cast(
+              bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#undef C2D_W3B_LOAD
+
+  if (wave_on) {
+    const int jj = j0 + wj * 32 + li;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      float* dw = a.dW + (size_t)q * a.I * a.J;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
+      }
+    }
+  }
+}
+
 void set_magic(ConvGeom* g);
 
 int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode) {
@@ -1547,6 +1845,24 @@ extern "C" int c2d_conv1x1_dgrad_multi_bf16(int nseg, const void* const* dcs, co
                           IgemmWs{nullptr, 0}, stream, 2);
 }
 
+// Tuning hooks (read only when C2D_TUNE is set at load time): C2D_WGRAD_BF16_MFMA=0 sends bf16
+// operands through the widening fp32 kernels, C2D_WGRAD3_WI forces the i-groups per block.
+static bool wgrad_bf16_mfma_enabled() {
+  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  if (!tune) return true;
+  const char* e = getenv("C2D_WGRAD_BF16_MFMA");
+  return !(e && e[0] == '0');
+}
+static int wgrad3_bf16_igroups(int cin) {
+  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  if (tune) {
+    const char* e = getenv("C2D_WGRAD3_WI");
+    if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
+  }
+  (void)cin;
+  return 1;   // measured: two i-groups (8 waves, one block per CU) 0-15 % slower on the 4x4 / 7x7 layers
+}
+
 template <int ES>
 static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, int ldc,
                            int coff, float* dw, int n, int ih, int iw, int cin, int cout,
@@ -1554,6 +1870,33 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   C2D_CHECK_ARG(x && dc && dw && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   C2D_CHECK_ARG(ldc % 4 == 0 && coff % 4 == 0);
+  // bf16 operands with 16-B aligned rows go to the bf16-MFMA kernels; anything else is widened
+  // to fp32 as it is staged (same results up to summation order)
+  const bool bf16_mfma = ES == 2 && cin % 8 == 0 && cout % 8 == 0 && ldx % 8 == 0 &&
+                         xoff % 8 == 0 && ldc % 8 == 0 && coff % 8 == 0 && wgrad_bf16_mfma_enabled();
+  if (bf16_mfma && kh == 3 && kw == 3 && stride == 1 && ih == iw && (iw == 4 || iw == 7) &&
+      cin % 32 == 0 && cout % 32 == 0 && n >= 256) {
+    const int wi = wgrad3_bf16_igroups(cin);
+    Wgrad3Args b;
+    b.A = x; b.lda = ldx; b.a_off = xoff; b.G = dc; b.ldg = ldc; b.g_off = coff; b.dW = dw;
+    b.M = n * ih * iw; b.I = cin; b.J = cout; b.h = ih; b.w = iw;
+    b.itiles = c2d_ceil_div(cin, 32 * wi); b.jtiles = c2d_ceil_div(cout, 128);
+    b.tiles = b.itiles * b.jtiles;
+    C2D_CHECK_ARG((long long)b.M * ldx * 2 < (long long)OOB_OFFSET && (long long)b.M * ldc * 2 < (long long)OOB_OFFSET);
+    const int slab = iw == 4 ? 8 * 16 : 2 * 49;            // whole images per slab
+    const int nslabs = c2d_ceil_div(b.M, slab);
+    int splits = c2d_ceil_div(wi == 1 ? 512 : 256, b.tiles);   // one round of resident blocks
+    if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
+    b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
+    b.splits = c2d_ceil_div(b.M, b.rows_per_split);
+    const dim3 grid(b.tiles * b.splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (iw == 4 && wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 1>), grid, dim3(256), 0, st, b);
+    else if (iw == 4) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 2>), grid, dim3(512), 0, st, b);
+    else if (wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 1>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 2>), grid, dim3(512), 0, st, b);
+    return c2d_launch_status();
+  }
   if (kh == 3 && kw == 3 && stride == 1 && ih == iw && (iw == 4 || iw == 7) && cin % 32 == 0 &&
       cout % 32 == 0 && n >= 256) {
     Wgrad3Args b;
@@ -1592,6 +1935,15 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)a.M * ldc * 4 < (long long)OOB_OFFSET);
   const bool plain = kh == 1 && kw == 1 && stride == 1;
   hipStream_t st = (hipStream_t)stream;
+  if (bf16_mfma) {
+    a.rows_per_split = c2d_ceil_div(a.rows_per_split, WB_KB) * WB_KB;
+    grid.z = c2d_ceil_div(a.M, a.rows_per_split);
+    if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, true>), grid, dim3(256), 0, st, a);
+    else if (narrow) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
+    else if (plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, false>), grid, dim3(256), 0, st, a);
+    return c2d_launch_status();
+  }
   if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true, ES>), grid, dim3(256), 0, st, a);
   else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false, ES>), grid, dim3(256), 0, st, a);
   else if (plain) hipLaunchKernelGGL((wgrad_tn_kernel<2, true, ES>), grid, dim3(256), 0, st, a);

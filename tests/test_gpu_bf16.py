@@ -79,6 +79,44 @@ def test_conv1x1_dgrad_multi_bf16():
   _check(dx, want, "multi-segment dgrad")
 
 
+WGRAD_CASES = [  # n, ih, iw, cin, cout, k, stride     (kernel the bf16 call dispatches to)
+    (300, 4, 4, 64, 160, 3, 1),    # nine-tap, 4x4 maps, two i-groups per block
+    (261, 4, 4, 96, 32, 3, 1),     # nine-tap, 4x4, one i-group, ragged last slab
+    (257, 7, 7, 32, 192, 3, 1),    # nine-tap, 7x7 (k-steps straddle image rows), one i-group
+    (256, 7, 7, 128, 96, 3, 1),    # nine-tap, 7x7, two i-groups
+    (900, 4, 4, 160, 200, 1, 1),   # per-tap PLAIN, ragged 128x128 tiles
+    (123, 7, 7, 72, 64, 1, 1),     # per-tap PLAIN, narrow j tile
+    (100, 7, 7, 64, 96, 3, 2),     # per-tap, stride 2 (7x7 -> 4x4)
+    (5, 9, 6, 40, 48, 3, 1),       # per-tap 3x3 on a map the nine-tap kernel does not take
+    (40, 4, 4, 36, 44, 1, 1)]      # channels not multiples of 8: widening fp32 kernels
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad_bf16(case):
+  """Filter gradient from bf16 activations / gradients (fp32 result): the operands are exact in
+  fp64, so only the fp32 accumulation order is left: |err| <= 2e-5 of the largest entry."""
+  from cap2det_amd import hip_ops as ops
+  n, ih, iw, cin, cout, k, s = case
+  rng = np.random.default_rng(sum(case))
+  x, x64 = _bf(rng.standard_normal((n, ih, iw, cin)))
+  oh, ow = (ih + s - 1) // s, (iw + s - 1) // s
+  dc, dc64 = _bf(rng.standard_normal((n, oh, ow, cout)))
+  _, want = ref_ops.conv2d_backward(x64, np.zeros((k, k, cin, cout)), dc64, s)
+  a8 = 8 if cin % 8 == 0 and cout % 8 == 0 else 4
+  ldx, xoff, ldc, coff = cin + 3 * a8, a8, cout + 2 * a8, 2 * a8
+  xb = torch.full((n, ih, iw, ldx), 3.0, device=DEV, dtype=torch.bfloat16); xb[..., xoff:xoff + cin] = x
+  db = torch.full((n, oh, ow, ldc), -5.0, device=DEV, dtype=torch.bfloat16); db[..., coff:coff + cout] = dc
+  dw = torch.zeros(k * k, cin, cout, device=DEV)
+  ops.conv_wgrad(xb, ldx, xoff, db, ldc, coff, dw, n, ih, iw, cin, cout, k, k, s)
+  got = dw.cpu().numpy().astype(np.float64).reshape(k, k, cin, cout)
+  err = np.abs(got - want).max()
+  assert err <= 2e-5 * np.abs(want).max(), "wgrad: max err %.3e at scale %.3e" % (err, np.abs(want).max())
+  # accumulates into dw (the engine zeroes the gradient buffer once per step)
+  ops.conv_wgrad(xb, ldx, xoff, db, ldc, coff, dw, n, ih, iw, cin, cout, k, k, s)
+  got2 = dw.cpu().numpy().astype(np.float64).reshape(k, k, cin, cout)
+  assert np.abs(got2 - 2 * want).max() <= 4e-5 * np.abs(want).max()
+
+
 def _rel_l2(got, want):
   got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
   return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
