@@ -50,6 +50,7 @@ class KernelTimer(object):
     import torch
     self.torch = torch
     self.records = []   # (family, work, start_event, end_event)
+    self.shapes = []    # (entry point, integer arguments) per record, for --per-call
     self.enabled = False
 
   def wrap(self, ops):
@@ -96,6 +97,7 @@ class KernelTimer(object):
         first = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
         low = family != "roi_crop_pool_fwd" and first.dtype == t.torch.bfloat16
         t.records.append((family + ("_bf16" if low else ""), w, s, e))
+        t.shapes.append((fn.__name__, tuple(a for a in args if isinstance(a, (int, bool)))))
         return r
       return inner
 
@@ -164,6 +166,8 @@ def main():
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-kernel-timing", action="store_true")
+  ap.add_argument("--per-call", action="store_true",
+                  help="also print one line per timed conv / ROI-crop call (stderr)")
   ap.add_argument("--graph", action="store_true", help="hipGraph replay of the step (measured: no gain over eager launches)")
   ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
                   help="fp32 = BASELINE configs[1] (the headline metric); bf16 = the same workload with "
@@ -263,16 +267,21 @@ def main():
     # absent.  See profiles/README.md.
     traffic = {}
     try:
-      with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+      name = "r01_traffic.json" if args.dtype == "fp32" else "r01_traffic_bf16.json"
+      with open(os.path.join(ROOT, "profiles", name)) as f:
         traffic = json.load(f)["families"]
     except Exception:
       traffic = {}
+    if not args.no_kernel_timing and args.per_call:
+      for (family, work, s, e), (name, ints) in zip(timer.records, timer.shapes):
+        ms = s.elapsed_time(e)
+        unit = "GB/s" if family.startswith("roi_crop") else "TFLOP/s"
+        rate = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
+        print("%-18s %-20s %-52s %8.1f us %8.1f %s" % (family, name, ints, ms * 1e3, rate, unit),
+              file=sys.stderr)
     if not args.no_kernel_timing:
       summ = timer.summary()
       low = args.dtype == "bf16"
-      if low:
-        traffic = {}      # the committed PMC passes are of the fp32 build (profiles/README.md)
-
       def mfma_family(key, kernel, traffic_key, peak):
         f = summ.get(key)
         if not f:

@@ -864,10 +864,25 @@ struct WgradArgs {
   int M;                                // conv output rows (reduction length)
   int I, J;                             // cin, cout
   int rows_per_split;                   // multiple of WBK
+  int tiles_x, tiles_y, nsplits;        // 1-D grid = tiles_x (tap, i-tile) * tiles_y (j-tile) * nsplits
   ConvGeom g;                           // mode 0
 };
 
-constexpr int WBK = 16;             // rows of M per slab
+// Block -> (x, y, split) with all tiles of one row split consecutive on ONE XCD (xcd_remap): the
+// x / dC rows of a split are then fetched into that XCD's L2 once and shared by its tiles.
+struct WgradBlock { int x, y, z; };
+__device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
+  const int txy = a.tiles_x * a.tiles_y;
+  const int logical = xcd_remap(blockIdx.x, txy * a.nsplits);
+  WgradBlock b;
+  b.z = logical / txy;
+  const int t = logical - b.z * txy;
+  b.y = t / a.tiles_x;
+  b.x = t - b.y * a.tiles_x;
+  return b;
+}
+
+constexpr int WBK = 16;             // rows of M per slab (32: the 128x128 form spills, 5 % slower overall)
 constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
 
 // Block tile 128(i) x 128(j); 4 waves as 2x2, each 64x64 (2x2 MFMA tiles); 3-D grid
@@ -887,11 +902,12 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int itiles = (a.I + 127) / 128;
-  const int tap = blockIdx.x / itiles;
-  const int i0 = (blockIdx.x - tap * itiles) * 128;
-  const int j0 = blockIdx.y * BJ;
+  const WgradBlock blk = wgrad_block(a);
+  const int tap = blk.x / itiles;
+  const int i0 = (blk.x - tap * itiles) * 128;
+  const int j0 = blk.y * BJ;
   const int ky = tap / a.g.kw, kx = tap - ky * a.g.kw;
-  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mbeg = blk.z * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
   // loader: thread -> (k row kr and kr+8, float4 column c4); columns beyond I/J are clamped
@@ -925,12 +941,13 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
         tile_bits |= 1u << (i * NTJ + j);
   tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
 
-  f32x4 ra[2], rg[2];
+  constexpr int LU = WBK / 8;      // loads per thread and operand per slab
+  f32x4 ra[LU], rg[LU];
   // PLAIN: splits are whole slabs except the last one, whose rows >= M fall outside the
   // descriptors, so the offsets never change and the slab's first row is the scalar offset.
-  unsigned aoffs[2], goffs[2];
+  unsigned aoffs[LU], goffs[LU];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < LU; ++u) {
     aoffs[u] = (unsigned)((kr + u * 8) * a.lda) * (unsigned)ES + acol;
     goffs[u] = (unsigned)((kr + u * 8) * a.ldg) * (unsigned)ES + gcol;
   }
@@ -938,12 +955,12 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   {                                                                                            \
     if (PLAIN) {                                                                               \
       const int sa = (MB) * a.lda * ES, sg = (MB) * a.ldg * ES;                                \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
+      _Pragma("unroll") for (int u = 0; u < LU; ++u) {                                          \
         ra[u] = buf_load_elems4<ES>(rsA, aoffs[u], sa);                                        \
         rg[u] = buf_load_elems4<ES>(rsG, goffs[u], sg);                                        \
       }                                                                                        \
     } else {                                                                                   \
-      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                          \
+      _Pragma("unroll") for (int u = 0; u < LU; ++u) {                                          \
         const int m = (MB) + kr + u * 8;                                                       \
         const RowPos p = decompose(m, mend, a.g);                                              \
         const int sr = src_row<0>(a.g, p, ky, kx);                                             \
@@ -957,20 +974,21 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   C2D_WG_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += WBK) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < LU; ++u) {
       *reinterpret_cast<f32x4*>(&As[(kr + u * 8) * WG_STRIDE + c4]) = ra[u];
       if (gload) *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) = rg[u];
     }
     __syncthreads();
     C2D_WG_LOAD(mb + WBK);   // next slab (rows past `mend` come back as zeros / are never used)
     __builtin_amdgcn_sched_barrier(0);
-    {
-      // all fragments of the slab first, then ONE scalar branch per 32x32 tile around its 8
-      // chained MFMAs (per-MFMA conditions make hipcc shuffle whole accumulators through copies)
+#pragma unroll
+    for (int kc = 0; kc < WBK / 16; ++kc) {
+      // all fragments of a 16-row chunk first, then ONE scalar branch per 32x32 tile around its
+      // 8 chained MFMAs (per-MFMA conditions make hipcc shuffle whole accumulators through copies)
       float af[2][8], bf[NTJ][8];
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const int k = lh * 8 + s;
+        const int k = kc * 16 + lh * 8 + s;
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i][s] = As[k * WG_STRIDE + wm * 64 + i * 32 + li];
 #pragma unroll
@@ -1216,11 +1234,12 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int itiles = (a.I + 127) / 128;
-  const int tap = blockIdx.x / itiles;
-  const int i0 = (blockIdx.x - tap * itiles) * 128;
-  const int j0 = blockIdx.y * BJ;
+  const WgradBlock blk = wgrad_block(a);
+  const int tap = blk.x / itiles;
+  const int i0 = (blk.x - tap * itiles) * 128;
+  const int j0 = blk.y * BJ;
   const int ky = tap / a.g.kw, kx = tap - ky * a.g.kw;
-  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mbeg = blk.z * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
   // loader: thread -> rows kr, kr+16 of the slab, 16-B chunk (8 channels) c8; columns beyond
@@ -1885,7 +1904,8 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     C2D_CHECK_ARG((long long)b.M * ldx * 2 < (long long)OOB_OFFSET && (long long)b.M * ldc * 2 < (long long)OOB_OFFSET);
     const int slab = iw == 4 ? 8 * 16 : 2 * 49;            // whole images per slab
     const int nslabs = c2d_ceil_div(b.M, slab);
-    int splits = c2d_ceil_div(wi == 1 ? 512 : 256, b.tiles);   // one round of resident blocks
+    int splits = (wi == 1 ? 512 : 256) / b.tiles;          // ONE round of resident blocks (see below)
+    if (splits < 1) splits = 1;
     if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
     b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
@@ -1906,7 +1926,10 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     C2D_CHECK_ARG((long long)b.M * ldx * 4 < (long long)OOB_OFFSET && (long long)b.M * ldc * 4 < (long long)OOB_OFFSET);
     const int slab = iw == 4 ? 32 : 49;                    // whole images per slab
     const int nslabs = c2d_ceil_div(b.M, slab);
-    int splits = c2d_ceil_div(512, b.tiles);               // 2 blocks per CU, one round
+    // 2 blocks per CU in ONE round: rounding the split count UP put a handful of blocks into a
+    // second round that cost half a round again (192->256 on 7x7: 516 blocks, 0.94 -> 0.64 ms)
+    int splits = 512 / b.tiles;
+    if (splits < 1) splits = 1;
     if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
     b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
@@ -1924,20 +1947,22 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   const bool narrow = cout % 128 != 0 && cout % 128 <= 64;   // 128x64 block tiles
   const int bj = narrow ? 64 : 128;
   const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, bj);
-  int splits = c2d_ceil_div(1024, tiles);                 // ~4 blocks per CU
+  int splits = 1024 / tiles;                              // 4 blocks per CU, one round
   const int max_splits = c2d_ceil_div(a.M, 4 * WBK);      // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), WBK) * WBK;
   splits = c2d_ceil_div(a.M, a.rows_per_split);
-  dim3 grid(kh * kw * c2d_ceil_div(cin, 128), c2d_ceil_div(cout, bj), splits);
+  a.tiles_x = kh * kw * c2d_ceil_div(cin, 128); a.tiles_y = c2d_ceil_div(cout, bj); a.nsplits = splits;
+  dim3 grid(a.tiles_x * a.tiles_y * a.nsplits);
   a.a_rows = (long long)n * ih * iw;
   C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)a.M * ldc * 4 < (long long)OOB_OFFSET);
   const bool plain = kh == 1 && kw == 1 && stride == 1;
   hipStream_t st = (hipStream_t)stream;
   if (bf16_mfma) {
     a.rows_per_split = c2d_ceil_div(a.rows_per_split, WB_KB) * WB_KB;
-    grid.z = c2d_ceil_div(a.M, a.rows_per_split);
+    a.nsplits = c2d_ceil_div(a.M, a.rows_per_split);
+    grid.x = a.tiles_x * a.tiles_y * a.nsplits;
     if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, true>), grid, dim3(256), 0, st, a);
     else if (narrow) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
     else if (plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, true>), grid, dim3(256), 0, st, a);
