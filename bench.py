@@ -95,7 +95,7 @@ class KernelTimer(object):
         w = work_fn(args, kwargs) if family == "roi_crop_pool_fwd" else work_fn(args)
         # families are kept per operand type: bf16 operands run on the bf16 MFMA kernels
         first = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
-        low = family != "roi_crop_pool_fwd" and first.dtype == t.torch.bfloat16
+        low = family != "roi_crop_pool_fwd" and getattr(first, "dtype", None) == t.torch.bfloat16
         t.records.append((family + ("_bf16" if low else ""), w, s, e))
         t.shapes.append((fn.__name__, tuple(a for a in args if isinstance(a, (int, bool)))))
         return r
@@ -107,6 +107,7 @@ class KernelTimer(object):
 
     ops.conv1x1_dgrad_multi = timed(ops.conv1x1_dgrad_multi, "igemm_nt", multi_work)
     ops.conv_fwd = timed(ops.conv_fwd, "igemm_nt", conv_work("fwd"))
+    ops.conv_fwd_grouped = timed(ops.conv_fwd_grouped, "igemm_nt", lambda args: args[0][2])
     ops.conv_dgrad = timed(ops.conv_dgrad, "igemm_nt", conv_work("dgrad"))
     ops.conv_wgrad = timed(ops.conv_wgrad, "wgrad_tn", wgrad_work)
     ops.roi_crop_pool_fwd = timed(ops.roi_crop_pool_fwd, "roi_crop_pool_fwd", crop_work)

@@ -759,13 +759,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel
 // second register set, and the 4 partial tiles are summed through LDS before the epilogue.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256) void igemm_small_kernel(IgemmArgs a) {
+__device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int tile) {
   __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int tile = blockIdx.x;
   const int m0 = (tile / a.n_tiles) * 32, n0 = (tile % a.n_tiles) * 32;
   const RowPos pos = decompose(m0 + li, a.M, a.g);
   const int ncol = min(n0 + li, a.N - 1);
@@ -854,6 +853,28 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(IgemmArgs a) {
     if (a.accumulate) v += *dst;
     *dst = v;
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void igemm_small_kernel(IgemmArgs a) {
+  igemm_small_body<MODE>(a, blockIdx.x);
+}
+
+// Several INDEPENDENT small problems in one launch (the convolutions of one dependency level of
+// an Inception block on the single-image first stage: 3-4 launches of 30-250 workgroups each,
+// every one bound by its own K-loop latency, become one launch that fills the chip).
+constexpr int SMALL_GROUP_MAX = 8;
+struct IgemmGroupArgs {
+  IgemmArgs a[SMALL_GROUP_MAX];
+  int first[SMALL_GROUP_MAX + 1];   // first workgroup of problem p; first[num] = grid size
+  int num;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void igemm_small_group_kernel(IgemmGroupArgs g) {
+  int p = 0;
+  for (int i = 1; i < g.num; ++i)
+    if ((int)blockIdx.x >= g.first[i]) p = i;
+  igemm_small_body<MODE>(g.a[p], (int)blockIdx.x - g.first[p]);
 }
 
 struct WgradArgs {
@@ -1634,9 +1655,19 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s, const IgemmWs& ws) {
   return launch_igemm_mode<1, WM, WN, MT, NT, BKT, PM, 4>(a, s, ws);
 }
 
+// Assembly of a grouped small-problem launch: while g_collect is set (host, one thread: the
+// C-ABI is not re-entrant across threads for grouped calls, see the header), run_igemm records
+// small problems instead of launching them and refuses everything else.
+struct SmallCollect {
+  IgemmGroupArgs args;
+  int num;
+  int mode;
+};
+static thread_local SmallCollect* g_collect = nullptr;
+
 int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{nullptr, 0}) {
   IgemmArgs a = a_in;
-  if (a.M <= 0 || a.N <= 0) return C2D_OK;
+  if (a.M <= 0 || a.N <= 0) return g_collect ? C2D_ERR_UNSUPPORTED : C2D_OK;
   // Pixel-major rows for multi-tap convolutions over small per-ROI maps (see decompose<true>).
   const int hw = a.g.rh * a.g.rw;
   // Tuning hooks for tools/sweep_igemm.py (read only when C2D_TUNE is set at load time):
@@ -1654,6 +1685,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   const bool narrow = force ? force == 2 : (a.N % 128 != 0 && a.N % 128 <= 64);
   if (!row_major_only && a.nseg == 1 && a.g.kh * a.g.kw > 1 && hw <= 64 && a.g.nimg >= 64 &&
       a.N % 4 == 0 && a.g.sub == 1) {
+    if (g_collect) return C2D_ERR_UNSUPPORTED;
     a.g.pm = 1;
     a.M = c2d_ceil_div(a.g.nimg, 32) * 32 * hw;
     // 128x64 tiles (4 waves per SIMD) measured best or within 3 % of best on every 3x3 layer of
@@ -1668,10 +1700,20 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);
     b.n_tiles = c2d_ceil_div(a.N, 32);
+    if (g_collect) {          // grouped launch being assembled (run_small_group)
+      if (g_collect->num < SMALL_GROUP_MAX && (g_collect->num == 0 || g_collect->mode == a.g.mode)) {
+        g_collect->args.a[g_collect->num++] = b;
+        g_collect->mode = a.g.mode;
+        return C2D_OK;
+      }
+      return C2D_ERR_UNSUPPORTED;
+    }
     const dim3 grid(b.m_tiles * b.n_tiles), block(256);
     if (a.g.mode == 0) hipLaunchKernelGGL(igemm_small_kernel<0>, grid, block, 0, s, b);
     else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, block, 0, s, b);
     return c2d_launch_status();
+  } else if (g_collect) {
+    return C2D_ERR_UNSUPPORTED;     // not a small problem: the caller launches it on its own
   } else if (big_blocks < 256) {
     return launch_igemm<2, 2, 1, 1, 32>(a, s, IgemmWs{nullptr, 0});          // 64x64 tiles
   } else if (narrow) {
@@ -1833,6 +1875,58 @@ extern "C" int c2d_conv1x1_dgrad_multi_ws(int nseg, const float* const* dcs, con
   C2D_CHECK_ARG(workspace && workspace_bytes > 0);
   return dgrad_multi_impl(nseg, dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
                           accumulate, IgemmWs{workspace, workspace_bytes}, stream);
+}
+
+// ---- grouped launches of independent small convolutions ---------------------------------------
+static int launch_small_group(SmallCollect& c, hipStream_t st) {
+  if (c.num == 0) return C2D_OK;
+  int first = 0;
+  for (int p = 0; p < c.num; ++p) {
+    c.args.first[p] = first;
+    first += c.args.a[p].m_tiles * c.args.a[p].n_tiles;
+  }
+  for (int p = c.num; p <= SMALL_GROUP_MAX; ++p) c.args.first[p] = first;
+  c.args.num = c.num;
+  if (c.mode == 0) hipLaunchKernelGGL(igemm_small_group_kernel<0>, dim3(first), dim3(256), 0, st, c.args);
+  else hipLaunchKernelGGL(igemm_small_group_kernel<1>, dim3(first), dim3(256), 0, st, c.args);
+  return c2d_launch_status();
+}
+
+static int conv_desc_run(const C2dConvDesc& d, int dgrad, void* stream) {
+  if (!dgrad)
+    return conv_fwd_impl(d.src, d.ld_src, d.off_src, d.weights, d.scale, d.shift, d.dst, d.ld_dst,
+                         d.off_dst, d.n, d.ih, d.iw, d.cin, d.cout, d.kh, d.kw, d.stride, d.flag,
+                         IgemmWs{nullptr, 0}, stream);
+  return conv_dgrad_impl(d.src, d.ld_src, d.off_src, d.weights, d.dst, d.ld_dst, d.off_dst, d.n,
+                         d.ih, d.iw, d.cin, d.cout, d.kh, d.kw, d.stride, d.flag,
+                         IgemmWs{nullptr, 0}, stream);
+}
+
+static int conv_grouped_impl(const C2dConvDesc* descs, int num, int dgrad, void* stream) {
+  C2D_CHECK_ARG(descs && num >= 1 && num <= 64);
+  // every problem of the group is "small" (run_igemm's one-tile-per-block domain): ONE launch;
+  // otherwise (or more than SMALL_GROUP_MAX sub-problems) each convolution is launched on its own
+  SmallCollect c;
+  c.num = 0; c.mode = 0;
+  g_collect = &c;
+  int rc = C2D_OK;
+  for (int i = 0; i < num && rc == C2D_OK; ++i) rc = conv_desc_run(descs[i], dgrad, stream);
+  g_collect = nullptr;
+  if (rc == C2D_OK) return launch_small_group(c, (hipStream_t)stream);
+  if (rc != C2D_ERR_UNSUPPORTED) return rc;
+  for (int i = 0; i < num; ++i) {
+    rc = conv_desc_run(descs[i], dgrad, stream);
+    if (rc) return rc;
+  }
+  return C2D_OK;
+}
+
+extern "C" int c2d_conv_fwd_grouped(const C2dConvDesc* descs, int num, void* stream) {
+  return conv_grouped_impl(descs, num, 0, stream);
+}
+
+extern "C" int c2d_conv_dgrad_grouped(const C2dConvDesc* descs, int num, void* stream) {
+  return conv_grouped_impl(descs, num, 1, stream);
 }
 
 // ---- bf16 storage / fp32 accumulate forms (BASELINE configs[2] / [4]) -------------------------

@@ -109,6 +109,39 @@ def conv_fwd(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout,
             ih, iw, cin, cout, kh, kw, stride, int(relu), _stream())
 
 
+class ConvDesc(ctypes.Structure):
+  """C2dConvDesc of include/cap2det_hip.h."""
+  _fields_ = [("src", ctypes.c_void_p), ("ld_src", ctypes.c_int), ("off_src", ctypes.c_int),
+              ("weights", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+              ("dst", ctypes.c_void_p), ("ld_dst", ctypes.c_int), ("off_dst", ctypes.c_int),
+              ("n", ctypes.c_int), ("ih", ctypes.c_int), ("iw", ctypes.c_int),
+              ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("kh", ctypes.c_int),
+              ("kw", ctypes.c_int), ("stride", ctypes.c_int), ("flag", ctypes.c_int)]
+
+
+def conv_group(calls):
+  """Packs [(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride,
+  relu), ...] (the arguments of conv_fwd) into a reusable descriptor array for conv_fwd_grouped.
+  The tensors must stay alive (and in place) for as long as the group is used."""
+  arr = (ConvDesc * len(calls))()
+  flops = 0.0
+  for d, c in zip(arr, calls):
+    (x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride, relu) = c
+    assert x.dtype == torch.float32 and y.dtype == torch.float32
+    d.src, d.ld_src, d.off_src, d.weights = _p(x), ldx, xoff, _p(wt)
+    d.scale, d.shift = _p(scale), _p(shift)
+    d.dst, d.ld_dst, d.off_dst = _p(y), ldy, yoff
+    d.n, d.ih, d.iw, d.cin, d.cout, d.kh, d.kw, d.stride, d.flag = (n, ih, iw, cin, cout, kh, kw,
+                                                                    stride, int(relu))
+    flops += 2.0 * n * (-(-ih // stride)) * (-(-iw // stride)) * cin * cout * kh * kw
+  return arr, len(calls), flops
+
+
+def conv_fwd_grouped(group):
+  """Independent convolutions of one dependency level in one call (c2d_conv_fwd_grouped)."""
+  _lib.call("c2d_conv_fwd_grouped", ctypes.cast(group[0], ctypes.c_void_p), group[1], _stream())
+
+
 def conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
                accumulate):
   if dc.dtype == torch.bfloat16:

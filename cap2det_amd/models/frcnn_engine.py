@@ -75,6 +75,9 @@ SECOND_STAGE = [
 ]
 
 
+GROUP_MAX_ROWS = 16384   # block inputs up to this many rows use grouped launches per level
+
+
 def _out_hw(h, w, stride):
   return -(-h // stride), -(-w // stride)
 
@@ -387,8 +390,12 @@ class Net(object):
           branches.append(bsteps)
           off += wdt
         y = Ref(ybuf, ctot, 0, ctot)
-        steps.append(dict(kind="block", name=op[1], branches=branches, x=x, y=y, n=n, ih=h, iw=w,
-                          oh=oh, ow=ow, cin=c))
+        # dependency levels: the i-th op of every branch only needs the (i-1)-th op of its own
+        # branch, so the ops of one level are independent of each other
+        depth = max(len(b) for b in branches)
+        levels = [[b[i] for b in branches if len(b) > i] for i in range(depth)]
+        steps.append(dict(kind="block", name=op[1], branches=branches, levels=levels, groups={},
+                          x=x, y=y, n=n, ih=h, iw=w, oh=oh, ow=ow, cin=c))
         x, h, w, c = y, oh, ow, ctot
     plan = dict(steps=steps, out=x, oh=h, ow=w, n=n, ih=ih, iw=iw, bwd_ready=False,
                 scratch_elems=scratch_rows_c)
@@ -410,10 +417,32 @@ class Net(object):
     elif kind == "pool":
       ops.pool3x3_fwd(x.t, x.ld, x.off, st["y"].t, st["y"].ld, st["y"].off, st["arg"], st["n"],
                       st["ih"], st["iw"], st["c"], st["stride"], st["mode"])
-    else:
+    elif self.dtype != torch.float32 or st["n"] * st["ih"] * st["iw"] > GROUP_MAX_ROWS:
       for bsteps in st["branches"]:
         for bst in bsteps:
           self._fwd_step(bst, x)
+    else:
+      # few rows (the single-image first stage): each convolution alone is a launch of 30-250
+      # workgroups bound by its own K-loop latency; the convolutions of one level go out as ONE
+      # grouped launch (c2d_conv_fwd_grouped), level by level
+      for li, level in enumerate(st["levels"]):
+        convs = [b for b in level if b["kind"] == "conv"]
+        if len(convs) >= 2:
+          key = (li, x.t.data_ptr(), x.ld, x.off)
+          group = st["groups"].get(key)
+          if group is None:
+            calls = []
+            for b in convs:
+              bx = b["x"] if b["x"] is not None else x
+              L = b["layer"]
+              calls.append((bx.t, bx.ld, bx.off, L.wt_for(self.dtype), L.scale, L.shift, b["y"].t,
+                            b["y"].ld, b["y"].off, b["n"], b["ih"], b["iw"], L.cin, L.cout, L.k,
+                            L.k, L.stride, True))
+            group = st["groups"][key] = ops.conv_group(calls)
+          ops.conv_fwd_grouped(group)
+        for b in level:
+          if b["kind"] != "conv" or len(convs) < 2:
+            self._fwd_step(b, x)
 
   # -- backward ---------------------------------------------------------------------
   def _prepare_backward(self, plan, first_idx):

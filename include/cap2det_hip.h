@@ -104,6 +104,24 @@ int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs, 
                             const float* const* ws, const int* couts, float* dx, int lddx,
                             int dxoff, int rows, int cin, int accumulate, void* stream);
 
+/* Several INDEPENDENT convolutions in one call: the convolutions of one dependency level of an
+ * Inception block (models/utils.py:133-136 runs the slim Inception graph; its branches do not
+ * depend on each other).  No destination of one descriptor may overlap a source or destination
+ * of another.  Same results as the single calls, bit for bit: when every problem is in the
+ * small-problem domain (fp32, <= 16384 rows, fewer than 256 128x128 tiles) they run as ONE launch
+ * (first stage on a single image: 30-250 workgroups each otherwise), else one launch each.
+ * HOST array of 1..64 descriptors. */
+typedef struct C2dConvDesc {
+  const float* src; int ld_src; int off_src;   /* fwd: x          dgrad: dc                   */
+  const float* weights;                        /* fwd: wt [taps][cout][cin]   dgrad: w (HWIO)  */
+  const float* scale; const float* shift;      /* fwd only, may be NULL                        */
+  float* dst; int ld_dst; int off_dst;         /* fwd: y          dgrad: dx                   */
+  int n, ih, iw, cin, cout, kh, kw, stride;    /* as in c2d_conv_fwd / c2d_conv_dgrad          */
+  int flag;                                    /* fwd: relu       dgrad: accumulate           */
+} C2dConvDesc;
+int c2d_conv_fwd_grouped(const C2dConvDesc* descs, int num, void* stream);
+int c2d_conv_dgrad_grouped(const C2dConvDesc* descs, int num, void* stream);
+
 /* Balanced ("stream-K") forms of the three calls above.  `workspace` is a caller-owned device
  * buffer of at least c2d_conv_workspace_bytes() bytes that is ZERO when first used (the kernels
  * leave its counters zero again) and is not shared by launches that may run concurrently.

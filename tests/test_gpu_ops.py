@@ -422,3 +422,31 @@ def test_adagrad_and_l2(ops):
   out = torch.zeros(1, device=DEV)
   ops.l2_loss(_t(w), 1e-2, out)
   np.testing.assert_allclose(_n(out)[0], 0.5e-2 * (w.astype(np.float64) ** 2).sum(), rtol=1e-5)
+
+
+def test_conv_fwd_grouped_matches_single_calls():
+  """c2d_conv_fwd_grouped: independent convolutions of one Inception level in ONE launch (all
+  small) or one launch each (a large one in the group): bit-identical to c2d_conv_fwd."""
+  from cap2det_amd import hip_ops as ops
+  rng = np.random.default_rng(11)
+  for n, hw, big in [(1, 32, False), (1, 63, False), (3, 9, False), (400, 7, True)]:
+    cin = 64
+    x = torch.from_numpy(rng.standard_normal((n * hw * hw, cin + 16)).astype(np.float32)).to(DEV)
+    calls, singles = [], []
+    for (cout, k, stride) in [(96, 1, 1), (32, 3, 1), (48, 3, 2), (20, 1, 1), (64, 1, 2)]:
+      oh = -(-hw // stride)
+      wt = torch.from_numpy((rng.standard_normal((k * k, cout, cin)) / np.sqrt(k * k * cin)).astype(np.float32)).to(DEV)
+      sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(DEV)
+      sh = torch.from_numpy((0.1 * rng.standard_normal(cout)).astype(np.float32)).to(DEV)
+      y1 = torch.full((n * oh * oh, cout + 8), -3.0, device=DEV)
+      y2 = y1.clone()
+      args = [x, cin + 16, 16, wt, sc, sh, None, cout + 8, 4, n, hw, hw, cin, cout, k, k, stride, True]
+      calls.append(tuple(args[:6] + [y1] + args[7:]))
+      singles.append((args, y2))
+    group = ops.conv_group(calls)
+    ops.conv_fwd_grouped(group)
+    ops.conv_fwd_grouped(group)      # descriptors are reusable
+    for (args, y2), c in zip(singles, calls):
+      ops.conv_fwd(*(args[:6] + [y2] + args[7:]))
+      assert torch.equal(c[6], y2), (n, hw, args[13:17])
+      assert float(y2[:, :4].max()) == -3.0
