@@ -1966,6 +1966,16 @@ static bool wgrad_bf16_mfma_enabled() {
   const char* e = getenv("C2D_WGRAD_BF16_MFMA");
   return !(e && e[0] == '0');
 }
+// C2D_WGRAD_BF16_SLOTS=<percent>: resident-workgroup budget of the bf16 filter-gradient launches
+// relative to the default (fewer workgroups = fewer split-K atomics, less latency hiding).
+static int wgrad_bf16_slots(int slots) {
+  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  if (tune) {
+    const char* e = getenv("C2D_WGRAD_BF16_SLOTS");
+    if (e && atoi(e) > 0) return slots * atoi(e) / 100;
+  }
+  return slots;
+}
 static int wgrad3_bf16_igroups(int cin) {
   static const bool tune = getenv("C2D_TUNE") != nullptr;
   if (tune) {
@@ -1998,7 +2008,10 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     C2D_CHECK_ARG((long long)b.M * ldx * 2 < (long long)OOB_OFFSET && (long long)b.M * ldc * 2 < (long long)OOB_OFFSET);
     const int slab = iw == 4 ? 8 * 16 : 2 * 49;            // whole images per slab
     const int nslabs = c2d_ceil_div(b.M, slab);
-    int splits = (wi == 1 ? 512 : 256) / b.tiles;          // ONE round of resident blocks (see below)
+    // ONE round of resident blocks (see the fp32 form below), and fewer of them than fit: at
+    // bf16 rates the split-K atomics (1.3 TB/s chip-wide) are 40 % of the launch, so half the
+    // workgroups (half the atomic bytes) win over the extra latency hiding (tools/bench_wgrad_bf16.py)
+    int splits = wgrad_bf16_slots(wi != 1 ? 256 : iw == 4 ? 256 : 384) / b.tiles;
     if (splits < 1) splits = 1;
     if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
     b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
@@ -2041,7 +2054,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   const bool narrow = cout % 128 != 0 && cout % 128 <= 64;   // 128x64 block tiles
   const int bj = narrow ? 64 : 128;
   const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, bj);
-  int splits = 1024 / tiles;                              // 4 blocks per CU, one round
+  int splits = (bf16_mfma ? wgrad_bf16_slots(512) : 1024) / tiles;   // 4 (bf16: 2) blocks per CU, one round
   const int max_splits = c2d_ceil_div(a.M, 4 * WBK);      // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

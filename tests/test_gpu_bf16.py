@@ -124,6 +124,42 @@ def _rel_l2(got, want):
 
 @pytest.mark.parametrize("dm,hw,n,nums", [(1.0, (64, 48), 6, [6, 4]), (0.5, (40, 72), 9, [9, 0])])
 def test_train_step_bf16_tracks_the_fp64_oracle(dm, hw, n, nums):
+  from oracle import ref_labels
+  from tests import util_model
+  _check_train_step_bf16(
+      util_model.load_pipeline(), dm, hw, n, nums,
+      lambda ex, classes: ref_labels.groundtruth_extract(ex["object_texts"], classes))
+
+
+def test_train_step_bf16_coco17_extend_match(tmp_path):
+  """BASELINE configs[2] as named: coco17_extend_match (caption label extractor + MIL) in the
+  bf16 storage mode.  The labels (fp32 / integer work) must equal the oracle's exactly."""
+  from oracle import ref_labels
+  from tests import util_model
+  from tests.test_gpu_model import _captions, _coco_like_classes
+  rng = np.random.default_rng(5)
+  classes, syn = _coco_like_classes(rng)
+  lf = tmp_path / "coco_label_synonyms.txt"
+  lf.write_text("\n".join("%s\t%s" % (c, ",".join(s)) for c, s in zip(classes, syn)))
+  pipeline = util_model.load_pipeline("coco17_extend_match_hotpath", LABEL_SYNONYMS_FILE=str(lf))
+  name2id, _ = ref_labels.read_synonym_file(str(lf))
+  caps = _captions(rng, classes, syn)
+  _check_train_step_bf16(
+      pipeline, 0.5, (48, 40), 7, [7, 5],
+      lambda ex, cl: ref_labels.extend_match_extract(ex["concat_caption_string"], name2id, len(cl)),
+      extra_examples=lambda r, cl: {"concat_caption_string": caps}, seed=5)
+
+
+def test_train_step_bf16_text_classifier_match(tmp_path):
+  """BASELINE configs[4] as named: *_text_classifier_match (Flickr30k-sized vocabulary) in the
+  bf16 storage mode; the text classifier itself stays fp32, labels equal the oracle's exactly."""
+  from tests.test_gpu_model import _text_classifier_setup
+  pipeline, make_labels, extra, check_oov = _text_classifier_setup(tmp_path, 211)
+  check_oov(_check_train_step_bf16(pipeline, 0.5, (48, 40), 7, [7, 5], make_labels,
+                                   extra_examples=extra, seed=99))
+
+
+def _check_train_step_bf16(pipeline, dm, hw, n, nums, make_labels, extra_examples=None, seed=99):
   """Full training step with compute_dtype='bf16' (ROI crop output + second stage in bf16
   storage, fp32 accumulation) against the float64 oracle of the reference semantics.  There is no
   bf16 reference: the stated tolerance is what ~12 bf16 roundings per path (2^-9 relative each)
@@ -131,10 +167,9 @@ def test_train_step_bf16_tracks_the_fp64_oracle(dm, hw, n, nums):
   gradient tensor within 10 % relative L2 error (these tiny cases sum over < 300 pixels; observed
   max 6.6 %), the whole gradient within 3 % and at cosine >= 0.999 of the oracle's; the fp32 path (tests/test_gpu_model.py) holds 1e-4."""
   from cap2det_amd.train.trainer import Trainer
-  from oracle import ref_labels, ref_model
+  from oracle import ref_model
   from tests import util_model
-  pipeline = util_model.load_pipeline()
-  rng = np.random.default_rng(99)
+  rng = np.random.default_rng(seed)
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=dm, compute_dtype="bf16")
   model = trainer.model
   assert model.engine.second.dtype == torch.bfloat16 and model.engine.first.dtype == torch.float32
@@ -143,10 +178,12 @@ def test_train_step_bf16_tracks_the_fp64_oracle(dm, hw, n, nums):
   P32, d = util_model.oracle_state(5, c, k, dm)
   model.load_state_dict(P32)
   ex = util_model.make_examples(rng, 2, hw[0], hw[1], n, nums, classes)
+  if extra_examples is not None:
+    ex.update(extra_examples(rng, classes))
   mask = (rng.uniform(size=(2 * n, d)) < 0.5).astype(np.uint8)
   P = {kk: v.astype(np.float64) for kk, v in P32.items()}
   acc = {kk: np.full(v.shape, 0.1) for kk, v in P.items()}
-  labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
+  labels = make_labels(ex, classes).astype(np.float64)
   ex64 = dict(image=ex["image"].astype(np.float64), number_of_proposals=ex["number_of_proposals"],
               proposals=ex["proposals"].astype(np.float64))
   opts = ref_model.FrcnnOptions(depth_multiplier=dm)
@@ -162,6 +199,7 @@ def test_train_step_bf16_tracks_the_fp64_oracle(dm, hw, n, nums):
   dev["number_of_proposals"] = torch.from_numpy(ex["number_of_proposals"]).to(DEV)
   losses = trainer.train_step(dev, dropout_mask=torch.from_numpy(mask).to(DEV))
   torch.cuda.synchronize()
+  np.testing.assert_array_equal(model._ctx["labels"].cpu().numpy(), labels)   # extractor parity
   pred, wp = trainer.predictions, want["predictions"]
   for name in ["midn_class_logits", "midn_proba_r_given_c"] + \
       ["oicr_proposal_scores_at_%d" % i for i in range(k + 1)]:
@@ -190,3 +228,4 @@ def test_train_step_bf16_tracks_the_fp64_oracle(dm, hw, n, nums):
   cos = float(g @ w / (np.linalg.norm(g) * np.linalg.norm(w)))
   assert cos >= 0.999, "whole-gradient cosine similarity %.5f" % cos
   assert _rel_l2(g, w) <= 3e-2
+  return trainer

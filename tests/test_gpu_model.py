@@ -150,12 +150,10 @@ def test_train_step_coco17_extend_match(tmp_path):
   assert tr.model.num_classes == 80
 
 
-@pytest.mark.parametrize("vocab_size", [300, 211])   # configs[3] (COCO vocab) / configs[4] (Flickr30k vocab): sizes differ
-def test_train_step_text_classifier_match(tmp_path, vocab_size):
-  """BASELINE configs[3]/[4]: *_text_classifier_match (labels = frozen text MLP over the caption
-  embeddings, overridden by exact matches against the raw class names), full step vs the
-  float64 oracle.  The open vocabulary / embedding / classifier weights are synthetic."""
-  rng = np.random.default_rng(8)
+def _text_classifier_setup(tmp_path, vocab_size, seed=8):
+  """Synthetic open vocabulary / embedding / text-classifier weights + the *_text_classifier_match
+  pipeline over them -> (pipeline, make_labels(ex, classes), extra_examples, check_oov(trainer))."""
+  rng = np.random.default_rng(seed)
   classes, syn = _coco_like_classes(rng)
   vocab = [c for c in classes if " " not in c] + [s for ss in syn for s in ss]
   vocab += ["w%03d" % i for i in range(vocab_size - len(vocab))]
@@ -171,7 +169,7 @@ def test_train_step_text_classifier_match(tmp_path, vocab_size):
   pipeline = util_model.load_pipeline(
       "coco17_text_classifier_match_hotpath", LABEL_FILE=str(lf), OPEN_VOCAB_FILE=str(vf),
       OPEN_VOCAB_EMBEDDING_NPY=str(ef), TEXT_CLASSIFIER_NPZ=str(wf))
-  caps = _captions(rng, classes, syn) 
+  caps = _captions(rng, classes, syn)
   caps[1] = ["zzz", "qqq"] + [""] * (len(caps[0]) - 2)        # all-OOV caption
 
   def make_labels(ex, cl):
@@ -198,10 +196,21 @@ def test_train_step_text_classifier_match(tmp_path, vocab_size):
   make_labels.oov = probe.label_extractor._embedding[-1].cpu().numpy()
   del probe
   np.random.seed(4321)
-  tr = _check_train_step(pipeline, 0.5, (48, 40), 7, [7, 5], make_labels,
-                         extra_examples=lambda r, cl: {"concat_caption_string": caps})
-  np.testing.assert_array_equal(tr.model.label_extractor._embedding[-1].cpu().numpy(),
-                                make_labels.oov)
+
+  def check_oov(trainer):
+    np.testing.assert_array_equal(trainer.model.label_extractor._embedding[-1].cpu().numpy(),
+                                  make_labels.oov)
+  return pipeline, make_labels, (lambda r, cl: {"concat_caption_string": caps}), check_oov
+
+
+@pytest.mark.parametrize("vocab_size", [300, 211])   # configs[3] (COCO vocab) / configs[4] (Flickr30k vocab): sizes differ
+def test_train_step_text_classifier_match(tmp_path, vocab_size):
+  """BASELINE configs[3]/[4]: *_text_classifier_match (labels = frozen text MLP over the caption
+  embeddings, overridden by exact matches against the raw class names), full step vs the
+  float64 oracle.  The open vocabulary / embedding / classifier weights are synthetic."""
+  pipeline, make_labels, extra, check_oov = _text_classifier_setup(tmp_path, vocab_size)
+  tr = _check_train_step(pipeline, 0.5, (48, 40), 7, [7, 5], make_labels, extra_examples=extra)
+  check_oov(tr)
 
 
 def test_builder_and_errors():
