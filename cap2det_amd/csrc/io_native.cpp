@@ -121,7 +121,7 @@ extern "C" long long c2d_tfrecord_next(const uint8_t* buf, long long size, long 
                                        int verify_crc) {
   if (!buf || !payload_off || !payload_len || pos < 0 || pos > size) return C2D_ERR_INVALID_ARG;
   if (pos == size) return 0;
-  if (size - pos < 12) return C2D_ERR_DATA;
+  if (size - pos < 16) return C2D_ERR_DATA;      // length + its CRC + payload CRC
   uint64_t len;
   uint32_t lcrc;
   memcpy(&len, buf + pos, 8);
@@ -305,6 +305,8 @@ struct BitReader {
   uint32_t buf;
   int bits;
   bool marker;           // a marker (other than stuffed 0xFF00) was reached: feed zeros
+  bool eof;              // the data ended inside entropy-coded bits (truncated / corrupted file)
+  int pad;               // zero bytes fed after a marker was reached (<= 4 in a valid stream)
 };
 
 inline void fill(BitReader& br) {
@@ -318,7 +320,11 @@ inline void fill(BitReader& br) {
       } else {
         ++br.p;
       }
-    }
+    } else if (!br.marker) {
+      br.eof = true;
+    } else if (++br.pad > 16) {
+      br.eof = true;     // the scan wants far more bits than it holds: stop instead of decoding
+    }                    // zeros for the rest of a (possibly huge, corrupted-size) image
     br.buf |= byte << (24 - br.bits);
     br.bits += 8;
   }
@@ -447,6 +453,8 @@ struct Header {
   Huff dc[4], ac[4];
   const uint8_t* scan;     // entropy-coded data of the first scan
   int scan_ncomp;
+  long long sos_pos;       // offset of the first SOS marker's length field
+  bool single_scan;        // sequential, one interleaved scan of all components (fast path)
 };
 
 bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* vals, int nvals) {
@@ -457,10 +465,12 @@ bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* vals, int nvals) 
     h.valptr[l] = k;
     h.mincode[l] = code;
     if (counts[l - 1]) {
-      for (int i = 0; i < counts[l - 1]; ++i, ++k, ++code)
+      for (int i = 0; i < counts[l - 1]; ++i, ++k, ++code) {
+        if (code >= (1 << l)) return false;       // over-subscribed code lengths
         if (l <= 9)
           for (int f = 0; f < (1 << (9 - l)); ++f)
             h.look[(code << (9 - l)) | f] = (uint16_t)((l << 8) | vals[k]);
+      }
       h.maxcode[l] = code - 1;
     } else {
       h.maxcode[l] = -1;
@@ -471,6 +481,36 @@ bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* vals, int nvals) 
   h.maxcode[17] = 0x7fffffff;
   h.present = true;
   return k == nvals;
+}
+
+// DQT / DHT / DRI segments (they may also appear between the scans of a multi-scan file).
+int parse_tables(int m, const uint8_t* s, int sl, Header& hd) {
+  if (m == 0xdb) {
+    int q = 0;
+    while (q < sl) {
+      const int pq = s[q] >> 4, tq = s[q] & 15;
+      if (tq > 3 || q + 1 + (pq ? 128 : 64) > sl) return C2D_ERR_DATA;
+      for (int i = 0; i < 64; ++i)
+        hd.quant[tq][kZigzag[i]] = pq ? (uint16_t)((s[q + 1 + 2 * i] << 8) | s[q + 2 + 2 * i]) : s[q + 1 + i];
+      hd.have_q[tq] = true;
+      q += 1 + (pq ? 128 : 64);
+    }
+  } else if (m == 0xc4) {
+    int q = 0;
+    while (q < sl) {
+      if (q + 17 > sl) return C2D_ERR_DATA;
+      const int tc = s[q] >> 4, th = s[q] & 15;
+      int nv = 0;
+      for (int i = 0; i < 16; ++i) nv += s[q + 1 + i];
+      if (th > 3 || tc > 1 || nv > 256 || q + 17 + nv > sl) return C2D_ERR_DATA;
+      if (!build_huff(tc ? hd.ac[th] : hd.dc[th], s + q + 1, s + q + 17, nv)) return C2D_ERR_DATA;
+      q += 17 + nv;
+    }
+  } else if (m == 0xdd) {
+    if (sl < 2) return C2D_ERR_DATA;
+    hd.restart = (s[0] << 8) | s[1];
+  }
+  return C2D_OK;
 }
 
 int parse_header(const uint8_t* d, long long n, Header& hd) {
@@ -508,49 +548,259 @@ int parse_header(const uint8_t* d, long long n, Header& hd) {
       hd.have_sof = true;
     } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
       return C2D_ERR_UNSUPPORTED;               // lossless / hierarchical / arithmetic
-    } else if (m == 0xdb) {
-      int q = 0;
-      while (q < sl) {
-        const int pq = s[q] >> 4, tq = s[q] & 15;
-        if (tq > 3 || q + 1 + (pq ? 128 : 64) > sl) return C2D_ERR_DATA;
-        for (int i = 0; i < 64; ++i)
-          hd.quant[tq][kZigzag[i]] = pq ? (uint16_t)((s[q + 1 + 2 * i] << 8) | s[q + 2 + 2 * i]) : s[q + 1 + i];
-        hd.have_q[tq] = true;
-        q += 1 + (pq ? 128 : 64);
-      }
-    } else if (m == 0xc4) {
-      int q = 0;
-      while (q < sl) {
-        if (q + 17 > sl) return C2D_ERR_DATA;
-        const int tc = s[q] >> 4, th = s[q] & 15;
-        int nv = 0;
-        for (int i = 0; i < 16; ++i) nv += s[q + 1 + i];
-        if (th > 3 || tc > 1 || nv > 256 || q + 17 + nv > sl) return C2D_ERR_DATA;
-        if (!build_huff(tc ? hd.ac[th] : hd.dc[th], s + q + 1, s + q + 17, nv)) return C2D_ERR_DATA;
-        q += 17 + nv;
-      }
-    } else if (m == 0xdd) {
-      if (sl < 2) return C2D_ERR_DATA;
-      hd.restart = (s[0] << 8) | s[1];
+    } else if (m == 0xdb || m == 0xc4 || m == 0xdd) {
+      const int rc = parse_tables(m, s, sl, hd);
+      if (rc) return rc;
     } else if (m == 0xda) {
       if (!hd.have_sof || sl < 1) return C2D_ERR_DATA;
-      if (hd.progressive) return C2D_ERR_UNSUPPORTED;
       const int ns = s[0];
-      if (ns != hd.ncomp || sl < 1 + 2 * ns + 3) return C2D_ERR_UNSUPPORTED;   // non-interleaved scans
-      for (int i = 0; i < ns; ++i) {
+      if (ns < 1 || ns > hd.ncomp || sl < 1 + 2 * ns + 3) return C2D_ERR_DATA;
+      hd.sos_pos = p;
+      hd.single_scan = !hd.progressive && ns == hd.ncomp;
+      for (int i = 0; i < ns && hd.single_scan; ++i) {
         int ci = -1;
         for (int j = 0; j < hd.ncomp; ++j) if (hd.comp[j].id == s[1 + 2 * i]) ci = j;
-        if (ci != i) return C2D_ERR_UNSUPPORTED;
+        if (ci != i) { hd.single_scan = false; break; }
         hd.comp[ci].td = s[2 + 2 * i] >> 4; hd.comp[ci].ta = s[2 + 2 * i] & 15;
         if (hd.comp[ci].td > 3 || hd.comp[ci].ta > 3) return C2D_ERR_DATA;
       }
       hd.scan = d + p + len;
       hd.scan_ncomp = ns;
+      {
+        // every 8x8 block costs at least one bit (its DC Huffman code): a header announcing more
+        // blocks than the file has bits is corrupt — refuse before anyone sizes buffers by it
+        const long long mcux = (hd.width + 8 * hd.maxh - 1) / (8 * hd.maxh);
+        const long long mcuy = (hd.height + 8 * hd.maxv - 1) / (8 * hd.maxv);
+        long long per_mcu = 0;
+        for (int i = 0; i < hd.ncomp; ++i) per_mcu += hd.comp[i].h * hd.comp[i].v;
+        if (mcux * mcuy * per_mcu > 8 * n) return C2D_ERR_DATA;
+      }
       return C2D_OK;
     }
     p += len;
   }
   return C2D_ERR_DATA;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-scan files: progressive (SOF2; jdphuff.c: DC / AC, first / refinement scans with EOB runs)
+// and sequential files whose components come in separate scans.  Every scan is entropy-decoded
+// into a coefficient image [component][block row][block column][64] (natural order, NOT
+// dequantised); the caller then dequantises and runs the same IDCT / upsampling / colour
+// conversion as the single-scan path, so a complete file decodes to the same pixels as
+// libjpeg-turbo (its block smoothing only acts on files whose scans are missing).
+// ---------------------------------------------------------------------------------------------
+struct ScanComp { int ci, td, ta; };
+
+inline void restart_sync(BitReader& br, int& next_rst, bool& ok) {
+  br.bits = 0; br.buf = 0;
+  const uint8_t* q = br.p;
+  while (q + 1 < br.end && !(q[0] == 0xff && q[1] >= 0xd0 && q[1] <= 0xd7)) ++q;
+  if (q + 1 >= br.end || q[1] != 0xd0 + next_rst) { ok = false; return; }
+  br.p = q + 2; br.marker = false; br.pad = 0;
+  next_rst = (next_rst + 1) & 7;
+}
+
+// one block of one scan; returns false on a corrupted stream
+inline bool decode_block_scan(BitReader& br, const Header& hd, bool progressive, const Huff* dct,
+                              const Huff* act, int ss, int se, int ah, int al, int& dc_pred,
+                              int& eobrun, short* blk) {
+  if (!progressive) {                       // sequential: the whole block
+    int t = decode_sym(br, *dct);
+    if (t < 0 || t > 11) return false;
+    dc_pred += t ? extend(get_bits(br, t), t) : 0;
+    if (dc_pred > 32767) dc_pred = 32767;
+    if (dc_pred < -32768) dc_pred = -32768;
+    blk[0] = (short)dc_pred;
+    for (int k = 1; k < 64;) {
+      const int rs = decode_sym(br, *act);
+      if (rs < 0) return false;
+      const int r = rs >> 4, s = rs & 15;
+      if (s == 0) {
+        if (r == 15) { k += 16; continue; }
+        break;
+      }
+      k += r;
+      if (k > 63) return false;
+      blk[kZigzag[k]] = (short)extend(get_bits(br, s), s);
+      ++k;
+    }
+    return true;
+  }
+  if (ss == 0) {
+    if (ah == 0) {                          // DC first
+      int t = decode_sym(br, *dct);
+      if (t < 0 || t > 11) return false;
+      dc_pred += t ? extend(get_bits(br, t), t) : 0;
+      if (dc_pred > 32767) dc_pred = 32767;
+      if (dc_pred < -32768) dc_pred = -32768;
+      blk[0] = (short)((unsigned)dc_pred << al);
+    } else if (get_bits(br, 1)) {           // DC refinement
+      blk[0] = (short)(blk[0] | (1 << al));
+    }
+    return true;
+  }
+  if (ah == 0) {                            // AC first
+    if (eobrun > 0) { --eobrun; return true; }
+    for (int k = ss; k <= se; ++k) {
+      const int rs = decode_sym(br, *act);
+      if (rs < 0) return false;
+      const int r = rs >> 4, s = rs & 15;
+      if (s) {
+        k += r;
+        if (k > 63) return false;
+        blk[kZigzag[k]] = (short)((unsigned)extend(get_bits(br, s), s) << al);
+      } else if (r == 15) {
+        k += 15;
+      } else {
+        eobrun = 1 << r;
+        if (r) eobrun += get_bits(br, r);
+        --eobrun;
+        break;
+      }
+    }
+    return true;
+  }
+  // AC refinement
+  const int p1 = 1 << al, m1 = -(1 << al);
+  int k = ss;
+  if (eobrun == 0) {
+    for (; k <= se; ++k) {
+      const int rs = decode_sym(br, *act);
+      if (rs < 0) return false;
+      int r = rs >> 4, s = rs & 15;
+      if (s) {
+        if (s != 1) return false;
+        s = get_bits(br, 1) ? p1 : m1;
+      } else if (r != 15) {
+        eobrun = 1 << r;
+        if (r) eobrun += get_bits(br, r);
+        break;
+      }
+      // pass over already-nonzero coefficients (each takes a correction bit) and r zeros
+      do {
+        short* c = blk + kZigzag[k];
+        if (*c != 0) {
+          if (get_bits(br, 1) && (*c & p1) == 0) *c = (short)(*c + (*c >= 0 ? p1 : m1));
+        } else if (--r < 0) {
+          break;
+        }
+        ++k;
+      } while (k <= se);
+      if (s) {
+        if (k > 63) return false;
+        blk[kZigzag[k]] = (short)s;
+      }
+    }
+  }
+  if (eobrun > 0) {
+    for (; k <= se; ++k) {
+      short* c = blk + kZigzag[k];
+      if (*c != 0 && get_bits(br, 1) && (*c & p1) == 0) *c = (short)(*c + (*c >= 0 ? p1 : m1));
+    }
+    --eobrun;
+  }
+  return true;
+}
+
+// Decodes every scan from the first SOS to EOI into coef[ci] ([ph/8][pw/8][64] shorts, zeroed by
+// the caller).  Components' dw/dh/pw/ph are set.
+int decode_scans(const uint8_t* d, long long n, Header& hd, short* const* coef) {
+  long long p = hd.sos_pos;                 // at the length field of an SOS segment
+  const int mcuw = 8 * hd.maxh, mcuh = 8 * hd.maxv;
+  const int mcux = (hd.width + mcuw - 1) / mcuw, mcuy = (hd.height + mcuh - 1) / mcuh;
+  int scans = 0;
+  for (;;) {
+    if (p + 2 > n) return C2D_ERR_DATA;
+    const int len = (d[p] << 8) | d[p + 1];
+    if (len < 2 || p + len > n) return C2D_ERR_DATA;
+    const uint8_t* s = d + p + 2;
+    const int sl = len - 2;
+    const int ns = sl >= 1 ? s[0] : 0;
+    if (ns < 1 || ns > hd.ncomp || sl < 1 + 2 * ns + 3) return C2D_ERR_DATA;
+    ScanComp sc[3];
+    for (int i = 0; i < ns; ++i) {
+      sc[i].ci = -1;
+      for (int j = 0; j < hd.ncomp; ++j) if (hd.comp[j].id == s[1 + 2 * i]) sc[i].ci = j;
+      sc[i].td = s[2 + 2 * i] >> 4; sc[i].ta = s[2 + 2 * i] & 15;
+      if (sc[i].ci < 0 || sc[i].td > 3 || sc[i].ta > 3) return C2D_ERR_DATA;
+      for (int j = 0; j < i; ++j) if (sc[j].ci == sc[i].ci) return C2D_ERR_DATA;
+    }
+    int ss = s[1 + 2 * ns], se = s[2 + 2 * ns];
+    int ah = s[3 + 2 * ns] >> 4, al = s[3 + 2 * ns] & 15;
+    if (hd.progressive) {
+      if (ss > se || se > 63 || ah > 13 || al > 13 || (ss == 0 && se != 0) || (ss > 0 && ns != 1))
+        return C2D_ERR_DATA;
+    } else {
+      ss = 0; se = 63; ah = 0; al = 0;
+    }
+    for (int i = 0; i < ns; ++i) {
+      const bool need_dc = !hd.progressive || (ss == 0 && ah == 0);
+      const bool need_ac = !hd.progressive || ss > 0;
+      if ((need_dc && !hd.dc[sc[i].td].present) || (need_ac && !hd.ac[sc[i].ta].present))
+        return C2D_ERR_DATA;
+    }
+    if (++scans > 1000) return C2D_ERR_DATA;
+    BitReader br = {d + p + len, d + n, 0, 0, false};
+    int pred[3] = {0, 0, 0};
+    int eobrun = 0, rst_left = hd.restart, next_rst = 0;
+    bool ok = true;
+    if (ns == 1) {
+      // non-interleaved: the component's own blocks in raster order (no MCU padding)
+      Comp& c = hd.comp[sc[0].ci];
+      const int bw = (c.dw + 7) / 8, bh = (c.dh + 7) / 8, pbw = c.pw / 8;
+      for (int by = 0; by < bh && ok && !br.eof; ++by)
+        for (int bx = 0; bx < bw; ++bx) {
+          if (hd.restart && rst_left == 0) {
+            restart_sync(br, next_rst, ok);
+            if (!ok) break;
+            rst_left = hd.restart; pred[0] = 0; eobrun = 0;
+          }
+          ok = decode_block_scan(br, hd, hd.progressive, &hd.dc[sc[0].td], &hd.ac[sc[0].ta], ss, se,
+                                 ah, al, pred[0], eobrun,
+                                 coef[sc[0].ci] + ((size_t)by * pbw + bx) * 64);
+          if (!ok) break;
+          if (hd.restart) --rst_left;
+        }
+    } else {
+      for (int my = 0; my < mcuy && ok && !br.eof; ++my)
+        for (int mx = 0; mx < mcux && ok; ++mx) {
+          if (hd.restart && rst_left == 0) {
+            restart_sync(br, next_rst, ok);
+            if (!ok) break;
+            rst_left = hd.restart; pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
+          }
+          for (int i = 0; i < ns && ok; ++i) {
+            Comp& c = hd.comp[sc[i].ci];
+            const int pbw = c.pw / 8;
+            for (int by = 0; by < c.v && ok; ++by)
+              for (int bx = 0; bx < c.h && ok; ++bx)
+                ok = decode_block_scan(br, hd, hd.progressive, &hd.dc[sc[i].td], &hd.ac[sc[i].ta],
+                                       ss, se, ah, al, pred[i], eobrun,
+                                       coef[sc[i].ci] + ((size_t)(my * c.v + by) * pbw + mx * c.h + bx) * 64);
+          }
+          if (hd.restart) --rst_left;
+        }
+    }
+    if (!ok || br.eof) return C2D_ERR_DATA;   // (truncated: tf.image.decode_jpeg fails too)
+    // ---- markers up to the next scan ----
+    long long q = br.p - d;
+    for (;;) {
+      while (q + 1 < n && !(d[q] == 0xff && d[q + 1] != 0x00 && d[q + 1] != 0xff &&
+                            !(d[q + 1] >= 0xd0 && d[q + 1] <= 0xd7))) ++q;
+      if (q + 1 >= n) return C2D_ERR_DATA;  // no EOI: the remaining scans are missing
+      const int m = d[q + 1];
+      q += 2;
+      if (m == 0xd9) return C2D_OK;
+      if (q + 2 > n) return C2D_ERR_DATA;
+      const int l2 = (d[q] << 8) | d[q + 1];
+      if (l2 < 2 || q + l2 > n) return C2D_ERR_DATA;
+      if (m == 0xda) { p = q; break; }
+      const int rc = parse_tables(m, d + q + 2, l2 - 2, hd);
+      if (rc) return rc;
+      q += l2;
+    }
+  }
 }
 
 }  // namespace
@@ -569,7 +819,8 @@ extern "C" int c2d_jpeg_info(const uint8_t* data, long long n, int* height, int*
 extern "C" long long c2d_jpeg_workspace_bytes(int height, int width) {
   if (height <= 0 || width <= 0) return -1;
   const long long ph = (height + 15) / 16 * 16, pw = (width + 15) / 16 * 16;
-  return 3 * ph * pw + 2 * 3 * (pw + 16) * 2 + 1024;   // component planes + upsampled row pairs
+  // component planes + upsampled row pairs + (multi-scan files) the 16-bit coefficient image
+  return 3 * ph * pw + 2 * 3 * (pw + 16) * 2 + 1024 + 3 * ph * pw * 2 + 64;
 }
 
 extern "C" int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* out, int height,
@@ -585,18 +836,47 @@ extern "C" int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* ou
   uint8_t* ws = (uint8_t*)workspace;
   for (int i = 0; i < hd.ncomp; ++i) {
     Comp& c = hd.comp[i];
-    if (!hd.have_q[c.tq] || !hd.dc[c.td].present || !hd.ac[c.ta].present) return C2D_ERR_DATA;
+    if (hd.single_scan && (!hd.have_q[c.tq] || !hd.dc[c.td].present || !hd.ac[c.ta].present))
+      return C2D_ERR_DATA;
     c.dw = (width * c.h + hd.maxh - 1) / hd.maxh;
     c.dh = (height * c.v + hd.maxv - 1) / hd.maxv;
     c.pw = mcux * c.h * 8; c.ph = mcuy * c.v * 8;
     c.plane = ws; ws += (size_t)c.pw * c.ph;
     c.dc_pred = 0;
   }
+  if (!hd.single_scan) {
+    // ---- multi-scan file: all scans into the coefficient image, then dequantise + IDCT ----
+    ws = (uint8_t*)(((uintptr_t)ws + 63) & ~(uintptr_t)63);
+    short* cimg[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < hd.ncomp; ++i) {
+      cimg[i] = (short*)ws;
+      const size_t bytes = (size_t)hd.comp[i].pw * hd.comp[i].ph * 2;
+      memset(cimg[i], 0, bytes);
+      ws += bytes;
+    }
+    // (the per-component table checks above looked at the FIRST scan's selectors only when it
+    // was interleaved; decode_scans re-checks every scan's tables)
+    rc = decode_scans(data, n, hd, cimg);
+    if (rc) return rc;
+    int blk[64];
+    for (int i = 0; i < hd.ncomp; ++i) {
+      Comp& c = hd.comp[i];
+      if (!hd.have_q[c.tq]) return C2D_ERR_DATA;
+      const uint16_t* q = hd.quant[c.tq];
+      const int pbw = c.pw / 8, pbh = c.ph / 8;
+      for (int by = 0; by < pbh; ++by)
+        for (int bx = 0; bx < pbw; ++bx) {
+          const short* src = cimg[i] + ((size_t)by * pbw + bx) * 64;
+          for (int k = 0; k < 64; ++k) blk[k] = clampc((long long)src[k] * q[k]);
+          idct_islow(blk, c.plane + (size_t)by * 8 * c.pw + bx * 8, c.pw);
+        }
+    }
+  } else {
   // ---- entropy decode + dequantize + IDCT, MCU by MCU -----------------------------------
   BitReader br = {hd.scan, data + n, 0, 0, false};
   int coef[64];
   int rst_left = hd.restart, next_rst = 0;
-  for (int my = 0; my < mcuy; ++my)
+  for (int my = 0; my < mcuy && !br.eof; ++my)
     for (int mx = 0; mx < mcux; ++mx) {
       if (hd.restart && rst_left == 0) {
         // byte-align, expect RSTn
@@ -604,7 +884,7 @@ extern "C" int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* ou
         const uint8_t* q = br.p;
         while (q + 1 < br.end && !(q[0] == 0xff && q[1] >= 0xd0 && q[1] <= 0xd7)) ++q;
         if (q + 1 >= br.end || q[1] != 0xd0 + next_rst) return C2D_ERR_DATA;
-        br.p = q + 2; br.marker = false;
+        br.p = q + 2; br.marker = false; br.pad = 0;
         next_rst = (next_rst + 1) & 7;
         rst_left = hd.restart;
         for (int i = 0; i < hd.ncomp; ++i) hd.comp[i].dc_pred = 0;
@@ -642,6 +922,8 @@ extern "C" int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* ou
       }
       if (hd.restart) --rst_left;
     }
+  if (br.eof) return C2D_ERR_DATA;            // truncated entropy data
+  }
   // ---- upsample + colour convert, one output row at a time -------------------------------
   if (hd.ncomp == 1) {
     const Comp& y = hd.comp[0];

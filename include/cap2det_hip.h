@@ -431,9 +431,11 @@ int c2d_example_parse(const uint8_t* rec, long long len, const char* const* keys
 /* TensorFlow's Hash64 (seed 0xDECAFCAFFE): tf.strings.to_hash_bucket(s, k) = hash % k, the
  * shard filter of readers/cap2det_reader.py:201-211. */
 unsigned long long c2d_tf_hash64(const void* data, long long n);
-/* Baseline / extended-sequential JPEG -> RGB u8 [height][width][3] with libjpeg's default
- * decompression choices (islow IDCT, fancy upsampling), i.e. tf.image.decode_jpeg(channels=3)
- * (readers/cap2det_reader.py:91-92).  Progressive streams: C2D_ERR_UNSUPPORTED. */
+/* Huffman-coded 8-bit JPEG (baseline, extended sequential, progressive; one or several scans;
+ * restart intervals; 4:4:4 / 4:2:2 / 4:4:0 / 4:2:0 / grayscale) -> RGB u8 [height][width][3]
+ * with libjpeg's default decompression choices (islow IDCT, fancy upsampling), i.e.
+ * tf.image.decode_jpeg(channels=3) (readers/cap2det_reader.py:91-92).  Truncated or corrupted
+ * streams: C2D_ERR_DATA; arithmetic-coded / lossless / 12-bit / CMYK: C2D_ERR_UNSUPPORTED. */
 int c2d_jpeg_info(const uint8_t* data, long long n, int* height, int* width, int* components);
 long long c2d_jpeg_workspace_bytes(int height, int width);
 int c2d_jpeg_decode_rgb(const uint8_t* data, long long n, uint8_t* out, int height, int width,

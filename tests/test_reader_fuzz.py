@@ -96,3 +96,39 @@ def test_tfrecord_reader_survives_corruption(tmp_path):
         assert all(isinstance(r, bytes) for r in recs)
       except (T.DataError, Cap2DetHipError):
         pass
+
+
+def test_sanitizer_findings_stay_fixed(tmp_path):
+  """Two inputs the ASan / UBSan harness (tools/fuzz_io.cpp) found: a record file ending 12-15
+  bytes after a record (the remaining-length subtraction went negative) and a DHT segment whose
+  code lengths over-subscribe the code space (lookahead-table index past its end)."""
+  rng = np.random.default_rng(3)
+  path = str(tmp_path / "f.record")
+  T.write_records(path, [b"payload"])
+  blob = open(path, "rb").read()
+  for extra in range(1, 16):
+    open(path, "wb").write(blob + bytes([255] * extra))
+    for verify in (True, False):
+      with pytest.raises((T.DataError, Cap2DetHipError)):
+        list(T.iterate_records(path, verify_crc=verify))
+  data = bytearray(_jpeg(rng, 24, 24, quality=80))
+  p = data.find(b"\xff\xc4")
+  assert p > 0
+  data[p + 5] = 3            # three codes of length 1
+  with pytest.raises((T.DataError, Cap2DetHipError)):
+    T.decode_jpeg(bytes(data))
+
+
+def test_progressive_jpeg_survives_corruption():
+  rng = np.random.default_rng(4)
+  ok = 0
+  for kw in (dict(quality=80), dict(quality=60, subsampling=0), dict(quality=85, restart_marker_blocks=2)):
+    data = _jpeg(rng, 41, 57, progressive=True, **kw)
+    for bad in _mutations(rng, data, 400):
+      try:
+        out = T.decode_jpeg(bad)
+        assert out.shape == (41, 57, 3) or out.ndim == 3
+        ok += 1
+      except (T.DataError, Cap2DetHipError, MemoryError, ValueError):
+        pass
+  assert ok > 0

@@ -135,13 +135,37 @@ def test_jpeg_decoder_bit_exact_vs_libjpeg_turbo(h, w, kw):
   np.testing.assert_array_equal(T.decode_jpeg(gray), R.decode_jpeg(gray))     # replicated to RGB
 
 
+@pytest.mark.parametrize("h,w,kw", [
+    (16, 16, dict(quality=90, subsampling=0)), (37, 53, dict(quality=90, subsampling=1)),
+    (37, 53, dict(quality=75, subsampling=2)), (1, 1, dict(quality=95)), (9, 8, dict(quality=40)),
+    (120, 161, dict(quality=30, subsampling=2)), (65, 47, dict(quality=100, subsampling=2)),
+    (67, 45, dict(quality=85, subsampling=2, restart_marker_blocks=3)),
+    (67, 45, dict(quality=85, subsampling=1, restart_marker_rows=1)),
+    (333, 500, dict(quality=92, subsampling=2, optimize=True))])
+def test_progressive_jpeg_bit_exact_vs_libjpeg_turbo(h, w, kw):
+  """SOF2 files (DC / AC first + refinement scans, EOB runs, per-scan Huffman tables, restart
+  intervals): tf.image.decode_jpeg of readers/cap2det_reader.py:91-92 takes them; a small share
+  of COCO / Flickr30k is stored this way."""
+  rng = np.random.default_rng(h * 1000 + w + 1)
+  for img in (_photo_like(rng, h, w), rng.integers(0, 256, (h, w, 3)).astype(np.uint8)):
+    data = _jpeg(img, progressive=True, **kw)
+    assert b"\xff\xc2" in data
+    np.testing.assert_array_equal(T.decode_jpeg(data), R.decode_jpeg(data))
+  gray = _jpeg(_photo_like(rng, h, w)[..., 0], quality=kw.get("quality", 90), progressive=True)
+  np.testing.assert_array_equal(T.decode_jpeg(gray), R.decode_jpeg(gray))
+
+
 def test_jpeg_decoder_rejects_what_it_does_not_support():
   rng = np.random.default_rng(3)
-  data = _jpeg(_photo_like(rng, 40, 40), quality=80, progressive=True)
   from cap2det_amd._lib import Cap2DetHipError
-  with pytest.raises(Cap2DetHipError):
-    T.decode_jpeg(data)                                  # progressive: C2D_ERR_UNSUPPORTED
+  prog = _jpeg(_photo_like(rng, 40, 40), quality=80, progressive=True)
+  with pytest.raises((T.DataError, Cap2DetHipError)):
+    T.decode_jpeg(prog[:len(prog) // 3])                 # cut inside the first scans
+  with pytest.raises((T.DataError, Cap2DetHipError)):
+    T.decode_jpeg(prog[:-2])                             # EOI (and nothing else) missing
   good = _jpeg(_photo_like(rng, 40, 40), quality=80)
+  with pytest.raises((T.DataError, Cap2DetHipError)):
+    T.decode_jpeg(good[:len(good) // 2])                 # truncated entropy-coded data
   with pytest.raises((T.DataError, Cap2DetHipError)):
     T.decode_jpeg(good[:100])
   with pytest.raises((T.DataError, Cap2DetHipError)):
