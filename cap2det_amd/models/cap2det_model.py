@@ -15,7 +15,7 @@ from cap2det_amd import hip_ops as ops
 from cap2det_amd.core import builder as function_builder
 from cap2det_amd.core.standard_fields import (Cap2DetPredictions, DetectionResultFields,
                                               InputDataFields)
-from cap2det_amd.models.frcnn_engine import FrcnnEngine, VariableStore
+from cap2det_amd.models.frcnn_engine import FIRST_SCOPE, SECOND_SCOPE, FrcnnEngine, VariableStore
 from cap2det_amd.models.label_extractor import build_label_extractor
 from cap2det_amd.models.model_base import ModelBase
 from cap2det_amd.models.registry import register_model_class
@@ -79,6 +79,16 @@ class Model(ModelBase):
     self._cache = {}
     self._ctx = None
     self.initialize(seed)
+    # the reference initialises both towers from `frcnn_options.checkpoint_path` at graph build
+    # (models/utils.py:181-186); when that file is present here the same happens, otherwise the
+    # synthetic initial values stay (benchmarks and tests run without the ImageNet checkpoint)
+    ckpt = self._model_proto.frcnn_options.checkpoint_path
+    self.restored_from = None
+    if ckpt:
+      from cap2det_amd.train import tf_checkpoint
+      if tf_checkpoint.checkpoint_exists(ckpt):
+        self.init_from_checkpoint(ckpt)
+        self.restored_from = ckpt
 
   # -- variables ----------------------------------------------------------------------
   @property
@@ -146,6 +156,20 @@ class Model(ModelBase):
     if strict and missing:
       raise KeyError("missing variables: %s ..." % missing[:5])
     self.refresh()
+
+  def init_from_checkpoint(self, path):
+    """models/utils.py:181-186: both towers take their variables from ONE ImageNet checkpoint,
+    `tf.train.init_from_checkpoint(path, {"/": "<tower scope>/"})`: model variable
+    `<scope>/InceptionV2/X` <- checkpoint tensor `InceptionV2/X` (V1 `inception_v2.ckpt` or a V2
+    prefix; cap2det_amd/train/tf_checkpoint.py).  The heads keep their initialiser."""
+    from cap2det_amd.train import tf_checkpoint
+    arrays = tf_checkpoint.read_checkpoint(path)
+    names = [n for n in self.variable_names()]
+    state = {}
+    for scope in (FIRST_SCOPE.split("/")[0], SECOND_SCOPE.split("/")[0]):
+      state.update(tf_checkpoint.assignment(arrays, names, scope))
+    self.load_state_dict(state, strict=False)
+    return sorted(state)
 
   def grad_dict(self):
     """Gradients of the last step under the reference variable names (numpy)."""

@@ -187,6 +187,12 @@ class TextClassifierMatchExtractor(_OpenVocabularyExtractor):
     ckpt = options.text_classifier_checkpoint_file
     if ckpt and ckpt.endswith(".npz"):
       self.load_weights(dict(np.load(ckpt)))
+    elif ckpt:
+      # a TensorFlow checkpoint written by the reference's text-classifier training
+      # (models/label_extractor.py:455-457 restores `text_classifier/*` from it)
+      from cap2det_amd.train import tf_checkpoint
+      if tf_checkpoint.checkpoint_exists(ckpt):
+        self.load_weights(tf_checkpoint.read_checkpoint(ckpt))
 
   def load_weights(self, arrays):
     """arrays: text_classifier/layer{1,2}/{weights,biases} (the reference restores these names

@@ -123,8 +123,28 @@ class Trainer(object):
              __adagrad_accumulators=store.accum.detach().cpu().numpy(), **state)
     return path
 
+  def export_tf_checkpoint(self, prefix):
+    """Writes the model variables (reference names) + `global_step` as a TensorFlow V2 checkpoint
+    `prefix.index` / `prefix.data-00000-of-00001`, the kind tf.estimator leaves in model_dir and
+    train/predict.py restores (cap2det_amd/train/tf_checkpoint.py)."""
+    import numpy as np
+    from cap2det_amd.train import tf_checkpoint
+    arrays = dict(self.model.state_dict())
+    arrays["global_step"] = np.array(self.global_step, dtype=np.int64)
+    tf_checkpoint.write_v2(prefix, arrays)
+    return prefix
+
   def load_checkpoint(self, path):
     import numpy as np
+    from cap2det_amd.train import tf_checkpoint
+    if not path.endswith(".npz") and tf_checkpoint.checkpoint_exists(path):
+      # a TensorFlow checkpoint of the reference (or of export_tf_checkpoint): variables and
+      # global_step; Adagrad slots (`<var>/Adagrad`) when the file carries them
+      arrays = tf_checkpoint.read_checkpoint(path)
+      self.global_step = int(arrays.pop("global_step", 0))
+      self.model.load_state_dict(arrays, strict=False)
+      self._graphs = None
+      return
     arrays = dict(np.load(path if path.endswith(".npz") else path + ".npz"))
     self.global_step = int(arrays.pop("__global_step"))
     accum = arrays.pop("__adagrad_accumulators")
