@@ -157,6 +157,45 @@ class Model(ModelBase):
       raise KeyError("missing variables: %s ..." % missing[:5])
     self.refresh()
 
+  def _slot_tensor(self, name):
+    """Adagrad accumulator of variable `name` (None for BatchNorm statistics / stem variables,
+    which the optimiser never touches)."""
+    if name in self.store.acc:
+      return self.store.acc[name]
+    try:
+      scope, leaf = name.rsplit("/", 1)
+    except ValueError:
+      return None
+    for hname, off, width in self._head_cols:
+      if hname == scope:
+        return (self.store.acc[HEADS_W][:, off:off + width] if leaf == "weights"
+                else self.store.acc[HEADS_B][off:off + width])
+    return None
+
+  def optimizer_slots(self):
+    """{`<variable>/Adagrad`: accumulator} — the slot names tf.train.AdagradOptimizer saves."""
+    out = {}
+    for n in self.variable_names():
+      t = self._slot_tensor(n)
+      if t is not None:
+        out[n + "/Adagrad"] = t.detach().cpu().numpy().copy()
+    return out
+
+  def load_optimizer_slots(self, arrays):
+    """Restores every `<variable>/Adagrad` tensor present in `arrays`; returns the names."""
+    done = []
+    for n in self.variable_names():
+      t = self._slot_tensor(n)
+      a = arrays.get(n + "/Adagrad")
+      if t is None or a is None:
+        continue
+      a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self._device)
+      if tuple(a.shape) != tuple(t.shape):
+        raise ValueError("shape mismatch for %s/Adagrad" % n)
+      t.copy_(a)
+      done.append(n)
+    return done
+
   def init_from_checkpoint(self, path):
     """models/utils.py:181-186: both towers take their variables from ONE ImageNet checkpoint,
     `tf.train.init_from_checkpoint(path, {"/": "<tower scope>/"})`: model variable

@@ -130,6 +130,7 @@ class Trainer(object):
     import numpy as np
     from cap2det_amd.train import tf_checkpoint
     arrays = dict(self.model.state_dict())
+    arrays.update(self.model.optimizer_slots())
     arrays["global_step"] = np.array(self.global_step, dtype=np.int64)
     tf_checkpoint.write_v2(prefix, arrays)
     return prefix
@@ -143,6 +144,7 @@ class Trainer(object):
       arrays = tf_checkpoint.read_checkpoint(path)
       self.global_step = int(arrays.pop("global_step", 0))
       self.model.load_state_dict(arrays, strict=False)
+      self.model.load_optimizer_slots(arrays)
       self._graphs = None
       return
     arrays = dict(np.load(path if path.endswith(".npz") else path + ".npz"))

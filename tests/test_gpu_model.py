@@ -429,11 +429,18 @@ def test_towers_restore_from_tf_checkpoint(tmp_path):
     np.testing.assert_array_equal(state["midn/proba_r_given_c/weights"], heads_before)
   # trained variables out and back in through the V2 format
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5)
+  ex = util_model.make_examples(rng, 1, 48, 40, 5, [5], trainer.model.label_extractor.classes)
+  trainer.train_step(_to_dev(ex), dropout_seed=0)            # makes the Adagrad slots non-trivial
   trainer.global_step = 12
   want = trainer.model.state_dict()
+  want_acc = trainer.model.store.accum.clone()
   prefix = trainer.export_tf_checkpoint(str(tmp_path / "model.ckpt-12"))
   other = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=99)
   other.load_checkpoint(prefix)
   assert other.global_step == 12
   for n, v in other.model.state_dict().items():
     np.testing.assert_array_equal(v, want[n], err_msg=n)
+  assert torch.equal(other.model.store.accum, want_acc)      # `<variable>/Adagrad` slots
+  l1 = trainer.train_step(_to_dev(ex), dropout_seed=1)
+  l2 = other.train_step(_to_dev(ex), dropout_seed=1)
+  assert float(l1["total_loss"]) == float(l2["total_loss"])  # resuming reproduces the next step
