@@ -220,7 +220,11 @@ def main():
   # Timed region: K steps.  The LAST timed step carries a HIP event pair around every
   # convolution / ROI-crop launch (instrumenting every step costs ~0.5 ms/step of extra gaps), so
   # the roofline numbers come from inside the timed region.
+  # one event per step boundary (no host synchronisation): per-step GPU durations for the
+  # p10 / p50 / p90 spread (SURVEY.md §8d "timing method")
+  marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   t0 = time.perf_counter()
+  marks[0].record()
   for i in range(args.steps):
     instrument = (not args.no_kernel_timing) and i == args.steps - 1
     if instrument:
@@ -230,8 +234,12 @@ def main():
     if instrument:
       timer.enabled = False
       trainer.use_graph = args.graph
+    marks[i + 1].record()
   sync()
   elapsed = time.perf_counter() - t0
+  # (the last step carries the per-kernel event pairs and is left out of the spread)
+  per_step = sorted(marks[i].elapsed_time(marks[i + 1])
+                    for i in range(args.steps - (0 if args.no_kernel_timing else 1)))
   timer.enabled = False
   total_loss = float(losses["total_loss"].item())
   if world > 1:
@@ -262,6 +270,10 @@ def main():
                    "launch": "hipGraph replay" if args.graph else "eager"},
         "final_total_loss": total_loss,
     }
+    if per_step:
+      pick = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
+      result["step_ms_gpu"] = {"p10": pick(0.1), "p50": pick(0.5), "p90": pick(0.9),
+                               "steps": len(per_step)}
     # HBM traffic (bytes per kernel launch, averaged over the family) from the committed
     # rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950,
     # + WRITE_SIZE, separate passes; tools/summarize_pmc.py); null when the summary file is

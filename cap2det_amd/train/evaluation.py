@@ -168,6 +168,175 @@ class PascalDetectionEvaluator(object):
     return metrics
 
 
+class CocoDetectionEvaluator(object):
+  """`coco_evaluation.CocoDetectionEvaluator(categories)` of train/predict.py:570-573 (third
+  party: object_detection.metrics.coco_evaluation over pycocotools' COCOeval, iouType 'bbox').
+  Restated protocol (pycocotools cocoeval.py `evaluateImg` / `accumulate` / `summarize`):
+
+    * IoU thresholds 0.50:0.05:0.95, recall thresholds 0:0.01:1, area ranges all / small
+      (< 32^2) / medium / large (>= 96^2) on the ground-truth BOX area (no masks here), maxDets
+      1 / 10 / 100; boxes are [ymin, xmin, ymax, xmax] in pixels, IoU on (w, h) = differences
+      of the corners (no +1);
+    * per image and category: the maxDet best detections by score (stable sort); ground truth
+      sorted non-ignored first (ignored = outside the area range; no crowd boxes in this reader);
+      each detection takes the still-unmatched ground truth of highest IoU >= t, never trading
+      a non-ignored match for an ignored one; a detection matched to an ignored box, or unmatched
+      with its own area outside the range, is ignored;
+    * per category: detections of all images merged by score (mergesort), tp / fp cumulated over
+      the non-ignored ones, precision made non-increasing from the right and sampled at the 101
+      recall thresholds (first index with recall >= r, 0 beyond the last); AP = mean over
+      thresholds / categories with ground truth, AR = mean of the final recall.
+
+  PARITY UNPINNED (pycocotools is not installable here): hand-computed cases in
+  tests/test_evaluation.py."""
+
+  IOU_THRS = np.linspace(0.5, 0.95, 10)
+  REC_THRS = np.linspace(0.0, 1.0, 101)
+  AREAS = [("all", 0.0, 1e10), ("small", 0.0, 32.0 ** 2), ("medium", 32.0 ** 2, 96.0 ** 2),
+           ("large", 96.0 ** 2, 1e10)]
+  MAX_DETS = [1, 10, 100]
+
+  def __init__(self, categories):
+    self._categories = list(categories)
+    self._ids = [c['id'] for c in self._categories]
+    self.clear()
+
+  def clear(self):
+    self._gt = {}
+    self._det = {}
+
+  def add_single_ground_truth_image_info(self, image_id, groundtruth_dict):
+    if image_id in self._gt:
+      return
+    boxes = np.asarray(groundtruth_dict['groundtruth_boxes'], np.float64).reshape(-1, 4)
+    classes = np.asarray(groundtruth_dict['groundtruth_classes']).reshape(-1).astype(np.int64)
+    self._gt[image_id] = (boxes, classes)
+
+  def add_single_detected_image_info(self, image_id, detections_dict):
+    if image_id in self._det:
+      return
+    boxes = np.asarray(detections_dict['detection_boxes'], np.float64).reshape(-1, 4)
+    scores = np.asarray(detections_dict['detection_scores'], np.float64).reshape(-1)
+    classes = np.asarray(detections_dict['detection_classes']).reshape(-1).astype(np.int64)
+    self._det[image_id] = (boxes, scores, classes)
+
+  @staticmethod
+  def _area(b):
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+  def _evaluate_image(self, image_id, cat, lo, hi, max_det):
+    gb, gc = self._gt.get(image_id, (np.zeros((0, 4)), np.zeros(0, np.int64)))
+    db, ds, dc = self._det.get(image_id, (np.zeros((0, 4)), np.zeros(0), np.zeros(0, np.int64)))
+    gb = gb[gc == cat]
+    sel = dc == cat
+    db, ds = db[sel], ds[sel]
+    if len(gb) == 0 and len(db) == 0:
+      return None
+    g_ignore = ~((self._area(gb) >= lo) & (self._area(gb) <= hi))
+    gorder = np.argsort(g_ignore, kind="mergesort")          # non-ignored first
+    gb, g_ignore = gb[gorder], g_ignore[gorder]
+    dorder = np.argsort(-ds, kind="mergesort")[:max_det]
+    db, ds = db[dorder], ds[dorder]
+    ious = iou_matrix(db, gb) if len(db) and len(gb) else np.zeros((len(db), len(gb)))
+    T = len(self.IOU_THRS)
+    gtm = -np.ones((T, len(gb)), np.int64)
+    dtm = -np.ones((T, len(db)), np.int64)
+    dt_ignore = np.zeros((T, len(db)), bool)
+    for ti, t in enumerate(self.IOU_THRS):
+      for d in range(len(db)):
+        best, m = min(t, 1 - 1e-10), -1
+        for g in range(len(gb)):
+          if gtm[ti, g] >= 0:
+            continue
+          if m > -1 and not g_ignore[m] and g_ignore[g]:
+            break
+          if ious[d, g] < best:
+            continue
+          best, m = ious[d, g], g
+        if m == -1:
+          continue
+        dt_ignore[ti, d] = g_ignore[m]
+        dtm[ti, d] = m
+        gtm[ti, m] = d
+    d_out = ~((self._area(db) >= lo) & (self._area(db) <= hi))
+    dt_ignore |= (dtm < 0) & d_out[None, :]
+    return ds, dtm >= 0, dt_ignore, int((~g_ignore).sum())
+
+  def evaluate(self):
+    T, R = len(self.IOU_THRS), len(self.REC_THRS)
+    K, A, M = len(self._ids), len(self.AREAS), len(self.MAX_DETS)
+    precision = -np.ones((T, R, K, A, M))
+    recall = -np.ones((T, K, A, M))
+    images = sorted(set(self._gt) | set(self._det), key=str)
+    for k, cat in enumerate(self._ids):
+      for a, (_, lo, hi) in enumerate(self.AREAS):
+        for mi, md in enumerate(self.MAX_DETS):
+          res = [r for r in (self._evaluate_image(i, cat, lo, hi, md) for i in images) if r]
+          npig = sum(r[3] for r in res)
+          if npig == 0:
+            continue
+          scores = np.concatenate([r[0] for r in res]) if res else np.zeros(0)
+          order = np.argsort(-scores, kind="mergesort")
+          matched = np.concatenate([r[1] for r in res], axis=1)[:, order]
+          ignored = np.concatenate([r[2] for r in res], axis=1)[:, order]
+          tps = np.cumsum(matched & ~ignored, axis=1).astype(np.float64)
+          fps = np.cumsum(~matched & ~ignored, axis=1).astype(np.float64)
+          for ti in range(T):
+            tp, fp = tps[ti], fps[ti]
+            nd = len(tp)
+            rc = tp / npig
+            pr = tp / (fp + tp + np.spacing(1))
+            recall[ti, k, a, mi] = rc[-1] if nd else 0.0
+            q = np.zeros(R)
+            pr = pr.tolist()
+            for i in range(nd - 1, 0, -1):
+              if pr[i] > pr[i - 1]:
+                pr[i - 1] = pr[i]
+            inds = np.searchsorted(rc, self.REC_THRS, side="left")
+            for ri, pi in enumerate(inds):
+              if pi < nd:
+                q[ri] = pr[pi]
+            precision[ti, :, k, a, mi] = q
+
+    def mean_valid(x):
+      x = x[x > -1]
+      return float(x.mean()) if x.size else -1.0
+
+    def ap(iou=None, area=0, md=2):
+      p = precision[:, :, :, area, md]
+      if iou is not None:
+        p = p[np.isclose(self.IOU_THRS, iou)]
+      return mean_valid(p)
+
+    def ar(area=0, md=2):
+      return mean_valid(recall[:, :, area, md])
+
+    metrics = {
+        'DetectionBoxes_Precision/mAP': ap(),
+        'DetectionBoxes_Precision/mAP@.50IOU': ap(0.5),
+        'DetectionBoxes_Precision/mAP@.75IOU': ap(0.75),
+        'DetectionBoxes_Precision/mAP (small)': ap(area=1),
+        'DetectionBoxes_Precision/mAP (medium)': ap(area=2),
+        'DetectionBoxes_Precision/mAP (large)': ap(area=3),
+        'DetectionBoxes_Recall/AR@1': ar(md=0),
+        'DetectionBoxes_Recall/AR@10': ar(md=1),
+        'DetectionBoxes_Recall/AR@100': ar(md=2),
+        'DetectionBoxes_Recall/AR@100 (small)': ar(area=1),
+        'DetectionBoxes_Recall/AR@100 (medium)': ar(area=2),
+        'DetectionBoxes_Recall/AR@100 (large)': ar(area=3),
+    }
+    return metrics
+
+
+def build_evaluators(name, categories, number_of_evaluators):
+  """train/predict.py:565-576: `--evaluator pascal|coco`, one evaluator per OICR iteration."""
+  if name.lower() == 'pascal':
+    return [PascalDetectionEvaluator(categories) for _ in range(max(1, number_of_evaluators))]
+  if name.lower() == 'coco':
+    return [CocoDetectionEvaluator(categories) for _ in range(max(1, number_of_evaluators))]
+  raise ValueError('Invalid evaluator {}.'.format(name))
+
+
 def run_evaluation(model, batches, evaluators, category_to_id, eval_coco_on_voc=False):
   """train/predict.py:328-420: feeds every OICR iteration's detections to its evaluator.
   batches: iterable of example dicts from the reader (evaluation mode).  Returns the list of

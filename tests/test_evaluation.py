@@ -5,6 +5,7 @@ core/training_utils.py:233-308."""
 import os
 
 import numpy as np
+import pytest
 
 from cap2det_amd.train import evaluation as ev
 
@@ -112,3 +113,60 @@ def test_best_checkpoint_bookkeeping(tmp_path):
   assert open(os.path.join(dst, "saved_info.txt")).read() == "300\t0.41000000"
   assert ev.get_best_model_checkpoint(dst).endswith("model.ckpt-300")
   assert ev.save_model_if_it_is_better(400, 0.1, path(300), dst, reverse=True) == (400, 0.1)
+
+
+def test_coco_evaluator_hand_computed_cases():
+  """pycocotools' bbox protocol (train/predict.py:570-573 instantiates CocoDetectionEvaluator):
+  AP over IoU 0.50:0.05:0.95 at 101 recall points, AR@1/10/100, area ranges."""
+  from cap2det_amd.train.evaluation import CocoDetectionEvaluator, build_evaluators
+  cats = [{'id': 1, 'name': 'a'}, {'id': 2, 'name': 'b'}, {'id': 3, 'name': 'never'}]
+
+  # (1) a perfect detection of one large box: everything 1, empty area ranges -1
+  ev = CocoDetectionEvaluator(cats)
+  ev.add_single_ground_truth_image_info('i', {'groundtruth_boxes': [[0, 0, 100, 100]], 'groundtruth_classes': [1]})
+  ev.add_single_detected_image_info('i', {'detection_boxes': [[0, 0, 100, 100]], 'detection_scores': [0.9], 'detection_classes': [1]})
+  m = ev.evaluate()
+  assert m['DetectionBoxes_Precision/mAP'] == pytest.approx(1.0)
+  assert m['DetectionBoxes_Precision/mAP (large)'] == pytest.approx(1.0)
+  assert m['DetectionBoxes_Precision/mAP (small)'] == -1.0 and m['DetectionBoxes_Precision/mAP (medium)'] == -1.0
+  assert m['DetectionBoxes_Recall/AR@1'] == pytest.approx(1.0)
+
+  # (2) IoU 0.78: a hit for the six thresholds 0.50 .. 0.75 only
+  ev = CocoDetectionEvaluator(cats)
+  ev.add_single_ground_truth_image_info('i', {'groundtruth_boxes': [[0, 0, 100, 100]], 'groundtruth_classes': [2]})
+  ev.add_single_detected_image_info('i', {'detection_boxes': [[0, 0, 100, 78]], 'detection_scores': [0.9], 'detection_classes': [2]})
+  m = ev.evaluate()
+  assert m['DetectionBoxes_Precision/mAP'] == pytest.approx(0.6)
+  assert m['DetectionBoxes_Precision/mAP@.50IOU'] == pytest.approx(1.0)
+  assert m['DetectionBoxes_Precision/mAP@.75IOU'] == pytest.approx(1.0)
+  assert m['DetectionBoxes_Recall/AR@100'] == pytest.approx(0.6)
+
+  # (3) TP, FP, TP over two images (merged by score) + a category that only has detections
+  ev = build_evaluators('coco', cats, 1)[0]
+  ev.add_single_ground_truth_image_info('i', {'groundtruth_boxes': [[0, 0, 50, 50]], 'groundtruth_classes': [1]})
+  ev.add_single_ground_truth_image_info('j', {'groundtruth_boxes': [[10, 10, 90, 60]], 'groundtruth_classes': [1]})
+  ev.add_single_detected_image_info('i', {'detection_boxes': [[0, 0, 50, 50], [200, 200, 260, 260]],
+                                          'detection_scores': [0.9, 0.8], 'detection_classes': [1, 1]})
+  ev.add_single_detected_image_info('j', {'detection_boxes': [[10, 10, 90, 60], [0, 0, 5, 5]],
+                                          'detection_scores': [0.7, 0.95], 'detection_classes': [1, 2]})
+  m = ev.evaluate()
+  want = (51 * 1.0 + 50 * (2.0 / 3.0)) / 101
+  assert m['DetectionBoxes_Precision/mAP'] == pytest.approx(want, abs=1e-9)
+  assert m['DetectionBoxes_Precision/mAP@.50IOU'] == pytest.approx(want, abs=1e-9)
+  assert m['DetectionBoxes_Recall/AR@1'] == pytest.approx(1.0)     # per IMAGE: each image's best detection hits
+  assert m['DetectionBoxes_Recall/AR@100'] == pytest.approx(1.0)
+  # gt areas 2500 / 4000: medium; the 60x60 false positive is medium too, the 5x5 one has no category gt
+  assert m['DetectionBoxes_Precision/mAP (medium)'] == pytest.approx(want, abs=1e-9)
+  assert m['DetectionBoxes_Precision/mAP (large)'] == -1.0
+
+  # (4) a detection never trades a non-ignored match for an ignored (out-of-range) one, and one
+  # ground truth is claimed once: the second, lower-scoring duplicate is a false positive
+  ev = CocoDetectionEvaluator(cats[:1])
+  ev.add_single_ground_truth_image_info('i', {'groundtruth_boxes': [[0, 0, 40, 40]], 'groundtruth_classes': [1]})
+  ev.add_single_detected_image_info('i', {'detection_boxes': [[0, 0, 40, 40], [0, 0, 40, 38]],
+                                          'detection_scores': [0.5, 0.9], 'detection_classes': [1, 1]})
+  m = ev.evaluate()
+  # at t <= 0.95 the 0.9-score box (IoU 0.95) claims the gt first -> [TP, FP]; AP = 1 at those t
+  assert m['DetectionBoxes_Precision/mAP@.50IOU'] == pytest.approx(1.0)
+  with pytest.raises(ValueError):
+    build_evaluators('nope', cats, 1)
