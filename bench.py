@@ -333,7 +333,7 @@ def main():
       if rc:
         gbs = rc["work"] / (rc["ms"] * 1e-3) / 1e9
         result["roofline_roi_crop"] = {
-            "kernel": "roi_crop_pool_fwd_kernel (crop_and_resize 14x14 fused with 2x2 max-pool)",
+            "kernel": "roi_crop_pool2_fwd_stream_kernel (crop_and_resize 14x14 fused with 2x2 max-pool, source columns streamed through registers)",
             "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": gbs / PEAK_HBM_GBPS, "traffic": traffic.get("roi_crop_pool_fwd", {}).get("hbm_bytes_per_launch"),
             "avg_launch_ms": rc["ms"] / rc["launches"],

@@ -8,6 +8,7 @@
 //
 // Layout: feature map NHWC fp32, channels vectorised as float4 (16 B/lane, coalesced).
 // One workgroup per ROI; the 2*crop sampling descriptors of the ROI live in LDS.
+#include <stdlib.h>
 #include "c2d_common.h"
 
 namespace {
@@ -136,6 +137,92 @@ __global__ __launch_bounds__(256) void roi_crop_pool_fwd_kernel(
     }
     c2d_st4(out + (obase + idx) * 4, best);
     if (argmax) argmax[obase + idx] = arg;
+  }
+}
+
+// Column-streaming form of the fused crop + 2x2/stride-2 max-pool (the shipped configuration).
+// The generic kernel above fetches 16 taps per pooled float4 and is bound by the L1 / address
+// path (64 B/clk/CU), not by HBM.  Here a thread owns one (pooled row, channel quad) and walks
+// the 14 crop columns left to right keeping the four source rows of the CURRENT and NEXT source
+// column in registers: a source column is fetched once per pooled row however many crop columns
+// interpolate from it (boxes narrower than 14 feature pixels — three quarters of Selective-Search
+// style proposals — sample every column 2-8 times).  Which columns are new is a property of the
+// box alone, so those branches are uniform over the workgroup.  Same operands, same lerp order,
+// same tie rule as the generic kernel: bit-identical outputs.
+template <typename TO>
+__global__ __launch_bounds__(256) void roi_crop_pool2_fwd_stream_kernel(
+    const float4* __restrict__ feat, const float* __restrict__ boxes,
+    const int32_t* __restrict__ box_ind, TO* __restrict__ out,
+    uchar4* __restrict__ argmax, int batch, int hf, int wf, int d4n, int crop, int pout) {
+  __shared__ SampleAxis ys[kMaxCrop], xs[kMaxCrop];
+  const int roi = blockIdx.x;
+  const int b = box_ind[roi];
+  if (b < 0 || b >= batch) return;
+  load_axes(ys, xs, boxes, roi, hf, wf, crop);
+  const float4* img = feat + (size_t)b * hf * wf * d4n;
+  const size_t obase = (size_t)roi * pout * pout * d4n;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int total = pout * d4n;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int d4 = idx % d4n;
+    const int py = idx / d4n;
+    const SampleAxis y0 = ys[2 * py], y1 = ys[2 * py + 1];
+    // row base pointers of the four source rows (clamped when the crop row is out of range: its
+    // samples are zeroed below, the loads only need a valid address)
+    const float4* r0 = img + (size_t)max(y0.lo, 0) * wf * d4n + d4;
+    const float4* r1 = img + (size_t)max(y0.hi, 0) * wf * d4n + d4;
+    const float4* r2 = img + (size_t)max(y1.lo, 0) * wf * d4n + d4;
+    const float4* r3 = img + (size_t)max(y1.hi, 0) * wf * d4n + d4;
+    float4 a0 = zero, a1 = zero, a2 = zero, a3 = zero;   // rows at source column acol
+    float4 b0 = zero, b1 = zero, b2 = zero, b3 = zero;   // rows at source column bcol
+    int acol = -1, bcol = -1;
+    float4 c0 = zero, c2 = zero;
+    for (int x = 0; x < 2 * pout; ++x) {
+      const SampleAxis sx = xs[x];                        // uniform over the workgroup
+      float4 v0 = zero, v1 = zero;
+      if (sx.lo >= 0) {
+        if (acol != sx.lo) {
+          if (bcol == sx.lo) { a0 = b0; a1 = b1; a2 = b2; a3 = b3; }
+          else {
+            const size_t o = (size_t)sx.lo * d4n;
+            a0 = r0[o]; a1 = r1[o]; a2 = r2[o]; a3 = r3[o];
+          }
+          acol = sx.lo;
+        }
+        if (bcol != sx.hi) {
+          if (sx.hi == acol) { b0 = a0; b1 = a1; b2 = a2; b3 = a3; }
+          else {
+            const size_t o = (size_t)sx.hi * d4n;
+            b0 = r0[o]; b1 = r1[o]; b2 = r2[o]; b3 = r3[o];
+          }
+          bcol = sx.hi;
+        }
+        if (y0.lo >= 0) v0 = lerp4(lerp4(a0, b0, sx.lerp), lerp4(a1, b1, sx.lerp), y0.lerp);
+        if (y1.lo >= 0) v1 = lerp4(lerp4(a2, b2, sx.lerp), lerp4(a3, b3, sx.lerp), y1.lerp);
+      }
+      if ((x & 1) == 0) {
+        c0 = v0; c2 = v1;                                 // window samples k = 0 and k = 2
+      } else {
+        // k = 0, 1, 2, 3 in order; strict '>' keeps the FIRST maximum (TF MaxPoolGrad tie rule)
+        float4 best = c0;
+        uchar4 arg = make_uchar4(0, 0, 0, 0);
+        if (v0.x > best.x) { best.x = v0.x; arg.x = 1; }
+        if (v0.y > best.y) { best.y = v0.y; arg.y = 1; }
+        if (v0.z > best.z) { best.z = v0.z; arg.z = 1; }
+        if (v0.w > best.w) { best.w = v0.w; arg.w = 1; }
+        if (c2.x > best.x) { best.x = c2.x; arg.x = 2; }
+        if (c2.y > best.y) { best.y = c2.y; arg.y = 2; }
+        if (c2.z > best.z) { best.z = c2.z; arg.z = 2; }
+        if (c2.w > best.w) { best.w = c2.w; arg.w = 2; }
+        if (v1.x > best.x) { best.x = v1.x; arg.x = 3; }
+        if (v1.y > best.y) { best.y = v1.y; arg.y = 3; }
+        if (v1.z > best.z) { best.z = v1.z; arg.z = 3; }
+        if (v1.w > best.w) { best.w = v1.w; arg.w = 3; }
+        const size_t o = obase + (size_t)(py * pout + (x >> 1)) * d4n + d4;
+        c2d_st4(out + o * 4, best);
+        if (argmax) argmax[o] = arg;
+      }
+    }
   }
 }
 
@@ -435,6 +522,14 @@ __global__ __launch_bounds__(256) void roi_bwd_sum_parts_kernel(const float4* __
 
 }  // namespace
 
+// 2x2 / stride-2 pooling over an even crop: the column-streaming kernel (C2D_TUNE=1
+// C2D_CROP_STREAM=0 keeps the generic one, for A/B timing).
+static bool crop_stream_form(int crop, int pool_k, int pool_s, int pout) {
+  static const bool off = getenv("C2D_TUNE") && getenv("C2D_CROP_STREAM") &&
+                          getenv("C2D_CROP_STREAM")[0] == '0';
+  return !off && pool_k == 2 && pool_s == 2 && crop == 2 * pout;
+}
+
 extern "C" int c2d_crop_and_resize_fwd(const float* feat, const float* boxes,
                                        const int32_t* box_ind, float* out, int batch, int hf,
                                        int wf, int depth, int num_boxes, int crop,
@@ -459,9 +554,14 @@ extern "C" int c2d_roi_crop_pool_fwd(const float* feat, const float* boxes,
   C2D_CHECK_ARG(pool_k > 0 && pool_s > 0 && pool_k <= crop && pool_k * pool_k <= 255);
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
-  hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<float>, dim3(num_boxes), dim3(256), 0,
-                     (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
-                     (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pool_k, pool_s, pout);
+  if (crop_stream_form(crop, pool_k, pool_s, pout))
+    hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<float>, dim3(num_boxes), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout);
+  else
+    hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<float>, dim3(num_boxes), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pool_k, pool_s, pout);
   return c2d_launch_status();
 }
 
@@ -475,9 +575,14 @@ extern "C" int c2d_roi_crop_pool_fwd_bf16(const float* feat, const float* boxes,
   C2D_CHECK_ARG(pool_k > 0 && pool_s > 0 && pool_k <= crop && pool_k * pool_k <= 255);
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
-  hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<c2d_bf16>, dim3(num_boxes), dim3(256), 0,
-                     (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,
-                     (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pool_k, pool_s, pout);
+  if (crop_stream_form(crop, pool_k, pool_s, pout))
+    hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<c2d_bf16>, dim3(num_boxes), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout);
+  else
+    hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<c2d_bf16>, dim3(num_boxes), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pool_k, pool_s, pout);
   return c2d_launch_status();
 }
 

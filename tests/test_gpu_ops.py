@@ -450,3 +450,27 @@ def test_conv_fwd_grouped_matches_single_calls():
       ops.conv_fwd(*(args[:6] + [y2] + args[7:]))
       assert torch.equal(c[6], y2), (n, hw, args[13:17])
       assert float(y2[:, :4].max()) == -3.0
+
+
+@pytest.mark.parametrize("hf,wf,d,n,crop,pk,ps", [(32, 32, 64, 300, 14, 2, 2), (9, 33, 16, 60, 14, 2, 2),
+                                                   (20, 20, 32, 50, 8, 2, 2), (16, 16, 32, 40, 9, 3, 3),
+                                                   (16, 16, 32, 40, 14, 2, 1)])
+def test_roi_crop_pool_forms_match_oracle(hf, wf, d, n, crop, pk, ps):
+  """The column-streaming 2x2/stride-2 kernel (first three cases) and the generic kernel (other
+  poolings) against crop_and_resize + max_pool of the oracle, bit for bit incl. the arg-max."""
+  from cap2det_amd import hip_ops as ops
+  rng = np.random.default_rng(hf * 100 + n)
+  feat = np.maximum(rng.standard_normal((2, hf, wf, d)), 0).astype(np.float32)
+  feat[0, 3:6] = 0.5                                  # ties inside pooling windows
+  boxes = np.concatenate([_edge_boxes(rng, n // 2), util_boxes(rng, n - n // 2)])
+  ind = rng.integers(0, 2, n).astype(np.int32)
+  c = ref_ops.crop_and_resize(feat, boxes, ind, crop)
+  want, want_arg = ref_ops.max_pool(c, pk, ps, "VALID")
+  out, arg = ops.roi_crop_pool_fwd(_t(feat), _t(boxes), _t(ind), crop, pk, ps)
+  np.testing.assert_array_equal(_n(out), want)
+  np.testing.assert_array_equal(_n(arg), want_arg)
+
+
+def util_boxes(rng, n):
+  from tests import util_model
+  return util_model.synthetic_boxes(rng, n)
