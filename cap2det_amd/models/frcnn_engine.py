@@ -15,6 +15,7 @@ in one flat parameter buffer with a mirrored flat gradient buffer (the RCCL all-
 and a mirrored Adagrad accumulator.
 """
 import math
+import os
 
 import torch
 
@@ -299,6 +300,8 @@ class Net(object):
     self.cin = cin
     self._plans = {}
 
+  side = None   # torch.cuda.Stream for the filter gradients, set by FrcnnEngine (eager mode only)
+
   def _depth(self, d):
     return max(int(d * self.dm), 16)
 
@@ -451,6 +454,12 @@ class Net(object):
       return
     dev = self.store.device
     plan["dc"] = torch.empty(plan["scratch_elems"], device=dev, dtype=self.dtype)
+    # filter gradients on a side stream (see _conv_bwd): a second scratch so that the next layer's
+    # BN/ReLU backward does not overwrite a dC the side stream is still reading
+    plan["dc_alt"] = (torch.empty(plan["scratch_elems"], device=dev, dtype=self.dtype)
+                      if self.side is not None else None)
+    plan["dc_events"] = [None, None]
+    plan["dc_slot"] = 0
     steps = plan["steps"]
     for i in range(first_idx, len(steps)):
       st = steps[i]
@@ -524,6 +533,10 @@ class Net(object):
         gx = dx_in
       x = st["x"] if st["x"] is not None else x_in
       self._bwd_step(plan, st, x, gx, False)
+    if plan.get("side_pending"):
+      torch.cuda.current_stream().wait_stream(self.side)      # join: gradients complete below here
+      plan["side_pending"] = False
+      plan["dc_events"] = [None, None]
     if plan["bn_num"]:
       ops.bn_partials_reduce_batched(plan["bn_desc"], plan["bn_num"], plan["bn_chunks"],
                                      plan["bn_ws"], self.store.grads)
@@ -533,8 +546,18 @@ class Net(object):
     L = st["layer"]
     gy, y = st["gy"], st["y"]
     rows = st["n"] * st["oh"] * st["ow"]
+    side = self.side if (L.trainable and plan.get("dc_alt") is not None) else None
+    slot = None
     if dc is None:
-      dc = plan["dc"][:rows * L.cout].view(rows, L.cout)
+      buf = plan["dc"]
+      if side is not None:
+        slot = plan["dc_slot"]
+        plan["dc_slot"] ^= 1
+        buf = plan["dc"] if slot == 0 else plan["dc_alt"]
+        if plan["dc_events"][slot] is not None:       # the side stream's last reader of this scratch
+          torch.cuda.current_stream().wait_event(plan["dc_events"][slot])
+          plan["dc_events"][slot] = None
+      dc = buf[:rows * L.cout].view(rows, L.cout)
     g = self.store.grad
     gamma = self.store.var.get(L.name + "/BatchNorm/gamma")
     beta = self.store.var[L.name + "/BatchNorm/beta"]
@@ -551,7 +574,20 @@ class Net(object):
                       g[L.name + "/BatchNorm/beta"] if tr else None,
                       g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
                       rows, L.cout)
-    if tr:
+    if tr and side is not None:
+      # dW only meets the rest of the step at the all-reduce / optimiser: it runs on a side stream
+      # beside the input-gradient GEMM of the same layer, each filling the other's partial rounds
+      ready = torch.cuda.Event()
+      ready.record()
+      side.wait_event(ready)
+      with torch.cuda.stream(side):
+        ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
+                       st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+        if slot is not None:
+          plan["dc_events"][slot] = torch.cuda.Event()
+          plan["dc_events"][slot].record()
+      plan["side_pending"] = True
+    elif tr:
       ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
                      st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
     if gx is not None:
@@ -650,6 +686,11 @@ class FrcnnEngine(object):
     self.second = Net(store, self.stats, SECOND_STAGE, SECOND_SCOPE, self.first.cout, bn_scale, dm,
                       dtype=act_dtype)
     self.feature_dims = self.second.cout
+    # Second-stage filter gradients run on a side stream beside the input-gradient GEMMs (Net.
+    # _conv_bwd): -4 % step time.  C2D_WGRAD_SIDE_STREAM=0 keeps everything on one stream (per-
+    # kernel durations are then separable: profiles/README.md); hipGraph capture turns it off too.
+    if os.environ.get("C2D_WGRAD_SIDE_STREAM", "1") != "0" and torch.device(store.device).type == "cuda":
+      self.second.side = torch.cuda.Stream(device=store.device)
     self._shape_cache = {}
     self.first_trainable_idx = None
 

@@ -202,6 +202,7 @@ class Trainer(object):
     lo, hi = self.bucket
     lr = self.learning_rate()
     labels = model.label_extractor.extract_labels(examples)      # host lookup + small kernel
+    model.engine.second.side = None        # one stream inside the captured graph
     key = (tuple(examples[F.image].shape), tuple(examples[F.proposals].shape), lr)
     if self._graphs is None or self._graphs["key"] != key:
       # eager warm-up on this shape (allocates every buffer), then capture
