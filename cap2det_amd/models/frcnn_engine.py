@@ -405,8 +405,9 @@ class Net(object):
     return plan
 
   # -- forward ----------------------------------------------------------------------
-  def forward(self, plan, x_in):
-    for st in plan["steps"]:
+  def forward(self, plan, x_in, first=0, last=None):
+    """Runs steps[first:last] (default: all)."""
+    for st in plan["steps"][first:last]:
       self._fwd_step(st, x_in)
     return plan["out"]
 
@@ -431,7 +432,7 @@ class Net(object):
       for li, level in enumerate(st["levels"]):
         convs = [b for b in level if b["kind"] == "conv"]
         if len(convs) >= 2:
-          key = (li, x.t.data_ptr(), x.ld, x.off)
+          key = (li, x.t.data_ptr(), x.ld, x.off, st["y"].t.data_ptr())
           group = st["groups"].get(key)
           if group is None:
             calls = []
@@ -689,8 +690,10 @@ class FrcnnEngine(object):
     # Second-stage filter gradients run on a side stream beside the input-gradient GEMMs (Net.
     # _conv_bwd): -4 % step time.  C2D_WGRAD_SIDE_STREAM=0 keeps everything on one stream (per-
     # kernel durations are then separable: profiles/README.md); hipGraph capture turns it off too.
+    self.prefetch_stream = None
     if os.environ.get("C2D_WGRAD_SIDE_STREAM", "1") != "0" and torch.device(store.device).type == "cuda":
       self.second.side = torch.cuda.Stream(device=store.device)
+      self.prefetch_stream = torch.cuda.Stream(device=store.device)
     self._shape_cache = {}
     self.first_trainable_idx = None
 
@@ -746,6 +749,7 @@ class FrcnnEngine(object):
     """Re-derives every (trainable) layer's kernel operands with two batched launches."""
     if not only_trainable:
       self._refresh_stem()
+      self.invalidate_prefetch()             # frozen weights may have changed under a look-ahead
     key = (bool(only_trainable), tuple(L.name for L in self._layers(only_trainable)))
     if self._tables.get("key") != key:
       self._tables = dict(key=key, t=self._build_tables(only_trainable))
@@ -790,6 +794,7 @@ class FrcnnEngine(object):
         idx = i
         break
     self.first_trainable_idx = idx
+    self.invalidate_prefetch()
 
   # -- shapes -----------------------------------------------------------------------
   def _buffers(self, b, h, w, n, training):
@@ -820,19 +825,95 @@ class FrcnnEngine(object):
     self._shape_cache[key] = bufs
     return bufs
 
-  # -- forward / backward -------------------------------------------------------------
-  def forward(self, image, proposals, is_training, dropout_seed=None, dropout_mask=None):
-    """image [B,H,W,3] fp32 0..255; proposals [B,N,4].  Returns (features [B*N, D], ctx)."""
+  # -- frozen prefix of the first stage, one image ahead ----------------------------------
+  def _prefix_len(self, bufs):
+    """Steps of plan1 in front of the first trainable layer (all of them when the whole first
+    stage is frozen): they depend on the image only, never on the optimiser."""
+    nsteps = len(bufs["plan1"]["steps"])
+    return nsteps if self.first_trainable_idx is None else self.first_trainable_idx
+
+  @staticmethod
+  def _output_refs(st):
+    refs = [st["y"]]
+    if st["kind"] == "block":
+      refs += [bsteps[-1]["y"] for bsteps in st["branches"]]
+    return refs
+
+  def _run_prefix(self, bufs, image, upto):
     b, h, w, _ = image.shape
-    n = proposals.shape[1]
-    bufs = self._buffers(b, h, w, n, is_training)
     ops.preprocess_pad4(image, bufs["x4"])
     ops.im2col4(bufs["x4"], bufs["cols"], b, h, w, 7, 7, 2, self.stem_kpad)
     st = bufs["stem"]
     ops.conv_fwd(bufs["cols"], self.stem_kpad, 0, self.stem_wt, self.stem_scale, self.stem_shift,
                  st.t, st.ld, 0, b * bufs["sh"] * bufs["sw"], 1, 1, self.stem_kpad, self.stem_cout,
                  1, 1, 1, True)
-    feat = self.first.forward(bufs["plan1"], st)
+    self.first.forward(bufs["plan1"], st, 0, upto)
+
+  def prefetch_first_stage(self, image, num_proposals, is_training=True):
+    """Starts the frozen part of the first stage for the NEXT step's image on a side stream, so
+    that its ~50 small, launch-latency-bound kernels run under the current step's GEMMs instead
+    of in front of the next one's (a data-loader style look-ahead: the same work per step, one
+    step earlier).  Its output goes to an alternate buffer that `forward` swaps in when it is
+    called with the same image tensor; anything else simply recomputes."""
+    if self.prefetch_stream is None:
+      return
+    b, h, w, _ = image.shape
+    bufs = self._shape_cache.get((b, h, w, num_proposals, is_training))
+    if bufs is None or "prefix_free" not in bufs:
+      return                                   # first step of this shape: nothing to overlap yet
+    upto = self._prefix_len(bufs)
+    if upto == 0:
+      return
+    last = bufs["plan1"]["steps"][upto - 1]
+    refs = self._output_refs(last)
+    if "prefix_alt" not in bufs:
+      bufs["prefix_alt"] = torch.empty_like(last["y"].t)
+    cur, alt = last["y"].t, bufs["prefix_alt"]
+    stream = self.prefetch_stream
+    stream.wait_event(bufs["prefix_free"])     # the prefix's internal buffers are idle again
+    for r in refs:
+      r.t = alt
+    try:
+      with torch.cuda.stream(stream):
+        self._run_prefix(bufs, image, upto)
+        done = torch.cuda.Event()
+        done.record()
+    finally:
+      for r in refs:
+        r.t = cur                              # the current step still reads its own features
+    bufs["prefetched"] = (image.data_ptr(), image._version, done)
+
+  def invalidate_prefetch(self):
+    for bufs in self._shape_cache.values():
+      pre = bufs.pop("prefetched", None)
+      if pre is not None:                      # later work must still come after the look-ahead
+        torch.cuda.current_stream().wait_event(pre[2])
+
+  # -- forward / backward -------------------------------------------------------------
+  def forward(self, image, proposals, is_training, dropout_seed=None, dropout_mask=None):
+    """image [B,H,W,3] fp32 0..255; proposals [B,N,4].  Returns (features [B*N, D], ctx)."""
+    b, h, w, _ = image.shape
+    n = proposals.shape[1]
+    bufs = self._buffers(b, h, w, n, is_training)
+    upto = self._prefix_len(bufs)
+    pre = bufs.pop("prefetched", None)
+    if pre is not None and pre[0] == image.data_ptr() and pre[1] == image._version and upto > 0:
+      # the look-ahead of the previous step computed this image's prefix: swap its buffer in
+      last = bufs["plan1"]["steps"][upto - 1]
+      cur = last["y"].t
+      for r in self._output_refs(last):
+        r.t = bufs["prefix_alt"]
+      bufs["prefix_alt"] = cur
+      torch.cuda.current_stream().wait_event(pre[2])
+    else:
+      if pre is not None:
+        torch.cuda.current_stream().wait_event(pre[2])   # (unused look-ahead: just order after it)
+      self._run_prefix(bufs, image, upto)
+    if self.prefetch_stream is not None:
+      bufs["prefix_free"] = torch.cuda.Event()
+      bufs["prefix_free"].record()
+    st = bufs["stem"]
+    feat = self.first.forward(bufs["plan1"], st, upto, None)
     boxes = proposals.reshape(-1, 4)
     feat4 = feat.t.view(b, bufs["fh"], bufs["fw"], feat.c)
     ops.roi_crop_pool_fwd(feat4, boxes, bufs["box_ind"], self.crop, self.pool_k, self.pool_s,

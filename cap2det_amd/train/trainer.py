@@ -162,11 +162,16 @@ class Trainer(object):
       lr = exponential_decay(lr, self.global_step, d.decay_steps, d.decay_rate, d.staircase)
     return lr
 
-  def _forward_backward(self, examples, after_second_stage=None, **kwargs):
+  def _forward_backward(self, examples, after_second_stage=None, prefetch=None, **kwargs):
     model, store = self.model, self.model.store
     lo, hi = self.bucket
     store.grads[lo:hi].zero_()
     predictions = model.build_prediction(examples, **kwargs)
+    if prefetch is not None:
+      # look-ahead: the frozen first-stage layers of the NEXT batch's image run on a side stream
+      # under this step's second stage (FrcnnEngine.prefetch_first_stage)
+      from cap2det_amd.core.standard_fields import InputDataFields as F
+      model.engine.prefetch_first_stage(prefetch[F.image], prefetch[F.proposals].shape[1], True)
     losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
     losses['regularization_loss'] = model.regularization_loss()
     model.backward(after_second_stage)
@@ -179,11 +184,14 @@ class Trainer(object):
                        m, scale)
     self.model.refresh(only_trainable=True)
 
-  def train_step(self, examples, **kwargs):
+  def train_step(self, examples, prefetch=None, **kwargs):
     """One synchronous step; returns {loss name: 0-d device tensor} (+ 'total_loss',
-    'regularization_loss').  No host synchronisation happens inside."""
+    'regularization_loss').  No host synchronisation happens inside.  `prefetch`: the NEXT
+    step's examples, when the caller already has them (an input pipeline always does): their
+    frozen first-stage layers are computed under this step's kernels."""
     if self.use_graph and "dropout_mask" not in kwargs:
       return self._graph_step(examples, **kwargs)
+    kwargs["prefetch"] = prefetch
     store = self.model.store
     lo, hi = self.bucket
     reducer = data_parallel.OverlappedReducer(store.grads[lo:hi], self._tail_split)
@@ -203,6 +211,7 @@ class Trainer(object):
     lr = self.learning_rate()
     labels = model.label_extractor.extract_labels(examples)      # host lookup + small kernel
     model.engine.second.side = None        # one stream inside the captured graph
+    model.engine.prefetch_stream = None
     key = (tuple(examples[F.image].shape), tuple(examples[F.proposals].shape), lr)
     if self._graphs is None or self._graphs["key"] != key:
       # eager warm-up on this shape (allocates every buffer), then capture

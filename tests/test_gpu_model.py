@@ -444,3 +444,36 @@ def test_towers_restore_from_tf_checkpoint(tmp_path):
   l1 = trainer.train_step(_to_dev(ex), dropout_seed=1)
   l2 = other.train_step(_to_dev(ex), dropout_seed=1)
   assert float(l1["total_loss"]) == float(l2["total_loss"])  # resuming reproduces the next step
+
+
+def test_first_stage_lookahead_is_neutral():
+  """Trainer.train_step(examples, prefetch=next_examples): the frozen first-stage layers of the
+  next image run one step early on a side stream.  Same losses and variables as the plain
+  sequence of steps — with matching, mismatching and absent look-aheads — up to the summation
+  order of the fp32 filter-gradient atomics (two plain runs differ by as much; a look-ahead that
+  was wrongly used would change the losses in the first digit)."""
+  from cap2det_amd.train.trainer import Trainer
+  pipeline = util_model.load_pipeline()
+  rng = np.random.default_rng(5)
+  classes = None
+  runs = []
+  for mode in ("plain", "lookahead"):
+    tr = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=3)
+    classes = tr.model.label_extractor.classes
+    r = np.random.default_rng(11)
+    batches = [_to_dev(util_model.make_examples(r, 1, 64, 48, 6, [6], classes)) for _ in range(4)]
+    losses = []
+    for i, ex in enumerate(batches):
+      nxt = None
+      if mode == "lookahead":
+        # step 0 -> correct next batch, step 1 -> a WRONG prediction of the next batch (must be
+        # ignored), step 2 -> correct, step 3 -> none
+        nxt = [batches[1], batches[0], batches[3], None][i]
+      out = tr.train_step(ex, dropout_seed=i, prefetch=nxt)
+      losses.append(float(out["total_loss"]))
+    torch.cuda.synchronize()
+    runs.append((losses, tr.model.state_dict()))
+  assert runs[0][0][0] == runs[1][0][0]                      # first step: identical inputs, bitwise
+  np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=2e-6)
+  for n, v in runs[0][1].items():
+    np.testing.assert_allclose(v, runs[1][1][n], rtol=1e-4, atol=2e-6, err_msg=n)
