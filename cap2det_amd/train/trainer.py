@@ -204,6 +204,26 @@ class Trainer(object):
     return losses
 
   # -- hipGraph path ------------------------------------------------------------------
+  def train(self, batches, max_steps=None, save_dir=None, save_every=None, log=None):
+    """train/trainer.py:210-235 (`tf.estimator.train_and_evaluate`'s training half): consumes an
+    iterable of example dicts (e.g. `cap2det_reader.get_input_fn(...)()`) until it ends or
+    `train_config.max_steps` / `max_steps` is reached, always holding ONE batch of look-ahead
+    for `train_step(prefetch=...)`; optional periodic checkpoints.  Returns the last losses."""
+    limit = max_steps if max_steps is not None else (self.train_config.max_steps or None)
+    it = iter(batches)
+    cur = next(it, None)
+    losses = None
+    while cur is not None and (limit is None or self.global_step < limit):
+      nxt = next(it, None)
+      last = limit is not None and self.global_step + 1 >= limit
+      losses = self.train_step(cur, prefetch=None if last else nxt)
+      if log is not None:
+        log(self.global_step, losses)
+      if save_dir and save_every and self.global_step % save_every == 0:
+        self.save_checkpoint(save_dir)
+      cur = nxt
+    return losses
+
   def _graph_step(self, examples, dropout_seed=None, **kwargs):
     from cap2det_amd.core.standard_fields import InputDataFields as F
     model, store = self.model, self.model.store

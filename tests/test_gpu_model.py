@@ -4,6 +4,8 @@ plugin API) against the float64 numpy oracle on identical seeded inputs.
 Tolerance: proposal-score tensors within 1e-4 absolute (BASELINE.json north_star); losses
 1e-4 relative; gradients / updated variables 5e-4 of the tensor's max magnitude (fp32 MFMA
 accumulation order and fp32 atomics differ from a float64 sum)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -477,3 +479,17 @@ def test_first_stage_lookahead_is_neutral():
   np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=2e-6)
   for n, v in runs[0][1].items():
     np.testing.assert_allclose(v, runs[1][1][n], rtol=1e-4, atol=2e-6, err_msg=n)
+
+
+def test_trainer_train_loop_with_lookahead(tmp_path):
+  from cap2det_amd.train.trainer import Trainer
+  pipeline = util_model.load_pipeline()
+  tr = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=3)
+  r = np.random.default_rng(2)
+  classes = tr.model.label_extractor.classes
+  batches = [_to_dev(util_model.make_examples(r, 1, 64, 48, 6, [6], classes)) for _ in range(5)]
+  seen = []
+  losses = tr.train(iter(batches), max_steps=4, save_dir=str(tmp_path), save_every=2,
+                    log=lambda step, l: seen.append(step))
+  assert tr.global_step == 4 and seen == [1, 2, 3, 4] and np.isfinite(float(losses["total_loss"]))
+  assert sorted(os.listdir(str(tmp_path))) == ["model.ckpt-2.npz", "model.ckpt-4.npz"]
