@@ -33,6 +33,41 @@ def _read_lines(path):
     return [line.strip('\n') for line in fid.readlines()]
 
 
+class _PinnedRing(object):
+  """Host -> device copies of the small id arrays without a host synchronisation: a pageable
+  `tensor.to(device)` makes the host wait for every kernel already queued (the whole forward pass,
+  when the labels are looked up in build_loss), after which the GPU idles while the host catches
+  up.  Eight pinned staging buffers are recycled; a slot is reused only after the copy that last
+  used it has completed."""
+
+  def __init__(self, slots=8):
+    self._slots = [None] * slots
+    self._events = [None] * slots
+    self._next = 0
+
+  def to_device(self, array, device):
+    if torch.device(device).type != "cuda":
+      return torch.from_numpy(array).to(device)
+    i = self._next
+    self._next = (i + 1) % len(self._slots)
+    if self._events[i] is not None:
+      self._events[i].synchronize()
+    n = array.size
+    buf = self._slots[i]
+    if buf is None or buf.numel() < n or buf.dtype != torch.from_numpy(array).dtype:
+      buf = torch.empty(max(n, 1024), dtype=torch.from_numpy(array).dtype).pin_memory()
+      self._slots[i] = buf
+    view = buf[:n].view(array.shape)
+    view.copy_(torch.from_numpy(array))
+    out = view.to(device, non_blocking=True)
+    self._events[i] = torch.cuda.Event()
+    self._events[i].record()
+    return out
+
+
+_ring = _PinnedRing()
+
+
 def tokens_to_ids(texts, table, oov, device, min_tokens=0):
   """Host side of `HashTable.lookup` / `index_table_from_tensor`: [B][T] strings (ragged rows
   are padded with OOV, like the reference's '' padding) -> int32 [B, T] device tensor."""
@@ -46,7 +81,7 @@ def tokens_to_ids(texts, table, oov, device, min_tokens=0):
       if isinstance(tok, bytes):
         tok = tok.decode("utf-8")
       ids[b, i] = table.get(tok, oov)
-  return torch.from_numpy(ids).to(device)
+  return _ring.to_device(ids, device)
 
 
 def _match_labels(class_texts, table, num_classes, device):
