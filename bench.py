@@ -277,7 +277,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: voc07_groundtruth (Inception-V2, 20 classes, OICR x3, "
                                "Mixed_4e + second stage + heads trainable), 1 image 500x500x3 per GPU, "
-                               "2000 proposals, fp32, Adagrad; fwd+loss+bwd+optimizer"
+                               "2000 proposals, %s, Adagrad; fwd+loss+bwd+optimizer"
+                               % ("fp32" if args.dtype == "fp32" else "bf16 storage / fp32 accumulate")
                                + ("+RCCL all-reduce" if world > 1 else ""),
                    "images_per_gpu": 1, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay" if args.graph else "eager"},
