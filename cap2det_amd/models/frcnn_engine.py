@@ -881,7 +881,9 @@ class FrcnnEngine(object):
     finally:
       for r in refs:
         r.t = cur                              # the current step still reads its own features
-    bufs["prefetched"] = (image.data_ptr(), image._version, done)
+    # (the image tensor itself is kept: while it is referenced here its memory cannot be handed
+    # to another tensor, so "same data_ptr and version" really means "same pixels")
+    bufs["prefetched"] = (image, image._version, done)
 
   def invalidate_prefetch(self):
     for bufs in self._shape_cache.values():
@@ -897,7 +899,8 @@ class FrcnnEngine(object):
     bufs = self._buffers(b, h, w, n, is_training)
     upto = self._prefix_len(bufs)
     pre = bufs.pop("prefetched", None)
-    if pre is not None and pre[0] == image.data_ptr() and pre[1] == image._version and upto > 0:
+    if (pre is not None and upto > 0 and pre[0].data_ptr() == image.data_ptr() and
+        pre[0].shape == image.shape and pre[0]._version == pre[1] == image._version):
       # the look-ahead of the previous step computed this image's prefix: swap its buffer in
       last = bufs["plan1"]["steps"][upto - 1]
       cur = last["y"].t
