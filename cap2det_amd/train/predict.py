@@ -1,0 +1,122 @@
+"""`python -m cap2det_amd.train.predict --pipeline_proto X.pbtxt --model_dir DIR --label_file F`
+
+The evaluation process of the reference (train/predict.py:532-619), flags kept: it evaluates the
+newest checkpoint of `--model_dir` over `pipeline.eval_reader` with one PASCAL (or COCO) evaluator
+per OICR iteration, keeps the best one in `--saved_ckpts_dir` by mAP of the last iteration
+(`save_model_if_it_is_better`), and either loops (a new checkpoint every 10 s) or stops after one
+pass (`--run_once`).  `--eval_coco_on_voc` remaps an 80-class COCO model onto the 20 VOC classes.
+Not kept: summaries for TensorBoard, the visualisation HTML and the per-image detection dumps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+
+def run_evaluation_once(pipeline_proto, checkpoint_path, evaluators, category_to_id, args,
+                        device="cuda:0"):
+  """train/predict.py:328-529 -> (metrics of every evaluator, metric that ranks checkpoints)."""
+  from cap2det_amd.models import builder
+  from cap2det_amd.readers import cap2det_reader
+  from cap2det_amd.train import evaluation, tf_checkpoint
+  import numpy as np
+  model = builder.build(pipeline_proto.model, is_training=False, device=device,
+                        depth_multiplier=args.depth_multiplier)
+  if checkpoint_path:
+    if os.path.exists(checkpoint_path + ".npz"):
+      arrays = dict(np.load(checkpoint_path + ".npz"))
+      arrays.pop("__global_step", None); arrays.pop("__adagrad_accumulators", None)
+    else:
+      arrays = tf_checkpoint.read_checkpoint(checkpoint_path)
+    model.load_state_dict(arrays, strict=False)
+  reader = pipeline_proto.eval_reader.cap2det_reader
+  if args.input_pattern:
+    reader.input_pattern = args.input_pattern
+  if args.shard_indicator:
+    reader.shard_indicator = args.shard_indicator
+
+  def batches():
+    seen = 0
+    for batch in cap2det_reader.get_input_fn(reader, device=device)():
+      yield batch
+      seen += len(batch["image_id"])
+      if args.max_eval_examples and seen >= args.max_eval_examples:
+        return
+
+  for e in evaluators:
+    e.clear()
+  metrics = evaluation.run_evaluation(model, batches(), evaluators, category_to_id,
+                                      eval_coco_on_voc=args.eval_coco_on_voc)
+  last = metrics[-1]
+  key = ('PascalBoxes_Precision/mAP@0.5IOU' if 'PascalBoxes_Precision/mAP@0.5IOU' in last
+         else 'DetectionBoxes_Precision/mAP')
+  return metrics, last[key]
+
+
+def main(argv=None):
+  ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+  ap.add_argument("--evaluator", default="pascal", help="`coco` or `pascal`.")
+  ap.add_argument("--pipeline_proto", required=True)
+  ap.add_argument("--model_dir", default="")
+  ap.add_argument("--saved_ckpts_dir", default="")
+  ap.add_argument("--label_file", required=True, help="One class name per line (ids are 1-based).")
+  ap.add_argument("--max_eval_examples", type=int, default=500)
+  ap.add_argument("--min_eval_steps", type=int, default=200)
+  ap.add_argument("--number_of_evaluators", type=int, default=4)
+  ap.add_argument("--results_dir", default="")
+  ap.add_argument("--eval_best_model", action="store_true")
+  ap.add_argument("--run_once", action="store_true")
+  ap.add_argument("--eval_coco_on_voc", action="store_true")
+  ap.add_argument("--shard_indicator", default="")
+  ap.add_argument("--input_pattern", default="")
+  ap.add_argument("--depth_multiplier", type=float, default=1.0, help=argparse.SUPPRESS)
+  args = ap.parse_args(argv)
+
+  from cap2det_amd.train import evaluation
+  from cap2det_amd.train.trainer_main import latest_checkpoint, load_pipeline_proto
+  pipeline_proto = load_pipeline_proto(args.pipeline_proto)
+  if args.model_dir:
+    pipeline_proto.model_dir = args.model_dir
+  categories, category_to_id = [], {}
+  with open(args.label_file, "r") as fp:
+    for line_id, line in enumerate(fp.readlines()):
+      name = line.strip("\n")
+      categories.append({'id': 1 + line_id, 'name': name})
+      category_to_id[name] = 1 + line_id
+  evaluators = evaluation.build_evaluators(args.evaluator, categories, args.number_of_evaluators)
+
+  def evaluate(checkpoint_path, step):
+    metrics, metric = run_evaluation_once(pipeline_proto, checkpoint_path, evaluators,
+                                          category_to_id, args)
+    if args.results_dir:
+      os.makedirs(args.results_dir, exist_ok=True)
+      name = os.path.basename(args.pipeline_proto).replace(".pbtxt", "") + ".step_%d.json" % step
+      with open(os.path.join(args.results_dir, name), "w") as f:
+        json.dump([{k: (None if v != v else v) for k, v in m.items()} for m in metrics], f, indent=1)
+    print("checkpoint %s: metric %.4f" % (checkpoint_path, metric), file=sys.stderr)
+    return metrics, metric
+
+  if args.run_once:
+    if args.eval_best_model:
+      path = evaluation.get_best_model_checkpoint(args.saved_ckpts_dir)
+    else:
+      path = latest_checkpoint(pipeline_proto.model_dir) if pipeline_proto.model_dir else None
+    step = int(path.split("-")[-1]) if path else 0
+    return evaluate(path, step)
+  latest_step = None
+  while True:                                    # train/predict.py:583-611
+    path = latest_checkpoint(pipeline_proto.model_dir)
+    if path is not None:
+      step = int(path.split("-")[-1])
+      if step != latest_step and step >= args.min_eval_steps:
+        latest_step = step
+        _, metric = evaluate(path, step)
+        if args.saved_ckpts_dir:
+          evaluation.save_model_if_it_is_better(step, metric, path, args.saved_ckpts_dir)
+        continue
+    time.sleep(10)
+
+
+if __name__ == "__main__":
+  main()

@@ -4,6 +4,7 @@ tf.Example protos (written here in the layout of dataset-tools/create_pascal_tf_
 the independent oracle (pure-Python framing + proto decoding, libjpeg-turbo via Pillow, numpy
 legacy-bilinear resize).  Images are compared BIT-EXACTLY: same fp32 operation order."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -198,3 +199,69 @@ def test_evaluation_loop_and_checkpoint_round_trip(tmp_path):
   step_best, metric_best = ev.save_model_if_it_is_better(2, 0.5, path, str(tmp_path / "best"))
   assert (step_best, metric_best) == (2, 0.5)
   assert ev.get_best_model_checkpoint(str(tmp_path / "best")).endswith("model.ckpt-2")
+
+
+def test_trainer_main_and_predict_cli(tmp_path):
+  """The reference's two entry points with their flags (train/trainer_main.py:15-20,
+  train/predict.py:36-78): records -> `trainer_main` (2 steps, checkpoint, resume for 1 more)
+  -> `predict --run_once` (multi-scale inference, NMS, PASCAL and COCO evaluators)."""
+  from cap2det_amd.train import predict, trainer_main
+  from tests import util_model
+  rng = np.random.default_rng(77)
+  classes = open(os.path.join(util_model.ROOT, "cap2det_amd", "data", "voc_label.txt")).read().split("\n")
+  classes = [c for c in classes if c]
+  recs = []
+  for i in range(4):
+    rec = _example(rng, "%06d" % i, 52 + 2 * i, 60, 8, 2, ["a", "b"])
+    recs.append(rec)
+  T.write_records(str(tmp_path / "t.record"), recs)
+  text = open(os.path.join(util_model.ROOT, "configs", "voc07_groundtruth_hotpath.pbtxt")).read()
+  text = text.replace("cap2det_amd/data/", os.path.join(util_model.ROOT, "cap2det_amd", "data") + "/")
+  reader = """
+    cap2det_reader {
+      input_pattern: "%s"
+      interleave_cycle_length: 1
+      is_training: %s
+      shuffle_buffer_size: 4
+      map_num_parallel_calls: 2
+      batch_size: 1
+      max_num_proposals: 8
+      image_resizer { keep_aspect_ratio_resizer { min_dimension: 48 } }
+    }"""
+  pattern = str(tmp_path / "t.record")
+  text += "\ntrain_reader {%s}\neval_reader {%s}\n" % (reader % (pattern, "true"), reader % (pattern, "false"))
+  text = text.replace("eval_min_dimension: 1200", "").replace("eval_min_dimension: 800", "") \
+             .replace("eval_min_dimension: 600", "eval_min_dimension: 48").replace("eval_min_dimension: 400", "eval_min_dimension: 40")
+  cfg = tmp_path / "pipeline.pbtxt"
+  cfg.write_text(text)
+  model_dir = str(tmp_path / "model_dir")
+
+  # the fixture's object texts are cls0..2: give the records real class names instead
+  import cap2det_amd.readers.cap2det_reader as cr
+  orig = cr.get_input_fn
+
+  def renamed(options, **kw):
+    fn = orig(options, **kw)
+
+    def gen():
+      for b in fn():
+        b["object_texts"] = [[classes[int(t[3:])] if t else "" for t in row] for row in b["object_texts"]]
+        yield b
+    return gen
+  cr.get_input_fn = renamed
+  try:
+    tr = trainer_main.main(["--pipeline_proto", str(cfg), "--model_dir", model_dir, "--max_steps", "2",
+                            "--depth_multiplier", "0.5"])
+    assert tr.global_step == 2 and os.path.exists(os.path.join(model_dir, "model.ckpt-2.npz"))
+    tr = trainer_main.main(["--pipeline_proto", str(cfg), "--model_dir", model_dir, "--max_steps", "3",
+                            "--depth_multiplier", "0.5"])
+    assert tr.global_step == 3 and trainer_main.latest_checkpoint(model_dir).endswith("model.ckpt-3")
+    label_file = os.path.join(util_model.ROOT, "cap2det_amd", "data", "voc_label.txt")
+    for evaluator, key in (("pascal", "PascalBoxes_Precision/mAP@0.5IOU"), ("coco", "DetectionBoxes_Precision/mAP")):
+      metrics, metric = predict.main(["--pipeline_proto", str(cfg), "--model_dir", model_dir,
+                                      "--label_file", label_file, "--run_once", "--evaluator", evaluator,
+                                      "--results_dir", str(tmp_path / "results"), "--depth_multiplier", "0.5"])
+      assert len(metrics) == 4 and key in metrics[-1] and (metric != metric or -1.0 <= metric <= 1.0)
+    assert len(os.listdir(str(tmp_path / "results"))) == 1
+  finally:
+    cr.get_input_fn = orig
