@@ -493,3 +493,31 @@ def test_trainer_train_loop_with_lookahead(tmp_path):
                     log=lambda step, l: seen.append(step))
   assert tr.global_step == 4 and seen == [1, 2, 3, 4] and np.isfinite(float(losses["total_loss"]))
   assert sorted(os.listdir(str(tmp_path))) == ["model.ckpt-2.npz", "model.ckpt-4.npz"]
+
+
+def test_multi_stream_schedule_matches_single_stream():
+  """The default schedule (filter gradients on a side stream, first-stage look-ahead on a third)
+  against the same steps with everything on one stream: a missing dependency between the streams
+  would show up as different losses / variables (tolerance: the fp32 atomic summation order)."""
+  from cap2det_amd.train.trainer import Trainer
+  pipeline = util_model.load_pipeline()
+  results = []
+  for single in (False, True):
+    tr = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=7)
+    eng = tr.model.engine
+    assert eng.second.side is not None and eng.prefetch_stream is not None
+    if single:
+      eng.second.side = None
+      eng.prefetch_stream = None
+    r = np.random.default_rng(31)
+    classes = tr.model.label_extractor.classes
+    batches = [_to_dev(util_model.make_examples(r, 1, 96, 80, 40, [40], classes)) for _ in range(3)]
+    losses = []
+    for i in range(6):
+      out = tr.train_step(batches[i % 3], dropout_seed=i, prefetch=batches[(i + 1) % 3])
+      losses.append(float(out["total_loss"]))
+    torch.cuda.synchronize()
+    results.append((losses, tr.model.state_dict()))
+  np.testing.assert_allclose(results[0][0], results[1][0], rtol=5e-6)
+  for n, v in results[0][1].items():
+    np.testing.assert_allclose(v, results[1][1][n], rtol=1e-4, atol=5e-6, err_msg=n)
