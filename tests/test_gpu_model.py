@@ -521,3 +521,32 @@ def test_multi_stream_schedule_matches_single_stream():
   np.testing.assert_allclose(results[0][0], results[1][0], rtol=5e-6)
   for n, v in results[0][1].items():
     np.testing.assert_allclose(v, results[1][1][n], rtol=1e-4, atol=5e-6, err_msg=n)
+
+
+def test_full_size_streams_agree():
+  """At BASELINE's full size (500x500, 2000 proposals, depth 1.0) kernels run for 100-700 us and
+  really overlap: three steps of the default multi-stream schedule (with look-ahead) give the
+  same losses and gradients as the same steps on one stream, up to the fp32 atomic order."""
+  from cap2det_amd.train.trainer import Trainer
+  pipeline = util_model.load_pipeline()
+  out = []
+  for single in (False, True):
+    tr = Trainer(pipeline, device=DEV, seed=11)
+    eng = tr.model.engine
+    if single:
+      eng.second.side = None
+      eng.prefetch_stream = None
+    r = np.random.default_rng(3)
+    classes = tr.model.label_extractor.classes
+    batches = [_to_dev(util_model.make_examples(r, 1, 500, 500, 2000, [2000], classes)) for _ in range(2)]
+    losses = []
+    for i in range(3):
+      res = tr.train_step(batches[i % 2], dropout_seed=i, prefetch=batches[(i + 1) % 2])
+      losses.append(float(res["total_loss"]))
+    torch.cuda.synchronize()
+    out.append((losses, tr.model.store.grads.clone(), tr.model.store.values.clone()))
+  np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-5)
+  g0, g1 = out[0][1], out[1][1]
+  scale = float(g1.abs().max())
+  assert float((g0 - g1).abs().max()) <= 2e-4 * scale
+  assert float((out[0][2] - out[1][2]).abs().max()) <= 1e-4
