@@ -871,6 +871,11 @@ class FrcnnEngine(object):
     cur, alt = last["y"].t, bufs["prefix_alt"]
     stream = self.prefetch_stream
     stream.wait_event(bufs["prefix_free"])     # the prefix's internal buffers are idle again
+    # ... and not before everything the caller has queued so far (the forward pass): the
+    # look-ahead then starts in the loss phase, whose dozen tiny kernels leave the GPU empty
+    late = torch.cuda.Event()
+    late.record()
+    stream.wait_event(late)
     for r in refs:
       r.t = alt
     try:
