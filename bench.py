@@ -163,7 +163,7 @@ def cpu_baseline(classes):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-kernel-timing", action="store_true")
