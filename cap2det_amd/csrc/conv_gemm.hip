@@ -1682,7 +1682,9 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     e = getenv("C2D_IGEMM_CFG");
     force = e ? atoi(e) : 0;
   }
-  const bool narrow = force ? force == 2 : (a.N % 128 != 0 && a.N % 128 <= 64);
+  // bf16 operands: 128x64 tiles throughout (tools/bench_conv_bf16.py: 0.96 ms against 1.06 ms on
+  // the second-stage shapes; the stride-2 input gradients gain most, 108 -> 66 us)
+  const bool narrow = force ? force == 2 : (a.es == 2 || (a.N % 128 != 0 && a.N % 128 <= 64));
   if (!row_major_only && a.nseg == 1 && a.g.kh * a.g.kw > 1 && hw <= 64 && a.g.nimg >= 64 &&
       a.N % 4 == 0 && a.g.sub == 1) {
     if (g_collect) return C2D_ERR_UNSUPPORTED;
