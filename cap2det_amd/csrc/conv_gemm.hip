@@ -1684,7 +1684,10 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   }
   // bf16 operands: 128x64 tiles throughout (tools/bench_conv_bf16.py: 0.96 ms against 1.06 ms on
   // the second-stage shapes; the stride-2 input gradients gain most, 108 -> 66 us)
-  const bool narrow = force ? force == 2 : (a.es == 2 || (a.N % 128 != 0 && a.N % 128 <= 64));
+  // stride-2 input gradients (four parity-class launches of a quarter of the rows each): 128x64
+  // as well, the smaller launches fill the chip better (256->256 on 7x7: 310 -> 254 us)
+  const bool narrow = force ? force == 2
+                            : (a.es == 2 || a.g.sub > 1 || (a.N % 128 != 0 && a.N % 128 <= 64));
   if (!row_major_only && a.nseg == 1 && a.g.kh * a.g.kw > 1 && hw <= 64 && a.g.nimg >= 64 &&
       a.N % 4 == 0 && a.g.sub == 1) {
     if (g_collect) return C2D_ERR_UNSUPPORTED;
