@@ -29,13 +29,18 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (n
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
-def synthetic_batch(seed, device, classes):
-  """SURVEY.md §8d synthetic inputs (seeded)."""
+def synthetic_batch(seed, device, classes, pipeline, num_proposals=NUM_PROPOSALS):
+  """SURVEY.md §8d synthetic inputs (seeded): image, proposals, object labels and — for the
+  caption-driven configs — a 60-token caption over the extractor's open vocabulary."""
   import numpy as np
   import torch
-  from tests import util_model
+  from cap2det_amd import synthetic
   rng = np.random.default_rng(seed)
-  ex = util_model.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, NUM_PROPOSALS, [NUM_PROPOSALS], classes)
+  ex = synthetic.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, num_proposals, [num_proposals], classes)
+  vocab = synthetic.caption_vocabulary(pipeline)
+  single = [c for c in classes if " " not in c]
+  ex["concat_caption_string"] = synthetic.synthetic_captions(
+      rng, 1, vocab, tokens=60, must_contain=[single[int(rng.integers(0, len(single)))]])
   out = dict(ex)
   for k in ("image", "proposals", "number_of_proposals"):
     out[k] = torch.from_numpy(ex[k]).to(device).contiguous()
@@ -122,92 +127,215 @@ class KernelTimer(object):
     return out
 
 
-def cpu_baseline(classes):
-  """Times the numpy oracle (port of the reference semantics) on a bounded sample: one 500x500
-  image through the first stage + a full training step with 1/20 of the proposals, then
-  extrapolates the proposal-proportional part to 2000 proposals."""
+def cpu_baseline(pipeline, classes, num_proposals, budget_s=45.0):
+  """MEASURES full training steps of the CPU restatement of the reference semantics (the TF
+  reference cannot run here): oracle/ref_model.train_step in fp32 with its convolutions / GEMMs on
+  torch-CPU (all host cores) and numpy for crop_and_resize / MIDN / OICR — SURVEY.md §8d,
+  BASELINE.md §4.  1 warm-up + up to 3 timed steps at the benchmark's own size (one 500x500
+  image, `num_proposals` proposals); stops early once `budget_s` of timed work is spent (at
+  least one timed step always runs).  Reports the median."""
   import numpy as np
-  from oracle import ref_labels, ref_model
+  import torch
+  from oracle import ref_labels, ref_model, ref_ops
+  from cap2det_amd import synthetic
   from tests import util_model
-  sample_n = 100
-  rng = np.random.default_rng(0)
-  P, d = util_model.oracle_state(0, len(classes), 3, 1.0)
-  acc = {k: np.full(v.shape, 0.1, np.float32) for k, v in P.items()}
-  ex = util_model.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, sample_n, [sample_n], classes)
-  labels = ref_labels.groundtruth_extract(ex["object_texts"], classes)
-  mask = (rng.uniform(size=(sample_n, d)) < 0.5).astype(np.uint8)
-  opts = ref_model.FrcnnOptions()
-  loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
-                   oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
-  mults = [("first_stage_feature_extraction", 0.0), ("second_stage_feature_extraction", 1.0),
-           ("first_stage_feature_extraction/InceptionV2/Mixed_4e", 1.0)]
-  t0 = time.perf_counter()
-  x = ref_model.preprocess(ex["image"])
-  ref_model.net_forward(ref_model.FIRST_STAGE, x, P, ref_model.FIRST_SCOPE)
-  t_first = time.perf_counter() - t0
-  t0 = time.perf_counter()
-  ref_model.train_step(P, acc, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
-  t_step = time.perf_counter() - t0
-  t_full = t_first + max(t_step - t_first, 0.0) * (NUM_PROPOSALS / float(sample_n))
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  ref_ops.set_conv_backend("torch")
   try:
-    import threadpoolctl
-    cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
-  except Exception:
-    cores = os.cpu_count() or 1
-  return dict(value=1.0 / t_full, unit="images/s", cores=int(cores), kind="port",
-              sample=("numpy oracle, 1 image 500x500, first stage %.2fs + full train step with %d "
-                      "proposals %.2fs; proposal-proportional part scaled x%d to 2000 proposals"
-                      % (t_first, sample_n, t_step, NUM_PROPOSALS // sample_n)))
+    rng = np.random.default_rng(0)
+    P, d = util_model.oracle_state(0, len(classes), 3, 1.0)
+    acc = {k: np.full(v.shape, 0.1, np.float32) for k, v in P.items()}
+    ex = synthetic.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, num_proposals, [num_proposals], classes)
+    labels = ref_labels.groundtruth_extract(ex["object_texts"], classes)
+    mask = (rng.uniform(size=(num_proposals, d)) < 0.5).astype(np.uint8)
+    opts = ref_model.FrcnnOptions()
+    loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
+                     oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+    mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
+    times = []
+    for i in range(4):
+      t0 = time.perf_counter()
+      ref_model.train_step(P, acc, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
+      dt = time.perf_counter() - t0
+      if i > 0:
+        times.append(dt)
+      elif dt > budget_s:          # a slow host: the warm-up step is the sample
+        times.append(dt)
+        break
+      if sum(times) > budget_s:
+        break
+  finally:
+    ref_ops.set_conv_backend("numpy")
+  times.sort()
+  med = times[len(times) // 2]
+  return dict(value=1.0 / med, unit="images/s", cores=int(cores), kind="port",
+              step_s={"median": med, "min": times[0], "max": times[-1], "timed_steps": len(times)},
+              sample=("CPU restatement of the reference semantics (not TensorFlow): oracle fp32 "
+                      "train step (fwd + losses + bwd + Adagrad), torch-CPU convolutions on %d "
+                      "threads + numpy crop_and_resize/MIDN/OICR, 1 image 500x500 with %d "
+                      "proposals, 1 warm-up + %d timed full steps, median"
+                      % (cores, num_proposals, len(times))))
 
 
-def main():
+def parse_args(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--config", choices=["c1", "c2", "c3", "c4"], default="c1",
+                  help="BASELINE.json configs[k]: c1 voc07_groundtruth fp32 (the headline metric), c2 "
+                       "coco17_extend_match bf16, c3 coco17_text_classifier_match fp32, c4 "
+                       "flickr30k_text_classifier_match bf16; all with 2000 proposals and the "
+                       "caption -> label branch inside the timed step")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-kernel-timing", action="store_true")
   ap.add_argument("--per-call", action="store_true",
                   help="also print one line per timed conv / ROI-crop call (stderr)")
   ap.add_argument("--graph", action="store_true", help="hipGraph replay of the step (measured: no gain over eager launches)")
-  ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
-                  help="fp32 = BASELINE configs[1] (the headline metric); bf16 = the same workload with "
-                       "the ROI crop output and the second stage in bf16 storage / fp32 accumulate "
-                       "(configs[2]/[4] precision), reported as a secondary number")
-  args = ap.parse_args()
+  ap.add_argument("--dtype", choices=["fp32", "bf16"], default=None,
+                  help="override the config's precision: fp32 = exact fp32 everywhere; bf16 = ROI crop "
+                       "output and second stage in bf16 storage / fp32 accumulate")
+  return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+  """`python bench.py --gpus N` as a plain command: this parent never touches the GPU
+  (`torch.cuda.device_count()` does not initialise it on this image); it starts
+  `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (no
+  exec), relays its output and returns its exit code.  One process per GPU, as the reference's
+  workers (train_wsod.sh:46-88).  With fewer devices than ranks (a 1-GPU box) every rank shares
+  cuda:0 over gloo (C2D_BENCH_SAME_DEVICE: code-path validation only, flagged in the JSON)."""
+  import socket
+  import subprocess
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  env.setdefault("MASTER_ADDR", "127.0.0.1")
+  if env.get("C2D_BENCH_STUB") != "1" and env.get("C2D_BENCH_SAME_DEVICE") != "1":
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+      print("bench.py: no GPU visible (set C2D_BENCH_STUB=1 for the CPU launcher test)", file=sys.stderr)
+      return 2
+    if ndev < args.gpus:
+      env["C2D_BENCH_SAME_DEVICE"] = "1"
+  port = env.get("MASTER_PORT")
+  if not port:
+    with socket.socket() as sock:
+      sock.bind(("127.0.0.1", 0))
+      port = str(sock.getsockname()[1])
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+         str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", port,
+         os.path.abspath(__file__)] + list(argv)
+  proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+  for line in proc.stdout:
+    sys.stdout.write(line)
+    sys.stdout.flush()
+  return proc.wait()
+
+
+def stub_main(args):
+  """C2D_BENCH_STUB=1 (tests/test_bench_launcher.py, CPU): the launcher / rank / barrier /
+  max-over-ranks / JSON plumbing of this file with the training step replaced by the
+  data-parallel exchange alone — the two-bucket OverlappedReducer over gloo on a CPU bucket of
+  the real size — so that the multi-rank path is exercised where no GPU exists."""
+  import torch
+  import torch.distributed as dist
+  from cap2det_amd.train import data_parallel
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+  if os.environ.get("C2D_BENCH_STUB_FAIL") == "1" and rank == world - 1:
+    raise SystemExit(3)                      # (launcher test: a failing rank fails the command)
+  bucket = torch.zeros(7_100_000)
+  split = 1_110_000
+  def step(i):
+    bucket.fill_(float(rank + 1 + i))
+    red = data_parallel.OverlappedReducer(bucket, split)
+    red.start_tail()
+    scale = red.finish()
+    want = sum(r + 1 + i for r in range(world)) * scale
+    got = bucket * scale
+    assert abs(float(got[0]) - want) < 1e-6 and abs(float(got[-1]) - want) < 1e-6, (float(got[0]), want)
+  for i in range(args.warmup):
+    step(i)
+  if world > 1:
+    dist.barrier()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    step(args.warmup + i)
+  if world > 1:
+    dist.barrier()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  if rank == 0:
+    print(json.dumps({"metric": "STUB (no training step): launcher + gradient exchange only",
+                      "value": world * args.steps / elapsed, "unit": "exchanges/s",
+                      "n_gpus": args.gpus, "world_size": world, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "stub": True, "backend": "gloo"}))
+  if world > 1:
+    dist.destroy_process_group()
+  return 0
+
+
+def main(argv=None):
+  argv = sys.argv[1:] if argv is None else argv
+  args = parse_args(argv)
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(launch_ranks(args, argv))
+  if os.environ.get("C2D_BENCH_STUB") == "1":
+    sys.exit(stub_main(args))
 
   import torch
   import torch.distributed as dist
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
   # C2D_BENCH_SAME_DEVICE=1 (validation of the multi-rank code path on a 1-GPU box only): every
   # rank uses cuda:0 and the process group runs over gloo; the reported number is meaningless.
   same_device = os.environ.get("C2D_BENCH_SAME_DEVICE") == "1"
   if same_device:
     local_rank = 0
+  backend = None
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="gloo" if same_device else "nccl", rank=rank,
-                            world_size=world)
-  elif args.gpus > 1:
-    raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    backend = "gloo" if same_device else "nccl"
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    assert dist.get_world_size() == world
   device = "cuda:%d" % local_rank
   torch.cuda.set_device(local_rank)
 
-  from cap2det_amd import hip_ops
+  import shutil
+  import tempfile
+  from cap2det_amd import hip_ops, synthetic
   from cap2det_amd.train.trainer import Trainer
-  from tests import util_model
   timer = KernelTimer()
   if not args.no_kernel_timing:
     timer.wrap(hip_ops)
-  pipeline = util_model.load_pipeline("voc07_groundtruth_hotpath")
-  trainer = Trainer(pipeline, device=device, seed=1234, use_graph=args.graph,
-                    compute_dtype=args.dtype)
+  spec = synthetic.BASELINE_CONFIGS[args.config]
+  if args.dtype is None:
+    args.dtype = spec["dtype"]
+  scratch = tempfile.mkdtemp(prefix="c2d_bench_")      # synthetic GloVe / classifier files (c3, c4)
+  try:
+    pipeline = synthetic.baseline_pipeline(args.config, scratch)
+    trainer = Trainer(pipeline, device=device, seed=1234, use_graph=args.graph,
+                      compute_dtype=args.dtype, allow_missing_pretrained=True)
+  finally:
+    shutil.rmtree(scratch, ignore_errors=True)
   classes = trainer.model.label_extractor.classes
-  batch, _ = synthetic_batch(1000 + rank, device, classes)
+  assert len(classes) == spec["classes"]
+  batch, _ = synthetic_batch(1000 + rank, device, classes, pipeline)
 
   def sync():
     if world > 1:
@@ -275,13 +403,19 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if args.dtype == "fp32" else "bf16 storage (ROI crop output + second stage), f32 accumulate",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: voc07_groundtruth (Inception-V2, 20 classes, OICR x3, "
-                               "Mixed_4e + second stage + heads trainable), 1 image 500x500x3 per GPU, "
-                               "2000 proposals, %s, Adagrad; fwd+loss+bwd+optimizer"
-                               % ("fp32" if args.dtype == "fp32" else "bf16 storage / fp32 accumulate")
-                               + ("+RCCL all-reduce" if world > 1 else ""),
+        "config": {"workload": "%s%s: Inception-V2, %d classes, label extractor %s inside the step, "
+                               "OICR x3, Mixed_4e + second stage + heads trainable, 1 image 500x500x3 "
+                               "per GPU, %d proposals, %s, Adagrad; fwd+loss+bwd+optimizer%s"
+                               % (spec["title"],
+                                  "" if args.dtype == spec["dtype"] else " [precision overridden]",
+                                  len(classes), type(trainer.model.label_extractor).__name__,
+                                  NUM_PROPOSALS,
+                                  "fp32" if args.dtype == "fp32" else "bf16 storage / fp32 accumulate",
+                                  "+RCCL all-reduce" if world > 1 else ""),
+                   "baseline_config": args.config, "pipeline": spec["pipeline"] + ".pbtxt",
                    "images_per_gpu": 1, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay" if args.graph else "eager"},
+        "world_size": world,
         "final_total_loss": total_loss,
     }
     if per_step:
@@ -364,8 +498,12 @@ def main():
             "avg_launch_ms": rc["ms"] / rc["launches"],
             "algorithmic_bytes_per_launch": rc["work"] / rc["launches"]}
     if not args.no_cpu_baseline and world == 1:
-      result["cpu_baseline"] = cpu_baseline(classes)
+      result["cpu_baseline"] = cpu_baseline(pipeline, classes, NUM_PROPOSALS)
+    if world > 1:
+      result["backend"] = ("gloo, all ranks on cuda:0 (C2D_BENCH_SAME_DEVICE: code-path validation, "
+                           "the value is not a scaling point)" if same_device else "nccl (RCCL)")
     print(json.dumps(result))
+    sys.stdout.flush()
   if world > 1:
     dist.destroy_process_group()
 

@@ -18,9 +18,30 @@
 // lets each lane fetch its 16 k-values with four ds_read_b128).  fp32 in, fp32 accumulate:
 // bit-for-bit an fmaf chain, no reduced precision anywhere.
 #include "c2d_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
+
+// Dispatch record of the calling thread's LAST convolution entry point (c2d_debug_last_dispatch):
+// which kernel template instances it launched, spelled the way rocprofv3 prints them, so a parity
+// test can prove which tile path produced the numbers it compared.  A few integer stores per
+// launch; formatted only when queried.
+struct DispatchRec {
+  const char* fmt;
+  int p[8];
+};
+constexpr int DISPATCH_MAX = 8;
+thread_local DispatchRec g_dispatch[DISPATCH_MAX];
+thread_local int g_ndispatch = 0;
+inline void dispatch_reset() { g_ndispatch = 0; }
+inline void dispatch_note(const char* fmt, int a = 0, int b = 0, int c = 0, int d = 0, int e = 0,
+                          int f = 0, int g = 0, int h = 0) {
+  if (g_ndispatch >= DISPATCH_MAX) return;
+  DispatchRec& r = g_dispatch[g_ndispatch++];
+  r.fmt = fmt;
+  r.p[0] = a; r.p[1] = b; r.p[2] = c; r.p[3] = d; r.p[4] = e; r.p[5] = f; r.p[6] = g; r.p[7] = h;
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Native vector type for register staging: HIP's float4 struct is copied with memcpy, which
@@ -1635,12 +1656,16 @@ int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
     int err = C2D_OK;
     if (make_sk_plan<MODE, BM, BN, BKT, PM>(a, slots, ws, &p.sk, &err)) {
       const int grid = c2d_ceil_div(p.sk.total, p.sk.share);
+      dispatch_note(PM ? "igemm_sk_kernel<%d, %d, %d, %d, %d, %d, true, %d>"
+                       : "igemm_sk_kernel<%d, %d, %d, %d, %d, %d, false, %d>", MODE, WM, WN, MT, NT, BKT, ES);
       hipLaunchKernelGGL((igemm_sk_kernel<MODE, WM, WN, MT, NT, BKT, PM, ES>), dim3(grid), block, 0, s, p);
       return c2d_launch_status();
     }
     if (err) return err;
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
+  dispatch_note(PM ? "igemm_nt_kernel<%d, %d, %d, %d, %d, %d, true, %d>"
+                   : "igemm_nt_kernel<%d, %d, %d, %d, %d, %d, false, %d>", MODE, WM, WN, MT, NT, BKT, ES);
   hipLaunchKernelGGL((igemm_nt_kernel<MODE, WM, WN, MT, NT, BKT, PM, ES>), grid, block, 0, s, a);
   return c2d_launch_status();
 }
@@ -1714,6 +1739,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
       return C2D_ERR_UNSUPPORTED;
     }
     const dim3 grid(b.m_tiles * b.n_tiles), block(256);
+    dispatch_note("igemm_small_kernel<%d>", a.g.mode);
     if (a.g.mode == 0) hipLaunchKernelGGL(igemm_small_kernel<0>, grid, block, 0, s, b);
     else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, block, 0, s, b);
     return c2d_launch_status();
@@ -1737,6 +1763,22 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
 extern "C" int c2d_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; return C2D_OK; }
 #endif
 
+extern "C" int c2d_debug_last_dispatch(char* buf, int len) {
+  C2D_CHECK_ARG(buf && len > 0);
+  int pos = 0;
+  buf[0] = 0;
+  for (int i = 0; i < g_ndispatch; ++i) {
+    const DispatchRec& r = g_dispatch[i];
+    const int n = snprintf(buf + pos, (size_t)(len - pos), r.fmt, r.p[0], r.p[1], r.p[2], r.p[3],
+                           r.p[4], r.p[5], r.p[6], r.p[7]);
+    if (n < 0 || pos + n + 2 >= len) return C2D_ERR_WORKSPACE;
+    pos += n;
+    if (i + 1 < g_ndispatch) buf[pos++] = ';';
+    buf[pos] = 0;
+  }
+  return C2D_OK;
+}
+
 extern "C" long long c2d_conv_workspace_bytes(void) {
   // <= 1024 resident workgroups x 2 slabs of a 128x128 fp32 tile + the tile counters
   return 1024ll * 2 * 128 * 128 * 4 + (4ll << 20);
@@ -1746,6 +1788,7 @@ static int conv_fwd_impl(const float* x, int ldx, int xoff, const float* wt,
                          const float* scale, const float* shift, float* y, int ldy,
                          int yoff, int n, int ih, int iw, int cin, int cout, int kh, int kw,
                          int stride, int relu, IgemmWs ws, void* stream, int es = 4) {
+  dispatch_reset();
   C2D_CHECK_ARG(x && wt && y && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 16 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   IgemmArgs a;
@@ -1782,6 +1825,7 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
                            int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
                            int kh, int kw, int stride, int accumulate, IgemmWs ws, void* stream,
                            int es = 4) {
+  dispatch_reset();
   C2D_CHECK_ARG(dc && w && dx && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cout % 16 == 0 && ldc % 4 == 0 && coff % 4 == 0);
   IgemmArgs a;
@@ -1840,6 +1884,7 @@ static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
                             const int* couts, float* dx, int lddx, int dxoff,
                             int rows, int cin, int accumulate, IgemmWs wsp, void* stream,
                             int es = 4) {
+  dispatch_reset();
   C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && dcs && ldcs && coffs && ws && couts && dx);
   C2D_CHECK_ARG(rows > 0 && cin > 0 && cin % 4 == 0 && lddx % 4 == 0 && dxoff % 4 == 0);
   IgemmArgs a;
@@ -1892,6 +1937,7 @@ static int launch_small_group(SmallCollect& c, hipStream_t st) {
   }
   for (int p = c.num; p <= SMALL_GROUP_MAX; ++p) c.args.first[p] = first;
   c.args.num = c.num;
+  dispatch_note("igemm_small_group_kernel<%d>", c.mode);
   if (c.mode == 0) hipLaunchKernelGGL(igemm_small_group_kernel<0>, dim3(first), dim3(256), 0, st, c.args);
   else hipLaunchKernelGGL(igemm_small_group_kernel<1>, dim3(first), dim3(256), 0, st, c.args);
   return c2d_launch_status();
@@ -1908,6 +1954,7 @@ static int conv_desc_run(const C2dConvDesc& d, int dgrad, void* stream) {
 }
 
 static int conv_grouped_impl(const C2dConvDesc* descs, int num, int dgrad, void* stream) {
+  dispatch_reset();
   C2D_CHECK_ARG(descs && num >= 1 && num <= 64);
   // every problem of the group is "small" (run_igemm's one-tile-per-block domain): ONE launch;
   // otherwise (or more than SMALL_GROUP_MAX sub-problems) each convolution is launched on its own
@@ -1995,6 +2042,7 @@ template <int ES>
 static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, int ldc,
                            int coff, float* dw, int n, int ih, int iw, int cin, int cout,
                            int kh, int kw, int stride, void* stream) {
+  dispatch_reset();
   C2D_CHECK_ARG(x && dc && dw && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   C2D_CHECK_ARG(ldc % 4 == 0 && coff % 4 == 0);
@@ -2023,6 +2071,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
+    dispatch_note("wgrad3x3_bf16_kernel<%d, %d, %d>", iw, iw == 4 ? 8 : 2, wi);
     if (iw == 4 && wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 1>), grid, dim3(256), 0, st, b);
     else if (iw == 4) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 2>), grid, dim3(512), 0, st, b);
     else if (wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 1>), grid, dim3(256), 0, st, b);
@@ -2047,6 +2096,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
+    dispatch_note("wgrad3x3_kernel<%d, %d, %d>", iw, iw == 4 ? 2 : 1, ES);
     if (iw == 4) hipLaunchKernelGGL((wgrad3x3_kernel<4, 2, ES>), grid, dim3(256), 0, st, b);
     else hipLaunchKernelGGL((wgrad3x3_kernel<7, 1, ES>), grid, dim3(256), 0, st, b);
     return c2d_launch_status();
@@ -2075,12 +2125,14 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     a.rows_per_split = c2d_ceil_div(a.rows_per_split, WB_KB) * WB_KB;
     a.nsplits = c2d_ceil_div(a.M, a.rows_per_split);
     grid.x = a.tiles_x * a.tiles_y * a.nsplits;
+    dispatch_note(plain ? "wgrad_tn_bf16_kernel<%d, true>" : "wgrad_tn_bf16_kernel<%d, false>", narrow ? 1 : 2);
     if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, true>), grid, dim3(256), 0, st, a);
     else if (narrow) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
     else if (plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, false>), grid, dim3(256), 0, st, a);
     return c2d_launch_status();
   }
+  dispatch_note(plain ? "wgrad_tn_kernel<%d, true, %d>" : "wgrad_tn_kernel<%d, false, %d>", narrow ? 1 : 2, ES);
   if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true, ES>), grid, dim3(256), 0, st, a);
   else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false, ES>), grid, dim3(256), 0, st, a);
   else if (plain) hipLaunchKernelGGL((wgrad_tn_kernel<2, true, ES>), grid, dim3(256), 0, st, a);

@@ -541,6 +541,92 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float* __restrict__ w,
   }
 }
 
+// The general form of the optimiser step (reference branches no shipped config takes):
+//   g' = m * (grad_scale*g + l2*w + l1*sign(w)),  m = mult * (col_mult ? col_mult[i % ld] : 1)
+// m <= 0 freezes the element (train/trainer.py:104-125); lr may be read from device memory
+// (a hipGraph then replays across a continuous learning-rate decay).
+__global__ __launch_bounds__(256) void adagrad_ex_kernel(float* __restrict__ w,
+                                                         const float* __restrict__ g,
+                                                         float* __restrict__ acc, long long n,
+                                                         float lr, const float* __restrict__ lr_dev,
+                                                         float l1, float l2, float mult,
+                                                         float grad_scale,
+                                                         const float* __restrict__ col_mult,
+                                                         int ld) {
+  if (lr_dev) lr = lr_dev[0];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float m = col_mult ? mult * col_mult[i % ld] : mult;
+    if (!(m > 0.f)) continue;
+    const float wi = w[i];
+    const float sg = wi > 0.f ? 1.f : (wi < 0.f ? -1.f : 0.f);
+    const float gi = m * (g[i] * grad_scale + l2 * wi + l1 * sg);
+    const float a = acc[i] + gi * gi;
+    acc[i] = a;
+    w[i] = wi - lr * gi / sqrtf(a);
+  }
+}
+
+// tf.contrib.training.clip_gradient_norms (train/trainer.py:134-136): every variable's FINAL
+// gradient g' (scaled, regularised, multiplied) is clipped on its OWN L2 norm:
+// g' * max_norm / max(|g'|, max_norm).  One workgroup per variable (a [rows][cols] window of a
+// row-major buffer with row stride ld): pass 1 writes g' in place and sums its squares in a fixed
+// order (bitwise reproducible), pass 2 scales.
+struct ClipDesc {
+  long long offset;   // first element in the flat gradient / value buffers
+  int rows, cols, ld;
+  float l1, l2, mult;
+};
+__global__ __launch_bounds__(1024) void clip_gradient_norms_kernel(
+    float* __restrict__ grads, const float* __restrict__ values,
+    const ClipDesc* __restrict__ desc, float grad_scale, float max_norm) {
+  const ClipDesc d = desc[blockIdx.x];
+  float* g = grads + d.offset;
+  const float* w = values + d.offset;
+  const long long n = (long long)d.rows * d.cols;
+  __shared__ float red[16];
+  __shared__ float factor;
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const long long e = (i / d.cols) * d.ld + (i % d.cols);
+    const float wi = w[e];
+    const float sg = wi > 0.f ? 1.f : (wi < 0.f ? -1.f : 0.f);
+    const float gi = d.mult * (g[e] * grad_scale + d.l2 * wi + d.l1 * sg);
+    g[e] = gi;
+    s += gi * gi;
+  }
+  s = c2d_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
+    const float norm = sqrtf(t);
+    factor = max_norm / fmaxf(norm, max_norm);
+  }
+  __syncthreads();
+  const float f = factor;
+  if (f == 1.f) return;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    const long long e = (i / d.cols) * d.ld + (i % d.cols);
+    g[e] *= f;
+  }
+}
+
+// out[0] += weight * sum |w|   (slim l1_regularizer)
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ w, long long n,
+                                                      float weight, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    s += fabsf(w[i]);
+  s = c2d_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, weight * (red[0] + red[1] + red[2] + red[3]));
+}
+
 // out[0] += 0.5 * weight * sum w^2
 __global__ __launch_bounds__(256) void l2_loss_kernel(const float* __restrict__ w, long long n,
                                                       float weight, float* __restrict__ out) {
@@ -941,6 +1027,40 @@ extern "C" int c2d_adagrad_step(float* w, const float* g, float* acc, long long 
   if (n == 0) return C2D_OK;
   hipLaunchKernelGGL(adagrad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, g,
                      acc, n, lr, l2, mult, grad_scale);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_adagrad_step_ex(float* w, const float* g, float* acc, long long n, float lr,
+                                   const float* lr_dev, float l1, float l2, float mult,
+                                   float grad_scale, const float* col_mult, int ld,
+                                   void* stream) {
+  C2D_CHECK_ARG(w && g && acc && n >= 0 && (!col_mult || ld > 0));
+  if (n == 0) return C2D_OK;
+  hipLaunchKernelGGL(adagrad_ex_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w,
+                     g, acc, n, lr, lr_dev, l1, l2, mult, grad_scale, col_mult, ld);
+  return c2d_launch_status();
+}
+
+static_assert(sizeof(ClipDesc) == sizeof(C2dClipDesc), "C2dClipDesc layout");
+extern "C" int c2d_clip_gradient_norms(float* grads, const float* values,
+                                       const C2dClipDesc* desc, int num, float grad_scale,
+                                       float max_norm, void* stream) {
+  C2D_CHECK_ARG(grads && values && desc && num >= 0 && max_norm > 0.f);
+  if (num == 0) return C2D_OK;
+  hipLaunchKernelGGL(clip_gradient_norms_kernel, dim3(num), dim3(1024), 0, (hipStream_t)stream,
+                     grads, values, reinterpret_cast<const ClipDesc*>(desc), grad_scale,
+                     max_norm);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_l1_loss(const float* w, long long n, float weight, float* out,
+                           void* stream) {
+  C2D_CHECK_ARG(w && out && n >= 0);
+  if (n == 0) return C2D_OK;
+  long long b = (n + 255) / 256;
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(l1_loss_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, w, n,
+                     weight, out);
   return c2d_launch_status();
 }
 

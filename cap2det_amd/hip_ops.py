@@ -414,3 +414,40 @@ def adagrad_step(w, g, acc, lr, l2, mult, grad_scale=1.0):
 
 def l2_loss(w, weight, out):
   _lib.call("c2d_l2_loss", _p(w), w.numel(), float(weight), _p(out), _stream())
+
+
+def l1_loss(w, weight, out):
+  _lib.call("c2d_l1_loss", _p(w), w.numel(), float(weight), _p(out), _stream())
+
+
+def adagrad_step_ex(w, g, acc, lr, l1=0.0, l2=0.0, mult=1.0, grad_scale=1.0, col_mult=None, ld=0,
+                    lr_dev=None):
+  _lib.call("c2d_adagrad_step_ex", _p(w), _p(g), _p(acc), w.numel(), float(lr), _p(lr_dev),
+            float(l1), float(l2), float(mult), float(grad_scale), _p(col_mult), int(ld), _stream())
+
+
+class ClipDesc(ctypes.Structure):
+  """C2dClipDesc of include/cap2det_hip.h."""
+  _fields_ = [("offset", ctypes.c_longlong), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+              ("ld", ctypes.c_int), ("l1", ctypes.c_float), ("l2", ctypes.c_float),
+              ("mult", ctypes.c_float)]
+
+
+def clip_descriptors(records, device):
+  """records: [(offset, rows, cols, ld, l1, l2, mult)] -> uint8 device tensor of C2dClipDesc."""
+  arr = (ClipDesc * len(records))()
+  for d, r in zip(arr, records):
+    d.offset, d.rows, d.cols, d.ld, d.l1, d.l2, d.mult = r
+  return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(records)
+
+
+def clip_gradient_norms(grads, values, desc, num, grad_scale, max_norm):
+  _lib.call("c2d_clip_gradient_norms", _p(grads), _p(values), _p(desc), num, float(grad_scale),
+            float(max_norm), _stream())
+
+
+def last_dispatch():
+  """Kernel template instances launched by this thread's last convolution call (debug query)."""
+  buf = ctypes.create_string_buffer(1024)
+  _lib.call("c2d_debug_last_dispatch", ctypes.cast(buf, ctypes.c_void_p), 1024)
+  return [k for k in buf.value.decode().split(";") if k]

@@ -30,10 +30,14 @@ class Model(ModelBase):
   """Cap2Det model."""
 
   def __init__(self, model_proto, is_training=False, device="cuda:0", depth_multiplier=1.0,
-               bn_scale=True, seed=0, compute_dtype="fp32"):
+               bn_scale=True, seed=0, compute_dtype="fp32", allow_missing_pretrained=False):
     """compute_dtype: "fp32" (BASELINE configs[0], [1], [3]: exact fp32 everywhere) or "bf16"
     (configs[2], [4]: ROI crop output and second stage in bf16 storage with fp32 accumulation;
-    first stage, heads, losses, variables and optimiser stay fp32)."""
+    first stage, heads, losses, variables and optimiser stay fp32).
+    allow_missing_pretrained: keep the synthetic initial values when
+    `frcnn_options.checkpoint_path` names a file that does not exist (benchmarks and tests; the
+    reference's tf.train.init_from_checkpoint fails hard, models/utils.py:181-186, and so does
+    this class by default)."""
     model_proto = unwrap(model_proto)
     super(Model, self).__init__(model_proto, is_training)
     if not isinstance(model_proto, cap2det_model_pb2.Cap2DetModel):
@@ -69,19 +73,20 @@ class Model(ModelBase):
     self.store.finalize()
     self.engine.finalize(extra_transposes=[(HEADS_W, "heads/wt", 1, d, self._npad)])
     self._heads_wt = self.engine.stats.derived["heads/wt"]
-    self._l2_weight = 0.0
+    # core/training_utils.py:152-171 `_build_slim_regularizer` (FC weights only)
+    self._l2_weight = self._l1_weight = 0.0
     reg = options.fc_hyperparams.regularizer
     if reg.WhichOneof('regularizer_oneof') == 'l2_regularizer':
       self._l2_weight = reg.l2_regularizer.weight
     elif reg.WhichOneof('regularizer_oneof') == 'l1_regularizer':
-      raise NotImplementedError('l1_regularizer is not used by any shipped config')
+      self._l1_weight = reg.l1_regularizer.weight
     self._losses = torch.zeros(2 + k, device=self._device)   # midn, oicr_1..K, regularisation
     self._cache = {}
     self._ctx = None
     self.initialize(seed)
     # the reference initialises both towers from `frcnn_options.checkpoint_path` at graph build
-    # (models/utils.py:181-186); when that file is present here the same happens, otherwise the
-    # synthetic initial values stay (benchmarks and tests run without the ImageNet checkpoint)
+    # (models/utils.py:181-186) and fails when the file is missing; so does this class, unless
+    # the caller explicitly asks for the synthetic initial values (benchmarks / tests)
     ckpt = self._model_proto.frcnn_options.checkpoint_path
     self.restored_from = None
     if ckpt:
@@ -89,6 +94,10 @@ class Model(ModelBase):
       if tf_checkpoint.checkpoint_exists(ckpt):
         self.init_from_checkpoint(ckpt)
         self.restored_from = ckpt
+      elif not allow_missing_pretrained:
+        raise FileNotFoundError(
+            "frcnn_options.checkpoint_path %r does not exist (pass allow_missing_pretrained=True "
+            "to train from the synthetic initial values)" % ckpt)
 
   # -- variables ----------------------------------------------------------------------
   @property
@@ -102,6 +111,14 @@ class Model(ModelBase):
   @property
   def l2_weight(self):
     return self._l2_weight
+
+  @property
+  def l1_weight(self):
+    return self._l1_weight
+
+  def head_columns(self):
+    """[(reference scope of the head, first column, width)] inside the fused heads buffers."""
+    return list(self._head_cols)
 
   def head_view(self, name):
     """Strided view of one head inside the fused buffers, under the reference variable name
@@ -153,9 +170,17 @@ class Model(ModelBase):
       if tuple(a.shape) != tuple(t.shape):
         raise ValueError("shape mismatch for %s: %s vs %s" % (n, tuple(a.shape), tuple(t.shape)))
       t.copy_(a)
-    if strict and missing:
+    if strict == "checkpoint":
+      # a checkpoint of the reference: its Inception-V2 BatchNorm has no gamma (slim's
+      # inception arg_scope leaves `scale` off), which equals the gamma = 1 kept here; any other
+      # absent variable means the file does not belong to this model
+      hard = [n for n in missing if not n.endswith("/BatchNorm/gamma")]
+      if hard:
+        raise KeyError("checkpoint lacks %d model variables: %s ..." % (len(hard), hard[:5]))
+    elif strict and missing:
       raise KeyError("missing variables: %s ..." % missing[:5])
     self.refresh()
+    return missing
 
   def _slot_tensor(self, name):
     """Adagrad accumulator of variable `name` (None for BatchNorm statistics / stem variables,
@@ -282,7 +307,8 @@ class Model(ModelBase):
     return self._cache[key]
 
   # -- reference API ------------------------------------------------------------------
-  def _build_prediction(self, examples, dropout_seed=None, dropout_mask=None):
+  def _build_prediction(self, examples, dropout_seed=None, dropout_mask=None,
+                        feature_map_dropout_mask=None):
     """models/cap2det_model.py:152-216."""
     image = examples[InputDataFields.image]
     num_proposals = examples[InputDataFields.num_proposals]
@@ -290,7 +316,7 @@ class Model(ModelBase):
     b, n = proposals.shape[0], proposals.shape[1]
     c, k = self._num_classes, self._oicr_iterations
     features, fctx = self.engine.forward(image, proposals, self._is_training, dropout_seed,
-                                         dropout_mask)
+                                         dropout_mask, feature_map_dropout_mask)
     bufs = self._bufs(b, n)
     d = self.engine.feature_dims
     # all five heads in one GEMM: logits = X . W + b  (activation_fn=None, :79-88,:191-197)
@@ -350,7 +376,8 @@ class Model(ModelBase):
     options = self._model_proto
     if self._is_training or len(options.eval_min_dimension) == 0 or kwargs.get("single_scale"):
       predictions = self._build_prediction(examples, kwargs.get("dropout_seed"),
-                                           kwargs.get("dropout_mask"))
+                                           kwargs.get("dropout_mask"),
+                                           kwargs.get("feature_map_dropout_mask"))
       if kwargs.get("postprocess", not self._is_training):
         predictions.update(self._postprocess(examples, predictions))
       return predictions
@@ -423,11 +450,13 @@ class Model(ModelBase):
     return loss_dict
 
   def regularization_loss(self):
-    """Sum of the slim L2 regularisers (FC weights only), as a 0-d tensor."""
+    """Sum of the slim L2 / L1 regularisers (FC weights only), as a 0-d tensor."""
     out = self._losses[-1:]
     out.zero_()
     if self._l2_weight > 0:
       ops.l2_loss(self.store.var[HEADS_W], self._l2_weight, out)
+    if self._l1_weight > 0:
+      ops.l1_loss(self.store.var[HEADS_W], self._l1_weight, out)
     return self._losses[-1]
 
   def backward(self, after_second_stage=None):

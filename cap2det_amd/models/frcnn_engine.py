@@ -658,9 +658,9 @@ class FrcnnEngine(object):
     self.pool_k = options.maxpool_kernel_size
     self.pool_s = options.maxpool_stride
     self.keep_prob = options.dropout_keep_prob
-    if options.dropout_on_feature_map:
-      # true only by proto default; every shipped config sets it false (configs/*.pbtxt:55)
-      raise NotImplementedError("dropout_on_feature_map is not supported on the HIP path")
+    # slim.dropout on features_to_crop (models/utils.py:138-142): true by proto default
+    # (protos/frcnn.proto:29), false in every shipped config (configs/*.pbtxt:55)
+    self.dropout_on_feature_map = bool(options.dropout_on_feature_map)
     self.stats = DerivedStore(self.device)
     dm = depth_multiplier
     self.stem_cout = max(int(64 * dm), 16)
@@ -897,8 +897,12 @@ class FrcnnEngine(object):
         torch.cuda.current_stream().wait_event(pre[2])
 
   # -- forward / backward -------------------------------------------------------------
-  def forward(self, image, proposals, is_training, dropout_seed=None, dropout_mask=None):
-    """image [B,H,W,3] fp32 0..255; proposals [B,N,4].  Returns (features [B*N, D], ctx)."""
+  FMAP_SEED = 0x9E3779B97F4A7C15      # decorrelates the feature-map mask from the ROI-feature mask
+
+  def forward(self, image, proposals, is_training, dropout_seed=None, dropout_mask=None,
+              feature_map_dropout_mask=None):
+    """image [B,H,W,3] fp32 0..255; proposals [B,N,4].  Returns (features [B*N, D], ctx).
+    dropout_mask / feature_map_dropout_mask inject the two slim.dropout draws (parity tests)."""
     b, h, w, _ = image.shape
     n = proposals.shape[1]
     bufs = self._buffers(b, h, w, n, is_training)
@@ -923,7 +927,25 @@ class FrcnnEngine(object):
     st = bufs["stem"]
     feat = self.first.forward(bufs["plan1"], st, upto, None)
     boxes = proposals.reshape(-1, 4)
-    feat4 = feat.t.view(b, bufs["fh"], bufs["fw"], feat.c)
+    fmask = None
+    crop_src = feat.t
+    if self.dropout_on_feature_map and is_training and self.keep_prob < 1.0:
+      if "fmap_mask" not in bufs:
+        bufs["fmap_mask"] = torch.empty(feat.t.shape, dtype=torch.uint8, device=self.device)
+        bufs["fmap_dropped"] = torch.empty_like(feat.t)
+      fmask = bufs["fmap_mask"]
+      if feature_map_dropout_mask is not None:
+        fmask.copy_(feature_map_dropout_mask.reshape(fmask.shape))
+      elif isinstance(dropout_seed, torch.Tensor):
+        raise NotImplementedError("dropout_on_feature_map under hipGraph replay")
+      else:
+        ops.dropout_mask(fmask, (0 if dropout_seed is None else int(dropout_seed)) ^ self.FMAP_SEED,
+                         self.keep_prob)
+      # (the Mixed_4e output itself is kept: its ReLU mask is needed by the backward pass)
+      ops.spatial_mean_dropout_fwd(feat.t, bufs["fmap_dropped"], fmask, feat.t.shape[0], 1, feat.c,
+                                   self.keep_prob)
+      crop_src = bufs["fmap_dropped"]
+    feat4 = crop_src.view(b, bufs["fh"], bufs["fw"], feat.c)
     ops.roi_crop_pool_fwd(feat4, boxes, bufs["box_ind"], self.crop, self.pool_k, self.pool_s,
                           out=bufs["pooled"].t.view(b * n, bufs["p"], bufs["p"], feat.c),
                           argmax=bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], feat.c))
@@ -939,7 +961,7 @@ class FrcnnEngine(object):
         ops.dropout_mask(mask, 0 if dropout_seed is None else dropout_seed, self.keep_prob)
     ops.spatial_mean_dropout_fwd(net.t, bufs["features"], mask, b * n, bufs["spatial"], net.c,
                                  self.keep_prob if mask is not None else 1.0)
-    ctx = dict(bufs=bufs, b=b, n=n, boxes=boxes, mask=mask, feat4=feat4)
+    ctx = dict(bufs=bufs, b=b, n=n, boxes=boxes, mask=mask, feat4=feat4, fmask=fmask)
     return bufs["features"], ctx
 
   def backward(self, dfeatures, lddf, dfoff, ctx, after_second_stage=None):
@@ -963,11 +985,16 @@ class FrcnnEngine(object):
     if need_first:
       plan1 = bufs["plan1"]
       gfeat = self.first.out_grad(plan1, self.first_trainable_idx)
-      gfeat.t.zero_()
       d = self.first.cout
+      gcrop = gfeat.t            # d(loss)/d(features_to_crop)
+      if ctx.get("fmask") is not None:
+        if "gfmap" not in bufs:
+          bufs["gfmap"] = torch.empty_like(gfeat.t)
+        gcrop = bufs["gfmap"]
+      gcrop.zero_()
       dp4 = dpooled.t.view(b * n, bufs["p"], bufs["p"], d)
       arg4 = bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], d)
-      gf4 = gfeat.t.view(b, bufs["fh"], bufs["fw"], d)
+      gf4 = gcrop.view(b, bufs["fh"], bufs["fw"], d)
       if self.pool_k == 2 and bufs["p"] <= 16 and bufs["fw"] <= 64 and d % 16 == 0:
         # atomic-free, bitwise reproducible row-owner form (needs a workspace)
         if "crop_ws" not in bufs:
@@ -979,4 +1006,7 @@ class FrcnnEngine(object):
       else:
         ops.roi_crop_pool_bwd(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
                               self.pool_k, self.pool_s)
+      if ctx.get("fmask") is not None:          # through the feature-map dropout
+        ops.spatial_mean_dropout_bwd(gcrop, d, 0, gfeat.t, ctx["fmask"], gcrop.shape[0], 1, d,
+                                     self.keep_prob)
       self.first.backward(plan1, bufs["stem"], self.first_trainable_idx, None)

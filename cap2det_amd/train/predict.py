@@ -12,6 +12,7 @@ import json
 import os
 import sys
 import time
+import zipfile
 
 
 def run_evaluation_once(pipeline_proto, checkpoint_path, evaluators, category_to_id, args,
@@ -29,7 +30,7 @@ def run_evaluation_once(pipeline_proto, checkpoint_path, evaluators, category_to
       arrays.pop("__global_step", None); arrays.pop("__adagrad_accumulators", None)
     else:
       arrays = tf_checkpoint.read_checkpoint(checkpoint_path)
-    model.load_state_dict(arrays, strict=False)
+    model.load_state_dict(arrays, strict="checkpoint")
   reader = pipeline_proto.eval_reader.cap2det_reader
   if args.input_pattern:
     reader.input_pattern = args.input_pattern
@@ -110,8 +111,14 @@ def main(argv=None):
     if path is not None:
       step = int(path.split("-")[-1])
       if step != latest_step and step >= args.min_eval_steps:
+        try:
+          _, metric = evaluate(path, step)
+        except (FileNotFoundError, EOFError, zipfile.BadZipFile) as e:
+          # the trainer pruned (or is still renaming) this checkpoint: look again
+          print("checkpoint %s unreadable (%s); retrying" % (path, e), file=sys.stderr)
+          time.sleep(2)
+          continue
         latest_step = step
-        _, metric = evaluate(path, step)
         if args.saved_ckpts_dir:
           evaluation.save_model_if_it_is_better(step, metric, path, args.saved_ckpts_dir)
         continue

@@ -60,43 +60,79 @@ class Trainer(object):
     if opt != 'adagrad':
       raise ValueError('Invalid optimizer: {}.'.format(opt) if opt is None else
                        'optimizer %s is not implemented on the HIP path (configs use adagrad)' % opt)
-    if self.train_config.HasField('max_gradient_norm'):
-      raise NotImplementedError('max_gradient_norm is unset in every shipped config')
     self.global_step = 0
     store = self.model.store
     store.accum.fill_(self.train_config.optimizer.adagrad.initial_accumulator_value)
-    # gradient multipliers on the reference variable names; fused head buffers inherit the
-    # multiplier of their first head (all heads share scope-less names midn/*, oicr/*).
+    # gradient multipliers on the reference variable names (train/trainer.py:104-125)
     names = self.model.get_variables_to_train()
     mult = resolve_gradient_multipliers(names, self.train_config.gradient_multiplier)
     self.multipliers = mult
     self.model.set_trainable(mult.keys())
-    head_names = [n for n in names if n.startswith("midn/") or n.startswith("oicr/")]
-    head_mults = set(mult.get(n, 0.0) for n in head_names)
-    if len(head_mults) != 1:
-      raise NotImplementedError("per-head gradient multipliers are not supported (fused heads)")
-    head_mult = head_mults.pop()
-    # Adagrad segments over the flat buffers: runs of consecutive variables sharing (mult, l2).
+    # The five heads live in ONE fused [D][npad] buffer.  With one multiplier for all of them
+    # (every shipped config) the buffer is an ordinary segment; otherwise a per-column multiplier
+    # vector drives c2d_adagrad_step_ex (columns of frozen heads and the zero padding get 0).
+    head_cols = self.model.head_columns()
+    npad = store.var[HEADS_W].shape[1]
+    wcol, bcol = [0.0] * npad, [0.0] * npad
+    for hname, off, width in head_cols:
+      for c in range(off, off + width):
+        wcol[c] = mult.get(hname + "/weights", 0.0)
+        bcol[c] = mult.get(hname + "/biases", 0.0)
+    real = [c for _, off, width in head_cols for c in range(off, off + width)]
+    uniform = len(set(wcol[c] for c in real) | set(bcol[c] for c in real)) == 1
+    l1, l2 = self.model.l1_weight, self.model.l2_weight
+    # Adagrad segments over the flat buffers: runs of consecutive variables sharing
+    # (multiplier, l1, l2); [off, end, mult, l1, l2, column multipliers or None, their 0/1 mask]
     segs = []
     for name in store.names():
+      cols = None
       if name == HEADS_W:
-        m, l2 = head_mult, self.model.l2_weight
+        m, r1, r2 = (wcol[real[0]] if uniform else 1.0), l1, l2
+        cols = None if uniform else wcol
       elif name == HEADS_B:
-        m, l2 = head_mult, 0.0
+        m, r1, r2 = (bcol[real[0]] if uniform else 1.0), 0.0, 0.0
+        cols = None if uniform else bcol
       else:
-        m, l2 = mult.get(name, 0.0), 0.0
+        m, r1, r2 = mult.get(name, 0.0), 0.0, 0.0
       off, numel = store.offset[name]
       end = off + -(-numel // store.ALIGN) * store.ALIGN
-      if m <= 0:
+      if m <= 0 or (cols is not None and max(cols) <= 0):
         continue
-      if segs and segs[-1][1] == off and segs[-1][2] == m and segs[-1][3] == l2:
+      if cols is not None:
+        cols = torch.tensor(cols, dtype=torch.float32, device=self.device)
+      if (segs and cols is None and segs[-1][5] is None and segs[-1][1] == off and
+          segs[-1][2:5] == [m, r1, r2]):
         segs[-1][1] = end
       else:
-        segs.append([off, end, m, l2])
+        segs.append([off, end, m, r1, r2, cols,
+                     None if cols is None else (cols > 0).to(torch.float32)])
     self.segments = segs
     if not segs:
       raise ValueError("no trainable variables")
     self.bucket = (min(s[0] for s in segs), max(s[1] for s in segs))
+    # tf.contrib.training.clip_gradient_norms (train/trainer.py:132-136): one descriptor per
+    # reference variable (each head is its own variable = a column window of the fused buffer)
+    self._clip = None
+    if self.train_config.HasField('max_gradient_norm'):
+      recs = []
+      d = store.var[HEADS_W].shape[0]
+      for name in store.names():
+        off, numel = store.offset[name]
+        if name == HEADS_W:
+          for hname, coff, width in head_cols:
+            m = mult.get(hname + "/weights", 0.0)
+            if m > 0:
+              recs.append((off + coff, d, width, npad, l1, l2, m))
+        elif name == HEADS_B:
+          for hname, coff, width in head_cols:
+            m = mult.get(hname + "/biases", 0.0)
+            if m > 0:
+              recs.append((off + coff, 1, width, npad, 0.0, 0.0, m))
+        elif mult.get(name, 0.0) > 0:
+          recs.append((off, 1, numel, numel, 0.0, 0.0, mult[name]))
+      desc, num = ops.clip_descriptors(recs, self.device)
+      self._clip = (desc, num, float(self.train_config.max_gradient_norm))
+    self._lr_dev = None
     self.rank, self.world_size = data_parallel.world_info()
     # first flat offset of the second stage: everything from there on (second stage + heads) is
     # final before the ROI-crop / first-stage backward starts (data_parallel.OverlappedReducer)
@@ -119,8 +155,15 @@ class Trainer(object):
     path = os.path.join(model_dir, "model.ckpt-%d" % self.global_step)
     state = self.model.state_dict()
     store = self.model.store
-    np.savez(path + ".npz", __global_step=np.int64(self.global_step),
-             __adagrad_accumulators=store.accum.detach().cpu().numpy(), **state)
+    # written under a temporary name and renamed: a concurrent evaluator polling model_dir
+    # (train/predict.py) or a resume after a crash never sees a half-written file
+    tmp = path + ".tmp-%d.npz" % os.getpid()
+    with open(tmp, "wb") as f:
+      np.savez(f, __global_step=np.int64(self.global_step),
+               __adagrad_accumulators=store.accum.detach().cpu().numpy(), **state)
+      f.flush()
+      os.fsync(f.fileno())
+    os.replace(tmp, path + ".npz")
     return path
 
   def export_tf_checkpoint(self, prefix):
@@ -143,7 +186,7 @@ class Trainer(object):
       # global_step; Adagrad slots (`<var>/Adagrad`) when the file carries them
       arrays = tf_checkpoint.read_checkpoint(path)
       self.global_step = int(arrays.pop("global_step", 0))
-      self.model.load_state_dict(arrays, strict=False)
+      self.model.load_state_dict(arrays, strict="checkpoint")
       self.model.load_optimizer_slots(arrays)
       self._graphs = None
       return
@@ -177,11 +220,31 @@ class Trainer(object):
     model.backward(after_second_stage)
     return predictions, losses
 
-  def _apply_gradients(self, scale, lr):
+  def _apply_gradients(self, scale, lr, lr_dev=None):
+    """Adagrad over the trainable segments of the flat buffers.  The common case (one multiplier
+    per segment, L2 only, no clipping) is one c2d_adagrad_step per segment; l1 regularisers,
+    per-head multipliers, `max_gradient_norm` and a device-resident learning rate go through
+    c2d_clip_gradient_norms / c2d_adagrad_step_ex."""
     store = self.model.store
-    for off, end, m, l2 in self.segments:
-      ops.adagrad_step(store.values[off:end], store.grads[off:end], store.accum[off:end], lr, l2,
-                       m, scale)
+    v, g, a = store.values, store.grads, store.accum
+    clipped = self._clip is not None
+    if clipped:
+      desc, num, max_norm = self._clip
+      ops.clip_gradient_norms(g, v, desc, num, scale, max_norm)    # g <- final clipped gradient
+    for off, end, m, l1, l2, cols, mask in self.segments:
+      if clipped:
+        # the descriptors applied scale / regularisers / multipliers; what is left is the
+        # frozen-column mask of a fused heads buffer
+        if cols is None and lr_dev is None:
+          ops.adagrad_step(v[off:end], g[off:end], a[off:end], lr, 0.0, 1.0, 1.0)
+        else:
+          ops.adagrad_step_ex(v[off:end], g[off:end], a[off:end], lr, 0.0, 0.0, 1.0, 1.0, mask,
+                              0 if mask is None else mask.numel(), lr_dev)
+      elif cols is None and l1 == 0.0 and lr_dev is None:
+        ops.adagrad_step(v[off:end], g[off:end], a[off:end], lr, l2, m, scale)
+      else:
+        ops.adagrad_step_ex(v[off:end], g[off:end], a[off:end], lr, l1, l2, m, scale, cols,
+                            0 if cols is None else cols.numel(), lr_dev)
     self.model.refresh(only_trainable=True)
 
   def train_step(self, examples, prefetch=None, **kwargs):
@@ -189,7 +252,12 @@ class Trainer(object):
     'regularization_loss').  No host synchronisation happens inside.  `prefetch`: the NEXT
     step's examples, when the caller already has them (an input pipeline always does): their
     frozen first-stage layers are computed under this step's kernels."""
-    if self.use_graph and "dropout_mask" not in kwargs:
+    if kwargs.get("dropout_seed") is None and kwargs.get("dropout_mask") is None:
+      # slim.dropout draws a fresh mask every step on every worker (models/utils.py:171-174):
+      # the counter-based generator is keyed on (global step, rank)
+      kwargs["dropout_seed"] = self.global_step * self.world_size + self.rank
+    if (self.use_graph and "dropout_mask" not in kwargs and
+        not self.model.engine.dropout_on_feature_map):
       return self._graph_step(examples, **kwargs)
     kwargs["prefetch"] = prefetch
     store = self.model.store
@@ -232,7 +300,13 @@ class Trainer(object):
     labels = model.label_extractor.extract_labels(examples)      # host lookup + small kernel
     model.engine.second.side = None        # one stream inside the captured graph
     model.engine.prefetch_stream = None
-    key = (tuple(examples[F.image].shape), tuple(examples[F.proposals].shape), lr)
+    if self._lr_dev is None:
+      self._lr_dev = torch.zeros(1, device=self.device)
+    # the learning rate lives in device memory (like the dropout seed): a continuous
+    # exponential_decay changes it every step without a re-capture
+    self._lr_dev.fill_(lr)
+    lr_dev = self._lr_dev
+    key = (tuple(examples[F.image].shape), tuple(examples[F.proposals].shape))
     if self._graphs is None or self._graphs["key"] != key:
       # eager warm-up on this shape (allocates every buffer), then capture
       st = {F.image: examples[F.image].clone(), F.proposals: examples[F.proposals].clone(),
@@ -242,7 +316,7 @@ class Trainer(object):
             F.num_proposals: st[F.num_proposals]}
       state = (store.values.clone(), store.accum.clone())
       self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
-      self._apply_gradients(1.0 / self.world_size, lr)
+      self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
       torch.cuda.synchronize()
       store.values.copy_(state[0]); store.accum.copy_(state[1])   # undo the warm-up update
       self.model.refresh(only_trainable=True)
@@ -254,7 +328,7 @@ class Trainer(object):
           predictions, losses = self._forward_backward(ex, labels=st["labels"],
                                                        dropout_seed=st["seed"])
         with torch.cuda.graph(g_opt, stream=side):
-          self._apply_gradients(1.0 / self.world_size, lr)
+          self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
           total = self.model._losses.sum()
       torch.cuda.current_stream().wait_stream(side)
       losses['total_loss'] = total

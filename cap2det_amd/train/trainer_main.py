@@ -65,10 +65,11 @@ def main(argv=None):
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  # (before the first GPU call: the runtime reads the IPC mode when it initialises)
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   torch.cuda.set_device(local_rank)
   if world > 1:
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     reader = pipeline_proto.train_reader.cap2det_reader
     if not reader.shard_indicator:

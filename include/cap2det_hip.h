@@ -122,6 +122,13 @@ typedef struct C2dConvDesc {
 int c2d_conv_fwd_grouped(const C2dConvDesc* descs, int num, void* stream);
 int c2d_conv_dgrad_grouped(const C2dConvDesc* descs, int num, void* stream);
 
+/* Debug query: the kernel template instances launched by the calling thread's LAST convolution
+ * entry point (c2d_conv_fwd / _dgrad / _wgrad / c2d_conv1x1_dgrad_multi, their _bf16 / _ws /
+ * _grouped forms), spelled as rocprofv3 prints them and separated by ';', e.g.
+ * "igemm_nt_kernel<0, 2, 2, 2, 1, 32, true, 4>".  Lets a parity test prove WHICH tile path
+ * produced the result it compared with the oracle.  C2D_ERR_WORKSPACE if buf is too small. */
+int c2d_debug_last_dispatch(char* buf, int len);
+
 /* Balanced ("stream-K") forms of the three calls above.  `workspace` is a caller-owned device
  * buffer of at least c2d_conv_workspace_bytes() bytes that is ZERO when first used (the kernels
  * leave its counters zero again) and is not shared by launches that may run concurrently.
@@ -318,6 +325,31 @@ int c2d_adagrad_step(float* w, const float* g, float* acc, long long n, float lr
                      float mult, float grad_scale, void* stream);
 /* *out += 0.5*weight*sum(w^2)  (slim l2_regularizer). */
 int c2d_l2_loss(const float* w, long long n, float weight, float* out, void* stream);
+/* *out += weight*sum(|w|)  (slim l1_regularizer, core/training_utils.py:167-168). */
+int c2d_l1_loss(const float* w, long long n, float weight, float* out, void* stream);
+
+/* General optimiser step for the reference branches no shipped config takes:
+ *   g' = m*(grad_scale*g + l2*w + l1*sign(w)),  m = mult * (col_mult ? col_mult[i % ld] : 1);
+ *   elements with m <= 0 are frozen (gradient multipliers <= 0, train/trainer.py:104-125; the
+ *   per-column form serves the five heads fused in one [D][ld] buffer when their multipliers
+ *   differ).  lr_dev != NULL: the learning rate is read from device memory (a captured hipGraph
+ *   then follows a continuous tf.train.exponential_decay, train/trainer.py:76-82). */
+int c2d_adagrad_step_ex(float* w, const float* g, float* acc, long long n, float lr,
+                        const float* lr_dev, float l1, float l2, float mult, float grad_scale,
+                        const float* col_mult, int ld, void* stream);
+
+/* One variable = a [rows][cols] window (row stride ld) at `offset` of the flat buffers. */
+typedef struct C2dClipDesc {
+  long long offset;
+  int rows, cols, ld;
+  float l1, l2, mult;
+} C2dClipDesc;
+/* tf.contrib.training.clip_gradient_norms (train/trainer.py:132-136): per variable, in place,
+ *   g' = mult*(grad_scale*g + l2*w + l1*sign(w));  g' *= max_norm / max(||g'||_2, max_norm).
+ * desc: DEVICE array of `num` descriptors.  Afterwards c2d_adagrad_step runs with l2 = 0,
+ * mult = 1, grad_scale = 1.  Deterministic (fixed summation order). */
+int c2d_clip_gradient_norms(float* grads, const float* values, const C2dClipDesc* desc, int num,
+                            float grad_scale, float max_norm, void* stream);
 
 /* Atomic-free, bitwise-reproducible form of c2d_roi_crop_pool_bwd (same semantics: adds into
  * dfeat).  Needs a caller-owned device workspace of at least

@@ -196,7 +196,7 @@ def _conv_fwd(op, x, P, name):
   else:
     c = ops.conv2d(x, P[name + "/weights"], op[4], "SAME")
   gamma, beta, mean, var, _ = _bn_terms(P, name, x.dtype)
-  y = np.maximum(ops.batch_norm_inference(c, gamma, beta, mean, var, BN_EPS), 0)
+  y = ops.batch_norm_relu(c, gamma, beta, mean, var, BN_EPS)
   return y, (x, c, y)
 
 
@@ -306,15 +306,20 @@ def preprocess(image):
 
 
 def extract_frcnn_feature(image, num_proposals, proposals, P, options, is_training=False,
-                          dropout_mask=None):
+                          dropout_mask=None, feature_map_dropout_mask=None):
   """models/utils.py:108-188.  `dropout_mask` [B*N, D] of {0,1} injects the RNG of
   slim.dropout (models/utils.py:171-174); None means no dropout (inference, or keep_prob 1).
   Returns (proposal_features [B,N,D], tape)."""
   del num_proposals  # unused by the reference on this path as well
   x = preprocess(image)
   feat, tape1 = net_forward(FIRST_STAGE, x, P, FIRST_SCOPE)
-  if options.dropout_on_feature_map and is_training:
-    raise NotImplementedError("dropout_on_feature_map is false in every shipped config")
+  fmask = None
+  feat_pre = feat
+  if options.dropout_on_feature_map and is_training and feature_map_dropout_mask is not None:
+    # models/utils.py:138-142: slim.dropout on features_to_crop (the mask injects its RNG)
+    f = feat.dtype.type
+    fmask = feature_map_dropout_mask.reshape(feat.shape).astype(feat.dtype)
+    feat = feat * f(1.0 / options.dropout_keep_prob) * fmask
   batch, n, _ = proposals.shape
   box_ind = np.repeat(np.arange(batch, dtype=np.int32), n)          # models/utils.py:147-149
   boxes = proposals.reshape(-1, 4)
@@ -328,7 +333,7 @@ def extract_frcnn_feature(image, num_proposals, proposals, P, options, is_traini
     out = avg * f(1.0 / options.dropout_keep_prob) * dropout_mask.astype(avg.dtype)
   else:
     out = avg
-  tape = dict(tape1=tape1, feat=feat, boxes=boxes, box_ind=box_ind, cropped_shape=cropped.shape,
+  tape = dict(tape1=tape1, feat=feat, feat_pre=feat_pre, fmap_mask=fmask, boxes=boxes, box_ind=box_ind, cropped_shape=cropped.shape,
               pool_arg=pool_arg, pooled=pooled, tape2=tape2, net_shape=net.shape,
               dropout_mask=dropout_mask if is_training else None)
   return out.reshape(batch, n, -1), tape
@@ -354,6 +359,8 @@ def extract_frcnn_feature_backward(dfeatures, tape, P, options, first_stage_from
                                   options.maxpool_kernel_size, options.maxpool_stride, "VALID")
     dfeat = ops.crop_and_resize_grad_image(dcrop, tape["boxes"], tape["box_ind"],
                                            tape["feat"].shape)
+    if tape.get("fmap_mask") is not None:
+      dfeat = dfeat * dfeat.dtype.type(1.0 / options.dropout_keep_prob) * tape["fmap_mask"]
     _, g1 = net_backward(FIRST_STAGE, tape["tape1"], dfeat, P, FIRST_SCOPE, first_stage_from, False)
     grads.update(g1)
     grads["__dfeat__"] = dfeat
@@ -395,14 +402,14 @@ def build_midn_network_backward(dclass_logits, saved):
 
 
 def build_prediction(examples, P, options, oicr_iterations, is_training=False,
-                     dropout_mask=None):
+                     dropout_mask=None, feature_map_dropout_mask=None):
   """models/cap2det_model.py:152-216 (without the NMS post-process, which `train_op` never
   fetches).  examples: dict with 'image' [B,H,W,3] 0..255, 'number_of_proposals' [B],
   'proposals' [B,N,4]."""
   image, num_proposals, proposals = (examples["image"], examples["number_of_proposals"],
                                      examples["proposals"])
   features, tape = extract_frcnn_feature(image, num_proposals, proposals, P, options,
-                                         is_training, dropout_mask)
+                                         is_training, dropout_mask, feature_map_dropout_mask)
   class_logits, scores, proba, midn_saved = build_midn_network(num_proposals, features, P)
   predictions = {
       "num_proposals": num_proposals,
@@ -532,13 +539,15 @@ def first_trainable_index(multipliers_resolved):
 
 
 def train_step(P, accum, examples, labels, options, loss_opts, multipliers, learning_rate,
-               l2_weight, dropout_mask=None):
+               l2_weight, dropout_mask=None, feature_map_dropout_mask=None, l1_weight=0.0,
+               max_gradient_norm=None):
   """One step of train/trainer.py:_model_fn in TRAIN mode with Adagrad
   (core/training_utils.py:45-50; tf.train.AdagradOptimizer: acc += g^2; w -= lr*g*rsqrt(acc)).
 
   Returns dict(losses, total_loss, grads, predictions); P and accum are updated in place."""
   K = loss_opts["oicr_iterations"]
-  predictions, saved = build_prediction(examples, P, options, K, True, dropout_mask)
+  predictions, saved = build_prediction(examples, P, options, K, True, dropout_mask,
+                                        feature_map_dropout_mask)
   loss_dict, loss_grads = build_loss(predictions, labels, loss_opts)
   dfeatures, grads = heads_backward(loss_grads, saved, P, K)
   trainable_names = [k for k in P if not (k.endswith("moving_mean") or
@@ -550,14 +559,22 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
   reg = {}
   for name in P:
     if is_regularized(name):
-      reg[name] = dt(l2_weight) * dt(0.5) * np.sum(P[name] * P[name])
-      grads[name] = grads[name] + dt(l2_weight) * P[name]
+      # slim.l2_regularizer: w * sum(x^2)/2; slim.l1_regularizer: w * sum|x|
+      # (core/training_utils.py:152-171; one of the two is configured)
+      reg[name] = (dt(l2_weight) * dt(0.5) * np.sum(P[name] * P[name]) +
+                   dt(l1_weight) * np.sum(np.abs(P[name])))
+      grads[name] = grads[name] + dt(l2_weight) * P[name] + dt(l1_weight) * np.sign(P[name])
   total = sum(loss_dict.values()) + sum(reg.values())
   applied = {}
   for name, m in mult.items():
     if name not in grads:
       continue
     g = grads[name].astype(P[name].dtype) * dt(m)
+    if max_gradient_norm is not None:
+      # tf.contrib.training.clip_gradient_norms (train/trainer.py:132-136): tf.clip_by_norm of
+      # every gradient on its own L2 norm, after the multipliers
+      norm = np.sqrt(np.sum(g * g))
+      g = g * dt(max_gradient_norm) / np.maximum(norm, dt(max_gradient_norm))
     accum[name] += g * g
     P[name] -= dt(learning_rate) * g / np.sqrt(accum[name])
     applied[name] = g

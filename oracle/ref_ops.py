@@ -269,8 +269,62 @@ def _windows(x, kh, kw, s, pad_value, padding):
   return view, (oh, ow, pt, pl, xp.shape)
 
 
+_CONV_BACKEND = "numpy"
+
+
+def set_conv_backend(name):
+  """"numpy" (default: im2col + matmul in the input dtype, the arbiter of the parity tests) or
+  "torch" (torch-CPU conv2d on all host threads, float32 only: bench.py's measured CPU baseline,
+  SURVEY.md §8d; tests/test_oracle_vs_torch.py checks the two backends against each other)."""
+  global _CONV_BACKEND
+  if name not in ("numpy", "torch"):
+    raise ValueError(name)
+  _CONV_BACKEND = name
+
+
+def _torch_conv_operands(x, w, stride, padding):
+  """NCHW views of NHWC memory (channels_last: no copy).  A symmetric SAME padding is handed to
+  torch's own `padding` argument; an asymmetric one (extra cell at the bottom / right) is
+  materialised with F.pad."""
+  import torch
+  import torch.nn.functional as F
+  kh, kw, _, _ = w.shape
+  if padding == "SAME":
+    _, pt, pb = same_padding(x.shape[1], kh, stride)
+    _, pl, pr = same_padding(x.shape[2], kw, stride)
+  else:
+    pt = pb = pl = pr = 0
+  xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)      # NCHW view, NHWC memory
+  wt = torch.from_numpy(np.ascontiguousarray(w)).permute(3, 2, 0, 1)      # OIHW view of HWIO
+  if pt == pb and pl == pr:
+    return torch, F, xt, wt, (0, 0), (pt, pl)
+  return torch, F, F.pad(xt, (pl, pr, pt, pb)), wt, (pt, pl), (0, 0)
+
+
+def _conv2d_torch(x, w, stride, padding):
+  torch, F, xp, wt, _, pad = _torch_conv_operands(x, w, stride, padding)
+  with torch.no_grad():
+    y = F.conv2d(xp, wt, stride=stride, padding=pad)
+  return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
+
+
+def _conv2d_backward_torch(x, w, dy, stride, padding, need_dx):
+  torch, F, xp, wt, (pt, pl), pad = _torch_conv_operands(x, w, stride, padding)
+  g = torch.from_numpy(np.ascontiguousarray(dy)).permute(0, 3, 1, 2)
+  with torch.no_grad():
+    dw = torch.nn.grad.conv2d_weight(xp, wt.shape, g, stride=stride, padding=pad)
+    dx = None
+    if need_dx:
+      dxp = torch.nn.grad.conv2d_input(xp.shape, wt, g, stride=stride, padding=pad)
+      dx = np.ascontiguousarray(
+          dxp[:, :, pt:pt + x.shape[1], pl:pl + x.shape[2]].permute(0, 2, 3, 1).numpy())
+  return dx, np.ascontiguousarray(dw.permute(2, 3, 1, 0).numpy())
+
+
 def conv2d(x, w, stride=1, padding="SAME"):
   """tf.nn.conv2d NHWC/HWIO (slim.conv2d core), no bias."""
+  if _CONV_BACKEND == "torch" and x.dtype == np.float32:
+    return _conv2d_torch(x, w.astype(np.float32, copy=False), stride, padding)
   kh, kw, cin, cout = w.shape
   view, (oh, ow, _, _, _) = _windows(x, kh, kw, stride, 0.0, padding)
   cols = view.reshape(x.shape[0] * oh * ow, kh * kw * cin)
@@ -279,6 +333,9 @@ def conv2d(x, w, stride=1, padding="SAME"):
 
 def conv2d_backward(x, w, dy, stride=1, padding="SAME", need_dx=True):
   """Gradients of conv2d: returns (dx or None, dw)."""
+  if _CONV_BACKEND == "torch" and x.dtype == np.float32:
+    return _conv2d_backward_torch(x, w.astype(np.float32, copy=False),
+                                  dy.astype(np.float32, copy=False), stride, padding, need_dx)
   kh, kw, cin, cout = w.shape
   n = x.shape[0]
   view, (oh, ow, pt, pl, pshape) = _windows(x, kh, kw, stride, 0.0, padding)
@@ -311,8 +368,62 @@ def batch_norm_inference(x, gamma, beta, mean, var, eps=0.001):
   return (x - mean) * scaling.astype(x.dtype) + beta
 
 
+def _pool_geometry(h, w, k, stride, padding):
+  if padding == "SAME":
+    oh, pt, pb = same_padding(h, k, stride)
+    ow, pl, pr = same_padding(w, k, stride)
+  else:
+    oh, ow = (h - k) // stride + 1, (w - k) // stride + 1
+    pt = pb = pl = pr = 0
+  return oh, ow, pt, pb, pl, pr
+
+
+def _max_pool_torch(x, k, stride, padding):
+  """torch-CPU form (conv backend "torch"): same values; the returned `arg` is torch's flat
+  index into the PADDED plane (int64) instead of the window index — `max_pool_backward`
+  recognises it by dtype.  torch keeps the first maximum in scan order, as TF does."""
+  import torch
+  import torch.nn.functional as F
+  n, h, w, c = x.shape
+  oh, ow, pt, pb, pl, pr = _pool_geometry(h, w, k, stride, padding)
+  xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+  xp = F.pad(xt, (pl, pr, pt, pb), value=float("-inf"))
+  with torch.no_grad():
+    y, idx = F.max_pool2d(xp, k, stride, return_indices=True)
+  return (np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy()),
+          np.ascontiguousarray(idx.permute(0, 2, 3, 1).numpy()))
+
+
+def _max_pool_backward_torch(x_shape, arg, dy, k, stride, padding):
+  import torch
+  n, h, w, c = x_shape
+  oh, ow, pt, pb, pl, pr = _pool_geometry(h, w, k, stride, padding)
+  hp, wp = h + pt + pb, w + pl + pr
+  idx = torch.from_numpy(arg).reshape(n, oh * ow, c)                   # NHWC throughout: no copies
+  g = torch.from_numpy(np.ascontiguousarray(dy)).reshape(n, oh * ow, c)
+  dxp = torch.zeros(n, hp * wp, c, dtype=g.dtype)
+  dxp.scatter_add_(1, idx, g)
+  return np.ascontiguousarray(dxp.view(n, hp, wp, c)[:, pt:pt + h, pl:pl + w, :].numpy())
+
+
+def batch_norm_relu(x, gamma, beta, mean, var, eps=0.001):
+  """relu(batch_norm_inference(x)) — the tail of every slim conv2d of the extractor."""
+  if _CONV_BACKEND == "torch" and x.dtype == np.float32:
+    import torch
+    f = np.float32
+    scaling = ((f(1) / np.sqrt(var + f(eps))) * (gamma if gamma is not None else f(1))).astype(f)
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+      y = torch.relu_((xt - torch.from_numpy(mean.astype(f))) * torch.from_numpy(scaling) +
+                      torch.from_numpy(beta.astype(f)))
+    return y.numpy()
+  return np.maximum(batch_norm_inference(x, gamma, beta, mean, var, eps), 0)
+
+
 def max_pool(x, k, stride, padding):
   """slim.max_pool2d.  Returns (y, argmax) with argmax = first maximum in (ky,kx) scan order."""
+  if _CONV_BACKEND == "torch" and x.dtype == np.float32:
+    return _max_pool_torch(x, k, stride, padding)
   view, (oh, ow, _, _, _) = _windows(x, k, k, stride, -np.inf, padding)
   flat = np.moveaxis(view.reshape(x.shape[0], oh, ow, k * k, x.shape[3]), 3, -1)
   arg = np.argmax(flat, axis=-1)
@@ -322,6 +433,8 @@ def max_pool(x, k, stride, padding):
 
 def max_pool_backward(x_shape, arg, dy, k, stride, padding):
   """MaxPoolGrad: the whole gradient goes to the first maximum of each window."""
+  if arg.dtype == np.int64:
+    return _max_pool_backward_torch(x_shape, arg, dy, k, stride, padding)
   n, h, w, c = x_shape
   if padding == "SAME":
     oh, pt, pb = same_padding(h, k, stride)
@@ -339,6 +452,13 @@ def max_pool_backward(x_shape, arg, dy, k, stride, padding):
 
 def avg_pool_same(x, k=3):
   """slim.avg_pool2d stride 1 SAME: padded cells are excluded from the divisor (TF AvgPool)."""
+  if _CONV_BACKEND == "torch" and x.dtype == np.float32 and k % 2 == 1:
+    import torch
+    import torch.nn.functional as F
+    xt = torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2)
+    with torch.no_grad():
+      y = F.avg_pool2d(xt, k, 1, k // 2, count_include_pad=False)
+    return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
   view, _ = _windows(x, k, k, 1, 0.0, "SAME")
   ones = np.ones((1,) + x.shape[1:3] + (1,), dtype=x.dtype)
   cnt, _ = _windows(ones, k, k, 1, 0.0, "SAME")
@@ -347,6 +467,16 @@ def avg_pool_same(x, k=3):
 
 def avg_pool_same_backward(x_shape, dy, k=3):
   n, h, w, c = x_shape
+  if _CONV_BACKEND == "torch" and dy.dtype == np.float32 and k % 2 == 1:
+    # the adjoint of "sum over the window / valid count": g = dy / count, summed over windows
+    import torch
+    import torch.nn.functional as F
+    ones = torch.ones(1, 1, h, w)
+    cnt = F.avg_pool2d(ones, k, 1, k // 2, count_include_pad=True) * float(k * k)
+    g = torch.from_numpy(np.ascontiguousarray(dy)).permute(0, 3, 1, 2) / cnt
+    with torch.no_grad():
+      dx = F.avg_pool2d(g, k, 1, k // 2, count_include_pad=True) * float(k * k)
+    return np.ascontiguousarray(dx.permute(0, 2, 3, 1).numpy())
   ones = np.ones((1, h, w, 1), dtype=dy.dtype)
   cnt, _ = _windows(ones, k, k, 1, 0.0, "SAME")
   g = dy / cnt.sum(axis=(3, 4))

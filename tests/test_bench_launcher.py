@@ -1,0 +1,51 @@
+"""`python bench.py --gpus N` as a plain command (the shape of the driver's BENCH / SCALE
+commands): the parent starts one rank per GPU through torch.distributed.run as a child process.
+On this CPU box the ranks run the stubbed step (C2D_BENCH_STUB=1: launcher, rendezvous on
+127.0.0.1, barrier, two-bucket gradient exchange over gloo, max-over-ranks timing, one JSON line
+from rank 0) — the one-process-per-GPU layout of the reference's workers (train_wsod.sh:46-88)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *argv):
+  env = dict(os.environ, **extra_env)
+  env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+  return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_plain_command_launches_two_ranks():
+  r = _run({"C2D_BENCH_STUB": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout                      # rank 0 only
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["stub"] is True
+  assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+  assert out["value"] > 0 and out["ms_per_step"] > 0
+
+
+def test_single_rank_stub_runs_in_process():
+  r = _run({"C2D_BENCH_STUB": "1"}, "--steps", "2", "--warmup", "0")
+  assert r.returncode == 0, r.stderr[-2000:]
+  out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+  assert out["n_gpus"] == 1 and out["world_size"] == 1
+
+
+def test_failing_rank_propagates_exit_code():
+  # WORLD_SIZE/--gpus mismatch inside the child: the parent must not report success
+  r = _run({"C2D_BENCH_STUB": "1", "C2D_BENCH_STUB_FAIL": "1"}, "--gpus", "2", "--steps", "1",
+           "--warmup", "0")
+  assert r.returncode != 0
+
+
+def test_without_gpu_and_without_stub_fails_loudly():
+  import torch
+  if torch.cuda.device_count() > 0:
+    return
+  r = _run({}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+  assert r.returncode != 0 and "no GPU" in r.stderr

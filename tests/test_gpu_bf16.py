@@ -141,7 +141,7 @@ def test_train_step_bf16_coco17_extend_match(tmp_path):
   classes, syn = _coco_like_classes(rng)
   lf = tmp_path / "coco_label_synonyms.txt"
   lf.write_text("\n".join("%s\t%s" % (c, ",".join(s)) for c, s in zip(classes, syn)))
-  pipeline = util_model.load_pipeline("coco17_extend_match_hotpath", LABEL_SYNONYMS_FILE=str(lf))
+  pipeline = util_model.load_pipeline("coco17_extend_match_hotpath", label_file=str(lf))
   name2id, _ = ref_labels.read_synonym_file(str(lf))
   caps = _captions(rng, classes, syn)
   _check_train_step_bf16(

@@ -53,8 +53,8 @@ def _setup(tmp_path, rng, vocab_size=150, classes=80):
   emb = (0.4 * rng.standard_normal((len(vocab), 300))).astype(np.float32)
   lf, vf, ef = tmp_path / "labels.txt", tmp_path / "vocab.txt", tmp_path / "emb.npy"
   lf.write_text("\n".join(names)); vf.write_text("\n".join(vocab)); np.save(str(ef), emb)
-  pipeline = util_model.load_pipeline("coco17_text_hotpath", LABEL_FILE=str(lf),
-                                      OPEN_VOCAB_FILE=str(vf), OPEN_VOCAB_EMBEDDING_NPY=str(ef))
+  pipeline = util_model.load_pipeline("coco17_text_hotpath", label_file=str(lf),
+                                      open_vocabulary_file=str(vf), open_vocabulary_word_embedding_file=str(ef))
   return pipeline, names, vocab, emb
 
 

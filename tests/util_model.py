@@ -4,43 +4,10 @@ import os
 import numpy as np
 
 from oracle import ref_model
+from cap2det_amd.synthetic import (load_pipeline, make_examples, synthetic_boxes,  # noqa: F401
+                                   synthetic_captions)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def load_pipeline(name="voc07_groundtruth_hotpath", **subst):
-  from cap2det_amd.protos import pipeline_pb2, text_format
-  text = open(os.path.join(ROOT, "configs", name + ".pbtxt")).read()
-  text = text.replace("cap2det_amd/data/", os.path.join(ROOT, "cap2det_amd", "data") + "/")
-  for k, v in subst.items():
-    text = text.replace(k, v)
-  p = pipeline_pb2.Pipeline()
-  text_format.Merge(text, p)
-  return p
-
-
-def synthetic_boxes(rng, n, min_side=0.04):
-  """centre ~U(0,1), log-size ~U(log 0.04, log 1), clipped to [0,1]."""
-  c = rng.uniform(0, 1, (n, 2))
-  s = np.exp(rng.uniform(np.log(min_side), 0.0, (n, 2)))
-  lo = np.clip(c - s / 2, 0, 1)
-  hi = np.clip(c + s / 2, 0, 1)
-  hi = np.maximum(hi, np.minimum(lo + min_side, 1.0))
-  lo = np.minimum(lo, hi - min_side)
-  return np.concatenate([lo, hi], axis=1).astype(np.float32)
-
-
-def make_examples(rng, batch, h, w, n, num_proposals, classes, labels_per_image=2):
-  image = rng.integers(0, 256, (batch, h, w, 3)).astype(np.float32)
-  proposals = np.stack([synthetic_boxes(rng, n) for _ in range(batch)])
-  num = np.asarray(num_proposals, np.int32)
-  for b in range(batch):
-    proposals[b, num[b]:] = 0.0          # padded_batch zero pad (readers/cap2det_reader.py:237)
-  texts = []
-  for b in range(batch):
-    picks = rng.choice(len(classes), labels_per_image, replace=False)
-    texts.append([classes[i] for i in picks] + ["", "not_a_class"])
-  return dict(image=image, number_of_proposals=num, proposals=proposals, object_texts=texts)
 
 
 def oracle_state(seed, num_classes, oicr_iterations, dm=1.0, dtype=np.float32, head_std=0.05):
