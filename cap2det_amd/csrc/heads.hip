@@ -255,47 +255,196 @@ __global__ __launch_bounds__(256) void labels_from_ids_kernel(const int32_t* __r
   }
 }
 
-// One block per caption.  hidden = relu(masked_maximum_t(E[id_t] . W1 + b1)); logits = hidden . W2 + b2.
-__global__ __launch_bounds__(256) void text_classifier_kernel(
+// One 1024-thread block per caption.  hidden = relu(masked_maximum_t(E[id_t] . W1 + b1));
+// logits = hidden . W2 + b2.  masked_maximum is the reference's literal formula
+// max_t((v_t - min_T v) * m_t) + min_T v (core/utils.py:75-79), so the pre-activations are
+// evaluated twice (sweep 0: min over ALL tokens, sweep 1: the masked maximum) instead of being
+// kept: T x H floats do not fit beside the staged embedding rows, and the second sweep costs
+// ~10 us.  Work split: thread -> (hidden unit h, token slice); the embedding rows of a chunk of
+// TXT_TC tokens are staged in LDS and read as broadcasts, a W1 element is loaded once per chunk
+// and reused for the slice's tokens of that chunk (the previous form walked tokens serially with
+// a block barrier per token: 8 ms per caption at T = 60 — longer than the whole detector step).
+constexpr int TXT_TC = 16;      // tokens per staged chunk
+constexpr int TXT_MAXJ = 16;    // tokens of a chunk one thread may own (= TXT_TC when nslice = 1)
+__global__ __launch_bounds__(1024) void text_classifier_kernel(
     const int32_t* __restrict__ ids, int T, const float* __restrict__ emb, int vocab, int E,
     const float* __restrict__ w1, const float* __restrict__ b1, int H,
     const float* __restrict__ w2, const float* __restrict__ b2, int C,
     float* __restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* hid = smem;       // [H]
-  float* erow = smem + H;  // [E] current token embedding
+  const int Epad = (E + 3) & ~3;
+  float* hid = smem;                      // [H]   final hidden layer
+  float* part = hid + H;                  // [nslice][H] per-slice partial min / max
   const int b = blockIdx.x;
-  // per hidden unit h (thread-strided): running min over all tokens, max over (v - min)*mask is
-  // evaluated in two sweeps like the reference formula max((h - min_T h) * m) + min_T h.
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int h0 = 0; h0 < H; h0 += blockDim.x) {
-      const int h = h0 + threadIdx.x;
-      float mn = INFINITY, best = -INFINITY;
-      if (pass == 1 && h < H) mn = hid[h];
-      for (int t = 0; t < T; ++t) {
-        int id = ids[b * T + t];
-        if (id < 0 || id > vocab) id = vocab;
+  const int hspan = min(((H + 63) / 64) * 64, (int)blockDim.x);   // threads per token slice
+  const int nslice = max(1, min((int)blockDim.x / hspan, TXT_TC));
+  float* erow = part + nslice * H;        // [TXT_TC][Epad] staged embedding rows
+  int* eid = reinterpret_cast<int*>(erow + TXT_TC * Epad);    // [TXT_TC] their (clamped) ids
+  const int slice = threadIdx.x / hspan;
+  const int hl = threadIdx.x - slice * hspan;
+  const bool worker = slice < nslice;
+  for (int h0 = 0; h0 < H; h0 += hspan) {
+    const int h = h0 + hl;
+    const bool on = worker && h < H;
+    const float bias = on ? b1[h] : 0.f;
+    float mn = INFINITY;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      float best = -INFINITY, smin = INFINITY;
+      for (int t0 = 0; t0 < T; t0 += TXT_TC) {
+        const int nt = min(TXT_TC, T - t0);
+        __syncthreads();                  // the previous chunk's rows are no longer read
+        for (int i = threadIdx.x; i < nt * Epad; i += blockDim.x) {
+          const int t = i / Epad, e = i - t * Epad;
+          int id = ids[b * T + t0 + t];
+          if (id < 0 || id > vocab) id = vocab;
+          erow[i] = e < E ? emb[(size_t)id * E + e] : 0.f;
+          if (e == 0) eid[t] = id;
+        }
         __syncthreads();
-        for (int e = threadIdx.x; e < E; e += blockDim.x) erow[e] = emb[(size_t)id * E + e];
-        __syncthreads();
-        if (h < H) {
-          float v = 0.f;
-          for (int e = 0; e < E; ++e) v += erow[e] * w1[(size_t)e * H + h];
-          v += b1[h];
-          if (pass == 0) mn = fminf(mn, v);
-          else best = fmaxf(best, (v - mn) * (id != vocab ? 1.0f : 0.0f));
+        if (on) {
+          float acc[TXT_MAXJ];
+#pragma unroll
+          for (int j = 0; j < TXT_MAXJ; ++j) acc[j] = 0.f;
+          for (int e = 0; e < E; ++e) {
+            const float w = w1[(size_t)e * H + h];
+#pragma unroll
+            for (int j = 0; j < TXT_MAXJ; ++j) {
+              const int t = slice + j * nslice;
+              if (t < nt) acc[j] += erow[t * Epad + e] * w;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < TXT_MAXJ; ++j) {
+            const int t = slice + j * nslice;
+            if (t < nt) {
+              const float v = acc[j] + bias;
+              if (sweep == 0) smin = fminf(smin, v);
+              else best = fmaxf(best, (v - mn) * (eid[t] != vocab ? 1.0f : 0.0f));
+            }
+          }
         }
       }
+      // combine the token slices of hidden unit h (min / max: order-independent, exact)
+      if (on) part[slice * H + h] = sweep == 0 ? smin : best;
       __syncthreads();
-      if (h < H) hid[h] = pass == 0 ? mn : fmaxf(best + mn, 0.0f);
+      if (on) {
+        float r = part[h];
+        for (int q = 1; q < nslice; ++q)
+          r = sweep == 0 ? fminf(r, part[q * H + h]) : fmaxf(r, part[q * H + h]);
+        if (sweep == 0) mn = r;
+        else if (slice == 0) hid[h] = fmaxf(r + mn, 0.0f);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float v = 0.f;
     for (int h = 0; h < H; ++h) v += hid[h] * w2[(size_t)h * C + c];
     logits[b * C + c] = v + b2[c];
   }
+}
+
+// Workspace form (the one the detector's label extractor uses): the hidden layer is independent
+// per hidden unit, so the grid is (hidden units / 64, captions) instead of one workgroup per
+// caption, and a workgroup keeps ITS 64 columns of W1 in LDS ([E][64] fp32, 75 KiB at E = 300)
+// for both sweeps and every token chunk: 20 000 LDS-fed FMAs per lane and no global load inside
+// the loops (the one-workgroup form re-reads W1 from L2 once per chunk and sweep: ~1 ms per
+// caption).  hidden[b][h] goes to the caller's workspace; text_logits_kernel finishes.
+constexpr int TXT_HB = 64;      // hidden units per workgroup
+__global__ __launch_bounds__(256) void text_hidden_kernel(
+    const int32_t* __restrict__ ids, int T, const float* __restrict__ emb, int vocab, int E,
+    const float* __restrict__ w1, const float* __restrict__ b1, int H,
+    float* __restrict__ hidden) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Epad = (E + 3) & ~3;
+  float* wl = smem;                               // [E][TXT_HB]
+  float* erow = wl + (size_t)E * TXT_HB;          // [TXT_TC][Epad]
+  float* part = erow + TXT_TC * Epad;             // [4][TXT_HB]
+  int* eid = reinterpret_cast<int*>(part + 4 * TXT_HB);
+  const int b = blockIdx.y, h0 = blockIdx.x * TXT_HB;
+  const int hl = threadIdx.x & (TXT_HB - 1), slice = threadIdx.x >> 6;   // 4 token slices
+  const int h = h0 + hl;
+  const bool on = h < H;
+  for (int i = threadIdx.x; i < E * TXT_HB; i += 256) {
+    const int e = i >> 6, c = i & (TXT_HB - 1);
+    wl[i] = h0 + c < H ? w1[(size_t)e * H + h0 + c] : 0.f;
+  }
+  const float bias = on ? b1[h] : 0.f;
+  float mn = INFINITY;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    float best = -INFINITY, smin = INFINITY;
+    for (int t0 = 0; t0 < T; t0 += TXT_TC) {
+      const int nt = min(TXT_TC, T - t0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < nt * Epad; i += 256) {
+        const int t = i / Epad, e = i - t * Epad;
+        int id = ids[b * T + t0 + t];
+        if (id < 0 || id > vocab) id = vocab;
+        erow[i] = e < E ? emb[(size_t)id * E + e] : 0.f;
+        if (e == 0) eid[t] = id;
+      }
+      __syncthreads();
+      float acc[TXT_TC / 4];
+#pragma unroll
+      for (int j = 0; j < TXT_TC / 4; ++j) acc[j] = 0.f;
+      for (int e = 0; e < E; ++e) {
+        const float w = wl[e * TXT_HB + hl];
+#pragma unroll
+        for (int j = 0; j < TXT_TC / 4; ++j) {
+          const int t = slice + 4 * j;            // (rows past nt hold stale data: never used below)
+          acc[j] += erow[t * Epad + e] * w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TXT_TC / 4; ++j) {
+        const int t = slice + 4 * j;
+        if (t < nt) {
+          const float v = acc[j] + bias;
+          if (sweep == 0) smin = fminf(smin, v);
+          else best = fmaxf(best, (v - mn) * (eid[t] != vocab ? 1.0f : 0.0f));
+        }
+      }
+    }
+    part[slice * TXT_HB + hl] = sweep == 0 ? smin : best;
+    __syncthreads();
+    float r = part[hl];
+    for (int q = 1; q < 4; ++q)
+      r = sweep == 0 ? fminf(r, part[q * TXT_HB + hl]) : fmaxf(r, part[q * TXT_HB + hl]);
+    if (sweep == 0) mn = r;
+    else if (slice == 0 && on) hidden[(size_t)b * H + h] = fmaxf(r + mn, 0.0f);
+    __syncthreads();
+  }
+}
+
+// logits[b][c] = hidden[b] . W2[:, c] + b2[c]; one wave per class (lanes stride the hidden units,
+// wave-shuffle sum), then the label merge of text_labels_merge_kernel.
+__global__ __launch_bounds__(256) void text_logits_kernel(
+    const float* __restrict__ hidden, int H, const float* __restrict__ w2,
+    const float* __restrict__ b2, int C, const float* __restrict__ exact, float thr,
+    float* __restrict__ logits, float* __restrict__ labels) {
+  extern __shared__ __attribute__((aligned(16))) float hid[];   // [H]
+  __shared__ int any_exact;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) any_exact = 0;
+  for (int h = threadIdx.x; h < H; h += blockDim.x) hid[h] = hidden[(size_t)b * H + h];
+  __syncthreads();
+  if (labels)
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+      if (exact[b * C + c] > 0.f) any_exact = 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < C; c += 4) {
+    float v = 0.f;
+    for (int h = lane; h < H; h += 64) v += hid[h] * w2[(size_t)h * C + c];
+    v = c2d_wave_sum(v);
+    if (lane == 0) logits[b * C + c] = v + b2[c];
+  }
+  __syncthreads();
+  if (labels)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float ml = sigmoidf(logits[b * C + c]) > thr ? 1.0f : 0.0f;
+      labels[b * C + c] = any_exact ? exact[b * C + c] : ml;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,14 +706,55 @@ extern "C" int c2d_text_classifier_fwd(const int32_t* ids, int batch, int num_to
   C2D_CHECK_ARG(batch > 0 && num_tokens > 0 && vocab_size > 0 && emb_dims > 0);
   C2D_CHECK_ARG(hidden_units > 0 && num_classes > 0);
   C2D_CHECK_ARG(!labels || exact_labels);
-  const size_t smem = (size_t)(hidden_units + emb_dims) * sizeof(float);
+  const int hspan = hidden_units > 1024 ? 1024 : ((hidden_units + 63) / 64) * 64;
+  int nslice = 1024 / hspan;
+  if (nslice < 1) nslice = 1;
+  if (nslice > TXT_TC) nslice = TXT_TC;
+  const size_t smem = ((size_t)hidden_units * (1 + nslice) + (size_t)TXT_TC * ((emb_dims + 3) & ~3)) *
+                          sizeof(float) + TXT_TC * sizeof(int);
   if (smem > 64 * 1024) return C2D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(text_classifier_kernel, dim3(batch), dim3(256), smem, (hipStream_t)stream,
+  hipLaunchKernelGGL(text_classifier_kernel, dim3(batch), dim3(1024), smem, (hipStream_t)stream,
                      ids, num_tokens, embedding, vocab_size, emb_dims, w1, b1, hidden_units, w2,
                      b2, num_classes, logits);
   if (labels)
     hipLaunchKernelGGL(text_labels_merge_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream,
                        logits, exact_labels, label_threshold, num_classes, labels);
+  return c2d_launch_status();
+}
+
+extern "C" long long c2d_text_classifier_workspace_bytes(int batch, int hidden_units) {
+  if (batch <= 0 || hidden_units <= 0) return -1;
+  return (long long)batch * hidden_units * (long long)sizeof(float);
+}
+
+extern "C" int c2d_text_classifier_fwd_ws(const int32_t* ids, int batch, int num_tokens,
+                                          const float* embedding, int vocab_size, int emb_dims,
+                                          const float* w1, const float* b1, int hidden_units,
+                                          const float* w2, const float* b2, int num_classes,
+                                          const float* exact_labels, float label_threshold,
+                                          float* logits, float* labels, void* workspace,
+                                          long long workspace_bytes, void* stream) {
+  C2D_CHECK_ARG(ids && embedding && w1 && b1 && w2 && b2 && logits && workspace);
+  C2D_CHECK_ARG(batch > 0 && num_tokens > 0 && vocab_size > 0 && emb_dims > 0);
+  C2D_CHECK_ARG(hidden_units > 0 && num_classes > 0);
+  C2D_CHECK_ARG(!labels || exact_labels);
+  if (workspace_bytes < c2d_text_classifier_workspace_bytes(batch, hidden_units))
+    return C2D_ERR_WORKSPACE;
+  const size_t smem = ((size_t)emb_dims * TXT_HB + (size_t)TXT_TC * ((emb_dims + 3) & ~3) +
+                       4 * TXT_HB) * sizeof(float) + TXT_TC * sizeof(int);
+  if (smem > 150 * 1024 || (size_t)hidden_units * sizeof(float) > 60 * 1024)
+    return C2D_ERR_UNSUPPORTED;
+  static const hipError_t attr = hipFuncSetAttribute(
+      (const void*)text_hidden_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)attr;
+  float* hidden = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(text_hidden_kernel, dim3(c2d_ceil_div(hidden_units, TXT_HB), batch),
+                     dim3(256), smem, st, ids, num_tokens, embedding, vocab_size, emb_dims, w1,
+                     b1, hidden_units, hidden);
+  hipLaunchKernelGGL(text_logits_kernel, dim3(batch), dim3(256),
+                     (size_t)hidden_units * sizeof(float), st, hidden, hidden_units, w2, b2,
+                     num_classes, exact_labels, label_threshold, logits, labels);
   return c2d_launch_status();
 }
 

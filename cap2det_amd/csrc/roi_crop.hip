@@ -332,13 +332,17 @@ __global__ __launch_bounds__(512) void roi_crop_pool_bwd_lds_kernel(
 //   2. roi_bin_rows_kernel  : for every feature-map row y, the ORDERED list of pooled cells
 //                             (roi, py, px) that can touch row y (a stable compaction, so the
 //                             summation order below is fixed).
-//   3. roi_bwd_rows_kernel  : one workgroup per (row y, 16-channel chunk, image) walks its list;
-//                             its 16 lane groups accumulate into private [wf][16] LDS strips with
-//                             plain read-modify-writes (a strip is touched by one 16-lane group,
-//                             one lane per channel), then the strips are summed in a fixed order
-//                             and the row is written with plain stores.
-// LDS float atomics (the privatised kernel above) retire ~1.4 lane-adds per clock per CU and
-// global float atomics are at the chip-wide atomic rate already; this form has neither.
+//   3. roi_bwd_strip_kernel : one workgroup per (row y, channel chunk, list part) walks its list.
+//                             ONE LANE OWNS ONE CHANNEL of the row strip [wf][chunk] in LDS for the
+//                             whole walk, so its read-modify-writes race with nobody (no atomics,
+//                             no private copies); a list entry's operands are wave-uniform (scalar
+//                             loads) and the dpooled / arg-max reads of an entry are contiguous
+//                             chunk-wide segments of the cell's channel row.
+//   4. roi_bwd_sum_parts_kernel : adds the parts in a fixed order into the gradient map.
+// LDS float atomics retire ~1.4 lane-adds per clock per CU and global float atomics are at the
+// chip-wide atomic rate already; this form has neither.
+// (Round 1 walked the lists with 16 lane groups x 16 channels and 16 private strips per
+// workgroup: 64-byte gathers and two dependent global round trips per trip — 365 us, 8 % of HBM.)
 // ---------------------------------------------------------------------------------------------
 struct AxisRec { int lo, hi; float lerp; int pad; };
 
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void roi_axes_kernel(const float* __restrict__
   xs[i] = {sx.lo, sx.hi, sx.lerp, 0};
 }
 
-constexpr int kBinSegs = 8;   // cell-range segments per row list (parallelism of the binning)
+constexpr int kBinSegs = 16;  // cell-range segments per row list = list parts of the strip kernel
 
 // One list entry = everything about (cell, row y) that does not depend on the channel: the row
 // weight of either vertical sample of the 2x2 pooling window and the column taps of either
@@ -431,67 +435,66 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
   if (threadIdx.x == 0) counts[((size_t)b * hf + y) * kBinSegs + seg] = running;
 }
 
-constexpr int kRowParts = 4;  // workgroups sharing one (row, chunk): finer grains -> better balance
+constexpr int kRowParts = kBinSegs;   // one list segment per workgroup (and per partial map)
 
-// grid (hf, depth/CH, batch*kRowParts), block 256 = (256/CH) lane groups x CH channels.  Part q
-// walks segments [q*kBinSegs/kRowParts, ...) of the row list and writes its partial row into
-// part[q] (plain stores); roi_bwd_sum_parts_kernel then adds the parts in a fixed order.
-template <int CH, typename TG>
-__global__ __launch_bounds__(256) void roi_bwd_rows_kernel(
+// grid (hf, depth / CHUNK, batch * kRowParts), block = CHUNK threads (lane <-> channel c0 + tid).
+// Part q walks segment q of the row list and writes its partial row into parts[q] (plain
+// stores); roi_bwd_sum_parts_kernel then adds the parts in a fixed order.
+// U list entries per trip: their scalar entry loads, then their 2*U vector loads, are issued
+// together before the first read-modify-write.
+template <int CHUNK, typename TG>
+__global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
     const TG* __restrict__ dout, const uint8_t* __restrict__ argmax,
     const RowEntry* __restrict__ lists, const int32_t* __restrict__ counts,
     float* __restrict__ parts, int batch, int hf, int wf, int depth, int pout, int cap) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];   // [NG groups][wf][CH]
-  constexpr int NG = 256 / CH;
-  const int y = blockIdx.x, c0 = blockIdx.y * CH;
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [wf][CHUNK]
+  const int y = blockIdx.x, c0 = blockIdx.y * CHUNK;
   const int b = blockIdx.z / kRowParts, part = blockIdx.z % kRowParts;
-  const int ch = threadIdx.x % CH, grp = threadIdx.x / CH;
-  for (int i = threadIdx.x; i < NG * wf * CH; i += 256) acc[i] = 0.0f;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < wf * CHUNK; i += CHUNK) acc[i] = 0.0f;
   __syncthreads();
   const int p2 = pout * pout;
-  float* mine = acc + (size_t)grp * wf * CH + ch;
-  constexpr int U = 4;   // list entries per trip: their loads are issued together
-  constexpr int SEGS = kBinSegs / kRowParts;
-  for (int seg = part * SEGS; seg < (part + 1) * SEGS; ++seg) {   // fixed summation order
-    const size_t lrow = ((size_t)b * hf + y) * kBinSegs + seg;
-    const RowEntry* list = lists + lrow * cap;
-    const int count = counts[lrow];
-    for (int i0 = grp; i0 < count; i0 += NG * U) {
-      RowEntry e[U];
-      float g[U];
-      int k[U];
+  const size_t lrow = ((size_t)b * hf + y) * kBinSegs + part;
+  const RowEntry* __restrict__ list = lists + lrow * cap;
+  const int count = __builtin_amdgcn_readfirstlane(counts[lrow]);
+  float* mine = acc + tid;
+  const bool on = c0 + tid < depth;                 // (ragged last chunk: depth % CHUNK != 0)
+  const int cc = on ? c0 + tid : c0;
+  const TG* gcol = dout + cc;
+  const uint8_t* kcol = argmax + cc;
+  constexpr int U = 8;
+  for (int i0 = 0; i0 < count; i0 += U) {          // fixed order: the sum is reproducible
+    RowEntry e[U];
+    float g[U];
+    int k[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + NG * u;
-        const bool in = i < count;
-        e[u] = list[in ? i : (count - 1)];
-        const int roi = e[u].id >> 8, py = (e[u].id >> 4) & 15, px = e[u].id & 15;
-        const size_t o = ((size_t)roi * p2 + py * pout + px) * depth + c0 + ch;
-        g[u] = in ? (float)dout[o] : 0.0f;
-        k[u] = argmax[o];
-      }
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u, count - 1);         // (wave-uniform: scalar loads)
+      e[u] = list[i];
+    }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float wy = (k[u] >> 1) ? e[u].wy1 : e[u].wy0;
-        const int xp = (k[u] & 1) ? e[u].x1 : e[u].x0;
-        const float lx = (k[u] & 1) ? e[u].lx1 : e[u].lx0;
-        const float v = wy * g[u];
-        if (v == 0.0f || xp < 0) continue;
-        // (plain read-modify-writes on purpose: ds_add_f32 retires at the LDS atomic rate and
-        // measured 3.4x slower here, 1.25 ms vs 0.37 ms)
-        mine[(xp & 0xffff) * CH] += (1.0f - lx) * v;
-        mine[(xp >> 16) * CH] += lx * v;
-      }
+    for (int u = 0; u < U; ++u) {
+      const int roi = e[u].id >> 8, py = (e[u].id >> 4) & 15, px = e[u].id & 15;
+      const size_t o = ((size_t)roi * p2 + py * pout + px) * depth;
+      g[u] = (on && i0 + u < count) ? (float)gcol[o] : 0.0f;
+      k[u] = kcol[o];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float wy = (k[u] >> 1) ? e[u].wy1 : e[u].wy0;
+      const int xp = (k[u] & 1) ? e[u].x1 : e[u].x0;
+      const float lx = (k[u] & 1) ? e[u].lx1 : e[u].lx0;
+      const float v = wy * g[u];
+      if (v == 0.0f || xp < 0) continue;
+      // TF CropAndResizeGradImage: (1 - lx) * dtop to column lo, lx * dtop to column hi
+      mine[(xp & 0xffff) * CHUNK] += (1.0f - lx) * v;
+      mine[(xp >> 16) * CHUNK] += lx * v;
     }
   }
   __syncthreads();
-  float* drow = parts + ((((size_t)part * batch + b) * hf + y) * wf) * depth + c0;
-  for (int i = threadIdx.x; i < wf * CH; i += 256) {
-    float s = 0.0f;
-#pragma unroll
-    for (int gq = 0; gq < NG; ++gq) s += acc[(size_t)gq * wf * CH + i];
-    drow[(size_t)(i / CH) * depth + (i % CH)] = s;
-  }
+  float* drow = parts + ((((size_t)part * batch + b) * hf + y) * wf) * depth + c0 + tid;
+  if (on)
+    for (int x = 0; x < wf; ++x) drow[(size_t)x * depth] = mine[x * CHUNK];
 }
 
 // dfeat += part[0] + part[1] + ... (fixed order), float4 per lane.
@@ -683,15 +686,18 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
                      dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
   hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
                      box_ind, lists, counts, num_boxes, hf, pool_s, pout, crop, cap);
-  const int chsel = 16;   // measured: 16-channel chunks 447 us, 32: 492, 64: ~1000 (N=2000, 32x32x576)
-#define C2D_ROWS(CHV)                                                                          \
-  hipLaunchKernelGGL((roi_bwd_rows_kernel<CHV, TG>), dim3(hf, depth / CHV, batch * kRowParts),    \
-                     dim3(256), (size_t)256 * wf * sizeof(float), st, dout, argmax, lists, counts, \
-                     parts, batch, hf, wf, depth, pout, cap)
-  if (depth % 64 == 0 && chsel == 64) { C2D_ROWS(64); }
-  else if (depth % 32 == 0 && chsel == 32) { C2D_ROWS(32); }
-  else { C2D_ROWS(16); }
-#undef C2D_ROWS
+  // channel chunk = workgroup size: the largest of 256 / 192 / 128 / 64 that divides the depth
+  // (576 -> 192: three 768-byte segments per cell, 24 KiB of LDS, six workgroups per CU)
+#define C2D_STRIP(CHV)                                                                          \
+  hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>),                                          \
+                     dim3(hf, (depth + CHV - 1) / CHV, batch * kRowParts),                      \
+                     dim3(CHV), (size_t)CHV * wf * sizeof(float), st, dout, argmax, lists,     \
+                     counts, parts, batch, hf, wf, depth, pout, cap)
+  if (depth % 256 == 0) { C2D_STRIP(256); }
+  else if (depth % 192 == 0) { C2D_STRIP(192); }
+  else if (depth % 128 == 0) { C2D_STRIP(128); }
+  else { C2D_STRIP(64); }
+#undef C2D_STRIP
   const long long n4 = (long long)batch * hf * wf * depth / 4;
   hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, st,
                      (const float4*)parts, (float4*)dfeat, n4);

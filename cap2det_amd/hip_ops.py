@@ -316,8 +316,16 @@ def labels_from_ids(ids, num_classes, labels):
 
 
 def text_classifier_fwd(ids, embedding, w1, b1, w2, b2, exact_labels, label_threshold, logits,
-                        labels):
+                        labels, workspace=None):
+  """workspace: float32 device tensor [batch, hidden] -> the multi-workgroup form
+  (c2d_text_classifier_fwd_ws); None -> the one-workgroup-per-caption form."""
   batch, t = ids.shape
+  if workspace is not None:
+    _lib.call("c2d_text_classifier_fwd_ws", _p(ids), batch, t, _p(embedding),
+              embedding.shape[0] - 1, embedding.shape[1], _p(w1), _p(b1), w1.shape[1], _p(w2),
+              _p(b2), w2.shape[1], _p(exact_labels), float(label_threshold), _p(logits), _p(labels),
+              _p(workspace), workspace.numel() * workspace.element_size(), _stream())
+    return
   _lib.call("c2d_text_classifier_fwd", _p(ids), batch, t, _p(embedding), embedding.shape[0] - 1,
             embedding.shape[1], _p(w1), _p(b1), w1.shape[1], _p(w2), _p(b2), w2.shape[1],
             _p(exact_labels), float(label_threshold), _p(logits), _p(labels), _stream())

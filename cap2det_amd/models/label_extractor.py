@@ -240,6 +240,12 @@ class TextClassifierMatchExtractor(_OpenVocabularyExtractor):
     if self._weights[0].shape[1] != self._options.hidden_units:
       raise ValueError("text classifier hidden_units mismatch")
 
+  def _hidden_ws(self, batch):
+    ws = getattr(self, "_ws", None)
+    if ws is None or ws.shape[0] < batch:
+      ws = self._ws = torch.empty(batch, self._options.hidden_units, device=self._device)
+    return ws
+
   def _ids(self, examples):
     return tokens_to_ids(examples[InputDataFields.concat_caption_string], self._vocab_table,
                          len(self._open_vocabulary_list), self._device, min_tokens=1)
@@ -253,7 +259,8 @@ class TextClassifierMatchExtractor(_OpenVocabularyExtractor):
     ids = self._ids(examples)
     w1, b1, w2, b2 = self._weights
     logits = torch.empty(ids.shape[0], self._num_classes, device=self._device)
-    ops.text_classifier_fwd(ids, self._embedding, w1, b1, w2, b2, None, 0.0, logits, None)
+    ops.text_classifier_fwd(ids, self._embedding, w1, b1, w2, b2, None, 0.0, logits, None,
+                            workspace=self._hidden_ws(ids.shape[0]))
     return logits
 
   def extract_labels(self, examples):
@@ -267,7 +274,8 @@ class TextClassifierMatchExtractor(_OpenVocabularyExtractor):
     logits = torch.empty(ids.shape[0], self._num_classes, device=self._device)
     labels = torch.empty_like(logits)
     ops.text_classifier_fwd(ids, self._embedding, w1, b1, w2, b2, exact,
-                            self._options.label_threshold, logits, labels)
+                            self._options.label_threshold, logits, labels,
+                            workspace=self._hidden_ws(ids.shape[0]))
     return labels
 
 

@@ -304,6 +304,18 @@ int c2d_text_classifier_fwd(const int32_t* ids, int batch, int num_tokens,
                             const float* w1, const float* b1, int hidden_units, const float* w2,
                             const float* b2, int num_classes, const float* exact_labels,
                             float label_threshold, float* logits, float* labels, void* stream);
+/* Same computation with a caller-owned workspace of c2d_text_classifier_workspace_bytes(batch,
+ * hidden_units) bytes (the hidden layer): grid over (hidden units / 64, captions) with the
+ * workgroup's W1 columns held in LDS — the form the detector's training step uses (the
+ * one-workgroup form above needs ~1 ms per 60-token caption, this one ~30 us). */
+long long c2d_text_classifier_workspace_bytes(int batch, int hidden_units);
+int c2d_text_classifier_fwd_ws(const int32_t* ids, int batch, int num_tokens,
+                               const float* embedding, int vocab_size, int emb_dims,
+                               const float* w1, const float* b1, int hidden_units,
+                               const float* w2, const float* b2, int num_classes,
+                               const float* exact_labels, float label_threshold, float* logits,
+                               float* labels, void* workspace, long long workspace_bytes,
+                               void* stream);
 
 /* WordVectorMatchExtractor (models/label_extractor.py:251-328): cosine similarity of every
  * token with every class name (class_ids = vocabulary ids of the class names) in the embedding

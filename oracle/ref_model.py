@@ -555,7 +555,14 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
   mult = resolve_gradient_multipliers(trainable_names, multipliers)
   first_from = first_trainable_index(mult)
   grads.update(extract_frcnn_feature_backward(dfeatures, saved["frcnn"], P, options, first_from))
-  dt = dfeatures.dtype.type
+  return finish_step(P, accum, grads, loss_dict, mult, dfeatures.dtype.type, learning_rate,
+                     l2_weight, l1_weight, max_gradient_norm, predictions)
+
+
+def finish_step(P, accum, grads, loss_dict, mult, dt, learning_rate, l2_weight, l1_weight=0.0,
+                max_gradient_norm=None, predictions=None):
+  """Tail of `train_step`: regularisers, gradient multipliers, per-variable norm clipping,
+  Adagrad (shared with oracle/torch_step.py, bench.py's timed CPU baseline)."""
   reg = {}
   for name in P:
     if is_regularized(name):

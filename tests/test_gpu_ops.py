@@ -400,12 +400,39 @@ def test_labels_and_text_classifier(ops):
   exact = np.zeros((b, c), np.float32); exact[3, 2] = 1
   want_logits = ref_labels.text_classifier_logits(ids, emb, w1, b1, w2, b2)
   want_labels = ref_labels.text_classifier_match_extract(ids, exact, emb, w1, b1, w2, b2, 0.5)
-  logits = torch.empty(b, c, device=DEV); labels = torch.empty(b, c, device=DEV)
-  ops.text_classifier_fwd(_t(ids), _t(emb), _t(w1), _t(b1), _t(w2), _t(b2), _t(exact), 0.5, logits,
-                          labels)
-  np.testing.assert_allclose(_n(logits), want_logits, rtol=1e-4, atol=1e-4)
   safe = np.abs(ref_ops.sigmoid(want_logits) - 0.5) > 1e-3
-  np.testing.assert_array_equal(_n(labels)[safe], want_labels[safe])
+  # one workgroup per caption, and the workspace form (hidden units spread over workgroups)
+  for ws in (None, torch.empty(b, h, device=DEV)):
+    logits = torch.full((b, c), 7.0, device=DEV); labels = torch.full((b, c), 7.0, device=DEV)
+    ops.text_classifier_fwd(_t(ids), _t(emb), _t(w1), _t(b1), _t(w2), _t(b2), _t(exact), 0.5,
+                            logits, labels, workspace=ws)
+    np.testing.assert_allclose(_n(logits), want_logits, rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(_n(labels)[safe], want_labels[safe])
+
+
+@pytest.mark.parametrize("t,h,c", [(60, 400, 80), (1, 400, 80), (17, 96, 20), (33, 130, 5)])
+def test_text_classifier_real_sizes(ops, t, h, c):
+  """BASELINE configs[3]/[4] sizes (60 tokens, 300-d GloVe, 400 hidden units, 80 classes) and
+  ragged ones (token counts that are not a multiple of the 16-token chunk, hidden widths that
+  are not a multiple of 64), both kernel forms, incl. an all-OOV and a one-real-token caption."""
+  rng = np.random.default_rng(43 + t)
+  b, v, e = 3, 500, 300
+  ids = rng.integers(0, v + 1, (b, t)).astype(np.int32)
+  ids[1, :] = v
+  ids[2, 1:] = v
+  emb = (0.4 * rng.standard_normal((v + 1, e))).astype(np.float32)
+  w1 = (rng.standard_normal((e, h)) / np.sqrt(e)).astype(np.float32)
+  b1 = (0.1 * rng.standard_normal(h)).astype(np.float32)
+  w2 = (rng.standard_normal((h, c)) / np.sqrt(h)).astype(np.float32)
+  b2 = (0.1 * rng.standard_normal(c)).astype(np.float32)
+  want = ref_labels.text_classifier_logits(ids, emb, w1, b1, w2, b2)
+  got = []
+  for ws in (None, torch.empty(b, h, device=DEV)):
+    logits = torch.full((b, c), 7.0, device=DEV)
+    ops.text_classifier_fwd(_t(ids), _t(emb), _t(w1), _t(b1), _t(w2), _t(b2), None, 0.0, logits,
+                            None, workspace=ws)
+    np.testing.assert_allclose(_n(logits), want, rtol=1e-4, atol=1e-4)
+    got.append(_n(logits))
 
 
 def test_adagrad_and_l2(ops):

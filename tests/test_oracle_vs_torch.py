@@ -263,3 +263,78 @@ def test_text_training_oracle_matches_torch_autograd():
   np.testing.assert_allclose(loss, tl.item(), rtol=1e-12)
   for k, t in (("w1", tw1), ("b1", tb1), ("w2", tw2), ("b2", tb2)):
     np.testing.assert_allclose(grads[k], t.grad.numpy(), rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+def test_torch_cpu_step_equals_numpy_oracle_step():
+  """oracle/torch_step.py (bench.py's timed CPU baseline: torch-CPU towers + autograd) against the
+  numpy oracle's hand-derived step on the same inputs: losses, every applied gradient, every
+  updated variable — and the torch conv / pool backends of ref_ops against the numpy forms."""
+  from oracle import ref_labels, torch_step
+  from cap2det_amd import synthetic
+  from tests import util_model
+  classes = synthetic.read_lines(synthetic.DATA + "/voc_label.txt")
+  dm, n = 0.5, 9
+  rng = np.random.default_rng(0)
+  P, d = util_model.oracle_state(0, len(classes), 3, dm)
+  ex = synthetic.make_examples(rng, 2, 72, 56, n, [n, 6], classes)
+  ex["proposals"][0, 1] = [0.0, 0.0, 1.0, 1.0]       # touches both borders
+  ex["proposals"][0, 2] = [0.7, 0.2, 0.3, 0.9]       # y2 < y1
+  labels = ref_labels.groundtruth_extract(ex["object_texts"], classes)
+  mask = (rng.uniform(size=(2 * n, d)) < 0.5).astype(np.uint8)
+  opts = ref_model.FrcnnOptions(depth_multiplier=dm)
+  loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
+                   oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+  mults = [("first_stage_feature_extraction", 0.0), ("second_stage_feature_extraction", 1.0),
+           ("first_stage_feature_extraction/InceptionV2/Mixed_4e", 1.0)]
+  P1 = {k: v.copy() for k, v in P.items()}
+  P2 = {k: v.copy() for k, v in P.items()}
+  a1 = {k: np.full(v.shape, 0.1, np.float32) for k, v in P.items()}
+  a2 = {k: v.copy() for k, v in a1.items()}
+  r1 = ref_model.train_step(P1, a1, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
+  r2 = torch_step.train_step(P2, a2, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
+  np.testing.assert_allclose(r2["total_loss"], r1["total_loss"], rtol=1e-5)
+  assert set(r1["applied"]) == set(r2["applied"]) and len(r1["applied"]) > 60
+  for k, g in r1["applied"].items():
+    scale = max(np.abs(g).max(), 1e-30)
+    assert np.abs(g - r2["applied"][k]).max() <= 2e-3 * scale + 1e-6, k
+    assert np.abs(P1[k] - P2[k]).max() <= 1e-4, k
+  for k in P:
+    if k not in r1["applied"]:
+      np.testing.assert_array_equal(P1[k], P2[k])
+
+
+def test_torch_backends_of_ref_ops_match_numpy():
+  rng = np.random.default_rng(1)
+  try:
+    for (n, h, w, cin, cout, k, s) in [(3, 7, 7, 16, 24, 3, 2), (2, 8, 5, 8, 8, 3, 1),
+                                       (2, 4, 4, 8, 16, 1, 1), (1, 10, 10, 4, 8, 3, 2)]:
+      x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+      wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+      ref_ops.set_conv_backend("numpy")
+      y0 = ref_ops.conv2d(x, wt, s)
+      dy = rng.standard_normal(y0.shape).astype(np.float32)
+      dx0, dw0 = ref_ops.conv2d_backward(x, wt, dy, s)
+      ref_ops.set_conv_backend("torch")
+      y1 = ref_ops.conv2d(x, wt, s)
+      dx1, dw1 = ref_ops.conv2d_backward(x, wt, dy, s)
+      for a, b in ((y0, y1), (dx0, dx1), (dw0, dw1)):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-4)
+    xi = rng.integers(0, 4, (2, 7, 7, 8)).astype(np.float32)      # ties: first maximum wins
+    for k, s, pad in ((3, 2, "SAME"), (3, 1, "SAME"), (2, 2, "VALID")):
+      ref_ops.set_conv_backend("numpy")
+      y0, a0 = ref_ops.max_pool(xi, k, s, pad)
+      dy = rng.standard_normal(y0.shape).astype(np.float32)
+      d0 = ref_ops.max_pool_backward(xi.shape, a0, dy, k, s, pad)
+      ref_ops.set_conv_backend("torch")
+      y1, a1 = ref_ops.max_pool(xi, k, s, pad)
+      d1 = ref_ops.max_pool_backward(xi.shape, a1, dy, k, s, pad)
+      np.testing.assert_array_equal(y1, y0)
+      np.testing.assert_allclose(d1, d0, rtol=1e-6, atol=1e-6)
+    ref_ops.set_conv_backend("numpy")
+    y0 = ref_ops.avg_pool_same(xi, 3)
+    d0 = ref_ops.avg_pool_same_backward(xi.shape, y0, 3)
+    ref_ops.set_conv_backend("torch")
+    np.testing.assert_allclose(ref_ops.avg_pool_same(xi, 3), y0, rtol=1e-6)
+    np.testing.assert_allclose(ref_ops.avg_pool_same_backward(xi.shape, y0, 3), d0, rtol=1e-5, atol=1e-6)
+  finally:
+    ref_ops.set_conv_backend("numpy")
