@@ -100,7 +100,8 @@ class KernelTimer(object):
         w = work_fn(args, kwargs) if family == "roi_crop_pool_fwd" else work_fn(args)
         # families are kept per operand type: bf16 operands run on the bf16 MFMA kernels
         first = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
-        low = family != "roi_crop_pool_fwd" and getattr(first, "dtype", None) == t.torch.bfloat16
+        low = (family != "roi_crop_pool_fwd" and not family.endswith("_bf16") and
+               getattr(first, "dtype", None) == t.torch.bfloat16)
         t.records.append((family + ("_bf16" if low else ""), w, s, e))
         t.shapes.append((fn.__name__, tuple(a for a in args if isinstance(a, (int, bool)))))
         return r
@@ -115,6 +116,10 @@ class KernelTimer(object):
     ops.conv_fwd_grouped = timed(ops.conv_fwd_grouped, "igemm_nt", lambda args: args[0][2])
     ops.conv_dgrad = timed(ops.conv_dgrad, "igemm_nt", conv_work("dgrad"))
     ops.conv_wgrad = timed(ops.conv_wgrad, "wgrad_tn", wgrad_work)
+    # bf16 mode: split-K slabs (same argument positions as conv_wgrad) + the batched reduction of
+    # the slabs, whose time belongs to the filter gradients (it replaces their atomics)
+    ops.conv_wgrad_bf16_partial = timed(ops.conv_wgrad_bf16_partial, "wgrad_tn", wgrad_work)
+    ops.wgrad_reduce_batched = timed(ops.wgrad_reduce_batched, "wgrad_tn_bf16", lambda args: 0.0)
     ops.roi_crop_pool_fwd = timed(ops.roi_crop_pool_fwd, "roi_crop_pool_fwd", crop_work)
 
   def summary(self):
@@ -481,11 +486,13 @@ def main(argv=None):
       else:
         # second stage on bf16 operands (MFMA 32x32x16 bf16, fp32 accumulate); the frozen /
         # Mixed_4e first stage and the heads stay on the fp32 kernels
-        ig16 = mfma_family("igemm_nt_bf16", "igemm_nt_kernel<*, ES=2> (implicit-GEMM conv fwd + dgrad of "
-                           "the second stage, bf16 MFMA 32x32x16, fp32 accumulate)", "igemm_bf16",
+        ig16 = mfma_family("igemm_nt_bf16", "igemm_bf16_kernel<*> (implicit-GEMM conv fwd + dgrad of "
+                           "the second stage, bf16 MFMA 32x32x16, fp32 accumulate, direct-to-LDS "
+                           "operand slabs)", "igemm_bf16",
                            PEAK_BF16_MFMA_TFLOPS)
         wg16 = mfma_family("wgrad_tn_bf16", "wgrad_tn_bf16_kernel<*> + wgrad3x3_bf16_kernel<*> (conv "
-                           "filter gradient, bf16 MFMA 32x32x16 through ds_read_b64_tr_b16)",
+                           "filter gradient, bf16 MFMA 32x32x16 through ds_read_b64_tr_b16, split-K "
+                           "slabs) + wgrad_reduce_kernel (their batched reduction)",
                            "wgrad_bf16", PEAK_BF16_MFMA_TFLOPS)
         if ig16: result["roofline"] = ig16
         if wg16: result["roofline_wgrad"] = wg16

@@ -771,6 +771,284 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16-native implicit GEMM (second stage in the bf16 storage mode, BASELINE configs[2] / [4]).
+//
+// Same iteration space, tap masks, pixel-major tile skipping, multi-segment mode and epilogue as
+// igemm_body, but the operand path is built for the bf16 MFMA rate (a 32x32x16 MFMA retires in 32
+// cycles, 16x faster than the fp32 one, so what the fp32 kernel could afford per slab — a register
+// round trip global -> VGPR -> ds_write_b128 (79 B/clk/CU), two barriers — is what bounds it):
+//   * slabs go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction:
+//     no staging VGPRs, no LDS store instructions), into TWO LDS buffers: the DMA of slab it+1
+//     flies under the MFMAs of slab it and ONE barrier per slab orders both hazards;
+//   * LDS rows are the slab's 128 unpadded bytes (an LDS-DMA image is lane-linear); the 16-byte
+//     chunk c of row r sits at position c ^ ((r >> 1) & 7) — applied to the per-lane GLOBAL address
+//     of the DMA and to the fragment reads — which makes every ds_read_b128 lane group hit 16
+//     distinct 16-byte slots (conflict-free; lane groups: MI355X_MICROARCH.md §LDS);
+//   * rows a tap sends into the SAME padding carry an out-of-range buffer offset (the DMA writes
+//     zeros), K tails (K % 64 != 0, K % 16 == 0) simply run fewer 16-deep MFMA steps.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM>
+__global__ __launch_bounds__(WM * WN * 64,
+                             (160 * 1024) / ((WM * MT + WN * NT) * 32 * 256) >= 3
+                                 ? 3 : ((160 * 1024) / ((WM * MT + WN * NT) * 32 * 256) >= 2 ? 2 : 1))
+void igemm_bf16_kernel(IgemmArgs a) {
+  constexpr int BKT = 64;                       // bf16 elements of K per slab (128 B per row)
+  constexpr int BM = WM * MT * 32;
+  constexpr int BN = WN * NT * 32;
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int ROWS_PER_PASS = NTHREADS / 8;   // a wave-instruction stages 8 rows x 128 B
+  constexpr int A_LOADS = BM / ROWS_PER_PASS;
+  constexpr int B_LOADS = BN / ROWS_PER_PASS;
+  constexpr int BUF_BYTES = (BM + BN) * 128;
+  static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile vs block size");
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  // DMA: this lane fetches the chunk that belongs at LDS position lane & 7 of its row
+  const int lrow = tid >> 3;                                        // row inside a pass
+  const int kchunk = (lane & 7) ^ ((lrow >> 1) & 7);                // ((pass rows are multiples of 16))
+  const int q4 = kchunk * 8;                                        // element offset inside the slab
+
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lb / a.n_tiles, nt = lb - mt * a.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ntaps = a.g.nky * a.g.nkx;
+  const int kslabs = (a.K + BKT - 1) / BKT;
+  const size_t tap_stride = (size_t)a.N * a.K;
+
+  RowPos apos[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) apos[i] = decompose<PM>(m0 + lrow + i * ROWS_PER_PASS, a.M, a.g);
+  int brow_off[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) brow_off[i] = min(n0 + lrow + i * ROWS_PER_PASS, a.N - 1);
+
+  int lda = a.lda, Kc = a.K, sgi = 0;
+  __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
+                                           (a.a_rows * a.lda - a.a_off) * 2);
+  __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
+      a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  unsigned row_bits = 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+    if (m0 + (wm * MT + i) * 32 < a.M) row_bits |= 1u << i;
+  row_bits = __builtin_amdgcn_readfirstlane(row_bits);
+
+  unsigned long long tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1ull);
+  int wy[MT], wx[MT];
+  if (PM) {
+    tapmask = 0;
+    const int hw = a.g.rh * a.g.rw;
+#pragma unroll
+    for (int tb = 0; tb < BM / 32; ++tb) {
+      const unsigned t = (unsigned)(m0 >> 5) + tb;
+      const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
+      const unsigned px = t - grp * (unsigned)hw;
+      const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
+      const int x = (int)px - y * a.g.rw;
+      if (tb / MT == wm) { wy[tb % MT] = y; wx[tb % MT] = x; }
+      for (int tp = 0; tp < ntaps; ++tp) {
+        const int ty_ = tp / a.g.nkx;
+        if (tap_ok<MODE>(a.g, y, x, a.g.ky0 + a.g.kstep * ty_,
+                         a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx)))
+          tapmask |= 1ull << tp;
+      }
+    }
+  }
+  int cnt = __builtin_popcountll(tapmask) * kslabs;
+  if (a.nseg > 1) cnt = a.total_slabs;
+
+  int ky = a.g.ky0, kx = a.g.kx0, kc = 0;
+  unsigned long long taps_left = tapmask;
+  unsigned tv_load = ~0u, tv_mma = ~0u;
+  unsigned aoff[A_LOADS], boff[B_LOADS];
+
+#define C2D_RETAP()                                                                            \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                      \
+      const int sr = src_row<MODE>(a.g, apos[i], ky, kx);                                      \
+      aoff[i] = sr >= 0 ? (unsigned)(sr * lda + q4) * 2u : OOB_OFFSET;                         \
+    }                                                                                          \
+    const int toff = (ky * a.g.kw + kx) * (int)tap_stride;                                     \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
+        boff[i] = (unsigned)(brow_off[i] * Kc + toff + q4) * 2u;                               \
+    if (PM) {                                                                                  \
+      tv_load = 0;                                                                             \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
+          tv_load |= (tap_ok<MODE>(a.g, wy[i], wx[i], ky, kx) ? 1u : 0u) << i;                 \
+    }                                                                                          \
+  }
+#define C2D_TAP_FROM_MASK()                                                                    \
+  {                                                                                            \
+    const int tp = taps_left ? __builtin_ctzll(taps_left) : 0;                                 \
+    const int ty_ = tp / a.g.nkx;                                                              \
+    ky = a.g.ky0 + a.g.kstep * ty_;                                                            \
+    kx = a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx);                                           \
+  }
+  // DMA of the slab at the cursor into LDS buffer BUF (8 rows x 128 B per wave-instruction)
+#define C2D_ISSUE(BUF)                                                                         \
+  {                                                                                            \
+    const int soff = kc * 2;                                                                   \
+    const bool in = kc + q4 < Kc;         /* (lanes past a K tail: zeros, never multiplied) */ \
+    char* const abase = smem + (BUF) * BUF_BYTES + wave * 1024;                                \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+            rsA, (lds_void_t*)(abase + i * ROWS_PER_PASS * 128), 16,                           \
+            (int)(in ? aoff[i] : OOB_OFFSET), soff, 0, 0);                                     \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+            rsB, (lds_void_t*)(abase + (BM + i * ROWS_PER_PASS) * 128), 16,                    \
+            (int)(in ? boff[i] : OOB_OFFSET), soff, 0, 0);                                     \
+  }
+
+  if (cnt > 0) {
+    C2D_TAP_FROM_MASK();
+    C2D_RETAP();
+    C2D_ISSUE(0);
+  }
+  // fragment addresses inside a buffer: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
+  int arow_b[MT], brow_b[NT], asw[MT], bsw[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int r = (wm * MT + i) * 32 + li;
+    arow_b[i] = r * 128; asw[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int r = (wn * NT + j) * 32 + li;
+    brow_b[j] = (BM + r) * 128; bsw[j] = (r >> 1) & 7;
+  }
+
+  for (int it = 0; it < cnt; ++it) {
+    tv_mma = tv_load;
+    // bit i: row tile i of this wave is inside M and (PM) real for the tap being multiplied
+    const unsigned onbits = __builtin_amdgcn_readfirstlane(row_bits & tv_mma);
+    // slab `it` has landed (this wave's DMA: vmcnt; everybody's: the barrier), and every wave is
+    // done reading the other buffer, which the next DMA overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 < cnt) {
+      kc += BKT;
+      if (kc >= Kc) {
+        kc = 0;
+        if (a.nseg > 1) {
+          ++sgi;
+          lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
+          rsA = make_rsrc_b((const char*)a.segA[sgi] + (size_t)a.seg_off[sgi] * 2,
+                            (a.a_rows * lda - a.seg_off[sgi]) * 2);
+          rsB = make_rsrc_b(a.segB[sgi], (long long)a.N * Kc * 2);
+        } else {
+          taps_left &= taps_left - 1ull;
+          C2D_TAP_FROM_MASK();
+        }
+        C2D_RETAP();
+      }
+      if ((it + 1) & 1) { C2D_ISSUE(1); } else { C2D_ISSUE(0); }
+    }
+    const char* const buf = smem + (it & 1) * BUF_BYTES;
+    // B fragments of the whole slab, then per 32-row tile of this wave (one scalar branch each:
+    // a tile whose rows are SAME padding for this tap, or lie beyond M, costs nothing) its four A
+    // fragments and 4 x NT MFMAs in straight-line code.  Columns beyond N are computed on clamped
+    // weight rows and never stored; K tails are zeros (out-of-range DMA lanes).
+    bf16x8 bf[NT][4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j][st] = *reinterpret_cast<const bf16x8*>(buf + brow_b[j] + (((2 * st + lh) ^ bsw[j]) << 4));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if ((onbits >> i) & 1u) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          af[st] = *reinterpret_cast<const bf16x8*>(buf + arow_b[i] + (((2 * st + lh) ^ asw[i]) << 4));
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+#undef C2D_RETAP
+#undef C2D_ISSUE
+#undef C2D_TAP_FROM_MASK
+  __syncthreads();     // every wave is done with the slab buffers: the epilogue reuses them
+
+  // Epilogue (as igemm_body): 32-row strips transposed through a per-wave LDS slice so that the
+  // global stores are 8 B per lane (4 bf16) on contiguous row segments.
+  constexpr int SCOLS = NT * 32;
+  constexpr int SSTR = SCOLS + 4;
+  static_assert(WM * WN * 32 * SSTR * 4 <= 2 * BUF_BYTES, "epilogue staging exceeds LDS");
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SSTR);
+  constexpr int C4 = SCOLS / 4;
+  constexpr int RPP = 64 / C4;
+  const int ec4 = lane % C4, er = lane / C4;
+  const int ncol = n0 + wn * SCOLS + ec4 * 4;
+  f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+  const bool ncol_ok = ncol < a.N;
+  if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
+  if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+      const int row = pass * RPP + er;
+      const int m = m0 + (wm * MT + i) * 32 + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
+      bool row_ok = m < a.M;
+      int drow = m;
+      if (PM || (MODE == 1 && a.g.sub > 1)) {
+        const RowPos p = decompose<PM>(m, a.M, a.g);
+        row_ok = p.valid;
+        drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
+                         : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
+                               p.x * a.g.sub + a.g.x0;
+      }
+      if (row_ok && ncol_ok) {
+        v = v * esc + esh;
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
+                                                (size_t)drow * a.ldc + a.c_off + ncol);
+        if (a.accumulate) {
+          const bf16x4 o = *dst;
+          v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+        }
+        bf16x4 o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        *dst = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small-problem kernel (first stage: one image, 32x32 .. 125x125 maps => 1k-16k rows).
 // A 64x64-tile launch gives only 16-126 workgroups and every wave owns one 32x32 tile for the
 // whole K loop: K*taps/2 dependent MFMAs (15 us for a 3x3x128 conv) whatever the chip size.
@@ -907,6 +1185,8 @@ struct WgradArgs {
   int I, J;                             // cin, cout
   int rows_per_split;                   // multiple of WBK
   int tiles_x, tiles_y, nsplits;        // 1-D grid = tiles_x (tap, i-tile) * tiles_y (j-tile) * nsplits
+  long long part_stride;                // > 0: split z stores (plain) into dW + z * part_stride
+                                        // floats (its own slab) instead of adding atomically
   ConvGeom g;                           // mode 0
 };
 
@@ -1087,6 +1367,7 @@ struct Wgrad3Args {
   int M, I, J;
   int rows_per_split, itiles, jtiles, tiles, splits;
   int h, w;
+  long long part_stride;                // as WgradArgs::part_stride
 };
 
 // WC = compile-time (square) map width, IMGS = whole images per slab (even).  The x slab is
@@ -1376,7 +1657,12 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
   }
 #undef C2D_WB_LOAD
 
-  float* dw = a.dW + (size_t)tap * a.I * a.J;
+  // Split-K result: fp32 atomics into dW, or (part_stride > 0) plain stores into this split's own
+  // slab — global float atomics run at 1.3 TB/s chip-wide against 6 TB/s for stores of the same
+  // shape (MI355X_MICROARCH.md), which at bf16 MFMA rates was 40 % of these launches; the slabs
+  // are summed in split order by wgrad_reduce_kernel (one batched launch per backward pass).
+  float* dw = a.dW + (size_t)tap * a.I * a.J + (size_t)blk.z * a.part_stride;
+  const bool part = a.part_stride > 0;
 #pragma unroll
   for (int j = 0; j < NTJ; ++j) {
     const int jj = j0 + (wn * NTJ + j) * 32 + li;
@@ -1387,7 +1673,8 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int ii = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (ii >= a.I) continue;
-        atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
+        if (part) dw[(size_t)ii * a.J + jj] = acc[i][j][r];
+        else atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
       }
   }
 }
@@ -1523,16 +1810,44 @@ __global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kerne
 
   if (wave_on) {
     const int jj = j0 + wj * 32 + li;
+    const bool part = a.part_stride > 0;     // (see wgrad_tn_bf16_kernel)
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      float* dw = a.dW + (size_t)q * a.I * a.J;
+      float* dw = a.dW + (size_t)q * a.I * a.J + (size_t)split * a.part_stride;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ii = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
+        if (part) dw[(size_t)ii * a.J + jj] = acc[q][r];
+        else atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
       }
     }
   }
+}
+
+// dW[i] += sum over splits (in split order: reproducible) of the slabs written by the bf16
+// filter-gradient kernels in their partial mode; one launch for all layers of a backward pass.
+struct WgradReduceDesc {
+  long long ws_off;      // first float of split 0's slab in the workspace
+  long long dw_off;      // first float of the filter gradient in the flat gradient buffer
+  int numel;             // taps * cin * cout
+  int splits;
+  int begin;             // first 1024-element chunk of this layer in the launch
+  int pad;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceDesc* __restrict__ desc,
+                                                           int num, const float* __restrict__ ws,
+                                                           float* __restrict__ grads) {
+  int d = 0;
+  for (int i = 1; i < num; ++i)
+    if ((int)blockIdx.x >= desc[i].begin) d = i;
+  const WgradReduceDesc L = desc[d];
+  const int e = ((int)blockIdx.x - L.begin) * 1024 + threadIdx.x * 4;
+  if (e >= L.numel) return;              // numel is a multiple of 4 (cin, cout multiples of 8)
+  const float* src = ws + L.ws_off + e;
+  f32x4 sum = *reinterpret_cast<const f32x4*>(src);
+  for (int z = 1; z < L.splits; ++z) sum += *reinterpret_cast<const f32x4*>(src + (size_t)z * L.numel);
+  f32x4* dst = reinterpret_cast<f32x4*>(grads + L.dw_off + e);
+  *dst = *dst + sum;
 }
 
 void set_magic(ConvGeom* g);
@@ -1670,8 +1985,42 @@ int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
   return c2d_launch_status();
 }
 
+// C2D_TUNE=1 C2D_BF16_GLDS=0: bf16 operands through the register-staged igemm_body (A/B timing)
+bool bf16_glds_enabled() {
+  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  if (!tune) return true;
+  const char* e = getenv("C2D_BF16_GLDS");
+  return !(e && e[0] == '0');
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM>
+int launch_igemm_bf16(IgemmArgs a, hipStream_t s) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  a.m_tiles = c2d_ceil_div(a.M, BM);
+  a.n_tiles = c2d_ceil_div(a.N, BN);
+  if (a.nseg > 1) {
+    a.total_slabs = 0;
+    for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], 64);
+  }
+  dispatch_note(PM ? "igemm_bf16_kernel<%d, %d, %d, %d, %d, true>"
+                   : "igemm_bf16_kernel<%d, %d, %d, %d, %d, false>", MODE, WM, WN, MT, NT);
+  // C2D_TUNE=1 C2D_BF16_LDS_PAD=<bytes>: unused dynamic LDS, to study occupancy (tools only)
+  static const int lds_pad = (getenv("C2D_TUNE") && getenv("C2D_BF16_LDS_PAD"))
+                                 ? atoi(getenv("C2D_BF16_LDS_PAD")) : 0;
+  if (lds_pad > 0)
+    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+  hipLaunchKernelGGL((igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM>), dim3(a.m_tiles * a.n_tiles),
+                     dim3(WM * WN * 64), lds_pad, s, a);
+  return c2d_launch_status();
+}
+
 template <int WM, int WN, int MT, int NT, int BKT, bool PM = false>
 int launch_igemm(const IgemmArgs& a, hipStream_t s, const IgemmWs& ws) {
+  if (a.es == 2 && bf16_glds_enabled()) {
+    if (a.g.mode == 0) return launch_igemm_bf16<0, WM, WN, MT, NT, PM>(a, s);
+    return launch_igemm_bf16<1, WM, WN, MT, NT, PM>(a, s);
+  }
   if (a.es == 2) {   // bf16 operands: 64 elements per 128-B slab row
     if (a.g.mode == 0) return launch_igemm_mode<0, WM, WN, MT, NT, 2 * BKT, PM, 2>(a, s, ws);
     return launch_igemm_mode<1, WM, WN, MT, NT, 2 * BKT, PM, 2>(a, s, ws);
@@ -1720,6 +2069,18 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     a.M = c2d_ceil_div(a.g.nimg, 32) * 32 * hw;
     // 128x64 tiles (4 waves per SIMD) measured best or within 3 % of best on every 3x3 layer of
     // the second stage (tools/sweep_igemm.py); 128x128 only when forced by the tuning hook.
+    if (force == 4 && a.es == 2) {      // 256x128 block, 128x64 per wave (bf16 only)
+      if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 2, 4, 2, true>(a, s);
+      return launch_igemm_bf16<1, 2, 2, 4, 2, true>(a, s);
+    }
+    if (force == 5 && a.es == 2) {      // 256x128 block, 8 waves of 64x64
+      if (a.g.mode == 0) return launch_igemm_bf16<0, 4, 2, 2, 2, true>(a, s);
+      return launch_igemm_bf16<1, 4, 2, 2, 2, true>(a, s);
+    }
+    if (force == 6 && a.es == 2) {      // 128x256 block, 8 waves of 64x64
+      if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 4, 2, 2, true>(a, s);
+      return launch_igemm_bf16<1, 2, 4, 2, 2, true>(a, s);
+    }
     if (force != 3) return launch_igemm<2, 2, 2, 1, 32, true>(a, s, ws);
     return launch_igemm<2, 2, 2, 2, 32, true>(a, s, ws);
   }
@@ -1747,6 +2108,15 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     return C2D_ERR_UNSUPPORTED;     // not a small problem: the caller launches it on its own
   } else if (big_blocks < 256) {
     return launch_igemm<2, 2, 1, 1, 32>(a, s, IgemmWs{nullptr, 0});          // 64x64 tiles
+  } else if (force == 4 && a.es == 2) {
+    if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 2, 4, 2, false>(a, s);
+    return launch_igemm_bf16<1, 2, 2, 4, 2, false>(a, s);
+  } else if (force == 5 && a.es == 2) {
+    if (a.g.mode == 0) return launch_igemm_bf16<0, 4, 2, 2, 2, false>(a, s);
+    return launch_igemm_bf16<1, 4, 2, 2, 2, false>(a, s);
+  } else if (force == 6 && a.es == 2) {
+    if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 4, 2, 2, false>(a, s);
+    return launch_igemm_bf16<1, 2, 4, 2, 2, false>(a, s);
   } else if (narrow) {
     // N = 192, 320, 576, 160 ...: 128x64 tiles (waves 2x2, each 64x32) waste at most half a
     // 64-wide tile instead of half a 128-wide one, and the smaller accumulator file leaves room
@@ -2038,11 +2408,18 @@ static int wgrad3_bf16_igroups(int cin) {
   return 1;   // measured: two i-groups (8 waves, one block per CU) 0-15 % slower on the 4x4 / 7x7 layers
 }
 
+// partial != null (bf16 MFMA forms only): every split stores its own slab at partial +
+// split * taps*cin*cout floats; *splits_out receives the number of slabs.  splits_only: just
+// report how many splits the launch would use (workspace sizing), launch nothing.
 template <int ES>
 static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, int ldc,
                            int coff, float* dw, int n, int ih, int iw, int cin, int cout,
-                           int kh, int kw, int stride, void* stream) {
+                           int kh, int kw, int stride, void* stream, float* partial = nullptr,
+                           int* splits_out = nullptr, bool splits_only = false) {
   dispatch_reset();
+  if (splits_only) { x = dc = reinterpret_cast<const float*>(16); dw = reinterpret_cast<float*>(16); }
+  if (partial) dw = partial;
+  const long long dw_numel = (long long)kh * kw * cin * cout;
   C2D_CHECK_ARG(x && dc && dw && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
   C2D_CHECK_ARG(ldc % 4 == 0 && coff % 4 == 0);
@@ -2069,6 +2446,10 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
     b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
+    if (splits_out) *splits_out = b.splits;
+    if (splits_only) return C2D_OK;
+    b.part_stride = partial ? dw_numel : 0;
+    if (partial) b.dW = partial;
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
     dispatch_note("wgrad3x3_bf16_kernel<%d, %d, %d>", iw, iw == 4 ? 8 : 2, wi);
@@ -2094,6 +2475,8 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
     b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
+    b.part_stride = 0;
+    if (partial || splits_only) return C2D_ERR_UNSUPPORTED;   // (only the bf16 MFMA forms)
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
     dispatch_note("wgrad3x3_kernel<%d, %d, %d>", iw, iw == 4 ? 2 : 1, ES);
@@ -2121,9 +2504,13 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)a.M * ldc * 4 < (long long)OOB_OFFSET);
   const bool plain = kh == 1 && kw == 1 && stride == 1;
   hipStream_t st = (hipStream_t)stream;
+  a.part_stride = 0;
   if (bf16_mfma) {
     a.rows_per_split = c2d_ceil_div(a.rows_per_split, WB_KB) * WB_KB;
     a.nsplits = c2d_ceil_div(a.M, a.rows_per_split);
+    if (splits_out) *splits_out = a.nsplits;
+    if (splits_only) return C2D_OK;
+    if (partial) { a.part_stride = dw_numel; a.dW = partial; }
     grid.x = a.tiles_x * a.tiles_y * a.nsplits;
     dispatch_note(plain ? "wgrad_tn_bf16_kernel<%d, true>" : "wgrad_tn_bf16_kernel<%d, false>", narrow ? 1 : 2);
     if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, true>), grid, dim3(256), 0, st, a);
@@ -2133,6 +2520,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     return c2d_launch_status();
   }
   dispatch_note(plain ? "wgrad_tn_kernel<%d, true, %d>" : "wgrad_tn_kernel<%d, false, %d>", narrow ? 1 : 2, ES);
+  if (partial || splits_only) return C2D_ERR_UNSUPPORTED;     // (only the bf16 MFMA forms)
   if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true, ES>), grid, dim3(256), 0, st, a);
   else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false, ES>), grid, dim3(256), 0, st, a);
   else if (plain) hipLaunchKernelGGL((wgrad_tn_kernel<2, true, ES>), grid, dim3(256), 0, st, a);
@@ -2154,4 +2542,37 @@ extern "C" int c2d_conv_wgrad_bf16(const void* x, int ldx, int xoff, const void*
                                    int kh, int kw, int stride, void* stream) {
   return conv_wgrad_impl<2>((const float*)x, ldx, xoff, (const float*)dc, ldc, coff, dw, n, ih, iw,
                             cin, cout, kh, kw, stride, stream);
+}
+
+// ---- split-K slabs instead of atomics (bf16 MFMA filter gradients) -----------------------------
+extern "C" int c2d_conv_wgrad_bf16_splits(int ldx, int xoff, int ldc, int coff, int n, int ih,
+                                          int iw, int cin, int cout, int kh, int kw, int stride) {
+  int splits = 0;
+  const int rc = conv_wgrad_impl<2>(nullptr, ldx, xoff, nullptr, ldc, coff, nullptr, n, ih, iw, cin,
+                                    cout, kh, kw, stride, nullptr, nullptr, &splits, true);
+  return rc == C2D_OK ? splits : rc;
+}
+
+extern "C" int c2d_conv_wgrad_bf16_partial(const void* x, int ldx, int xoff, const void* dc,
+                                           int ldc, int coff, float* partials,
+                                           long long partial_floats, int n, int ih, int iw,
+                                           int cin, int cout, int kh, int kw, int stride,
+                                           void* stream) {
+  C2D_CHECK_ARG(partials);
+  const int splits = c2d_conv_wgrad_bf16_splits(ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh, kw,
+                                                stride);
+  if (splits < 0) return splits;
+  if ((long long)splits * kh * kw * cin * cout > partial_floats) return C2D_ERR_WORKSPACE;
+  return conv_wgrad_impl<2>((const float*)x, ldx, xoff, (const float*)dc, ldc, coff, nullptr, n, ih,
+                            iw, cin, cout, kh, kw, stride, stream, partials);
+}
+
+static_assert(sizeof(WgradReduceDesc) == sizeof(C2dWgradReduceDesc), "C2dWgradReduceDesc layout");
+extern "C" int c2d_wgrad_reduce_batched(const C2dWgradReduceDesc* desc, int num, int total_chunks,
+                                        const float* workspace, float* grads, void* stream) {
+  C2D_CHECK_ARG(desc && workspace && grads && num >= 0 && total_chunks >= 0);
+  if (num == 0 || total_chunks == 0) return C2D_OK;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const WgradReduceDesc*>(desc), num, workspace, grads);
+  return c2d_launch_status();
 }

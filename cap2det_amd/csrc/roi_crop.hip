@@ -363,18 +363,24 @@ __global__ __launch_bounds__(256) void roi_axes_kernel(const float* __restrict__
 
 constexpr int kBinSegs = 16;  // cell-range segments per row list = list parts of the strip kernel
 
-// One list entry = everything about (cell, row y) that does not depend on the channel: the row
-// weight of either vertical sample of the 2x2 pooling window and the column taps of either
-// horizontal sample.  Computed once by the binning kernel instead of 576 times per cell.
+// One list entry = everything about (cell, row y) that does not depend on the channel, in the
+// form the strip kernel consumes without a branch: the cell's element offset in dpooled / arg-max,
+// the weight of row y for either vertical sample of the 2x2 pooling window, and for either
+// horizontal sample the BYTE offsets of its two column taps inside the workgroup's LDS strip
+// ([wf + 1][chunk] fp32) with the lerp weight of the right one.  A sample outside the map points
+// both taps at the strip's spare column wf (never stored); taps that coincide (integer coordinate)
+// are moved apart with weight 0 on the second.  Computed once per cell and row instead of 576 times.
 struct RowEntry {
-  int id;            // roi << 8 | py << 4 | px
+  int cell_off;      // (roi * p*p + py * p + px) * depth
   float wy0, wy1;    // weight of row y if the argmax sample is the upper / lower one
-  int x0;            // lo | hi << 16 of the left sample (lo < 0: outside the map)
+  int off0;          // lo_bytes | hi_bytes << 16 of the left sample
   float lx0;
-  int x1;
+  int off1;
   float lx1;
   int pad;
 };
+constexpr int kListPad = 16;   // zero-weight entries behind every list: the strip kernel walks
+                               // whole trips without a tail test
 
 __device__ __forceinline__ float row_weight(const AxisRec& r, int y) {
   if (r.lo < 0) return 0.0f;
@@ -384,12 +390,23 @@ __device__ __forceinline__ float row_weight(const AxisRec& r, int y) {
   return w;
 }
 
+__device__ __forceinline__ void column_taps(const AxisRec& a, int wf, int chunk, int* off,
+                                            float* lx) {
+  int lo = a.lo, hi = a.hi;
+  *lx = a.lerp;
+  if (lo < 0) { lo = hi = wf; *lx = 0.0f; }                  // outside: the spare column
+  else if (hi == lo) { hi = lo + 1 < wf ? lo + 1 : lo - 1; *lx = 0.0f; }
+  if (hi < 0) hi = wf;                                       // (wf == 1)
+  *off = (lo * chunk * 4) | ((hi * chunk * 4) << 16);
+}
+
 // grid (hf, kBinSegs, batch): stable compaction of the cells of one segment whose 2x2 pooling
 // window has a sample on row y (pool_k == 2).
 __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
     const AxisRec* __restrict__ ys, const AxisRec* __restrict__ xs,
     const int32_t* __restrict__ box_ind, RowEntry* __restrict__ lists,
-    int32_t* __restrict__ counts, int num_boxes, int hf, int ps, int pout, int crop, int cap) {
+    int32_t* __restrict__ counts, int num_boxes, int hf, int wf, int depth, int chunk, int ps,
+    int pout, int crop, int cap) {
   __shared__ int wave_cnt[4];
   __shared__ int running;
   const int y = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
@@ -411,14 +428,13 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
       if (box_ind[roi] == b) {
         const int c = cell - roi * p2;
         const int py = c / pout, px = c - py * pout;
-        e.id = (roi << 8) | (py << 4) | px;
+        e.cell_off = cell * depth;
         e.wy0 = row_weight(ys[roi * crop + py * ps], y);
         e.wy1 = row_weight(ys[roi * crop + py * ps + 1], y);
         hit = e.wy0 != 0.0f || e.wy1 != 0.0f;
         if (hit) {
-          const AxisRec a0 = xs[roi * crop + px * ps], a1 = xs[roi * crop + px * ps + 1];
-          e.x0 = a0.lo < 0 ? -1 : (a0.lo | (a0.hi << 16)); e.lx0 = a0.lerp;
-          e.x1 = a1.lo < 0 ? -1 : (a1.lo | (a1.hi << 16)); e.lx1 = a1.lerp;
+          column_taps(xs[roi * crop + px * ps], wf, chunk, &e.off0, &e.lx0);
+          column_taps(xs[roi * crop + px * ps + 1], wf, chunk, &e.off1, &e.lx1);
         }
       }
     }
@@ -431,6 +447,12 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
     __syncthreads();
     if (threadIdx.x == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
+  }
+  if (threadIdx.x < kListPad) {          // zero-weight tail (cell 0 is always a valid address)
+    RowEntry z;
+    z.cell_off = 0; z.wy0 = 0.0f; z.wy1 = 0.0f; z.lx0 = 0.0f; z.lx1 = 0.0f; z.pad = 0;
+    z.off0 = z.off1 = (wf * chunk * 4) | ((wf * chunk * 4) << 16);
+    list[running + threadIdx.x] = z;
   }
   if (threadIdx.x == 0) counts[((size_t)b * hf + y) * kBinSegs + seg] = running;
 }
@@ -447,54 +469,73 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
     const TG* __restrict__ dout, const uint8_t* __restrict__ argmax,
     const RowEntry* __restrict__ lists, const int32_t* __restrict__ counts,
     float* __restrict__ parts, int batch, int hf, int wf, int depth, int pout, int cap) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];   // [wf][CHUNK]
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [wf + 1][CHUNK] (+1: spare column)
   const int y = blockIdx.x, c0 = blockIdx.y * CHUNK;
   const int b = blockIdx.z / kRowParts, part = blockIdx.z % kRowParts;
   const int tid = threadIdx.x;
-  for (int i = tid; i < wf * CHUNK; i += CHUNK) acc[i] = 0.0f;
+  for (int i = tid; i < (wf + 1) * CHUNK; i += CHUNK) acc[i] = 0.0f;
   __syncthreads();
-  const int p2 = pout * pout;
   const size_t lrow = ((size_t)b * hf + y) * kBinSegs + part;
   const RowEntry* __restrict__ list = lists + lrow * cap;
   const int count = __builtin_amdgcn_readfirstlane(counts[lrow]);
-  float* mine = acc + tid;
+  char* const mine = reinterpret_cast<char*>(acc + tid);
   const bool on = c0 + tid < depth;                 // (ragged last chunk: depth % CHUNK != 0)
   const int cc = on ? c0 + tid : c0;
   const TG* gcol = dout + cc;
   const uint8_t* kcol = argmax + cc;
+  // U list entries per trip, two register sets in ping-pong: the dpooled / arg-max values of trip
+  // t+1 are in flight while trip t is accumulated into the lane's own channel column, in list
+  // order (reproducible sum).  An entry's fields are wave-uniform (scalar loads); it is read
+  // twice (addresses, then weights) rather than kept: two live sets do not fit the 102 SGPRs.
+  // Straight-line code: zero-weight entries pad the list to whole trips, samples outside the map
+  // land in the spare column, and a lane whose arg-max sample does not touch this row adds 0.
   constexpr int U = 8;
-  for (int i0 = 0; i0 < count; i0 += U) {          // fixed order: the sum is reproducible
-    RowEntry e[U];
-    float g[U];
-    int k[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = min(i0 + u, count - 1);         // (wave-uniform: scalar loads)
-      e[u] = list[i];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int roi = e[u].id >> 8, py = (e[u].id >> 4) & 15, px = e[u].id & 15;
-      const size_t o = ((size_t)roi * p2 + py * pout + px) * depth;
-      g[u] = (on && i0 + u < count) ? (float)gcol[o] : 0.0f;
-      k[u] = kcol[o];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float wy = (k[u] >> 1) ? e[u].wy1 : e[u].wy0;
-      const int xp = (k[u] & 1) ? e[u].x1 : e[u].x0;
-      const float lx = (k[u] & 1) ? e[u].lx1 : e[u].lx0;
-      const float v = wy * g[u];
-      if (v == 0.0f || xp < 0) continue;
-      // TF CropAndResizeGradImage: (1 - lx) * dtop to column lo, lx * dtop to column hi
-      mine[(xp & 0xffff) * CHUNK] += (1.0f - lx) * v;
-      mine[(xp >> 16) * CHUNK] += lx * v;
+  TG g[U], gn[U];               // raw loaded values: nothing consumes them before their trip
+  unsigned k[U], kn[U];
+#define C2D_STRIP_FETCH(G, K, I0)                                                              \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
+    const int o = list[(I0) + u].cell_off;                                                     \
+    (G)[u] = gcol[o];                                                                          \
+    (K)[u] = kcol[o];                                                                          \
+  }
+  /* (all scalar entry loads of the trip first: SMEM and LDS share one wait counter, and an  */
+  /*  entry load in flight would turn every LDS wait below into a wait for it as well)       */
+#define C2D_STRIP_ADD(G, K, I0)                                                                \
+  {                                                                                            \
+    RowEntry e[U];                                                                             \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) e[u] = list[(I0) + u];                       \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
+      const bool sx = (K)[u] & 1u, sy = (K)[u] >> 1;                                           \
+      const int off = sx ? e[u].off1 : e[u].off0;                                              \
+      float* const plo = reinterpret_cast<float*>(mine + (off & 0xffff));                      \
+      float* const phi = reinterpret_cast<float*>(mine + ((unsigned)off >> 16));               \
+      const float alo = *plo, ahi = *phi;              /* (distinct columns by construction) */ \
+      const float v = (sy ? e[u].wy1 : e[u].wy0) * (float)(G)[u];                              \
+      const float whi = v * (sx ? e[u].lx1 : e[u].lx0);                                        \
+      /* TF CropAndResizeGradImage: (1 - lx) * dtop to column lo, lx * dtop to column hi */    \
+      *plo = alo + (v - whi);                                                                  \
+      *phi = ahi + whi;                                                                        \
+    }                                                                                          \
+  }
+  if (count > 0) {
+    C2D_STRIP_FETCH(g, k, 0);
+    for (int i0 = 0; i0 < count; i0 += 2 * U) {    // fixed order: the sum is reproducible
+      C2D_STRIP_FETCH(gn, kn, i0 + U);             // (reads into the zero-weight tail at most)
+      __builtin_amdgcn_sched_barrier(0);
+      C2D_STRIP_ADD(g, k, i0);
+      __builtin_amdgcn_sched_barrier(0);
+      C2D_STRIP_FETCH(g, k, min(i0 + 2 * U, count));
+      __builtin_amdgcn_sched_barrier(0);
+      C2D_STRIP_ADD(gn, kn, i0 + U);
     }
   }
+#undef C2D_STRIP_ADD
+#undef C2D_STRIP_FETCH
   __syncthreads();
   float* drow = parts + ((((size_t)part * batch + b) * hf + y) * wf) * depth + c0 + tid;
   if (on)
-    for (int x = 0; x < wf; ++x) drow[(size_t)x * depth] = mine[x * CHUNK];
+    for (int x = 0; x < wf; ++x) drow[(size_t)x * depth] = acc[x * CHUNK + tid];
 }
 
 // dfeat += part[0] + part[1] + ... (fixed order), float4 per lane.
@@ -648,7 +689,7 @@ extern "C" long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, in
     return -1;
   const long long pout = (crop - pool_k) / pool_s + 1;
   const long long cells = (long long)num_boxes * pout * pout;
-  const long long seg_cap = ((cells + kBinSegs - 1) / kBinSegs + 255) / 256 * 256;
+  const long long seg_cap = ((cells + kBinSegs - 1) / kBinSegs + 255) / 256 * 256 + kListPad;
   return 2ll * num_boxes * crop * (long long)sizeof(AxisRec) + 256 +
          (long long)batch * hf * kBinSegs * 4 + 256 +
          (long long)batch * hf * kBinSegs * seg_cap * (long long)sizeof(RowEntry) + 256 +
@@ -663,7 +704,9 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   C2D_CHECK_ARG(dout && argmax && boxes && box_ind && dfeat && workspace);
   C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 16 == 0);
   C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0 && pool_s > 0);
-  if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) || wf > 64)
+  if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) || wf > 64 ||
+      wf < 2 || (long long)num_boxes * ((crop - pool_k) / pool_s + 1) * ((crop - pool_k) / pool_s + 1) *
+                        depth >= (1ll << 31))
     return C2D_ERR_UNSUPPORTED;
   if (num_boxes == 0) return C2D_OK;
   if (workspace_bytes <
@@ -671,7 +714,7 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
                                             pool_s))
     return C2D_ERR_WORKSPACE;
   const int pout = (crop - pool_k) / pool_s + 1;
-  const int cap = ((num_boxes * pout * pout + kBinSegs - 1) / kBinSegs + 255) / 256 * 256;
+  const int cap = ((num_boxes * pout * pout + kBinSegs - 1) / kBinSegs + 255) / 256 * 256 + kListPad;
   char* w = (char*)workspace;
   AxisRec* ys = (AxisRec*)w;
   AxisRec* xs = ys + (size_t)num_boxes * crop;
@@ -684,18 +727,21 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(roi_axes_kernel, dim3(c2d_ceil_div((long long)num_boxes * crop, 256)),
                      dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
+  // channel chunk = workgroup size: the largest of 256 / 192 / 128 that divides the depth, else
+  // 64 with a ragged last chunk (576 -> 192: 768-byte segments per cell, 25 KiB of LDS, six
+  // workgroups per CU)
+  const int chunk = depth % 256 == 0 ? 256 : depth % 192 == 0 ? 192 : depth % 128 == 0 ? 128 : 64;
   hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
-                     box_ind, lists, counts, num_boxes, hf, pool_s, pout, crop, cap);
-  // channel chunk = workgroup size: the largest of 256 / 192 / 128 / 64 that divides the depth
-  // (576 -> 192: three 768-byte segments per cell, 24 KiB of LDS, six workgroups per CU)
+                     box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout, crop,
+                     cap);
 #define C2D_STRIP(CHV)                                                                          \
   hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>),                                          \
                      dim3(hf, (depth + CHV - 1) / CHV, batch * kRowParts),                      \
-                     dim3(CHV), (size_t)CHV * wf * sizeof(float), st, dout, argmax, lists,     \
+                     dim3(CHV), (size_t)CHV * (wf + 1) * sizeof(float), st, dout, argmax, lists, \
                      counts, parts, batch, hf, wf, depth, pout, cap)
-  if (depth % 256 == 0) { C2D_STRIP(256); }
-  else if (depth % 192 == 0) { C2D_STRIP(192); }
-  else if (depth % 128 == 0) { C2D_STRIP(128); }
+  if (chunk == 256) { C2D_STRIP(256); }
+  else if (chunk == 192) { C2D_STRIP(192); }
+  else if (chunk == 128) { C2D_STRIP(128); }
   else { C2D_STRIP(64); }
 #undef C2D_STRIP
   const long long n4 = (long long)batch * hf * wf * depth / 4;

@@ -459,3 +459,39 @@ def last_dispatch():
   buf = ctypes.create_string_buffer(1024)
   _lib.call("c2d_debug_last_dispatch", ctypes.cast(buf, ctypes.c_void_p), 1024)
   return [k for k in buf.value.decode().split(";") if k]
+
+
+def conv_wgrad_bf16_splits(ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh, kw, stride):
+  """Number of split-K slabs c2d_conv_wgrad_bf16_partial writes for this layer (< 0: the layer
+  does not qualify for the bf16 MFMA kernels)."""
+  return int(_lib.load().c2d_conv_wgrad_bf16_splits(ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh,
+                                                    kw, stride))
+
+
+def conv_wgrad_bf16_partial(x, ldx, xoff, dc, ldc, coff, partials, n, ih, iw, cin, cout, kh, kw,
+                            stride):
+  assert x.dtype == dc.dtype == torch.bfloat16 and partials.dtype == torch.float32
+  _lib.call("c2d_conv_wgrad_bf16_partial", _p(x), ldx, xoff, _p(dc), ldc, coff, _p(partials),
+            partials.numel(), n, ih, iw, cin, cout, kh, kw, stride, _stream())
+
+
+class WgradReduceDesc(ctypes.Structure):
+  """C2dWgradReduceDesc of include/cap2det_hip.h."""
+  _fields_ = [("ws_off", ctypes.c_longlong), ("dw_off", ctypes.c_longlong),
+              ("numel", ctypes.c_int), ("splits", ctypes.c_int), ("begin", ctypes.c_int),
+              ("pad", ctypes.c_int)]
+
+
+def wgrad_reduce_descriptors(records, device):
+  """records: [(ws_off, dw_off, numel, splits)] -> (uint8 device tensor, num, total_chunks)."""
+  arr = (WgradReduceDesc * len(records))()
+  chunks = 0
+  for d, (ws_off, dw_off, numel, splits) in zip(arr, records):
+    d.ws_off, d.dw_off, d.numel, d.splits, d.begin, d.pad = ws_off, dw_off, numel, splits, chunks, 0
+    chunks += -(-numel // 1024)
+  return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(records), chunks
+
+
+def wgrad_reduce_batched(desc, num, total_chunks, workspace, grads):
+  _lib.call("c2d_wgrad_reduce_batched", _p(desc), num, total_chunks, _p(workspace), _p(grads),
+            _stream())

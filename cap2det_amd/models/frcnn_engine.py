@@ -508,6 +508,27 @@ class Net(object):
       recs.append((ws_size, voff[L.name + "/BatchNorm/beta"][0], g, nb, L.cout, chunks, 0))
       ws_size += nb * 2 * L.cout
       chunks += -(-L.cout // 64)
+    # bf16 networks: the split-K results of the filter gradients go to per-split slabs (plain
+    # stores) and ONE batched launch at the end of backward() adds them into the flat gradient
+    # buffer in split order — instead of fp32 atomics (c2d_conv_wgrad_bf16_partial)
+    wrecs, woff = [], 0
+    if self.dtype == torch.bfloat16 and os.environ.get("C2D_WGRAD_PARTIALS", "1") != "0":
+      for st in convs:
+        L = st["layer"]
+        if not L.trainable:
+          continue
+        x = st["x"]
+        ldx, xoff = (x.ld, x.off) if x is not None else (self.cin, 0)
+        splits = ops.conv_wgrad_bf16_splits(ldx, xoff, L.cout, 0, st["n"], st["ih"], st["iw"], L.cin,
+                                            L.cout, L.k, L.k, L.stride)
+        if splits <= 0:
+          continue
+        numel = L.k * L.k * L.cin * L.cout
+        st["wpart"] = (woff, splits * numel)
+        wrecs.append((woff, voff[L.name + "/weights"][0], numel, splits))
+        woff += splits * numel
+    plan["wpart_ws"] = torch.empty(max(woff, 4), device=dev) if wrecs else None
+    plan["wpart_desc"] = ops.wgrad_reduce_descriptors(wrecs, dev) if wrecs else None
     plan["bn_ws"] = torch.empty(max(ws_size, 4), device=dev)
     plan["bn_desc"] = (torch.from_numpy(np.array(recs, dtype=ddt).view(np.uint8).copy()).to(dev)
                        if recs else None)
@@ -541,6 +562,20 @@ class Net(object):
     if plan["bn_num"]:
       ops.bn_partials_reduce_batched(plan["bn_desc"], plan["bn_num"], plan["bn_chunks"],
                                      plan["bn_ws"], self.store.grads)
+    if plan.get("wpart_desc") is not None:
+      desc, num, chunks = plan["wpart_desc"]
+      ops.wgrad_reduce_batched(desc, num, chunks, plan["wpart_ws"], self.store.grads)
+
+  def _wgrad(self, plan, st, x, dc):
+    L = st["layer"]
+    part = st.get("wpart")
+    if part is not None:
+      off, size = part
+      ops.conv_wgrad_bf16_partial(x.t, x.ld, x.off, dc, L.cout, 0, plan["wpart_ws"][off:off + size],
+                                  st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+    else:
+      ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, self.store.grad[L.name + "/weights"],
+                     st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
 
   def _conv_bwd(self, plan, st, x, gx, accumulate, dc=None):
     """BN/ReLU backward -> dc, filter gradient, and (when gx is given) the input gradient."""
@@ -582,15 +617,13 @@ class Net(object):
       ready.record()
       side.wait_event(ready)
       with torch.cuda.stream(side):
-        ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
-                       st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+        self._wgrad(plan, st, x, dc)
         if slot is not None:
           plan["dc_events"][slot] = torch.cuda.Event()
           plan["dc_events"][slot].record()
       plan["side_pending"] = True
     elif tr:
-      ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, g[L.name + "/weights"], st["n"], st["ih"],
-                     st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+      self._wgrad(plan, st, x, dc)
     if gx is not None:
       ops.conv_dgrad(dc, L.cout, 0, L.w_for(self.dtype), gx.t, gx.ld, gx.off,
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)

@@ -410,6 +410,32 @@ int c2d_conv_wgrad_bf16(const void* x, int ldx, int xoff, const void* dc, int ld
                         float* dw, int n, int ih, int iw, int cin, int cout, int kh, int kw,
                         int stride, void* stream);
 
+/* Split-K slabs instead of atomics for the bf16 filter gradients.  Global float atomics run at
+ * 1.3 TB/s chip-wide, plain stores at 6 TB/s; at bf16 MFMA rates the atomics of
+ * c2d_conv_wgrad_bf16 are 40 % of its time.  c2d_conv_wgrad_bf16_partial makes every K split store
+ * its own fp32 slab (partials[split][kh*kw][cin][cout], `partial_floats` floats available;
+ * C2D_ERR_WORKSPACE if too few, C2D_ERR_UNSUPPORTED when the operands do not qualify for the bf16
+ * MFMA kernels); c2d_conv_wgrad_bf16_splits returns the number of slabs that launch writes (or a
+ * negative C2D_ERR_*); c2d_wgrad_reduce_batched adds the slabs of `num` layers, in split order
+ * (bitwise reproducible), into their filter gradients: ONE launch per backward pass.
+ * desc: DEVICE array; total_chunks = sum over layers of ceil(numel / 1024). */
+int c2d_conv_wgrad_bf16_splits(int ldx, int xoff, int ldc, int coff, int n, int ih, int iw,
+                               int cin, int cout, int kh, int kw, int stride);
+int c2d_conv_wgrad_bf16_partial(const void* x, int ldx, int xoff, const void* dc, int ldc,
+                                int coff, float* partials, long long partial_floats, int n,
+                                int ih, int iw, int cin, int cout, int kh, int kw, int stride,
+                                void* stream);
+typedef struct C2dWgradReduceDesc {
+  long long ws_off;   /* first float of split 0's slab in `workspace` */
+  long long dw_off;   /* first float of the filter gradient in `grads` */
+  int numel;          /* kh*kw*cin*cout */
+  int splits;
+  int begin;          /* first 1024-element chunk (= workgroup) of this layer */
+  int pad;
+} C2dWgradReduceDesc;
+int c2d_wgrad_reduce_batched(const C2dWgradReduceDesc* desc, int num, int total_chunks,
+                             const float* workspace, float* grads, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Inference post-processing
  * ------------------------------------------------------------------------------------- */

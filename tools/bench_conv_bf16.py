@@ -1,11 +1,20 @@
-"""bf16 igemm (fwd / dgrad) on the second-stage conv shapes, next to the fp32 kernels."""
+"""bf16 igemm (fwd / dgrad) and filter gradient on every distinct second-stage conv shape at
+N = 2000 ROIs.  Prints per call: time, TFLOP/s, the kernel instance dispatched.  Tuning hooks
+(C2D_TUNE=1 C2D_BF16_GLDS=0|1 C2D_IGEMM_CFG=2|3|4) select the variant; tools/_sweep_bf16.sh runs
+them side by side."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cap2det_amd import hip_ops as ops
 dev = "cuda:0"
-SHAPES = [(2000, 7, 576, 128, 1, 1), (2000, 7, 576, 192, 1, 1), (2000, 7, 192, 256, 3, 1),
-          (2000, 7, 256, 256, 3, 2), (2000, 4, 1024, 352, 1, 1), (2000, 4, 1024, 192, 1, 1),
-          (2000, 4, 192, 320, 3, 1), (2000, 4, 224, 224, 3, 1), (2000, 4, 1024, 128, 1, 1)]
+SHAPES = [(7, 576, 128, 1, 1), (7, 128, 192, 3, 2), (7, 576, 192, 1, 1), (7, 192, 256, 3, 1),
+          (7, 256, 256, 3, 2), (4, 1024, 352, 1, 1), (4, 1024, 192, 1, 1), (4, 192, 320, 3, 1),
+          (4, 1024, 160, 1, 1), (4, 160, 224, 3, 1), (4, 224, 224, 3, 1), (4, 192, 224, 3, 1),
+          (4, 1024, 128, 1, 1)]
+# how often each shape occurs in one step of Mixed_5a-c
+COUNT = {(4, 1024, 352, 1, 1): 2, (4, 1024, 192, 1, 1): 3, (4, 192, 320, 3, 1): 2,
+         (4, 224, 224, 3, 1): 2, (4, 1024, 128, 1, 1): 2}
+n = 2000
+what = sys.argv[1] if len(sys.argv) > 1 else "igemm"
 def timeit(fn, iters=20):
     for _ in range(3): fn()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
@@ -13,22 +22,27 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-tot = {}
-for (n, ih, cin, cout, k, st) in SHAPES:
+tot_t, tot_f = {}, {}
+dt = torch.bfloat16
+for (ih, cin, cout, k, st) in SHAPES:
     oh = -(-ih // st)
     fl = 2.0 * n * oh * oh * cin * cout * k * k
-    res = []
-    for dt in (torch.float32, torch.bfloat16):
-        x = torch.randn(n * ih * ih, cin, device=dev).to(dt)
-        w = (torch.randn(k * k, cin, cout, device=dev) / (k * k * cin) ** 0.5).to(dt)
-        wt = w.permute(0, 2, 1).contiguous()
-        y = torch.empty(n * oh * oh, cout, device=dev, dtype=dt); dy = torch.randn(n * oh * oh, cout, device=dev).to(dt)
-        dx = torch.empty_like(x)
-        sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
-        tf_ = timeit(lambda: ops.conv_fwd(x, cin, 0, wt, sc, sh, y, cout, 0, n, ih, ih, cin, cout, k, k, st, True))
-        td = timeit(lambda: ops.conv_dgrad(dy, cout, 0, w, dx, cin, 0, n, ih, ih, cin, cout, k, k, st, False))
-        name = "f32" if dt == torch.float32 else "bf16"
-        res.append("%s fwd %6.1f us %6.1f TF dgrad %6.1f us %6.1f TF" % (name, tf_ * 1e3, fl / tf_ / 1e9, td * 1e3, fl / td / 1e9))
-        tot[name] = tot.get(name, 0) + tf_ + td
-    print("n=%4d %dx%d cin=%4d cout=%3d k=%d s=%d | %s" % (n, ih, ih, cin, cout, k, st, " | ".join(res)))
-print("sum ms:", {k: round(v, 3) for k, v in tot.items()})
+    x = torch.randn(n * ih * ih, cin, device=dev).to(dt)
+    w = (torch.randn(k * k, cin, cout, device=dev) / (k * k * cin) ** 0.5).to(dt)
+    wt = w.permute(0, 2, 1).contiguous()
+    y = torch.empty(n * oh * oh, cout, device=dev, dtype=dt); dy = torch.randn(n * oh * oh, cout, device=dev).to(dt)
+    dx = torch.empty_like(x); dw = torch.zeros(k * k, cin, cout, device=dev)
+    sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
+    calls = {"fwd": lambda: ops.conv_fwd(x, cin, 0, wt, sc, sh, y, cout, 0, n, ih, ih, cin, cout, k, k, st, True),
+             "dgrad": lambda: ops.conv_dgrad(dy, cout, 0, w, dx, cin, 0, n, ih, ih, cin, cout, k, k, st, False),
+             "wgrad": lambda: ops.conv_wgrad(x, cin, 0, dy, cout, 0, dw, n, ih, ih, cin, cout, k, k, st)}
+    line = "%dx%d cin=%4d cout=%3d k=%d s=%d |" % (ih, ih, cin, cout, k, st)
+    for name in (("fwd", "dgrad") if what == "igemm" else ("wgrad",)):
+        t = timeit(calls[name])
+        inst = ops.last_dispatch()
+        c = COUNT.get((ih, cin, cout, k, st), 1)
+        tot_t[name] = tot_t.get(name, 0) + c * t; tot_f[name] = tot_f.get(name, 0) + c * fl
+        line += " %s %6.1f us %6.1f TF %s |" % (name, t * 1e3, fl / t / 1e9, inst[0].replace("_kernel", "") if inst else "?")
+    print(line)
+for k_ in tot_t:
+    print("per step %s: %.3f ms, %.1f TF (%.3f of 2500)" % (k_, tot_t[k_], tot_f[k_] / tot_t[k_] / 1e9, tot_f[k_] / tot_t[k_] / 1e9 / 2500))

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cap2det_amd import hip_ops as ops
 dev="cuda:0"; torch.manual_seed(0)
 hf=wf=32; D=576; N=2000
