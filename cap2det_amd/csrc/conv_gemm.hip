@@ -2049,13 +2049,19 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   // 128x128 tile, C2D_IGEMM_SK=0 the one-tile-per-block form.
   static const bool tune = getenv("C2D_TUNE") != nullptr;
   bool row_major_only = false;
-  int force = 0;
+  int force = 0;   // 2: 128x64, 3: 128x128, 4-6: bf16-only forms (see below)
   if (tune) {
     const char* e = getenv("C2D_IGEMM_ROW_MAJOR");
     row_major_only = e && e[0] == '1';
     e = getenv("C2D_IGEMM_CFG");
     force = e ? atoi(e) : 0;
   }
+  // bf16 (igemm_bf16_kernel) block tile, measured per layer shape of the second stage
+  // (tools/bench_conv_bf16.py, N = 2000 ROIs): 128x256 (8 waves) for output widths of 193..256 and
+  // >= 1024 columns, 128x128 when the last 128-wide tile is more than half full, else 128x64.
+  if (!force && a.es == 2 && a.g.sub == 1)
+    force = ((a.N > 192 && a.N <= 256) || a.N >= 1024) ? 6
+            : (a.N > 256 && (a.N % 128 == 0 || a.N % 128 > 64)) ? 3 : 2;
   // bf16 operands: 128x64 tiles throughout (tools/bench_conv_bf16.py: 0.96 ms against 1.06 ms on
   // the second-stage shapes; the stride-2 input gradients gain most, 108 -> 66 us)
   // stride-2 input gradients (four parity-class launches of a quarter of the rows each): 128x64

@@ -152,10 +152,11 @@ __global__ __launch_bounds__(256) void roi_crop_pool_fwd_kernel(
 template <typename TO>
 __device__ __forceinline__ void crop_pool2_stream_body(
     const float4* __restrict__ img, const SampleAxis* ys, const SampleAxis* xs,
-    TO* __restrict__ out, uchar4* __restrict__ argmax, size_t obase, int wf, int d4n, int pout) {
+    TO* __restrict__ out, uchar4* __restrict__ argmax, size_t obase, int wf, int d4n, int pout,
+    int part, int splits) {
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   const int total = pout * d4n;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+  for (int idx = part * blockDim.x + threadIdx.x; idx < total; idx += splits * blockDim.x) {
     const int d4 = idx % d4n;
     const int py = idx / d4n;
     const SampleAxis y0 = ys[2 * py], y1 = ys[2 * py + 1];
@@ -560,14 +561,17 @@ template <typename TO>
 __global__ __launch_bounds__(256) void roi_crop_pool2_fwd_stream_kernel(
     const float4* __restrict__ feat, const float* __restrict__ boxes,
     const int32_t* __restrict__ box_ind, TO* __restrict__ out,
-    uchar4* __restrict__ argmax, int batch, int hf, int wf, int d4n, int crop, int pout) {
+    uchar4* __restrict__ argmax, int batch, int hf, int wf, int d4n, int crop, int pout,
+    int splits) {
   __shared__ SampleAxis ys[kMaxCrop], xs[kMaxCrop];
-  const int roi = blockIdx.x;
+  // `splits` workgroups share a ROI (interleaved (pooled row, channel quad) items): shorter
+  // workgroups = a shorter tail when 2000 ROIs meet 256 CUs x 6 resident workgroups
+  const int roi = blockIdx.x / splits, part = blockIdx.x - roi * splits;
   const int b = box_ind[roi];
   if (b < 0 || b >= batch) return;
   load_axes(ys, xs, boxes, roi, hf, wf, crop);
   crop_pool2_stream_body<TO>(feat + (size_t)b * hf * wf * d4n, ys, xs, out, argmax,
-                             (size_t)roi * pout * pout * d4n, wf, d4n, pout);
+                             (size_t)roi * pout * pout * d4n, wf, d4n, pout, part, splits);
 }
 
 // (A prefetching variant — three-slot register ring over the sorted list of needed columns, the
@@ -577,6 +581,12 @@ __global__ __launch_bounds__(256) void roi_crop_pool2_fwd_stream_kernel(
 
 // 2x2 / stride-2 pooling over an even crop: the column-streaming kernel (C2D_TUNE=1
 // C2D_CROP_STREAM=0 keeps the generic one, for A/B timing).
+static int crop_stream_splits() {
+  static const char* e = getenv("C2D_TUNE") ? getenv("C2D_CROP_SPLIT") : nullptr;
+  const int v = e ? atoi(e) : 1;
+  return v >= 1 && v <= 8 ? v : 1;
+}
+
 static int crop_stream_form(int crop, int pool_k, int pool_s, int pout) {
   static const char* e = getenv("C2D_TUNE") ? getenv("C2D_CROP_STREAM") : nullptr;
   const int want = e ? atoi(e) : 1;
@@ -609,9 +619,10 @@ extern "C" int c2d_roi_crop_pool_fwd(const float* feat, const float* boxes,
   const int pout = (crop - pool_k) / pool_s + 1;
   const int form = crop_stream_form(crop, pool_k, pool_s, pout);
   if (form == 1)
-    hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<float>, dim3(num_boxes), dim3(256), 0,
+    hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<float>,
+                       dim3(num_boxes * crop_stream_splits()), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
-                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout);
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout, crop_stream_splits());
   else
     hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<float>, dim3(num_boxes), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
@@ -631,9 +642,10 @@ extern "C" int c2d_roi_crop_pool_fwd_bf16(const float* feat, const float* boxes,
   const int pout = (crop - pool_k) / pool_s + 1;
   const int form = crop_stream_form(crop, pool_k, pool_s, pout);
   if (form == 1)
-    hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<c2d_bf16>, dim3(num_boxes), dim3(256), 0,
+    hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<c2d_bf16>,
+                       dim3(num_boxes * crop_stream_splits()), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,
-                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout);
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout, crop_stream_splits());
   else
     hipLaunchKernelGGL(roi_crop_pool_fwd_kernel<c2d_bf16>, dim3(num_boxes), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,

@@ -324,5 +324,12 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   assert any(k.startswith("wgrad3x3_bf16_kernel<4") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad3x3_bf16_kernel<7") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad_tn_bf16_kernel") for k in bf16), sorted(bf16)
-  assert any(k.startswith("igemm_nt_kernel<0") and k.endswith("true, 2>") for k in bf16), sorted(bf16)
-  assert any(k.startswith("igemm_nt_kernel<1") and k.endswith("true, 2>") for k in bf16), sorted(bf16)
+  # the direct-to-LDS bf16 kernel in its three block tiles (128x64, 128x128, 128x256), row-major
+  # and pixel-major, forward and input gradient
+  for mode in (0, 1):
+    for pm in ("true", "false"):
+      assert any(k.startswith("igemm_bf16_kernel<%d" % mode) and k.endswith(pm + ">") for k in bf16), \
+          (mode, pm, sorted(bf16))
+  for tile in ("2, 2, 2, 1", "2, 2, 2, 2", "2, 4, 2, 2"):
+    assert any(k.startswith("igemm_bf16_kernel<") and (", " + tile + ", ") in k for k in bf16), \
+        (tile, sorted(bf16))
