@@ -434,13 +434,14 @@ def main(argv=None):
     # rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950,
     # + WRITE_SIZE, separate passes; tools/summarize_pmc.py); null when the summary file is
     # absent.  See profiles/README.md.
-    traffic = {}
-    try:
-      name = "r01_traffic.json" if args.dtype == "fp32" else "r01_traffic_bf16.json"
-      with open(os.path.join(ROOT, "profiles", name)) as f:
-        traffic = json.load(f)["families"]
-    except Exception:
-      traffic = {}
+    traffic, mfma = {}, {}
+    low_cfg = "c2" if args.dtype == "bf16" else "c1"
+    for name, into in (("r02_traffic_%s.json" % low_cfg, traffic), ("r02_mfma_%s.json" % low_cfg, mfma)):
+      try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+          into.update(json.load(f)["families"])
+      except Exception:
+        pass
     if not args.no_kernel_timing and args.per_call:
       for (family, work, s, e), (name, ints) in zip(timer.records, timer.shapes):
         ms = s.elapsed_time(e)
@@ -460,6 +461,10 @@ def main(argv=None):
                 "frac": tf / peak,
                 "traffic": traffic.get(traffic_key, {}).get("hbm_bytes_per_launch"),
                 "traffic_bytes_per_step": traffic.get(traffic_key, {}).get("hbm_bytes_per_step"),
+                # matrix-pipe busy fraction of the family's dispatches from the committed PMC pass
+                # (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); per-clock, so it
+                # sits above `frac` by the ratio of the nominal to the sustained clock)
+                "mfma_busy": mfma.get(traffic_key, {}).get("mfma_busy"),
                 "calls_per_step": f["launches"], "avg_call_ms": f["ms"] / f["launches"],
                 "family_ms_per_step": f["ms"], "algorithmic_gflop_per_step": f["work"] / 1e9,
                 "timed_with": "HIP events around every launch of the last timed step, which runs "

@@ -627,3 +627,103 @@ def test_reference_branches_no_shipped_config_takes():
   trainer.train_step(ex_dev)
   m2 = model.engine._shape_cache[next(iter(model.engine._shape_cache))]["mask"]
   assert (m1 != m2).float().mean().item() > 0.3
+
+
+@pytest.mark.parametrize("config,dtype", [("c2", "fp32"), ("c2", "bf16"), ("c3", "fp32"),
+                                          ("c4", "bf16")])
+def test_full_size_caption_configs(tmp_path, config, dtype):
+  """BASELINE configs[2]-[4] at their real size: 500x500 image, 2000 proposals, the 80 COCO
+  classes of the shipped label files (data/coco_label_synonyms.txt: 80 classes, 405 synonyms;
+  coco / flickr30k open vocabularies of 7379 / 5437 words; 403-column heads GEMM, MIDN / OICR on
+  2000 x 80), the caption -> label branch inside the step, fp32 and the bf16 storage mode.
+  The oracle does not finish this size in seconds, so the step is checked through properties:
+    * the labels the extractor produced equal the numpy oracle's on the same caption (exact);
+    * every class's proposal softmax sums to 1 over the real proposals, 0 on the padded ones;
+    * the step is reproducible: same inputs, same dropout seed -> bitwise equal scores (the
+      forward pass has no atomics), losses and gradients equal up to the fp32 atomics' order;
+    * the losses are finite and equal what the OICR / MIDN formulas give on the scores the
+      kernels produced (oracle loss functions on the GPU's own logits, C = 80, N = 2000);
+    * only Mixed_4e, the second stage and the heads move."""
+  from oracle import ref_model as rm
+  from cap2det_amd import synthetic
+  from cap2det_amd.train.trainer import Trainer
+  spec = synthetic.BASELINE_CONFIGS[config]
+  pipeline = synthetic.baseline_pipeline(config, str(tmp_path))
+  np.random.seed(99)                                     # (the OOV embedding row)
+  trainer = Trainer(pipeline, device=DEV, seed=5, compute_dtype=dtype)
+  model = trainer.model
+  classes = model.label_extractor.classes
+  assert len(classes) == 80 and model._npad == 416
+  rng = np.random.default_rng(31)
+  n, real = 2000, 1700
+  ex = util_model.make_examples(rng, 1, 500, 500, n, [real], classes)
+  vocab = synthetic.caption_vocabulary(pipeline)
+  ex["concat_caption_string"] = synthetic.synthetic_captions(
+      rng, 1, vocab, tokens=60, must_contain=["dog", "bicycle"])
+  dev = _to_dev(ex)
+  before = model.state_dict()
+
+  def step():
+    model.load_state_dict(before)
+    trainer.model.store.accum.fill_(0.1)
+    trainer.global_step = 0
+    losses = trainer.train_step(dev, dropout_seed=17)
+    torch.cuda.synchronize()
+    pred = {k: v.detach().clone() for k, v in trainer.predictions.items() if isinstance(v, torch.Tensor)}
+    lo, hi = trainer.bucket
+    return ({k: float(v.item()) for k, v in losses.items()}, pred,
+            model.store.grads[lo:hi].clone(), model._ctx["labels"].clone())
+
+  l1, p1, g1, lab1 = step()
+  after = model.state_dict()
+  l2, p2, g2, lab2 = step()
+  # labels: oracle extractor on the same strings
+  labels = lab1.cpu().numpy()
+  from oracle import ref_labels
+  caps = ex["concat_caption_string"]
+  if config == "c2":
+    name2id, cls2 = ref_labels.read_synonym_file(os.path.join(synthetic.DATA, "coco_label_synonyms.txt"))
+    assert cls2 == list(classes)
+    want = ref_labels.extend_match_extract(caps, name2id, 80)
+    np.testing.assert_array_equal(labels, want)
+    assert labels.sum() >= 2                              # "dog", "bicycle" are class names
+  else:
+    assert labels.shape == (1, 80) and set(np.unique(labels)) <= {0.0, 1.0}
+    # "dog" / "bicycle" are raw class names too: the exact-match vector wins (models/label_extractor.py:469-472)
+    want = ref_labels.match_labels(caps, list(classes))
+    assert want.sum() >= 2
+    np.testing.assert_array_equal(labels, want)
+  assert torch.equal(lab1, lab2)
+  # forward properties
+  proba = p1["midn_proba_r_given_c"][0]
+  np.testing.assert_allclose(proba[:real].sum(0).cpu().numpy(), np.ones(80), rtol=0, atol=3e-5)
+  assert float(proba[real:].abs().max()) == 0.0
+  for i in range(1, 4):
+    s = p1["oicr_proposal_scores_at_%d" % i][0]
+    assert s.shape == (n, 81) and bool(torch.isfinite(s).all())
+  for k in p1:
+    assert torch.equal(p1[k], p2[k]), "step not reproducible: " + k
+  for k in l1:
+    # (the loss scalars are block sums combined with fp32 atomics: equal up to their order)
+    assert np.isfinite(l1[k]) and abs(l1[k] - l2[k]) <= 2e-6 * abs(l1[k]), (k, l1[k], l2[k])
+  scale = float(g1.abs().max())
+  assert scale > 0 and float((g1 - g2).abs().max()) <= 2e-5 * scale
+  # the losses follow from the scores by the reference formulas (oracle functions, float64)
+  pred64 = {k: v.double().cpu().numpy() for k, v in p1.items() if v.is_floating_point()}
+  pred64["num_proposals"] = ex["number_of_proposals"]
+  pred64["proposal_boxes"] = ex["proposals"].astype(np.float64)
+  loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
+                   oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+  want_losses, _ = rm.build_loss(pred64, labels.astype(np.float64), loss_opts)
+  for k, v in want_losses.items():
+    np.testing.assert_allclose(l1[k], v, rtol=2e-4, err_msg=k)
+  # which variables moved
+  moved = [k for k in before if not np.array_equal(before[k], after[k])]
+  assert any(k.startswith("first_stage_feature_extraction/InceptionV2/Mixed_4e/") for k in moved)
+  assert any(k.startswith("second_stage_feature_extraction/") for k in moved)
+  assert any(k.startswith("oicr/iter3/") for k in moved)
+  for k in moved:
+    assert (k.startswith("first_stage_feature_extraction/InceptionV2/Mixed_4e/") or
+            k.startswith("second_stage_feature_extraction/") or k.startswith("midn/") or
+            k.startswith("oicr/")), "frozen variable moved: " + k
+  assert not any(k.endswith("moving_mean") or k.endswith("moving_variance") for k in moved)

@@ -1,29 +1,41 @@
 # Round profile set (run on the GPU box from the repo root: `bash tools/profile_round.sh`).
-# Kernel statistics of the default command, the same with every kernel on ONE stream
-# (C2D_WGRAD_SIDE_STREAM=0: no side-stream filter gradients, no first-stage look-ahead, so a
-# kernel's duration is that kernel alone), two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs,
-# never combined with tracing domains other than --kernel-trace), the bf16-mode equivalents and
-# the plain benchmark lines.  Copy the summaries you quote from gpurun_out/ into profiles/.
+# For the headline config (c1, fp32) and the bf16 config (c2): kernel statistics of the default
+# command, the same with every kernel on ONE stream (C2D_WGRAD_SIDE_STREAM=0: no side-stream filter
+# gradients, no first-stage look-ahead, so a kernel's duration is that kernel alone), three PMC
+# passes (FETCH_SIZE, WRITE_SIZE, matrix-pipe busy cycles: separate runs, never combined with
+# tracing domains other than --kernel-trace, the program directly after `--`), and the plain
+# benchmark lines of all four BASELINE configs.  Copy the summaries you quote from gpurun_out/
+# into profiles/ (tools/summarize_pmc.py, tools/summarize_mfma.py reduce the PMC passes).
 set -x
-cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-T=${PROFILE_TAG:-r01s5}
-B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -o s -- $B > $O/${T}_stats.log 2>&1
-export C2D_WGRAD_SIDE_STREAM=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_serial_stats -o s -- $B > $O/${T}_serial_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_fetch -o f -- $B --no-kernel-timing > $O/${T}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}_write -o w -- $B --no-kernel-timing > $O/${T}_write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}b_serial_stats -o s -- $B --dtype bf16 > $O/${T}b_serial_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}b_fetch -o f -- $B --dtype bf16 --no-kernel-timing > $O/${T}b_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}b_write -o w -- $B --dtype bf16 --no-kernel-timing > $O/${T}b_write.log 2>&1
-unset C2D_WGRAD_SIDE_STREAM
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}b_stats -o s -- $B --dtype bf16 > $O/${T}b_stats.log 2>&1
+T=${PROFILE_TAG:-r02}
+cd /tmp; export TMPDIR=/tmp
+for CFG in c1 c2; do
+  B="python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_${CFG}_stats -o s -- $B > $O/${T}_${CFG}_stats.log 2>&1
+  export C2D_WGRAD_SIDE_STREAM=0
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_${CFG}_serial_stats -o s -- $B > $O/${T}_${CFG}_serial_stats.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_${CFG}_fetch -o f -- $B --no-kernel-timing > $O/${T}_${CFG}_fetch.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}_${CFG}_write -o w -- $B --no-kernel-timing > $O/${T}_${CFG}_write.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${T}_${CFG}_mfma -o m -- $B --no-kernel-timing > $O/${T}_${CFG}_mfma.log 2>&1
+  unset C2D_WGRAD_SIDE_STREAM
+done
 cd $R
-python bench.py > $O/${T}_unprofiled.log 2>&1
-python bench.py --dtype bf16 > $O/${T}b_unprofiled.log 2>&1
-C2D_WGRAD_SIDE_STREAM=0 python bench.py --no-cpu-baseline > $O/${T}_serial_unprofiled.log 2>&1
-find $O -name "*kernel_trace.csv" -path "*${T}*_fetch*" -delete; find $O -name "*kernel_trace.csv" -path "*${T}*_write*" -delete
-find $O -name "*kernel_trace.csv" -path "*${T}b*" -delete
-du -sh $O/${T}*
+mkdir -p $O/${T}_summaries
+for CFG in c1 c2; do
+  python3 tools/summarize_pmc.py $O/${T}_summaries/${T}_traffic_${CFG}.json $O/${T}_${CFG}_fetch $O/${T}_${CFG}_write
+  python3 tools/summarize_mfma.py $O/${T}_summaries/${T}_mfma_${CFG}.json $O/${T}_${CFG}_mfma
+  for K in stats serial_stats; do
+    f=$(find $O/${T}_${CFG}_${K} -name "*kernel_stats.csv" | head -1)
+    if [ -n "$f" ]; then cp "$f" $O/${T}_summaries/${T}_bench_kernel_stats_${CFG}$( [ $K = serial_stats ] && echo _serial ).csv; fi
+  done
+done
+find $O -name "*kernel_trace.csv" -path "*${T}_c*" -delete
+find $O -name "*counter_collection.csv" -path "*${T}_c*" -delete
+timeout 400 python bench.py > $O/${T}_summaries/${T}_bench_c1.json 2> $O/${T}_bench_c1.err
+for CFG in c2 c3 c4; do timeout 300 python bench.py --config $CFG --no-cpu-baseline > $O/${T}_summaries/${T}_bench_${CFG}.json 2> $O/${T}_bench_${CFG}.err; done
+C2D_WGRAD_SIDE_STREAM=0 timeout 300 python bench.py --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c1_serial.json 2> $O/${T}_bench_c1_serial.err
+C2D_WGRAD_SIDE_STREAM=0 timeout 300 python bench.py --config c2 --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c2_serial.json 2> $O/${T}_bench_c2_serial.err
+timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/${T}_summaries/${T}_bench_gpus2_same_device.json 2> $O/${T}_bench_gpus2.err
+ls -la $O/${T}_summaries; du -sh $O/${T}_*

@@ -1,0 +1,70 @@
+"""MFMA-pipe utilisation per kernel family from a rocprofv3 PMC pass of bench.py
+(profiles/rNN_mfma.json; bench.py quotes it as `roofline.mfma_busy`).
+
+  python tools/summarize_mfma.py OUT.json PMC_DIR
+
+PMC_DIR: output of ONE pass (own run, `--kernel-trace` only beside `--pmc`, the program directly
+after `--`):
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE \\
+            --kernel-trace --output-format csv -d PMC_DIR -- python3 bench.py ...
+Formula (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over
+the SIMDs, 32 per v_mfma_f32_32x32x16_bf16, 64 per v_mfma_f32_32x32x2_f32; GRBM_GUI_ACTIVE is
+summed over the 8 XCDs):
+  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)
+i.e. the fraction of SIMD-cycles of the dispatch in which the matrix pipe was executing; it is a
+per-CLOCK figure (the chip's clock under load is below the 2.4 GHz the nominal peaks assume), so
+it sits above the time-based `roofline.frac` by the ratio of the two clocks."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_pmc import family_of  # noqa: E402
+
+
+def family(name):
+  if "igemm_bf16_kernel" in name:
+    return "igemm_bf16"
+  if "wgrad_reduce_kernel" in name:
+    return "wgrad_bf16"
+  return family_of(name)
+
+
+def main():
+  out_path, pmc_dir = sys.argv[1:3]
+  files = glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True)
+  if not files:
+    raise SystemExit("no counter_collection.csv under " + pmc_dir)
+  agg = collections.defaultdict(lambda: collections.defaultdict(float))
+  launches = collections.defaultdict(set)
+  for path in files:
+    with open(path) as f:
+      for row in csv.DictReader(f):
+        fam = family(row["Kernel_Name"])
+        if not fam:
+          continue
+        agg[fam][row["Counter_Name"]] += float(row["Counter_Value"])
+        launches[fam].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+  fams = {}
+  for fam, c in sorted(agg.items()):
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+    busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    fams[fam] = {
+        "launches": len(launches[fam]),
+        "SQ_VALU_MFMA_BUSY_CYCLES": busy,
+        "SQ_BUSY_CU_CYCLES": c.get("SQ_BUSY_CU_CYCLES"),
+        "GRBM_GUI_ACTIVE": gui,
+        "mfma_busy": (busy / (gui / 8.0 * 256 * 4)) if gui else None,
+    }
+  with open(out_path, "w") as f:
+    json.dump({"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4)",
+               "families": fams}, f, indent=1)
+  for fam, v in fams.items():
+    print("%-22s launches %5d  mfma_busy %s" % (fam, v["launches"], v["mfma_busy"]))
+
+
+if __name__ == "__main__":
+  main()

@@ -37,8 +37,10 @@ FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
 def family_of(name):
   # bf16-operand kernels (bench.py --dtype bf16) are separate families: their roofline is the
   # bf16 MFMA peak
-  if "wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16_kernel" in name:
+  if "wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16_kernel" in name or "wgrad_reduce_kernel" in name:
     return "wgrad_bf16"
+  if "igemm_bf16_kernel" in name:
+    return "igemm_bf16"
   m = re.search(r"igemm_nt_kernel<([^>]*)>", name)
   if m and len(m.group(1).split(",")) == 8 and m.group(1).split(",")[-1].strip() == "2":
     return "igemm_bf16"       # igemm_nt_kernel<MODE, WM, WN, MT, NT, BKT, PM, ES = 2>
