@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
   }
 }
 
-// out[j] += sum_m x[m][xoff + j]   (bias gradients)
+// out[j] += sum_m x[m][xoff + j]   (bias gradients).  grid (row blocks, 64-column chunks): a
+// [2000][416] operand (COCO heads) is 63 x 7 workgroups instead of 8 that walk the chunks in turn.
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ x, int ldx,
                                                       int xoff, float* __restrict__ out, int M,
                                                       int ncols, int rows_per_block) {
@@ -394,14 +395,14 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   const int r1 = min(M, r0 + rows_per_block);
   // 64 column lanes x 4 row lanes
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int c = tx; c < ncols; c += 64) {
-    float s = 0.f;
+  const int c = blockIdx.y * 64 + tx;
+  float s = 0.f;
+  if (c < ncols)
     for (int r = r0 + ty; r < r1; r += 4) s += x[(size_t)r * ldx + xoff + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (ty == 0) atomicAdd(out + c, red[tx] + red[tx + 64] + red[tx + 128] + red[tx + 192]);
-    __syncthreads();
-  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ty == 0 && c < ncols)
+    atomicAdd(out + c, red[tx] + red[tx + 64] + red[tx + 128] + red[tx + 192]);
 }
 
 // y[r][c] = mean_s x[r][s][c] * (mask ? mask[r][c] * inv_keep : 1)
@@ -922,9 +923,10 @@ extern "C" int c2d_bn_partials_reduce_batched(const void* desc, int num, int tot
 extern "C" int c2d_col_sum(const float* x, int ldx, int xoff, float* out, int rows, int ncols,
                            void* stream) {
   C2D_CHECK_ARG(x && out && rows > 0 && ncols > 0);
-  const int rows_per_block = 256;
-  hipLaunchKernelGGL(col_sum_kernel, dim3(c2d_ceil_div(rows, rows_per_block)), dim3(256), 0,
-                     (hipStream_t)stream, x, ldx, xoff, out, rows, ncols, rows_per_block);
+  const int rows_per_block = 32;
+  hipLaunchKernelGGL(col_sum_kernel,
+                     dim3(c2d_ceil_div(rows, rows_per_block), c2d_ceil_div(ncols, 64)), dim3(256),
+                     0, (hipStream_t)stream, x, ldx, xoff, out, rows, ncols, rows_per_block);
   return c2d_launch_status();
 }
 

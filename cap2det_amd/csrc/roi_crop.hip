@@ -713,8 +713,12 @@ template <typename TG>
 static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, const float* boxes,
                                      const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
                                      int depth, int num_boxes, int crop, int pool_k, int pool_s,
-                                     void* workspace, long long workspace_bytes, void* stream) {
-  C2D_CHECK_ARG(dout && argmax && boxes && box_ind && dfeat && workspace);
+                                     void* workspace, long long workspace_bytes, void* stream,
+                                     int phase = 0) {
+  // phase 0: everything; 1: only the box-dependent tables and row lists (c2d_roi_crop_pool_bwd_
+  // prepare: they depend on the boxes alone, so a caller can build them during the forward pass,
+  // off the critical path); 2: only the accumulation (c2d_roi_crop_pool_bwd_run)
+  C2D_CHECK_ARG(boxes && box_ind && workspace && (phase == 1 || (dout && argmax && dfeat)));
   C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 16 == 0);
   C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0 && pool_s > 0);
   if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) || wf > 64 ||
@@ -738,15 +742,18 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   off = (off + (size_t)batch * hf * kBinSegs * cap * sizeof(RowEntry) + 255) / 256 * 256;
   float* parts = (float*)(w + off);
   hipStream_t st = (hipStream_t)stream;
+  if (phase != 2)
   hipLaunchKernelGGL(roi_axes_kernel, dim3(c2d_ceil_div((long long)num_boxes * crop, 256)),
                      dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
   // channel chunk = workgroup size: the largest of 256 / 192 / 128 that divides the depth, else
   // 64 with a ragged last chunk (576 -> 192: 768-byte segments per cell, 25 KiB of LDS, six
   // workgroups per CU)
   const int chunk = depth % 256 == 0 ? 256 : depth % 192 == 0 ? 192 : depth % 128 == 0 ? 128 : 64;
+  if (phase != 2)
   hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
                      box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout, crop,
                      cap);
+  if (phase == 1) return c2d_launch_status();
 #define C2D_STRIP(CHV)                                                                          \
   hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>),                                          \
                      dim3(hf, (depth + CHV - 1) / CHV, batch * kRowParts),                      \
@@ -782,4 +789,36 @@ extern "C" int c2d_roi_crop_pool_bwd_ws_bf16(const void* dout, const uint8_t* ar
   return roi_crop_pool_bwd_ws_impl<c2d_bf16>((const c2d_bf16*)dout, argmax, boxes, box_ind, dfeat,
                                              batch, hf, wf, depth, num_boxes, crop, pool_k, pool_s,
                                              workspace, workspace_bytes, stream);
+}
+
+// The two halves of c2d_roi_crop_pool_bwd_ws (same workspace): `prepare` builds what depends on
+// the boxes alone, `run` accumulates.  prepare may run on another stream during the forward pass.
+extern "C" int c2d_roi_crop_pool_bwd_prepare(const float* boxes, const int32_t* box_ind, int batch,
+                                             int hf, int wf, int depth, int num_boxes, int crop,
+                                             int pool_k, int pool_s, void* workspace,
+                                             long long workspace_bytes, void* stream) {
+  return roi_crop_pool_bwd_ws_impl<float>(nullptr, nullptr, boxes, box_ind, nullptr, batch, hf, wf,
+                                          depth, num_boxes, crop, pool_k, pool_s, workspace,
+                                          workspace_bytes, stream, 1);
+}
+
+extern "C" int c2d_roi_crop_pool_bwd_run(const float* dout, const uint8_t* argmax,
+                                         const float* boxes, const int32_t* box_ind, float* dfeat,
+                                         int batch, int hf, int wf, int depth, int num_boxes,
+                                         int crop, int pool_k, int pool_s, void* workspace,
+                                         long long workspace_bytes, void* stream) {
+  return roi_crop_pool_bwd_ws_impl<float>(dout, argmax, boxes, box_ind, dfeat, batch, hf, wf, depth,
+                                          num_boxes, crop, pool_k, pool_s, workspace,
+                                          workspace_bytes, stream, 2);
+}
+
+extern "C" int c2d_roi_crop_pool_bwd_run_bf16(const void* dout, const uint8_t* argmax,
+                                              const float* boxes, const int32_t* box_ind,
+                                              float* dfeat, int batch, int hf, int wf, int depth,
+                                              int num_boxes, int crop, int pool_k, int pool_s,
+                                              void* workspace, long long workspace_bytes,
+                                              void* stream) {
+  return roi_crop_pool_bwd_ws_impl<c2d_bf16>((const c2d_bf16*)dout, argmax, boxes, box_ind, dfeat,
+                                             batch, hf, wf, depth, num_boxes, crop, pool_k, pool_s,
+                                             workspace, workspace_bytes, stream, 2);
 }

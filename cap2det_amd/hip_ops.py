@@ -73,6 +73,22 @@ def roi_crop_pool_bwd_ws(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool
   return dfeat
 
 
+def roi_crop_pool_bwd_prepare(boxes, box_ind, batch, hf, wf, depth, crop, pool_k, pool_s, workspace):
+  """Box-dependent half of roi_crop_pool_bwd_ws (any stream, e.g. during the forward pass)."""
+  _lib.call("c2d_roi_crop_pool_bwd_prepare", _p(boxes), _p(box_ind), batch, hf, wf, depth,
+            boxes.shape[0], crop, pool_k, pool_s, _p(workspace), workspace.numel(), _stream())
+
+
+def roi_crop_pool_bwd_run(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool_s, workspace):
+  """Accumulation half of roi_crop_pool_bwd_ws; needs roi_crop_pool_bwd_prepare on this workspace."""
+  b, hf, wf, d = dfeat.shape
+  fn = ("c2d_roi_crop_pool_bwd_run_bf16" if dout.dtype == torch.bfloat16
+        else "c2d_roi_crop_pool_bwd_run")
+  _lib.call(fn, _p(dout), _p(argmax), _p(boxes), _p(box_ind), _p(dfeat), b, hf, wf, d,
+            boxes.shape[0], crop, pool_k, pool_s, _p(workspace), workspace.numel(), _stream())
+  return dfeat
+
+
 # -- convolution ------------------------------------------------------------------------
 
 _conv_ws = None   # (tensor, nbytes): workspace of the balanced (stream-K) convolution forms

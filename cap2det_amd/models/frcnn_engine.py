@@ -858,6 +858,16 @@ class FrcnnEngine(object):
     self._shape_cache[key] = bufs
     return bufs
 
+  def _crop_bwd_ws_ok(self, bufs, d):
+    return (self.pool_k == 2 and bufs["p"] <= 16 and 2 <= bufs["fw"] <= 64 and d % 16 == 0)
+
+  def _crop_ws(self, bufs, b, n, d):
+    if "crop_ws" not in bufs:
+      nbytes = ops.roi_crop_pool_bwd_workspace_bytes(b, bufs["fh"], bufs["fw"], d, b * n,
+                                                     self.crop, self.pool_k, self.pool_s)
+      bufs["crop_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+    return bufs["crop_ws"]
+
   # -- frozen prefix of the first stage, one image ahead ----------------------------------
   def _prefix_len(self, bufs):
     """Steps of plan1 in front of the first trainable layer (all of them when the whole first
@@ -982,6 +992,20 @@ class FrcnnEngine(object):
     ops.roi_crop_pool_fwd(feat4, boxes, bufs["box_ind"], self.crop, self.pool_k, self.pool_s,
                           out=bufs["pooled"].t.view(b * n, bufs["p"], bufs["p"], feat.c),
                           argmax=bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], feat.c))
+    # The row lists of the atomic-free ROI-crop backward depend on the boxes only: they are built
+    # now, on the (idle) filter-gradient stream, under the second stage's forward pass.
+    crop_ready = None
+    if (is_training and self.first_trainable_idx is not None and self._crop_bwd_ws_ok(bufs, feat.c)
+        and self.second.side is not None):
+      ws = self._crop_ws(bufs, b, n, feat.c)
+      fork = torch.cuda.Event()
+      fork.record()
+      self.second.side.wait_event(fork)
+      with torch.cuda.stream(self.second.side):
+        ops.roi_crop_pool_bwd_prepare(boxes, bufs["box_ind"], b, bufs["fh"], bufs["fw"], feat.c,
+                                      self.crop, self.pool_k, self.pool_s, ws)
+        crop_ready = torch.cuda.Event()
+        crop_ready.record()
     net = self.second.forward(bufs["plan2"], bufs["pooled"])
     mask = None
     if is_training and self.keep_prob < 1.0:
@@ -994,7 +1018,8 @@ class FrcnnEngine(object):
         ops.dropout_mask(mask, 0 if dropout_seed is None else dropout_seed, self.keep_prob)
     ops.spatial_mean_dropout_fwd(net.t, bufs["features"], mask, b * n, bufs["spatial"], net.c,
                                  self.keep_prob if mask is not None else 1.0)
-    ctx = dict(bufs=bufs, b=b, n=n, boxes=boxes, mask=mask, feat4=feat4, fmask=fmask)
+    ctx = dict(bufs=bufs, b=b, n=n, boxes=boxes, mask=mask, feat4=feat4, fmask=fmask,
+               crop_ready=crop_ready)
     return bufs["features"], ctx
 
   def backward(self, dfeatures, lddf, dfoff, ctx, after_second_stage=None):
@@ -1028,14 +1053,16 @@ class FrcnnEngine(object):
       dp4 = dpooled.t.view(b * n, bufs["p"], bufs["p"], d)
       arg4 = bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], d)
       gf4 = gcrop.view(b, bufs["fh"], bufs["fw"], d)
-      if self.pool_k == 2 and bufs["p"] <= 16 and bufs["fw"] <= 64 and d % 16 == 0:
+      if self._crop_bwd_ws_ok(bufs, d):
         # atomic-free, bitwise reproducible row-owner form (needs a workspace)
-        if "crop_ws" not in bufs:
-          nbytes = ops.roi_crop_pool_bwd_workspace_bytes(b, bufs["fh"], bufs["fw"], d, b * n,
-                                                         self.crop, self.pool_k, self.pool_s)
-          bufs["crop_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        ops.roi_crop_pool_bwd_ws(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
-                                 self.pool_k, self.pool_s, bufs["crop_ws"])
+        ws = self._crop_ws(bufs, b, n, d)
+        if ctx.get("crop_ready") is not None:           # lists built during the forward pass
+          torch.cuda.current_stream().wait_event(ctx["crop_ready"])
+          ops.roi_crop_pool_bwd_run(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
+                                    self.pool_k, self.pool_s, ws)
+        else:
+          ops.roi_crop_pool_bwd_ws(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
+                                   self.pool_k, self.pool_s, ws)
       else:
         ops.roi_crop_pool_bwd(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
                               self.pool_k, self.pool_s)

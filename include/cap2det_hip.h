@@ -374,6 +374,21 @@ int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax, const flo
                              const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
                              int depth, int num_boxes, int crop, int pool_k, int pool_s,
                              void* workspace, long long workspace_bytes, void* stream);
+/* The two halves of c2d_roi_crop_pool_bwd_ws over the same workspace: `prepare` builds what
+ * depends on the boxes alone (sampling tables, per-row cell lists) and may run on another stream
+ * during the forward pass; `run` (after it) accumulates dout into dfeat. */
+int c2d_roi_crop_pool_bwd_prepare(const float* boxes, const int32_t* box_ind, int batch, int hf,
+                                  int wf, int depth, int num_boxes, int crop, int pool_k,
+                                  int pool_s, void* workspace, long long workspace_bytes,
+                                  void* stream);
+int c2d_roi_crop_pool_bwd_run(const float* dout, const uint8_t* argmax, const float* boxes,
+                              const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
+                              int depth, int num_boxes, int crop, int pool_k, int pool_s,
+                              void* workspace, long long workspace_bytes, void* stream);
+int c2d_roi_crop_pool_bwd_run_bf16(const void* dout, const uint8_t* argmax, const float* boxes,
+                                   const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
+                                   int depth, int num_boxes, int crop, int pool_k, int pool_s,
+                                   void* workspace, long long workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * bf16 storage forms of the activation-side kernels (BASELINE.json configs[2] / [4]: "bf16

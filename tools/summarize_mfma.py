@@ -46,8 +46,13 @@ def main():
         fam = family(row["Kernel_Name"])
         if not fam:
           continue
-        agg[fam][row["Counter_Name"]] += float(row["Counter_Value"])
-        launches[fam].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+        fams_of_row = [fam]
+        if fam == "igemm":     # the big-tile kernels apart from the single-image first-stage ones
+          fams_of_row.append("igemm_small_only" if "igemm_small" in row["Kernel_Name"]
+                             else "igemm_nt_only")
+        for fq in fams_of_row:
+          agg[fq][row["Counter_Name"]] += float(row["Counter_Value"])
+          launches[fq].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
   fams = {}
   for fam, c in sorted(agg.items()):
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
