@@ -118,8 +118,13 @@ class KernelTimer(object):
     ops.conv_wgrad = timed(ops.conv_wgrad, "wgrad_tn", wgrad_work)
     # bf16 mode: split-K slabs (same argument positions as conv_wgrad) + the batched reduction of
     # the slabs, whose time belongs to the filter gradients (it replaces their atomics)
-    ops.conv_wgrad_bf16_partial = timed(ops.conv_wgrad_bf16_partial, "wgrad_tn", wgrad_work)
-    ops.wgrad_reduce_batched = timed(ops.wgrad_reduce_batched, "wgrad_tn_bf16", lambda args: 0.0)
+    ops.conv_wgrad_partial = timed(ops.conv_wgrad_partial, "wgrad_tn", wgrad_work)
+    reduce_family = ["wgrad_tn"]        # (set to the step's storage mode once it is known)
+    t.reduce_family = reduce_family
+    inner_reduce = ops.wgrad_reduce_batched
+    def reduce_timed(*args, **kwargs):
+      return timed(inner_reduce, reduce_family[0], lambda a_: 0.0)(*args, **kwargs)
+    ops.wgrad_reduce_batched = reduce_timed
     ops.roi_crop_pool_fwd = timed(ops.roi_crop_pool_fwd, "roi_crop_pool_fwd", crop_work)
 
   def summary(self):
@@ -334,6 +339,8 @@ def main(argv=None):
   spec = synthetic.BASELINE_CONFIGS[args.config]
   if args.dtype is None:
     args.dtype = spec["dtype"]
+  if not args.no_kernel_timing and args.dtype == "bf16":
+    timer.reduce_family[0] = "wgrad_tn_bf16"
   scratch = tempfile.mkdtemp(prefix="c2d_bench_")      # synthetic GloVe / classifier files (c3, c4)
   try:
     pipeline = synthetic.baseline_pipeline(args.config, scratch)

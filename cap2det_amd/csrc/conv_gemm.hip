@@ -1330,7 +1330,9 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   }
 
 #undef C2D_WG_LOAD
-  float* dw = a.dW + (size_t)tap * a.I * a.J;
+  // split-K result: atomics into dW, or this split's own slab (see wgrad_tn_bf16_kernel)
+  float* dw = a.dW + (size_t)tap * a.I * a.J + (size_t)blk.z * a.part_stride;
+  const bool part = a.part_stride > 0;
 #pragma unroll
   for (int j = 0; j < NTJ; ++j) {
     const int jj = j0 + (wn * NTJ + j) * 32 + li;
@@ -1341,7 +1343,8 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int ii = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (ii >= a.I) continue;
-        atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
+        if (part) dw[(size_t)ii * a.J + jj] = acc[i][j][r];
+        else atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
       }
   }
 }
@@ -1505,13 +1508,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
 
   if (wave_on) {
     const int jj = j0 + wave * 32 + li;
+    const bool part = a.part_stride > 0;     // (see wgrad_tn_bf16_kernel)
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      float* dw = a.dW + (size_t)q * a.I * a.J;
+      float* dw = a.dW + (size_t)q * a.I * a.J + (size_t)split * a.part_stride;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ii = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
+        if (part) dw[(size_t)ii * a.J + jj] = acc[q][r];
+        else atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
       }
     }
   }
@@ -2414,7 +2419,7 @@ static int wgrad3_bf16_igroups(int cin) {
   return 1;   // measured: two i-groups (8 waves, one block per CU) 0-15 % slower on the 4x4 / 7x7 layers
 }
 
-// partial != null (bf16 MFMA forms only): every split stores its own slab at partial +
+// partial != null: every split stores its own slab at partial +
 // split * taps*cin*cout floats; *splits_out receives the number of slabs.  splits_only: just
 // report how many splits the launch would use (workspace sizing), launch nothing.
 template <int ES>
@@ -2481,8 +2486,10 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
     b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
-    b.part_stride = 0;
-    if (partial || splits_only) return C2D_ERR_UNSUPPORTED;   // (only the bf16 MFMA forms)
+    if (splits_out) *splits_out = b.splits;
+    if (splits_only) return C2D_OK;
+    b.part_stride = partial ? dw_numel : 0;
+    if (partial) b.dW = partial;
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
     dispatch_note("wgrad3x3_kernel<%d, %d, %d>", iw, iw == 4 ? 2 : 1, ES);
@@ -2525,8 +2532,10 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, false>), grid, dim3(256), 0, st, a);
     return c2d_launch_status();
   }
+  if (splits_out) *splits_out = a.nsplits;
+  if (splits_only) return C2D_OK;
+  if (partial) { a.part_stride = dw_numel; a.dW = partial; }
   dispatch_note(plain ? "wgrad_tn_kernel<%d, true, %d>" : "wgrad_tn_kernel<%d, false, %d>", narrow ? 1 : 2, ES);
-  if (partial || splits_only) return C2D_ERR_UNSUPPORTED;     // (only the bf16 MFMA forms)
   if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true, ES>), grid, dim3(256), 0, st, a);
   else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false, ES>), grid, dim3(256), 0, st, a);
   else if (plain) hipLaunchKernelGGL((wgrad_tn_kernel<2, true, ES>), grid, dim3(256), 0, st, a);
@@ -2571,6 +2580,26 @@ extern "C" int c2d_conv_wgrad_bf16_partial(const void* x, int ldx, int xoff, con
   if ((long long)splits * kh * kw * cin * cout > partial_floats) return C2D_ERR_WORKSPACE;
   return conv_wgrad_impl<2>((const float*)x, ldx, xoff, (const float*)dc, ldc, coff, nullptr, n, ih,
                             iw, cin, cout, kh, kw, stride, stream, partials);
+}
+
+extern "C" int c2d_conv_wgrad_splits(int ldx, int xoff, int ldc, int coff, int n, int ih, int iw,
+                                     int cin, int cout, int kh, int kw, int stride) {
+  int splits = 0;
+  const int rc = conv_wgrad_impl<4>(nullptr, ldx, xoff, nullptr, ldc, coff, nullptr, n, ih, iw, cin,
+                                    cout, kh, kw, stride, nullptr, nullptr, &splits, true);
+  return rc == C2D_OK ? splits : rc;
+}
+
+extern "C" int c2d_conv_wgrad_partial(const float* x, int ldx, int xoff, const float* dc, int ldc,
+                                      int coff, float* partials, long long partial_floats, int n,
+                                      int ih, int iw, int cin, int cout, int kh, int kw, int stride,
+                                      void* stream) {
+  C2D_CHECK_ARG(partials);
+  const int splits = c2d_conv_wgrad_splits(ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh, kw, stride);
+  if (splits < 0) return splits;
+  if ((long long)splits * kh * kw * cin * cout > partial_floats) return C2D_ERR_WORKSPACE;
+  return conv_wgrad_impl<4>(x, ldx, xoff, dc, ldc, coff, nullptr, n, ih, iw, cin, cout, kh, kw,
+                            stride, stream, partials);
 }
 
 static_assert(sizeof(WgradReduceDesc) == sizeof(C2dWgradReduceDesc), "C2dWgradReduceDesc layout");

@@ -477,18 +477,21 @@ def last_dispatch():
   return [k for k in buf.value.decode().split(";") if k]
 
 
-def conv_wgrad_bf16_splits(ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh, kw, stride):
-  """Number of split-K slabs c2d_conv_wgrad_bf16_partial writes for this layer (< 0: the layer
-  does not qualify for the bf16 MFMA kernels)."""
-  return int(_lib.load().c2d_conv_wgrad_bf16_splits(ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh,
-                                                    kw, stride))
+def conv_wgrad_splits(dtype, ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh, kw, stride):
+  """Number of split-K slabs conv_wgrad_partial writes for this layer (< 0: the layer does not
+  qualify, e.g. bf16 operands that miss the alignment of the bf16 MFMA kernels)."""
+  fn = "c2d_conv_wgrad_bf16_splits" if dtype == torch.bfloat16 else "c2d_conv_wgrad_splits"
+  return int(getattr(_lib.load(), fn)(ldx, xoff, ldc, coff, n, ih, iw, cin, cout, kh, kw, stride))
 
 
-def conv_wgrad_bf16_partial(x, ldx, xoff, dc, ldc, coff, partials, n, ih, iw, cin, cout, kh, kw,
-                            stride):
-  assert x.dtype == dc.dtype == torch.bfloat16 and partials.dtype == torch.float32
-  _lib.call("c2d_conv_wgrad_bf16_partial", _p(x), ldx, xoff, _p(dc), ldc, coff, _p(partials),
-            partials.numel(), n, ih, iw, cin, cout, kh, kw, stride, _stream())
+def conv_wgrad_partial(x, ldx, xoff, dc, ldc, coff, partials, n, ih, iw, cin, cout, kh, kw,
+                       stride):
+  """conv_wgrad with every K split storing its own fp32 slab (no atomics); wgrad_reduce_batched
+  adds the slabs into the filter gradient."""
+  assert x.dtype == dc.dtype and partials.dtype == torch.float32
+  fn = "c2d_conv_wgrad_bf16_partial" if x.dtype == torch.bfloat16 else "c2d_conv_wgrad_partial"
+  _lib.call(fn, _p(x), ldx, xoff, _p(dc), ldc, coff, _p(partials), partials.numel(), n, ih, iw,
+            cin, cout, kh, kw, stride, _stream())
 
 
 class WgradReduceDesc(ctypes.Structure):

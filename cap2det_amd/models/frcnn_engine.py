@@ -508,27 +508,36 @@ class Net(object):
       recs.append((ws_size, voff[L.name + "/BatchNorm/beta"][0], g, nb, L.cout, chunks, 0))
       ws_size += nb * 2 * L.cout
       chunks += -(-L.cout // 64)
-    # bf16 networks: the split-K results of the filter gradients go to per-split slabs (plain
-    # stores) and ONE batched launch at the end of backward() adds them into the flat gradient
-    # buffer in split order — instead of fp32 atomics (c2d_conv_wgrad_bf16_partial)
+    # The split-K results of the per-ROI filter gradients go to per-split slabs (plain stores) and
+    # a reduction launch right behind each of them adds the slabs into the flat gradient buffer in
+    # split order — instead of fp32 atomics (c2d_conv_wgrad_partial; reproducible as a side effect)
     wrecs, woff = [], 0
-    if self.dtype == torch.bfloat16 and os.environ.get("C2D_WGRAD_PARTIALS", "1") != "0":
+    # Opt-in (C2D_WGRAD_PARTIALS=1): measured at the benchmark size the slabs cost what they save
+    # (fp32 step 12.77 ms against 12.48 ms with atomics — the atomics of one workgroup hide under
+    # the MFMAs of the others —, bf16 4.22 against 4.22); what they buy is bitwise reproducible
+    # filter gradients.
+    if os.environ.get("C2D_WGRAD_PARTIALS", "0") == "1":
       for st in convs:
         L = st["layer"]
-        if not L.trainable:
+        # (per-ROI maps only: on the single first-stage image a launch has too few workgroups for
+        # its atomics to matter)
+        if not L.trainable or st["n"] < 64:
           continue
         x = st["x"]
         ldx, xoff = (x.ld, x.off) if x is not None else (self.cin, 0)
-        splits = ops.conv_wgrad_bf16_splits(ldx, xoff, L.cout, 0, st["n"], st["ih"], st["iw"], L.cin,
-                                            L.cout, L.k, L.k, L.stride)
-        if splits <= 0:
+        splits = ops.conv_wgrad_splits(self.dtype, ldx, xoff, L.cout, 0, st["n"], st["ih"], st["iw"],
+                                       L.cin, L.cout, L.k, L.k, L.stride)
+        if splits <= 1:
           continue
         numel = L.k * L.k * L.cin * L.cout
-        st["wpart"] = (woff, splits * numel)
-        wrecs.append((woff, voff[L.name + "/weights"][0], numel, splits))
+        # (its own one-layer descriptor: the slabs are added right behind the launch that wrote
+        # them, on the same stream, while they still sit in the Infinity Cache)
+        st["wpart"] = (woff, splits * numel,
+                       ops.wgrad_reduce_descriptors(
+                           [(woff, voff[L.name + "/weights"][0], numel, splits)], dev))
+        wrecs.append(st)
         woff += splits * numel
     plan["wpart_ws"] = torch.empty(max(woff, 4), device=dev) if wrecs else None
-    plan["wpart_desc"] = ops.wgrad_reduce_descriptors(wrecs, dev) if wrecs else None
     plan["bn_ws"] = torch.empty(max(ws_size, 4), device=dev)
     plan["bn_desc"] = (torch.from_numpy(np.array(recs, dtype=ddt).view(np.uint8).copy()).to(dev)
                        if recs else None)
@@ -562,17 +571,15 @@ class Net(object):
     if plan["bn_num"]:
       ops.bn_partials_reduce_batched(plan["bn_desc"], plan["bn_num"], plan["bn_chunks"],
                                      plan["bn_ws"], self.store.grads)
-    if plan.get("wpart_desc") is not None:
-      desc, num, chunks = plan["wpart_desc"]
-      ops.wgrad_reduce_batched(desc, num, chunks, plan["wpart_ws"], self.store.grads)
 
   def _wgrad(self, plan, st, x, dc):
     L = st["layer"]
     part = st.get("wpart")
     if part is not None:
-      off, size = part
-      ops.conv_wgrad_bf16_partial(x.t, x.ld, x.off, dc, L.cout, 0, plan["wpart_ws"][off:off + size],
-                                  st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+      off, size, (desc, num, chunks) = part
+      ops.conv_wgrad_partial(x.t, x.ld, x.off, dc, L.cout, 0, plan["wpart_ws"][off:off + size],
+                             st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+      ops.wgrad_reduce_batched(desc, num, chunks, plan["wpart_ws"], self.store.grads)
     else:
       ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, self.store.grad[L.name + "/weights"],
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)

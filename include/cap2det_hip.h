@@ -440,6 +440,12 @@ int c2d_conv_wgrad_bf16_partial(const void* x, int ldx, int xoff, const void* dc
                                 int coff, float* partials, long long partial_floats, int n,
                                 int ih, int iw, int cin, int cout, int kh, int kw, int stride,
                                 void* stream);
+/* The same for fp32 operands (c2d_conv_wgrad's kernels with slab stores). */
+int c2d_conv_wgrad_splits(int ldx, int xoff, int ldc, int coff, int n, int ih, int iw, int cin,
+                          int cout, int kh, int kw, int stride);
+int c2d_conv_wgrad_partial(const float* x, int ldx, int xoff, const float* dc, int ldc, int coff,
+                           float* partials, long long partial_floats, int n, int ih, int iw,
+                           int cin, int cout, int kh, int kw, int stride, void* stream);
 typedef struct C2dWgradReduceDesc {
   long long ws_off;   /* first float of split 0's slab in `workspace` */
   long long dw_off;   /* first float of the filter gradient in `grads` */

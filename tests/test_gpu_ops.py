@@ -501,3 +501,37 @@ def test_roi_crop_pool_forms_match_oracle(hf, wf, d, n, crop, pk, ps):
 def util_boxes(rng, n):
   from tests import util_model
   return util_model.synthetic_boxes(rng, n)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(300, 4, 4, 64, 96, 3, 1), (300, 7, 7, 32, 64, 1, 1),
+                                  (260, 7, 7, 32, 64, 3, 2), (257, 7, 7, 64, 160, 3, 1)])
+def test_conv_wgrad_partial_slabs(ops, case, dtype):
+  """c2d_conv_wgrad(_bf16)_partial + c2d_wgrad_reduce_batched (split-K slabs with plain stores,
+  summed in split order) against c2d_conv_wgrad's atomics and the float64 oracle; two runs are
+  bitwise equal (the point of the slab form)."""
+  n, ih, iw, cin, cout, k, s = case
+  rng = np.random.default_rng(77)
+  x, w = _conv_inputs(rng, n, ih, iw, cin, cout, k)
+  oh, ow = -(-ih // s), -(-iw // s)
+  dc = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+  tx, tdc = _t(x).to(dtype), _t(dc).to(dtype)
+  x64, dc64 = _n(tx.float()).astype(np.float64), _n(tdc.float()).astype(np.float64)
+  _, want = ref_ops.conv2d_backward(x64, w.astype(np.float64), dc64, s, need_dx=False)
+  splits = ops.conv_wgrad_splits(dtype, cin, 0, cout, 0, n, ih, iw, cin, cout, k, k, s)
+  assert splits >= 1
+  numel = k * k * cin * cout
+  outs = []
+  for _ in range(2):
+    ws = torch.full((splits * numel + 8,), 7.0, device=DEV)
+    ops.conv_wgrad_partial(tx, cin, 0, tdc, cout, 0, ws[:splits * numel], n, ih, iw, cin, cout, k, k, s)
+    grads = torch.full((numel + 64,), 0.5, device=DEV)
+    desc, num, chunks = ops.wgrad_reduce_descriptors([(0, 32, numel, splits)], DEV)
+    ops.wgrad_reduce_batched(desc, num, chunks, ws, grads)
+    assert float(ws[splits * numel:].min()) == 7.0 and float(grads[:32].max()) == 0.5
+    assert float(grads[32 + numel:].min()) == 0.5
+    outs.append(grads[32:32 + numel].clone())
+  assert torch.equal(outs[0], outs[1])
+  got = _n(outs[0]).reshape(want.shape) - 0.5
+  scale = np.abs(want).max()
+  np.testing.assert_allclose(got, want, rtol=2e-4, atol=(1e-4 if dtype == torch.bfloat16 else 2e-5) * scale)
