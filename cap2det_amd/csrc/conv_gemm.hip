@@ -1523,6 +1523,126 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
 }
 
 
+// The same plan for the two STRIDE-2 3x3 convolutions of Mixed_5a (7x7 -> 4x4, TF SAME: one pad
+// row / column on either side): x is staged per image as a zero-padded 9x9 map, dC as 16 rows; the
+// k-step (s = output pixel (oy, ox) of an image pair) reads tap (ky, kx) at padded input
+// (2 oy + ky, 2 ox + kx), a compile-time LDS row, and the taps that fall into the padding (oy or ox
+// = 3 with ky / kx = 2) are not issued.  The per-tap kernel these layers ran on before re-read x
+// and dC once per tap and tile and reached 86-97 TFLOP/s against 135-145 for the nine-tap form.
+template <int ES>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_s2_kernel(Wgrad3Args a) {
+  constexpr int WI = 7, WO = 4, IMGS = 2;
+  constexpr int PW = WI + 2;
+  constexpr int HWI = WI * WI, HWO = WO * WO;
+  constexpr int PIMG = PW * PW;
+  constexpr int R = IMGS * HWO;              // dC rows per slab (32)
+  constexpr int STEPS = R / 2;               // (image pair, output pixel)
+  constexpr int AROWS = IMGS * PIMG;         // staged (padded) x rows per slab (162)
+  constexpr int A_LD = (AROWS + 31) / 32;
+  constexpr int G_LD = (R + 7) / 8;
+  __shared__ __attribute__((aligned(16))) float As[AROWS * W3_ASTR];
+  __shared__ __attribute__((aligned(16))) float Gs[R * W3_GSTR];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
+  const int split = logical / a.tiles;
+  const int t = logical - split * a.tiles;
+  const int jt = t % a.jtiles, it_ = t / a.jtiles;
+  const int i0 = it_ * 32, j0 = jt * 128;
+  const int mbeg = split * a.rows_per_split;           // OUTPUT rows, multiple of R
+  const int mend = min(a.M, mbeg + a.rows_per_split);  // M = images * 16
+  const bool wave_on = j0 + wave * 32 < a.J;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+  const int gkr = tid >> 5, gc4 = (tid & 31) * 4;
+  const long long in_rows = (long long)(a.M / HWO) * HWI;
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * ES,
+                                                 ((long long)a.M * a.ldg - a.g_off) * ES);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * ES,
+                                                 (in_rows * a.lda - a.a_off) * ES);
+  const int aq4 = (tid & 7) * 4, ar0 = tid >> 3;
+  unsigned goffs[G_LD], aoffs[A_LD];
+#pragma unroll
+  for (int u = 0; u < G_LD; ++u) {
+    const int k = gkr + u * 8;
+    goffs[u] = k < R ? (unsigned)(k * a.ldg + min(j0 + gc4, a.J - 4)) * (unsigned)ES : OOB_OFFSET;
+  }
+#pragma unroll
+  for (int u = 0; u < A_LD; ++u) {
+    const int r = ar0 + u * 32;
+    const int im = r / PIMG, rr = r - im * PIMG;
+    const int yp = rr / PW, xp = rr - yp * PW;
+    const bool real = r < AROWS && yp >= 1 && yp <= WI && xp >= 1 && xp <= WI;
+    const int apix = im * HWI + (yp - 1) * WI + (xp - 1);
+    aoffs[u] = real ? (unsigned)(apix * a.lda + i0 + aq4) * (unsigned)ES : OOB_OFFSET;
+  }
+  f32x4 rg[G_LD], ra[A_LD];
+#define C2D_W3S_LOAD(MB)                                                                       \
+  {                                                                                            \
+    const int sg = (MB) * a.ldg * ES, sa = ((MB) / HWO) * HWI * a.lda * ES;                    \
+    _Pragma("unroll") for (int u = 0; u < G_LD; ++u)                                           \
+        rg[u] = buf_load_elems4<ES>(rsG, goffs[u], sg);                                        \
+    _Pragma("unroll") for (int u = 0; u < A_LD; ++u)                                           \
+        ra[u] = buf_load_elems4<ES>(rsA, aoffs[u], sa);                                        \
+  }
+  const float* const apl = &As[(lh * PIMG) * W3_ASTR + li];           // upper half-wave: odd image
+  const float* const gpl = &Gs[(lh * HWO) * W3_GSTR + wave * 32 + li];
+
+  C2D_W3S_LOAD(mbeg);
+  for (int mb = mbeg; mb < mend; mb += R) {
+#pragma unroll
+    for (int u = 0; u < G_LD; ++u)
+      if (gkr + u * 8 < R)
+        *reinterpret_cast<f32x4*>(&Gs[(gkr + u * 8) * W3_GSTR + gc4]) = rg[u];
+#pragma unroll
+    for (int u = 0; u < A_LD; ++u)
+      if (ar0 + u * 32 < AROWS)
+        *reinterpret_cast<f32x4*>(&As[(ar0 + u * 32) * W3_ASTR + aq4]) = ra[u];
+    __syncthreads();
+    C2D_W3S_LOAD(mb + R);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_on) {
+#pragma unroll
+      for (int p = 0; p < HWO; ++p) {        // STEPS = HWO with IMGS = 2: one image pair per slab
+        const int oy = p / WO, ox = p % WO;
+        const float* ap = apl + ((2 * oy + 1) * PW + (2 * ox + 1)) * W3_ASTR;
+        const float bv = gpl[p * W3_GSTR];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int dy = q / 3 - 1, dx = q % 3 - 1;
+          if (2 * oy + dy < 0 || 2 * oy + dy >= WI || 2 * ox + dx < 0 || 2 * ox + dx >= WI) continue;
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(dy * PW + dx) * W3_ASTR], bv, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#undef C2D_W3S_LOAD
+  static_assert(STEPS == HWO, "one image pair per slab");
+
+  if (wave_on) {
+    const int jj = j0 + wave * 32 + li;
+    const bool part = a.part_stride > 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      float* dw = a.dW + (size_t)q * a.I * a.J + (size_t)split * a.part_stride;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (part) dw[(size_t)ii * a.J + jj] = acc[q][r];
+        else atomicAdd(dw + (size_t)ii * a.J + jj, acc[q][r]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), BASELINE configs[2] / [4].
 //
@@ -2495,6 +2615,30 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     dispatch_note("wgrad3x3_kernel<%d, %d, %d>", iw, iw == 4 ? 2 : 1, ES);
     if (iw == 4) hipLaunchKernelGGL((wgrad3x3_kernel<4, 2, ES>), grid, dim3(256), 0, st, b);
     else hipLaunchKernelGGL((wgrad3x3_kernel<7, 1, ES>), grid, dim3(256), 0, st, b);
+    return c2d_launch_status();
+  }
+  if (!bf16_mfma && kh == 3 && kw == 3 && stride == 2 && ih == 7 && iw == 7 && cin % 32 == 0 &&
+      cout % 32 == 0 && n >= 256) {
+    // the two stride-2 convolutions of Mixed_5a (7x7 -> 4x4): nine taps per block
+    Wgrad3Args b;
+    b.A = x; b.lda = ldx; b.a_off = xoff; b.G = dc; b.ldg = ldc; b.g_off = coff; b.dW = dw;
+    b.M = n * 16; b.I = cin; b.J = cout; b.h = ih; b.w = iw;
+    b.itiles = cin / 32; b.jtiles = c2d_ceil_div(cout, 128); b.tiles = b.itiles * b.jtiles;
+    C2D_CHECK_ARG((long long)n * 49 * ldx * 4 < (long long)OOB_OFFSET && (long long)b.M * ldc * 4 < (long long)OOB_OFFSET);
+    const int slab = 32;                                   // an image pair
+    const int nslabs = c2d_ceil_div(b.M, slab);
+    int splits = 512 / b.tiles;                            // 2 blocks per CU in one round
+    if (splits < 1) splits = 1;
+    if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
+    b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
+    b.splits = c2d_ceil_div(b.M, b.rows_per_split);
+    if (splits_out) *splits_out = b.splits;
+    if (splits_only) return C2D_OK;
+    b.part_stride = partial ? dw_numel : 0;
+    if (partial) b.dW = partial;
+    dispatch_note("wgrad3x3_s2_kernel<%d>", ES);
+    hipLaunchKernelGGL((wgrad3x3_s2_kernel<ES>), dim3(b.tiles * b.splits), dim3(256), 0,
+                       (hipStream_t)stream, b);
     return c2d_launch_status();
   }
   WgradArgs a;

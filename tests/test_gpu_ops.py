@@ -109,6 +109,7 @@ CONV_CASES = [
     (65, 4, 4, 32, 192, 3, 1),    # pixel-major, 128x64 tile variant (N % 128 == 64)
     (700, 4, 4, 96, 224, 3, 1),   # enough tiles for stream-K shares that cut tiles (K = 9 x 3 slabs)
     (900, 7, 7, 64, 96, 1, 1),    # 1x1, row-major stream-K
+    (261, 7, 7, 32, 160, 3, 2),   # stride-2 nine-tap filter gradient (n >= 256), odd image count
 ]
 
 

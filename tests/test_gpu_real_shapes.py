@@ -51,7 +51,10 @@ R01_INSTANCES = {
     "igemm_nt_kernel<1, 2, 2, 2, 1, 32, false, 4>", "igemm_nt_kernel<0, 2, 2, 2, 2, 32, false, 4>",
     "igemm_nt_kernel<0, 2, 2, 1, 1, 32, false, 4>", "igemm_nt_kernel<1, 2, 2, 1, 1, 32, false, 4>",
     "wgrad3x3_kernel<4, 2, 4>", "wgrad3x3_kernel<7, 1, 4>", "wgrad_tn_kernel<2, true, 4>",
-    "wgrad_tn_kernel<1, true, 4>", "wgrad_tn_kernel<2, false, 4>", "wgrad_tn_kernel<1, false, 4>",
+    "wgrad_tn_kernel<1, true, 4>",
+    # (round 1's "wgrad_tn_kernel<2, false, 4>" / "<1, false, 4>" were the two stride-2 layers of
+    #  Mixed_5a: they run on the stride-2 nine-tap kernel now)
+    "wgrad3x3_s2_kernel<4>",
     "igemm_small_kernel<0>", "igemm_small_kernel<1>", "igemm_small_group_kernel<0>",
 }
 _seen = set()
