@@ -2649,7 +2649,8 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   const bool narrow = cout % 128 != 0 && cout % 128 <= 64;   // 128x64 block tiles
   const int bj = narrow ? 64 : 128;
   const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, bj);
-  int splits = (bf16_mfma ? wgrad_bf16_slots(512) : 1024) / tiles;   // 4 (bf16: 2) blocks per CU, one round
+  static const int fp32_slots = (getenv("C2D_TUNE") && getenv("C2D_WGRAD_SLOTS")) ? atoi(getenv("C2D_WGRAD_SLOTS")) : 1024;
+  int splits = (bf16_mfma ? wgrad_bf16_slots(512) : fp32_slots) / tiles;   // 4 (bf16: 2) blocks per CU, one round
   const int max_splits = c2d_ceil_div(a.M, 4 * WBK);      // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -15,6 +15,8 @@ COUNT = {(4, 1024, 352, 1, 1): 2, (4, 1024, 192, 1, 1): 3, (4, 192, 320, 3, 1): 
          (4, 224, 224, 3, 1): 2, (4, 1024, 128, 1, 1): 2}
 n = 2000
 what = sys.argv[1] if len(sys.argv) > 1 else "igemm"
+DT = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
+PEAK = 157.3 if DT == torch.float32 else 2500.0
 def timeit(fn, iters=20):
     for _ in range(3): fn()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
@@ -23,7 +25,7 @@ def timeit(fn, iters=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 tot_t, tot_f = {}, {}
-dt = torch.bfloat16
+dt = DT
 for (ih, cin, cout, k, st) in SHAPES:
     oh = -(-ih // st)
     fl = 2.0 * n * oh * oh * cin * cout * k * k
@@ -45,4 +47,4 @@ for (ih, cin, cout, k, st) in SHAPES:
         line += " %s %6.1f us %6.1f TF %s |" % (name, t * 1e3, fl / t / 1e9, inst[0].replace("_kernel", "") if inst else "?")
     print(line)
 for k_ in tot_t:
-    print("per step %s: %.3f ms, %.1f TF (%.3f of 2500)" % (k_, tot_t[k_], tot_f[k_] / tot_t[k_] / 1e9, tot_f[k_] / tot_t[k_] / 1e9 / 2500))
+    print("per step %s: %.3f ms, %.1f TF (%.3f of %.0f)" % (k_, tot_t[k_], tot_f[k_] / tot_t[k_] / 1e9, tot_f[k_] / tot_t[k_] / 1e9 / PEAK, PEAK))
