@@ -469,8 +469,8 @@ def main(argv=None):
                 "traffic": traffic.get(traffic_key, {}).get("hbm_bytes_per_launch"),
                 "traffic_bytes_per_step": traffic.get(traffic_key, {}).get("hbm_bytes_per_step"),
                 # matrix-pipe busy fraction of the family's dispatches from the committed PMC pass
-                # (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); per-clock, so it
-                # sits above `frac` by the ratio of the nominal to the sustained clock)
+                # (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)): per clock, and of
+                # the MFMAs actually issued — padding taps are skipped, `achieved` counts all taps
                 "mfma_busy": mfma.get(traffic_key, {}).get("mfma_busy"),
                 "calls_per_step": f["launches"], "avg_call_ms": f["ms"] / f["launches"],
                 "family_ms_per_step": f["ms"], "algorithmic_gflop_per_step": f["work"] / 1e9,

@@ -11,9 +11,13 @@ Formula (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy c
 the SIMDs, 32 per v_mfma_f32_32x32x16_bf16, 64 per v_mfma_f32_32x32x2_f32; GRBM_GUI_ACTIVE is
 summed over the 8 XCDs):
   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)
-i.e. the fraction of SIMD-cycles of the dispatch in which the matrix pipe was executing; it is a
-per-CLOCK figure (the chip's clock under load is below the 2.4 GHz the nominal peaks assume), so
-it sits above the time-based `roofline.frac` by the ratio of the two clocks."""
+i.e. the fraction of SIMD-cycles of the dispatch in which the matrix pipe was executing.  It is a
+per-CLOCK figure of the MFMAs actually ISSUED: the pixel-major kernels skip the MFMAs of taps that
+fall into the SAME padding (100 of 144 (pixel, tap) pairs are real on a 4x4 map), while
+`roofline.achieved` counts the algorithmic FLOPs of the convolution (all nine taps), so
+`mfma_busy` can sit BELOW `roofline.frac` — the difference is matrix-pipe time that was never
+spent.  On the other side it is not diluted by the clock: the chip holds ~2.1 GHz under this load,
+the nominal peaks assume 2.4."""
 import collections
 import csv
 import glob
