@@ -789,10 +789,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int MODE, int WM, int WN, int MT, int NT, bool PM>
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int NBUF>
 __global__ __launch_bounds__(WM * WN * 64,
-                             (160 * 1024) / ((WM * MT + WN * NT) * 32 * 256) >= 3
-                                 ? 3 : ((160 * 1024) / ((WM * MT + WN * NT) * 32 * 256) >= 2 ? 2 : 1))
+                             (160 * 1024) / ((WM * MT + WN * NT) * 32 * 128 * NBUF) >= 3
+                                 ? 3 : ((160 * 1024) / ((WM * MT + WN * NT) * 32 * 128 * NBUF) >= 2 ? 2 : 1))
 void igemm_bf16_kernel(IgemmArgs a) {
   constexpr int BKT = 64;                       // bf16 elements of K per slab (128 B per row)
   constexpr int BM = WM * MT * 32;
@@ -803,7 +803,9 @@ void igemm_bf16_kernel(IgemmArgs a) {
   constexpr int B_LOADS = BN / ROWS_PER_PASS;
   constexpr int BUF_BYTES = (BM + BN) * 128;
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile vs block size");
-  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+  // NBUF slab buffers: the DMA runs NBUF - 1 slabs ahead of the MFMAs
+  __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF_BYTES];
+  constexpr int PIECES = A_LOADS + B_LOADS;     // DMA instructions per slab and wave
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -875,7 +877,8 @@ void igemm_bf16_kernel(IgemmArgs a) {
 
   int ky = a.g.ky0, kx = a.g.kx0, kc = 0;
   unsigned long long taps_left = tapmask;
-  unsigned tv_load = ~0u, tv_mma = ~0u;
+  unsigned tv_load = ~0u;
+  unsigned tvq = ~0u;       // tap validity bits (8 per slab buffer) of the slabs in the ring
   unsigned aoff[A_LOADS], boff[B_LOADS];
 
 #define C2D_RETAP()                                                                            \
@@ -916,10 +919,44 @@ void igemm_bf16_kernel(IgemmArgs a) {
             (int)(in ? boff[i] : OOB_OFFSET), soff, 0, 0);                                     \
   }
 
+  // advance the slab cursor by one (next K slab, next real tap, or next segment)
+#define C2D_ADVANCE()                                                                          \
+  {                                                                                            \
+    kc += BKT;                                                                                 \
+    if (kc >= Kc) {                                                                            \
+      kc = 0;                                                                                  \
+      if (a.nseg > 1) {                                                                        \
+        ++sgi;                                                                                 \
+        lda = a.seg_lda[sgi]; Kc = a.segK[sgi];                                                \
+        rsA = make_rsrc_b((const char*)a.segA[sgi] + (size_t)a.seg_off[sgi] * 2,              \
+                          (a.a_rows * lda - a.seg_off[sgi]) * 2);                              \
+        rsB = make_rsrc_b(a.segB[sgi], (long long)a.N * Kc * 2);                               \
+      } else {                                                                                 \
+        taps_left &= taps_left - 1ull;                                                         \
+        C2D_TAP_FROM_MASK();                                                                   \
+      }                                                                                        \
+      C2D_RETAP();                                                                             \
+    }                                                                                          \
+  }
+#define C2D_PUSH(SLOT)                                                                         \
+  {                                                                                            \
+    C2D_ISSUE(SLOT);                                                                           \
+    tvq = (tvq & ~(0xffu << (8 * (SLOT)))) | ((tv_load & 0xffu) << (8 * (SLOT)));             \
+  }
+  // prologue: the first NBUF - 1 slabs
+  int issued = 0;          // slabs handed to the DMA so far
   if (cnt > 0) {
     C2D_TAP_FROM_MASK();
     C2D_RETAP();
-    C2D_ISSUE(0);
+    C2D_PUSH(0);
+    issued = 1;
+#pragma unroll
+    for (int d = 1; d < NBUF - 1; ++d)
+      if (issued < cnt) {
+        C2D_ADVANCE();
+        C2D_PUSH(d);
+        ++issued;
+      }
   }
   // fragment addresses inside a buffer: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
   int arow_b[MT], brow_b[NT], asw[MT], bsw[NT];
@@ -934,33 +971,27 @@ void igemm_bf16_kernel(IgemmArgs a) {
     brow_b[j] = (BM + r) * 128; bsw[j] = (r >> 1) & 7;
   }
 
+  int slot = 0;            // buffer of slab `it`
   for (int it = 0; it < cnt; ++it) {
-    tv_mma = tv_load;
-    // bit i: row tile i of this wave is inside M and (PM) real for the tap being multiplied
-    const unsigned onbits = __builtin_amdgcn_readfirstlane(row_bits & tv_mma);
-    // slab `it` has landed (this wave's DMA: vmcnt; everybody's: the barrier), and every wave is
-    // done reading the other buffer, which the next DMA overwrites
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 1 < cnt) {
-      kc += BKT;
-      if (kc >= Kc) {
-        kc = 0;
-        if (a.nseg > 1) {
-          ++sgi;
-          lda = a.seg_lda[sgi]; Kc = a.segK[sgi];
-          rsA = make_rsrc_b((const char*)a.segA[sgi] + (size_t)a.seg_off[sgi] * 2,
-                            (a.a_rows * lda - a.seg_off[sgi]) * 2);
-          rsB = make_rsrc_b(a.segB[sgi], (long long)a.N * Kc * 2);
-        } else {
-          taps_left &= taps_left - 1ull;
-          C2D_TAP_FROM_MASK();
-        }
-        C2D_RETAP();
-      }
-      if ((it + 1) & 1) { C2D_ISSUE(1); } else { C2D_ISSUE(0); }
+    // Slab `it` has landed: this wave's DMA pieces retire in order, so "at most the pieces of the
+    // newer slabs outstanding" (counted vmcnt) means its own are done; everybody's: the barrier.
+    // The barrier also says every wave is done reading the buffer of slab it - 1, which the DMA
+    // issued below overwrites (NBUF = 2: the other buffer).
+    const int newer = issued - 1 - it;         // slabs in flight behind slab `it` (uniform)
+    if (NBUF == 2 || newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (issued < cnt) {
+      C2D_ADVANCE();
+      int ns = slot + (NBUF - 1);
+      if (ns >= NBUF) ns -= NBUF;
+      C2D_PUSH(ns);
+      ++issued;
     }
-    const char* const buf = smem + (it & 1) * BUF_BYTES;
+    // bit i: row tile i of this wave is inside M and (PM) real for the tap being multiplied
+    const unsigned onbits = __builtin_amdgcn_readfirstlane(row_bits & (tvq >> (8 * slot)));
+    const char* const buf = smem + slot * BUF_BYTES;
     // B fragments of the whole slab, then per 32-row tile of this wave (one scalar branch each:
     // a tile whose rows are SAME padding for this tap, or lie beyond M, costs nothing) its four A
     // fragments and 4 x NT MFMAs in straight-line code.  Columns beyond N are computed on clamped
@@ -985,9 +1016,12 @@ void igemm_bf16_kernel(IgemmArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
       }
     }
+    if (++slot == NBUF) slot = 0;
   }
 #undef C2D_RETAP
 #undef C2D_ISSUE
+#undef C2D_ADVANCE
+#undef C2D_PUSH
 #undef C2D_TAP_FROM_MASK
   __syncthreads();     // every wave is done with the slab buffers: the epilogue reuses them
 
@@ -995,7 +1029,7 @@ void igemm_bf16_kernel(IgemmArgs a) {
   // global stores are 8 B per lane (4 bf16) on contiguous row segments.
   constexpr int SCOLS = NT * 32;
   constexpr int SSTR = SCOLS + 4;
-  static_assert(WM * WN * 32 * SSTR * 4 <= 2 * BUF_BYTES, "epilogue staging exceeds LDS");
+  static_assert(WM * WN * 32 * SSTR * 4 <= NBUF * BUF_BYTES, "epilogue staging exceeds LDS");
   float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SSTR);
   constexpr int C4 = SCOLS / 4;
   constexpr int RPP = 64 / C4;
@@ -2127,16 +2161,22 @@ int launch_igemm_bf16(IgemmArgs a, hipStream_t s) {
     a.total_slabs = 0;
     for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], 64);
   }
-  dispatch_note(PM ? "igemm_bf16_kernel<%d, %d, %d, %d, %d, true>"
-                   : "igemm_bf16_kernel<%d, %d, %d, %d, %d, false>", MODE, WM, WN, MT, NT);
-  // C2D_TUNE=1 C2D_BF16_LDS_PAD=<bytes>: unused dynamic LDS, to study occupancy (tools only)
-  static const int lds_pad = (getenv("C2D_TUNE") && getenv("C2D_BF16_LDS_PAD"))
-                                 ? atoi(getenv("C2D_BF16_LDS_PAD")) : 0;
-  if (lds_pad > 0)
-    (void)hipFuncSetAttribute((const void*)igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
-  hipLaunchKernelGGL((igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM>), dim3(a.m_tiles * a.n_tiles),
-                     dim3(WM * WN * 64), lds_pad, s, a);
+  // C2D_TUNE=1 C2D_BF16_NBUF=2|3: slab buffers (DMA runs NBUF - 1 slabs ahead)
+  static const int nbuf_env = (getenv("C2D_TUNE") && getenv("C2D_BF16_NBUF")) ? atoi(getenv("C2D_BF16_NBUF")) : 0;
+  constexpr bool can3 = 3 * (BM + BN) * 128 <= 160 * 1024;
+  const int nbuf = (nbuf_env == 3 && can3) ? 3 : 2;
+  const dim3 grid(a.m_tiles * a.n_tiles), block(WM * WN * 64);
+  if constexpr (can3) {
+    if (nbuf == 3) {
+      dispatch_note(PM ? "igemm_bf16_kernel<%d, %d, %d, %d, %d, true, 3>"
+                       : "igemm_bf16_kernel<%d, %d, %d, %d, %d, false, 3>", MODE, WM, WN, MT, NT);
+      hipLaunchKernelGGL((igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, 3>), grid, block, 0, s, a);
+      return c2d_launch_status();
+    }
+  }
+  dispatch_note(PM ? "igemm_bf16_kernel<%d, %d, %d, %d, %d, true, 2>"
+                   : "igemm_bf16_kernel<%d, %d, %d, %d, %d, false, 2>", MODE, WM, WN, MT, NT);
+  hipLaunchKernelGGL((igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, 2>), grid, block, 0, s, a);
   return c2d_launch_status();
 }
 

@@ -328,11 +328,14 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   assert any(k.startswith("wgrad3x3_bf16_kernel<7") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad_tn_bf16_kernel") for k in bf16), sorted(bf16)
   # the direct-to-LDS bf16 kernel in its three block tiles (128x64, 128x128, 128x256), row-major
-  # and pixel-major, forward and input gradient
-  for mode in (0, 1):
+  # and pixel-major, forward and input gradient:
+  # igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, NBUF>
+  import re
+  inst = [re.match(r"igemm_bf16_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d)>", k)
+          for k in bf16]
+  inst = [m.groups() for m in inst if m]
+  for mode in ("0", "1"):
     for pm in ("true", "false"):
-      assert any(k.startswith("igemm_bf16_kernel<%d" % mode) and k.endswith(pm + ">") for k in bf16), \
-          (mode, pm, sorted(bf16))
-  for tile in ("2, 2, 2, 1", "2, 2, 2, 2", "2, 4, 2, 2"):
-    assert any(k.startswith("igemm_bf16_kernel<") and (", " + tile + ", ") in k for k in bf16), \
-        (tile, sorted(bf16))
+      assert any(g[0] == mode and g[5] == pm for g in inst), (mode, pm, sorted(bf16))
+  for tile in (("2", "2", "2", "1"), ("2", "2", "2", "2"), ("2", "4", "2", "2")):
+    assert any(g[1:5] == tile for g in inst), (tile, sorted(bf16))
