@@ -203,6 +203,7 @@ struct IgemmArgs {
   int seg_lda[4], seg_off[4], segK[4];   // (every segment's A has a_rows rows)
   int total_slabs;
   int es;                   // operand / output element size: 4 (fp32) or 2 (bf16)
+  int dbg;                  // ablation bits (C2D_TUNE=1 C2D_IGEMM_DBG): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no epilogue
   ConvGeom g;
 #ifdef C2D_TRACE
   unsigned long long* trace;   // diagnostic build only: 8 x u64 per block (tools/trace_igemm.py)
@@ -373,26 +374,55 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     // nkx)).  PM: a tap that is SAME padding for every 32-row tile of the block is not visited at
     // all (no loads, no barriers), and within a visited tap each wave skips the MFMAs of its
     // padding tiles.
-    unsigned long long tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1ull);
-    int wy[MT], wx[MT];   // PM: pixel of the wave's i-th row tile
-    if (PM) {
-      tapmask = 0;
-      const int hw = a.g.rh * a.g.rw;
+    // Tap table, one tap per lane (every wave holds all of it): the row delta of the activation
+    // rows (the source row of a tap is row_base + delta wherever the tap reads a real pixel), the
+    // offset of the tap's weight plane and (PM) which 32-row tiles of the block are real for the
+    // tap are computed ONCE per tile here, so that a tap change in the K loop is three v_readlane
+    // and a few VALU per staged row instead of re-deriving every source row.
+    int tab_delta = 0, tab_toff = 0;
+    unsigned tab_tv = 0;
+    if (lane < ntaps) {
+      const int ty_ = lane / a.g.nkx;
+      const int ky = a.g.ky0 + a.g.kstep * ty_, kx = a.g.kx0 + a.g.kstep * (lane - ty_ * a.g.nkx);
+      tab_toff = (ky * a.g.kw + kx) * (int)tap_stride;
+      if (MODE == 0) {
+        tab_delta = (ky - a.g.pad_t) * a.g.iw + (kx - a.g.pad_l);
+      } else {
+        const int sh = a.g.stride - 1;   // (stride-2 launches hold the taps of ONE parity class)
+        tab_delta = ((a.g.y0 + a.g.pad_t - ky) >> sh) * a.g.ow + ((a.g.x0 + a.g.pad_l - kx) >> sh);
+      }
+      tab_tv = 0xffu;
+      if (PM) {
+        tab_tv = 0;
+        const int hw = a.g.rh * a.g.rw;
 #pragma unroll
-      for (int tb = 0; tb < BM / 32; ++tb) {
-        const unsigned t = (unsigned)(m0 >> 5) + tb;
-        const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
-        const unsigned px = t - grp * (unsigned)hw;
-        const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
-        const int x = (int)px - y * a.g.rw;
-        if (tb / MT == wm) { wy[tb % MT] = y; wx[tb % MT] = x; }
-        for (int tp = 0; tp < ntaps; ++tp) {
-          const int ty_ = tp / a.g.nkx;
-          if (tap_ok<MODE>(a.g, y, x, a.g.ky0 + a.g.kstep * ty_,
-                           a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx)))
-            tapmask |= 1ull << tp;
+        for (int tb = 0; tb < BM / 32; ++tb) {
+          const unsigned t = (unsigned)(m0 >> 5) + tb;
+          const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
+          const unsigned px = t - grp * (unsigned)hw;
+          const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
+          const int x = (int)px - y * a.g.rw;
+          tab_tv |= (tap_ok<MODE>(a.g, y, x, ky, kx) ? 1u : 0u) << tb;
         }
       }
+    }
+    // Taps this tile iterates over (bit t <-> lane t of the table).  PM: a tap that is SAME
+    // padding for every 32-row tile of the block is not visited at all (no loads, no barriers),
+    // and within a visited tap each wave skips the MFMAs of its padding tiles.
+    const unsigned long long tapmask = __ballot(lane < ntaps && tab_tv != 0);
+    // per staged activation row: its base row in the operand and the taps that are real for it
+    int row_base[A_LOADS];
+    unsigned long long amask[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      row_base[i] = MODE == 0
+                        ? (apos[i].img * a.g.ih + apos[i].y * a.g.stride) * a.g.iw + apos[i].x * a.g.stride
+                        : (apos[i].img * a.g.oh + apos[i].y) * a.g.ow + apos[i].x;
+      amask[i] = 0;
+      for (int ty_ = 0, tp = 0; ty_ < a.g.nky; ++ty_)
+        for (int tx_ = 0; tx_ < a.g.nkx; ++tx_, ++tp)
+          if (src_row<MODE>(a.g, apos[i], a.g.ky0 + a.g.kstep * ty_, a.g.kx0 + a.g.kstep * tx_) >= 0)
+            amask[i] |= 1ull << tp;
     }
     int cost = __builtin_popcountll(tapmask) * kslabs;   // slab iterations of the whole tile
     if (a.nseg > 1) cost = a.total_slabs;
@@ -400,7 +430,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     const bool whole = !SK || cnt == cost;
 
     f32x4 ra[A_LOADS], rb[B_LOADS];
-    int ky = a.g.ky0, kx = a.g.kx0, kc = 0;   // wave-uniform slab cursor
+    int tap = 0, kc = 0;   // wave-uniform slab cursor
     unsigned long long taps_left = tapmask;
     // bit i: the tap of the slab being LOADED (tv_load) / being MULTIPLIED (tv_mma, one slab
     // behind) is real for row tile i of this wave
@@ -427,26 +457,19 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     unsigned aoff[A_LOADS], boff[B_LOADS];   // per-lane BYTE offsets (operands are < 2 GB)
 #define C2D_RETAP()                                                                            \
   {                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                      \
-      const int sr = src_row<MODE>(a.g, apos[i], ky, kx);                                      \
-      aoff[i] = sr >= 0 ? (unsigned)(sr * lda + q4) * (unsigned)ES : OOB_OFFSET;               \
-    }                                                                                          \
-    const int toff = (ky * a.g.kw + kx) * (int)tap_stride;                                     \
+    const int delta = __builtin_amdgcn_readlane(tab_delta, tap);                               \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
+        aoff[i] = ((amask[i] >> tap) & 1ull)                                                   \
+                      ? (unsigned)((row_base[i] + delta) * lda + q4) * (unsigned)ES            \
+                      : OOB_OFFSET;                                                            \
+    const int toff = __builtin_amdgcn_readlane(tab_toff, tap);                                 \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
         boff[i] = (unsigned)(brow_off[i] * Kc + toff + q4) * (unsigned)ES;                     \
-    if (PM) {                                                                                  \
-      tv_load = 0;                                                                             \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
-          tv_load |= (tap_ok<MODE>(a.g, wy[i], wx[i], ky, kx) ? 1u : 0u) << i;                 \
-    }                                                                                          \
+    if (PM)                                                                                    \
+      tv_load = ((unsigned)__builtin_amdgcn_readlane((int)tab_tv, tap) >> (wm * MT)) &         \
+                ((1u << MT) - 1u);                                                             \
   }
-#define C2D_TAP_FROM_MASK()                                                                    \
-  {                                                                                            \
-    const int tp = taps_left ? __builtin_ctzll(taps_left) : 0;                                 \
-    const int ty_ = tp / a.g.nkx;                                                              \
-    ky = a.g.ky0 + a.g.kstep * ty_;                                                            \
-    kx = a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx);                                           \
-  }
+#define C2D_TAP_FROM_MASK() tap = taps_left ? __builtin_ctzll(taps_left) : 0;
 #define C2D_ISSUE()                                                                            \
   {                                                                                            \
     const int soff = kc * ES;                                                                  \
@@ -789,10 +812,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int MODE, int WM, int WN, int MT, int NT, bool PM, int NBUF>
+struct SlabCursor {
+  int tap, kc, sgi, Kc;
+  unsigned long long taps_left;
+};
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int DA>
 __global__ __launch_bounds__(WM * WN * 64,
-                             (160 * 1024) / ((WM * MT + WN * NT) * 32 * 128 * NBUF) >= 3
-                                 ? 3 : ((160 * 1024) / ((WM * MT + WN * NT) * 32 * 128 * NBUF) >= 2 ? 2 : 1))
+                             (160 * 1024) / ((WM * MT * DA + WN * NT * 2) * 32 * 128) >= 3
+                                 ? 3 : ((160 * 1024) / ((WM * MT * DA + WN * NT * 2) * 32 * 128) >= 2 ? 2 : 1))
 void igemm_bf16_kernel(IgemmArgs a) {
   constexpr int BKT = 64;                       // bf16 elements of K per slab (128 B per row)
   constexpr int BM = WM * MT * 32;
@@ -801,11 +829,16 @@ void igemm_bf16_kernel(IgemmArgs a) {
   constexpr int ROWS_PER_PASS = NTHREADS / 8;   // a wave-instruction stages 8 rows x 128 B
   constexpr int A_LOADS = BM / ROWS_PER_PASS;
   constexpr int B_LOADS = BN / ROWS_PER_PASS;
-  constexpr int BUF_BYTES = (BM + BN) * 128;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int LDS_BYTES = DA * A_BYTES + 2 * B_BYTES;
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile vs block size");
-  // NBUF slab buffers: the DMA runs NBUF - 1 slabs ahead of the MFMAs
-  __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF_BYTES];
-  constexpr int PIECES = A_LOADS + B_LOADS;     // DMA instructions per slab and wave
+  static_assert(DA >= 2 && DA <= 4, "activation ring depth");
+  // The weight slabs (L2 hits) are double-buffered; the activation slabs (HBM, several times
+  // the latency) go through a ring of DA buffers: DA = 2 issues both one slab ahead, DA = 3 the
+  // activation rows two slabs ahead (weights first, so that the counted wait below leaves only
+  // the newest activation pieces in flight).
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+  char* const smemB = smem + DA * A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -831,12 +864,6 @@ void igemm_bf16_kernel(IgemmArgs a) {
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i) brow_off[i] = min(n0 + lrow + i * ROWS_PER_PASS, a.N - 1);
 
-  int lda = a.lda, Kc = a.K, sgi = 0;
-  __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
-                                           (a.a_rows * a.lda - a.a_off) * 2);
-  __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
-      a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
-
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -851,112 +878,169 @@ void igemm_bf16_kernel(IgemmArgs a) {
     if (m0 + (wm * MT + i) * 32 < a.M) row_bits |= 1u << i;
   row_bits = __builtin_amdgcn_readfirstlane(row_bits);
 
-  unsigned long long tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1ull);
-  int wy[MT], wx[MT];
-  if (PM) {
-    tapmask = 0;
-    const int hw = a.g.rh * a.g.rw;
+  // Tap table, one tap per lane (every wave holds all of it): what changes from tap to tap is
+  // computed ONCE here — the row delta of the activation rows (the source row of a tap is
+  // row_base + delta wherever the tap reads a real pixel), the offset of the tap's weight plane
+  // and (PM) which 32-row tiles of the block are real for the tap — so that a tap change in the
+  // K loop costs three v_readlane and a few VALU per staged row instead of re-deriving every
+  // source row (the re-derivation was 40 % of the 7x7 3x3 layers' time).
+  int tab_delta = 0, tab_toff = 0;
+  unsigned tab_tv = 0;
+  if (lane < ntaps) {
+    const int ty_ = lane / a.g.nkx;
+    const int ky = a.g.ky0 + a.g.kstep * ty_, kx = a.g.kx0 + a.g.kstep * (lane - ty_ * a.g.nkx);
+    tab_toff = (ky * a.g.kw + kx) * (int)tap_stride;
+    if (MODE == 0) {
+      tab_delta = (ky - a.g.pad_t) * a.g.iw + (kx - a.g.pad_l);
+    } else {
+      const int sh = a.g.stride - 1;     // (stride-2 launches hold the taps of ONE parity class)
+      tab_delta = ((a.g.y0 + a.g.pad_t - ky) >> sh) * a.g.ow + ((a.g.x0 + a.g.pad_l - kx) >> sh);
+    }
+    tab_tv = 0xffu;
+    if (PM) {
+      tab_tv = 0;
+      const int hw = a.g.rh * a.g.rw;
 #pragma unroll
-    for (int tb = 0; tb < BM / 32; ++tb) {
-      const unsigned t = (unsigned)(m0 >> 5) + tb;
-      const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
-      const unsigned px = t - grp * (unsigned)hw;
-      const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
-      const int x = (int)px - y * a.g.rw;
-      if (tb / MT == wm) { wy[tb % MT] = y; wx[tb % MT] = x; }
-      for (int tp = 0; tp < ntaps; ++tp) {
-        const int ty_ = tp / a.g.nkx;
-        if (tap_ok<MODE>(a.g, y, x, a.g.ky0 + a.g.kstep * ty_,
-                         a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx)))
-          tapmask |= 1ull << tp;
+      for (int tb = 0; tb < BM / 32; ++tb) {
+        const unsigned t = (unsigned)(m0 >> 5) + tb;
+        const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
+        const unsigned px = t - grp * (unsigned)hw;
+        const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
+        const int x = (int)px - y * a.g.rw;
+        tab_tv |= (tap_ok<MODE>(a.g, y, x, ky, kx) ? 1u : 0u) << tb;
       }
     }
   }
+  const unsigned long long tapmask = __ballot(lane < ntaps && tab_tv != 0);
   int cnt = __builtin_popcountll(tapmask) * kslabs;
   if (a.nseg > 1) cnt = a.total_slabs;
 
-  int ky = a.g.ky0, kx = a.g.kx0, kc = 0;
-  unsigned long long taps_left = tapmask;
+  // per staged activation row: its base row in the operand and the set of taps that read a real
+  // pixel for it; per staged weight row: its offset inside a tap's plane
+  int row_base[A_LOADS];
+  unsigned long long amask[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    row_base[i] = MODE == 0 ? (apos[i].img * a.g.ih + apos[i].y * a.g.stride) * a.g.iw + apos[i].x * a.g.stride
+                            : (apos[i].img * a.g.oh + apos[i].y) * a.g.ow + apos[i].x;
+    amask[i] = 0;
+    for (int ty_ = 0, tp = 0; ty_ < a.g.nky; ++ty_)
+      for (int tx_ = 0; tx_ < a.g.nkx; ++tx_, ++tp)
+        if (src_row<MODE>(a.g, apos[i], a.g.ky0 + a.g.kstep * ty_, a.g.kx0 + a.g.kstep * tx_) >= 0)
+          amask[i] |= 1ull << tp;
+  }
+
+  // Two slab cursors over the same sequence (K slabs of a tap, real taps, segments): one for the
+  // activation rows, one for the weight rows.
+  SlabCursor ca = {0, 0, 0, a.K, tapmask}, cb = ca;
+  int lda = a.lda;
+  __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
+                                           (a.a_rows * a.lda - a.a_off) * 2);
+  __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
+      a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
   unsigned tv_load = ~0u;
-  unsigned tvq = ~0u;       // tap validity bits (8 per slab buffer) of the slabs in the ring
+  unsigned tvq = ~0u;       // tap validity bits (8 per activation buffer) of the slabs in the ring
   unsigned aoff[A_LOADS], boff[B_LOADS];
 
-#define C2D_RETAP()                                                                            \
+#define C2D_TAP_FROM_MASK(C) (C).tap = (C).taps_left ? __builtin_ctzll((C).taps_left) : 0;
+#define C2D_RETAP_A()                                                                          \
   {                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                      \
-      const int sr = src_row<MODE>(a.g, apos[i], ky, kx);                                      \
-      aoff[i] = sr >= 0 ? (unsigned)(sr * lda + q4) * 2u : OOB_OFFSET;                         \
-    }                                                                                          \
-    const int toff = (ky * a.g.kw + kx) * (int)tap_stride;                                     \
+    const int delta = __builtin_amdgcn_readlane(tab_delta, ca.tap);                            \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
+        aoff[i] = ((amask[i] >> ca.tap) & 1ull)                                                \
+                      ? (unsigned)((row_base[i] + delta) * lda + q4) * 2u : OOB_OFFSET;        \
+    if (PM)                                                                                    \
+      tv_load = ((unsigned)__builtin_amdgcn_readlane((int)tab_tv, ca.tap) >> (wm * MT)) &      \
+                ((1u << MT) - 1u);                                                             \
+  }
+#define C2D_RETAP_B()                                                                          \
+  {                                                                                            \
+    const int toff = __builtin_amdgcn_readlane(tab_toff, cb.tap);                              \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        boff[i] = (unsigned)(brow_off[i] * Kc + toff + q4) * 2u;                               \
-    if (PM) {                                                                                  \
-      tv_load = 0;                                                                             \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                           \
-          tv_load |= (tap_ok<MODE>(a.g, wy[i], wx[i], ky, kx) ? 1u : 0u) << i;                 \
-    }                                                                                          \
+        boff[i] = (unsigned)(brow_off[i] * cb.Kc + toff + q4) * 2u;                            \
   }
-#define C2D_TAP_FROM_MASK()                                                                    \
+  // DMA of the slab at a cursor into an LDS buffer (8 rows x 128 B per wave-instruction); lanes
+  // past a K tail fetch zeros (never multiplied)
+#define C2D_ISSUE_A(SLOT)                                                                      \
   {                                                                                            \
-    const int tp = taps_left ? __builtin_ctzll(taps_left) : 0;                                 \
-    const int ty_ = tp / a.g.nkx;                                                              \
-    ky = a.g.ky0 + a.g.kstep * ty_;                                                            \
-    kx = a.g.kx0 + a.g.kstep * (tp - ty_ * a.g.nkx);                                           \
-  }
-  // DMA of the slab at the cursor into LDS buffer BUF (8 rows x 128 B per wave-instruction)
-#define C2D_ISSUE(BUF)                                                                         \
-  {                                                                                            \
-    const int soff = kc * 2;                                                                   \
-    const bool in = kc + q4 < Kc;         /* (lanes past a K tail: zeros, never multiplied) */ \
-    char* const abase = smem + (BUF) * BUF_BYTES + wave * 1024;                                \
+    const bool in = ca.kc + q4 < ca.Kc;                                                        \
+    char* const base = smem + (SLOT) * A_BYTES + wave * 1024;                                  \
+    if (!(a.dbg & 1))                                                                          \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-            rsA, (lds_void_t*)(abase + i * ROWS_PER_PASS * 128), 16,                           \
-            (int)(in ? aoff[i] : OOB_OFFSET), soff, 0, 0);                                     \
-    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-            rsB, (lds_void_t*)(abase + (BM + i * ROWS_PER_PASS) * 128), 16,                    \
-            (int)(in ? boff[i] : OOB_OFFSET), soff, 0, 0);                                     \
-  }
-
-  // advance the slab cursor by one (next K slab, next real tap, or next segment)
-#define C2D_ADVANCE()                                                                          \
-  {                                                                                            \
-    kc += BKT;                                                                                 \
-    if (kc >= Kc) {                                                                            \
-      kc = 0;                                                                                  \
-      if (a.nseg > 1) {                                                                        \
-        ++sgi;                                                                                 \
-        lda = a.seg_lda[sgi]; Kc = a.segK[sgi];                                                \
-        rsA = make_rsrc_b((const char*)a.segA[sgi] + (size_t)a.seg_off[sgi] * 2,              \
-                          (a.a_rows * lda - a.seg_off[sgi]) * 2);                              \
-        rsB = make_rsrc_b(a.segB[sgi], (long long)a.N * Kc * 2);                               \
-      } else {                                                                                 \
-        taps_left &= taps_left - 1ull;                                                         \
-        C2D_TAP_FROM_MASK();                                                                   \
-      }                                                                                        \
-      C2D_RETAP();                                                                             \
-    }                                                                                          \
-  }
-#define C2D_PUSH(SLOT)                                                                         \
-  {                                                                                            \
-    C2D_ISSUE(SLOT);                                                                           \
+            rsA, (lds_void_t*)(base + i * ROWS_PER_PASS * 128), 16,                            \
+            (int)(in ? aoff[i] : OOB_OFFSET), ca.kc * 2, 0, 0);                                \
     tvq = (tvq & ~(0xffu << (8 * (SLOT)))) | ((tv_load & 0xffu) << (8 * (SLOT)));             \
   }
-  // prologue: the first NBUF - 1 slabs
-  int issued = 0;          // slabs handed to the DMA so far
+#define C2D_ISSUE_B(SLOT)                                                                      \
+  {                                                                                            \
+    const bool in = cb.kc + q4 < cb.Kc;                                                        \
+    char* const base = smemB + (SLOT) * B_BYTES + wave * 1024;                                 \
+    if (!(a.dbg & 2))                                                                          \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+            rsB, (lds_void_t*)(base + i * ROWS_PER_PASS * 128), 16,                            \
+            (int)(in ? boff[i] : OOB_OFFSET), cb.kc * 2, 0, 0);                                \
+  }
+  // advance a cursor by one slab (next K slab, next real tap, or next segment)
+#define C2D_ADVANCE_A()                                                                        \
+  {                                                                                            \
+    ca.kc += BKT;                                                                              \
+    if (ca.kc >= ca.Kc) {                                                                      \
+      ca.kc = 0;                                                                               \
+      if (a.nseg > 1) {                                                                        \
+        ++ca.sgi;                                                                              \
+        lda = a.seg_lda[ca.sgi]; ca.Kc = a.segK[ca.sgi];                                       \
+        rsA = make_rsrc_b((const char*)a.segA[ca.sgi] + (size_t)a.seg_off[ca.sgi] * 2,        \
+                          (a.a_rows * lda - a.seg_off[ca.sgi]) * 2);                           \
+      } else {                                                                                 \
+        ca.taps_left &= ca.taps_left - 1ull;                                                   \
+        C2D_TAP_FROM_MASK(ca);                                                                 \
+      }                                                                                        \
+      C2D_RETAP_A();                                                                           \
+    }                                                                                          \
+  }
+#define C2D_ADVANCE_B()                                                                        \
+  {                                                                                            \
+    cb.kc += BKT;                                                                              \
+    if (cb.kc >= cb.Kc) {                                                                      \
+      cb.kc = 0;                                                                               \
+      if (a.nseg > 1) {                                                                        \
+        ++cb.sgi;                                                                              \
+        cb.Kc = a.segK[cb.sgi];                                                                \
+        rsB = make_rsrc_b(a.segB[cb.sgi], (long long)a.N * cb.Kc * 2);                         \
+      } else {                                                                                 \
+        cb.taps_left &= cb.taps_left - 1ull;                                                   \
+        C2D_TAP_FROM_MASK(cb);                                                                 \
+      }                                                                                        \
+      C2D_RETAP_B();                                                                           \
+    }                                                                                          \
+  }
+  // prologue: activation slabs 0 .. DA - 2 and weight slab 0; the newest pieces of every wave are
+  // those of its newest activation slab
+  int issued_a = 0, issued_b = 0;          // slabs handed to the DMA so far
+  int slot_a_in = 0;                       // activation buffer the next activation slab goes to
   if (cnt > 0) {
-    C2D_TAP_FROM_MASK();
-    C2D_RETAP();
-    C2D_PUSH(0);
-    issued = 1;
+    C2D_TAP_FROM_MASK(ca);
+    cb.tap = ca.tap;
+    C2D_RETAP_A();
+    C2D_RETAP_B();
+    C2D_ISSUE_A(0);
+    issued_a = 1; slot_a_in = 1;
 #pragma unroll
-    for (int d = 1; d < NBUF - 1; ++d)
-      if (issued < cnt) {
-        C2D_ADVANCE();
-        C2D_PUSH(d);
-        ++issued;
+    for (int d = 1; d < DA - 2; ++d)
+      if (issued_a < cnt) {
+        C2D_ADVANCE_A();
+        C2D_ISSUE_A(d);
+        ++issued_a; slot_a_in = d + 1;
       }
+    C2D_ISSUE_B(0);
+    issued_b = 1;
+    if (DA > 2 && issued_a < cnt) {
+      C2D_ADVANCE_A();
+      C2D_ISSUE_A(DA - 2);
+      ++issued_a; slot_a_in = DA - 1;
+    }
   }
   // fragment addresses inside a buffer: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
   int arow_b[MT], brow_b[NT], asw[MT], bsw[NT];
@@ -968,47 +1052,52 @@ void igemm_bf16_kernel(IgemmArgs a) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int r = (wn * NT + j) * 32 + li;
-    brow_b[j] = (BM + r) * 128; bsw[j] = (r >> 1) & 7;
+    brow_b[j] = r * 128; bsw[j] = (r >> 1) & 7;
   }
 
-  int slot = 0;            // buffer of slab `it`
+  int slot_a = 0, slot_b = 0;            // buffers of slab `it`
   for (int it = 0; it < cnt; ++it) {
-    // Slab `it` has landed: this wave's DMA pieces retire in order, so "at most the pieces of the
-    // newer slabs outstanding" (counted vmcnt) means its own are done; everybody's: the barrier.
-    // The barrier also says every wave is done reading the buffer of slab it - 1, which the DMA
-    // issued below overwrites (NBUF = 2: the other buffer).
-    const int newer = issued - 1 - it;         // slabs in flight behind slab `it` (uniform)
-    if (NBUF == 2 || newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    // Slab `it` has landed: a wave's DMA pieces retire in order and the weights of a slab are
+    // issued in front of the activation slab that goes out with them, so "at most the pieces of
+    // the newest activation slab outstanding" says this wave's pieces of slab `it` are done;
+    // everybody's: the barrier.  The barrier also says every wave is done reading the buffers of
+    // slab it - 1, which the DMAs issued below overwrite.
+    if (DA > 2 && issued_a > it + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (issued < cnt) {
-      C2D_ADVANCE();
-      int ns = slot + (NBUF - 1);
-      if (ns >= NBUF) ns -= NBUF;
-      C2D_PUSH(ns);
-      ++issued;
+    if (issued_b < cnt) {
+      C2D_ADVANCE_B();
+      C2D_ISSUE_B(slot_b ^ 1);
+      ++issued_b;
+    }
+    if (issued_a < cnt) {
+      C2D_ADVANCE_A();
+      C2D_ISSUE_A(slot_a_in);
+      ++issued_a;
+      if (++slot_a_in == DA) slot_a_in = 0;
     }
     // bit i: row tile i of this wave is inside M and (PM) real for the tap being multiplied
-    const unsigned onbits = __builtin_amdgcn_readfirstlane(row_bits & (tvq >> (8 * slot)));
-    const char* const buf = smem + slot * BUF_BYTES;
+    const unsigned onbits = (a.dbg & 4) ? 0u : __builtin_amdgcn_readfirstlane(row_bits & (tvq >> (8 * slot_a)));
+    const char* const bufa = smem + slot_a * A_BYTES;
+    const char* const bufb = smemB + slot_b * B_BYTES;
     // B fragments of the whole slab, then per 32-row tile of this wave (one scalar branch each:
     // a tile whose rows are SAME padding for this tap, or lie beyond M, costs nothing) its four A
     // fragments and 4 x NT MFMAs in straight-line code.  Columns beyond N are computed on clamped
     // weight rows and never stored; K tails are zeros (out-of-range DMA lanes).
     bf16x8 bf[NT][4];
+    if (!(a.dbg & 4))
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        bf[j][st] = *reinterpret_cast<const bf16x8*>(buf + brow_b[j] + (((2 * st + lh) ^ bsw[j]) << 4));
+        bf[j][st] = *reinterpret_cast<const bf16x8*>(bufb + brow_b[j] + (((2 * st + lh) ^ bsw[j]) << 4));
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if ((onbits >> i) & 1u) {
         bf16x8 af[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st)
-          af[st] = *reinterpret_cast<const bf16x8*>(buf + arow_b[i] + (((2 * st + lh) ^ asw[i]) << 4));
+          af[st] = *reinterpret_cast<const bf16x8*>(bufa + arow_b[i] + (((2 * st + lh) ^ asw[i]) << 4));
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -1016,69 +1105,85 @@ void igemm_bf16_kernel(IgemmArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
       }
     }
-    if (++slot == NBUF) slot = 0;
+    if (++slot_a == DA) slot_a = 0;
+    slot_b ^= 1;
   }
-#undef C2D_RETAP
-#undef C2D_ISSUE
-#undef C2D_ADVANCE
-#undef C2D_PUSH
+#undef C2D_RETAP_A
+#undef C2D_RETAP_B
+#undef C2D_ISSUE_A
+#undef C2D_ISSUE_B
+#undef C2D_ADVANCE_A
+#undef C2D_ADVANCE_B
 #undef C2D_TAP_FROM_MASK
   __syncthreads();     // every wave is done with the slab buffers: the epilogue reuses them
+  if (a.dbg & 8) return;
 
   // Epilogue (as igemm_body): 32-row strips transposed through a per-wave LDS slice so that the
   // global stores are 8 B per lane (4 bf16) on contiguous row segments.
   constexpr int SCOLS = NT * 32;
   constexpr int SSTR = SCOLS + 4;
-  static_assert(WM * WN * 32 * SSTR * 4 <= NBUF * BUF_BYTES, "epilogue staging exceeds LDS");
-  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SSTR);
+  // (wide wave tiles: the 32-row strip goes through the staging slice as two halves of 16 rows)
+  constexpr int HALVES = WM * WN * 32 * SSTR * 4 <= LDS_BYTES ? 1 : 2;
+  constexpr int HROWS = 32 / HALVES;
+  static_assert(WM * WN * HROWS * SSTR * 4 <= LDS_BYTES, "epilogue staging exceeds LDS");
+  float* stage = reinterpret_cast<float*>(smem) + wave * (HROWS * SSTR);
   constexpr int C4 = SCOLS / 4;
   constexpr int RPP = 64 / C4;
+  static_assert(HROWS % RPP == 0, "epilogue passes vs strip rows");
   const int ec4 = lane % C4, er = lane / C4;
+  const bool lane_on = er < RPP;                // (C4 does not divide 64: the last lanes idle)
   const int ncol = n0 + wn * SCOLS + ec4 * 4;
   f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
-  const bool ncol_ok = ncol < a.N;
+  const bool ncol_ok = ncol < a.N && lane_on;
   if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
   if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int h = 0; h < HALVES; ++h) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int pass = 0; pass < 32 / RPP; ++pass) {
-      const int row = pass * RPP + er;
-      const int m = m0 + (wm * MT + i) * 32 + row;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
-      bool row_ok = m < a.M;
-      int drow = m;
-      if (PM || (MODE == 1 && a.g.sub > 1)) {
-        const RowPos p = decompose<PM>(m, a.M, a.g);
-        row_ok = p.valid;
-        drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
-                         : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
-                               p.x * a.g.sub + a.g.x0;
-      }
-      if (row_ok && ncol_ok) {
-        v = v * esc + esh;
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        for (int rr = 0; rr < 16 / HALVES; ++rr) {
+          const int r = h * (16 / HALVES) + rr;
+          // accumulator register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh of the
+          // strip, i.e. row (rr & 3) + 8 * (rr >> 2) + 4 * lh of half h
+          stage[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
         }
-        bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
-                                                (size_t)drow * a.ldc + a.c_off + ncol);
-        if (a.accumulate) {
-          const bf16x4 o = *dst;
-          v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < HROWS / RPP; ++pass) {
+        const int row = pass * RPP + (lane_on ? er : 0);
+        const int m = m0 + (wm * MT + i) * 32 + h * HROWS + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
+        bool row_ok = m < a.M;
+        int drow = m;
+        if (PM || (MODE == 1 && a.g.sub > 1)) {
+          const RowPos p = decompose<PM>(m, a.M, a.g);
+          row_ok = p.valid;
+          drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
+                           : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
+                                 p.x * a.g.sub + a.g.x0;
         }
-        bf16x4 o;
-        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        *dst = o;
+        if (row_ok && ncol_ok) {
+          v = v * esc + esh;
+          if (a.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+          bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
+                                                  (size_t)drow * a.ldc + a.c_off + ncol);
+          if (a.accumulate) {
+            const bf16x4 o = *dst;
+            v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+          }
+          bf16x4 o;
+          o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+          *dst = o;
+        }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -2161,9 +2266,11 @@ int launch_igemm_bf16(IgemmArgs a, hipStream_t s) {
     a.total_slabs = 0;
     for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], 64);
   }
-  // C2D_TUNE=1 C2D_BF16_NBUF=2|3: slab buffers (DMA runs NBUF - 1 slabs ahead)
+  static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
+  a.dbg = dbg_env;
+  // C2D_TUNE=1 C2D_BF16_NBUF=2|3: depth of the activation-slab ring
   static const int nbuf_env = (getenv("C2D_TUNE") && getenv("C2D_BF16_NBUF")) ? atoi(getenv("C2D_BF16_NBUF")) : 0;
-  constexpr bool can3 = 3 * (BM + BN) * 128 <= 160 * 1024;
+  constexpr bool can3 = (3 * BM + 2 * BN) * 128 <= 160 * 1024;
   const int nbuf = (nbuf_env == 3 && can3) ? 3 : 2;
   const dim3 grid(a.m_tiles * a.n_tiles), block(WM * WN * 64);
   if constexpr (can3) {
@@ -2178,6 +2285,25 @@ int launch_igemm_bf16(IgemmArgs a, hipStream_t s) {
                    : "igemm_bf16_kernel<%d, %d, %d, %d, %d, false, 2>", MODE, WM, WN, MT, NT);
   hipLaunchKernelGGL((igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, 2>), grid, block, 0, s, a);
   return c2d_launch_status();
+}
+
+// Full-width tiles: 128 rows x every output column (N <= 384, rounded up to 64) in ONE block of
+// 8 waves (4 x 2, each 32 rows x N/2 columns), one block per CU: the activations stream from HBM
+// exactly once and a launch of 2000 4x4 maps is 250 blocks, one round of the 256 CUs.
+template <bool PM>
+int launch_igemm_bf16_wide(const IgemmArgs& a, hipStream_t s) {
+  const int nt = c2d_ceil_div(a.N, 64);
+#define C2D_WIDE(NT_)                                                                 \
+  case NT_:                                                                           \
+    if (a.g.mode == 0) return launch_igemm_bf16<0, 4, 2, 1, NT_, PM>(a, s);           \
+    return launch_igemm_bf16<1, 4, 2, 1, NT_, PM>(a, s);
+  switch (nt) {
+    C2D_WIDE(2) C2D_WIDE(3) C2D_WIDE(4) C2D_WIDE(5) C2D_WIDE(6)
+    default: break;
+  }
+#undef C2D_WIDE
+  if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 4, 2, 2, PM>(a, s);
+  return launch_igemm_bf16<1, 2, 4, 2, 2, PM>(a, s);
 }
 
 template <int WM, int WN, int MT, int NT, int BKT, bool PM = false>
@@ -2224,8 +2350,12 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   // bf16 (igemm_bf16_kernel) block tile, measured per layer shape of the second stage
   // (tools/bench_conv_bf16.py, N = 2000 ROIs): 128x256 (8 waves) for output widths of 193..256 and
   // >= 1024 columns, 128x128 when the last 128-wide tile is more than half full, else 128x64.
+  // Output widths of 257..384 (Mixed_5b/5c: 320, 352): ONE 128-row x full-width tile per block (8
+  // waves 4 x 2), 250 blocks for 2000 4x4 maps = one round of the chip, the activations read once
+  // (192->320 3x3: 57 -> 45 us, 1024->352 1x1: 39 -> 34.5 us against 128x64 / 128x128 tiles).
   if (!force && a.es == 2 && a.g.sub == 1)
-    force = ((a.N > 192 && a.N <= 256) || a.N >= 1024) ? 6
+    force = (a.N > 256 && a.N <= 384) ? 7
+            : ((a.N > 192 && a.N <= 256) || a.N >= 1024) ? 6
             : (a.N > 256 && (a.N % 128 == 0 || a.N % 128 > 64)) ? 3 : 2;
   // bf16 operands: 128x64 tiles throughout (tools/bench_conv_bf16.py: 0.96 ms against 1.06 ms on
   // the second-stage shapes; the stride-2 input gradients gain most, 108 -> 66 us)
@@ -2252,6 +2382,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
       if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 4, 2, 2, true>(a, s);
       return launch_igemm_bf16<1, 2, 4, 2, 2, true>(a, s);
     }
+    if (force == 7 && a.es == 2) return launch_igemm_bf16_wide<true>(a, s);
     if (force != 3) return launch_igemm<2, 2, 2, 1, 32, true>(a, s, ws);
     return launch_igemm<2, 2, 2, 2, 32, true>(a, s, ws);
   }
@@ -2288,6 +2419,8 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   } else if (force == 6 && a.es == 2) {
     if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 4, 2, 2, false>(a, s);
     return launch_igemm_bf16<1, 2, 4, 2, 2, false>(a, s);
+  } else if (force == 7 && a.es == 2) {
+    return launch_igemm_bf16_wide<false>(a, s);
   } else if (narrow) {
     // N = 192, 320, 576, 160 ...: 128x64 tiles (waves 2x2, each 64x32) waste at most half a
     // 64-wide tile instead of half a 128-wide one, and the smaller accumulator file leaves room

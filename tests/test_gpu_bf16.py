@@ -29,7 +29,12 @@ def _check(got_bf16, want, what):
 CASES = [  # n, ih, iw, cin, cout, k, stride
     (3, 7, 7, 32, 64, 1, 1), (5, 7, 7, 48, 96, 3, 1), (5, 7, 7, 32, 64, 3, 2),
     (300, 7, 7, 64, 160, 3, 1), (70, 4, 4, 48, 96, 3, 1), (100, 7, 7, 32, 64, 3, 2),
-    (65, 4, 4, 32, 192, 3, 1), (900, 7, 7, 64, 96, 1, 1), (40, 4, 4, 80, 32, 1, 1)]
+    (65, 4, 4, 32, 192, 3, 1), (900, 7, 7, 64, 96, 1, 1), (40, 4, 4, 80, 32, 1, 1),
+    # full-width tiles (output widths 257..384: one 128 x N block of 8 waves), ragged in M and N:
+    # pixel-major forward (N = 288) / input gradient (N = cin = 320, accumulating epilogue with
+    # idle store lanes), row-major 1x1 forward (N = 352) / input gradient (N = 288)
+    (70, 4, 4, 48, 288, 3, 1), (70, 4, 4, 320, 64, 3, 1), (700, 4, 4, 64, 352, 1, 1),
+    (700, 4, 4, 288, 64, 1, 1)]
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -327,9 +327,10 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   assert any(k.startswith("wgrad3x3_bf16_kernel<4") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad3x3_bf16_kernel<7") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad_tn_bf16_kernel") for k in bf16), sorted(bf16)
-  # the direct-to-LDS bf16 kernel in its three block tiles (128x64, 128x128, 128x256), row-major
+  # the direct-to-LDS bf16 kernel in the block tiles the benchmark shapes dispatch (128x64,
+  # 128x256, and the full-width 128x320 / 128x384 of the 320- and 352-channel layers), row-major
   # and pixel-major, forward and input gradient:
-  # igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, NBUF>
+  # igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, DA>
   import re
   inst = [re.match(r"igemm_bf16_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d)>", k)
           for k in bf16]
@@ -337,5 +338,5 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   for mode in ("0", "1"):
     for pm in ("true", "false"):
       assert any(g[0] == mode and g[5] == pm for g in inst), (mode, pm, sorted(bf16))
-  for tile in (("2", "2", "2", "1"), ("2", "2", "2", "2"), ("2", "4", "2", "2")):
+  for tile in (("2", "2", "2", "1"), ("2", "4", "2", "2"), ("4", "2", "1", "5"), ("4", "2", "1", "6")):
     assert any(g[1:5] == tile for g in inst), (tile, sorted(bf16))

@@ -14,10 +14,14 @@ SHAPES = [(7, 576, 128, 1, 1), (7, 128, 192, 3, 2), (7, 576, 192, 1, 1), (7, 192
 COUNT = {(4, 1024, 352, 1, 1): 2, (4, 1024, 192, 1, 1): 3, (4, 192, 320, 3, 1): 2,
          (4, 224, 224, 3, 1): 2, (4, 1024, 128, 1, 1): 2}
 n = 2000
+if os.environ.get("C2D_BENCH_SHAPES"):        # e.g. "5,7": only these rows of SHAPES (profiling)
+    SHAPES = [SHAPES[int(i)] for i in os.environ["C2D_BENCH_SHAPES"].split(",")]
+ONLY = os.environ.get("C2D_BENCH_CALLS", "").split(",") if os.environ.get("C2D_BENCH_CALLS") else None
+ITERS = int(os.environ.get("C2D_BENCH_ITERS", "20"))
 what = sys.argv[1] if len(sys.argv) > 1 else "igemm"
 DT = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
 PEAK = 157.3 if DT == torch.float32 else 2500.0
-def timeit(fn, iters=20):
+def timeit(fn, iters=ITERS):
     for _ in range(3): fn()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record()
@@ -40,6 +44,8 @@ for (ih, cin, cout, k, st) in SHAPES:
              "wgrad": lambda: ops.conv_wgrad(x, cin, 0, dy, cout, 0, dw, n, ih, ih, cin, cout, k, k, st)}
     line = "%dx%d cin=%4d cout=%3d k=%d s=%d |" % (ih, ih, cin, cout, k, st)
     for name in (("fwd", "dgrad") if what == "igemm" else ("wgrad",)):
+        if ONLY and name not in ONLY:
+            continue
         t = timeit(calls[name])
         inst = ops.last_dispatch()
         c = COUNT.get((ih, cin, cout, k, st), 1)
