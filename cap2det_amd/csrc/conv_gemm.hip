@@ -1810,29 +1810,44 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int hi_off) {
 constexpr int WB_KB = 32;          // rows of M per slab: two 16-row MFMA k-steps
 constexpr int WB_RS = 256 + 64;    // bytes per staged row (128 bf16 + pad: stride = 64 mod 256)
 
-// Per-tap filter gradient, bf16 operands: same tiling / grid / split-K atomics as wgrad_tn_kernel.
-template <int NTJ, bool PLAIN>
-__global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
+// Per-tap filter gradient, bf16 operands: same tiling / grid as wgrad_tn_kernel.
+// KG = K-groups per block: KG x 4 waves work on the SAME 128 x BJ output tile, each group on its
+// own rows of the block's split with its own staging buffers; the groups' accumulators are summed
+// through LDS before ONE group adds the tile to dW.  The split-K atomics (1.3 TB/s chip-wide,
+// a third of these launches at bf16 MFMA rates) scale with the number of BLOCKS, the latency
+// hiding with the number of WAVES: KG decouples the two.
+template <int NTJ, bool PLAIN, int KG>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 4 : KG == 2 ? 2 : 1)
+void wgrad_tn_bf16_kernel(WgradArgs a) {
   constexpr int BJ = 2 * NTJ * 32;
-  __shared__ __attribute__((aligned(16))) char As[WB_KB * WB_RS];
-  __shared__ __attribute__((aligned(16))) char Gs[WB_KB * WB_RS];
+  constexpr int TILE_BYTES = WB_KB * WB_RS;
+  __shared__ __attribute__((aligned(16))) char smem[KG * 2 * TILE_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = wave >> 2, w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
   const int li = lane & 31, lh = lane >> 5;
+  char* const As = smem + kg * 2 * TILE_BYTES;
+  char* const Gs = As + TILE_BYTES;
   const int itiles = (a.I + 127) / 128;
   const WgradBlock blk = wgrad_block(a);
   const int tap = blk.x / itiles;
   const int i0 = (blk.x - tap * itiles) * 128;
   const int j0 = blk.y * BJ;
   const int ky = tap / a.g.kw, kx = tap - ky * a.g.kw;
-  const int mbeg = blk.z * a.rows_per_split;
-  const int mend = min(a.M, mbeg + a.rows_per_split);
+  // rows of this block's split, dealt to the K-groups in equal shares (host: rows_per_split is a
+  // multiple of KG * WB_KB); every group runs the same number of slabs (rows past M are zeros)
+  const int bbeg = blk.z * a.rows_per_split;
+  const int rpg = a.rows_per_split / KG;
+  const int mbeg = bbeg + kg * rpg;
+  const int mend = min(a.M, mbeg + rpg);
+  const int nslabs = (min(rpg, a.M - bbeg) + WB_KB - 1) / WB_KB;
 
   // loader: thread -> rows kr, kr+16 of the slab, 16-B chunk (8 channels) c8; columns beyond
   // I / J are clamped (their products land in dW rows / columns that are never stored)
-  const int kr = tid >> 4;
-  const int c8 = (tid & 15) * 8;
+  const int tg_ = tid & 255;
+  const int kr = tg_ >> 4;
+  const int c8 = (tg_ & 15) * 8;
   const bool gload = c8 < BJ;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
                                                  (a.a_rows * a.lda - a.a_off) * 2);
@@ -1865,6 +1880,8 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
     aoffs[u] = (unsigned)((kr + u * 16) * a.lda) * 2u + acol;
     goffs[u] = (unsigned)((kr + u * 16) * a.ldg) * 2u + gcol;
   }
+  // (PLAIN: rows >= M lie outside the descriptors and come back as zeros; a group's rows end
+  // where the next group's begin, so no row is counted twice)
 #define C2D_WB_LOAD(MB)                                                                        \
   {                                                                                            \
     if (PLAIN) {                                                                               \
@@ -1889,7 +1906,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
   const char* const gpl = Gs + (8 * lh + tq) * WB_RS + (wn * NTJ * 32 + 16 * tg + 4 * tp) * 2;
 
   C2D_WB_LOAD(mbeg);
-  for (int mb = mbeg; mb < mend; mb += WB_KB) {
+  for (int sl = 0, mb = mbeg; sl < nslabs; ++sl, mb += WB_KB) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       *reinterpret_cast<f32x4*>(As + (kr + u * 16) * WB_RS + c8 * 2) = ra[u];
@@ -1921,10 +1938,34 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
   }
 #undef C2D_WB_LOAD
 
+  // K-groups 1 .. KG-1 hand their accumulators to group 0 through LDS, one 32x32 tile per round
+  // ((KG - 1) x 16 KiB of the staging buffers); group 0 sums in group order
+  if constexpr (KG > 1) {
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NTJ; ++j) {
+        if (kg > 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[((kg - 1) * 4 + w4) * 1024 + r * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+          for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((g - 1) * 4 + w4) * 1024 + r * 64 + lane];
+        }
+        __syncthreads();
+      }
+    if (kg > 0) return;
+  }
+
   // Split-K result: fp32 atomics into dW, or (part_stride > 0) plain stores into this split's own
   // slab — global float atomics run at 1.3 TB/s chip-wide against 6 TB/s for stores of the same
-  // shape (MI355X_MICROARCH.md), which at bf16 MFMA rates was 40 % of these launches; the slabs
-  // are summed in split order by wgrad_reduce_kernel (one batched launch per backward pass).
+  // shape (MI355X_MICROARCH.md); the slabs are summed in split order by wgrad_reduce_kernel.
   float* dw = a.dW + (size_t)tap * a.I * a.J + (size_t)blk.z * a.part_stride;
   const bool part = a.part_stride > 0;
 #pragma unroll
@@ -1953,9 +1994,11 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_bf16_kernel(WgradArgs a) {
 constexpr int W3B_RSA = 64;         // 32 bf16 per x row: consecutive rows = 64 B apart
 constexpr int W3B_RSG = 256 + 64;   // 128 bf16 per dC row + pad
 
-template <int WC, int IMGS, int WI>
-__global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kernel(Wgrad3Args a) {
-  constexpr int NT = 256 * WI;
+// KG = K-groups (see wgrad_tn_bf16_kernel): KG x (4 * WI) waves on the same output tile, each
+// group on its own images with its own staging buffers, summed through LDS before the atomics.
+template <int WC, int IMGS, int WI, int KG>
+__global__ __launch_bounds__(256 * WI * KG, WI * KG == 1 ? 2 : 1) void wgrad3x3_bf16_kernel(Wgrad3Args a) {
+  constexpr int NT = 256 * WI;                // threads of one K-group
   constexpr int PW = WC + 2;
   constexpr int HW = WC * WC;
   constexpr int PIMG = PW * PW;
@@ -1965,9 +2008,12 @@ __global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kerne
   constexpr int AROWS = IMGS * PIMG;
   constexpr int A_LD = (R * 4 + 255) / 256;   // 16-B x chunks per thread (per i-group: 256 thr)
   constexpr int G_LD = (R * 16 + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) char As[WI * AROWS * W3B_RSA];
-  __shared__ __attribute__((aligned(16))) char Gs[RP * W3B_RSG];
-  const int tid = threadIdx.x;
+  constexpr int AS_BYTES = WI * AROWS * W3B_RSA, GS_BYTES = RP * W3B_RSG;
+  __shared__ __attribute__((aligned(16))) char smem[KG * (AS_BYTES + GS_BYTES)];
+  const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
+  const int tid = (int)threadIdx.x - kg * NT;    // thread inside the K-group
+  char* const As = smem + kg * (AS_BYTES + GS_BYTES);
+  char* const Gs = As + AS_BYTES;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 2, wj = wave & 3;
@@ -1977,8 +2023,12 @@ __global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kerne
   const int t = logical - split * a.tiles;
   const int jt = t % a.jtiles, it_ = t / a.jtiles;
   const int i0 = it_ * 32 * WI, j0 = jt * 128;
-  const int mbeg = split * a.rows_per_split;           // multiple of R
-  const int mend = min(a.M, mbeg + a.rows_per_split);
+  // the split's rows in equal shares per K-group (host: rows_per_split is a multiple of KG * R);
+  // every group runs the same number of slabs (rows past M are zeros)
+  const int bbeg = split * a.rows_per_split;
+  const int rpg = a.rows_per_split / KG;
+  const int mbeg = bbeg + kg * rpg;
+  const int nslabs = (min(rpg, a.M - bbeg) + R - 1) / R;
   const bool wave_on = (j0 + wj * 32 < a.J) && (i0 + wi * 32 < a.I);
 
   f32x16 acc[9];
@@ -1988,9 +2038,9 @@ __global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kerne
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
   // zero the border rows of x and the tail rows of dC once: the loaders only rewrite real rows
-  for (int e = tid; e < WI * AROWS * W3B_RSA / 16; e += NT)
+  for (int e = tid; e < AS_BYTES / 16; e += NT)
     reinterpret_cast<f32x4*>(As)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int e = tid; e < RP * W3B_RSG / 16; e += NT)
+  for (int e = tid; e < GS_BYTES / 16; e += NT)
     reinterpret_cast<f32x4*>(Gs)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * 2,
@@ -2041,7 +2091,7 @@ __global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kerne
 
   C2D_W3B_LOAD(mbeg);
   __syncthreads();
-  for (int mb = mbeg; mb < mend; mb += R) {
+  for (int sl = 0, mb = mbeg; sl < nslabs; ++sl, mb += R) {
 #pragma unroll
     for (int u = 0; u < G_LD; ++u)
       if (gdst[u] >= 0) *reinterpret_cast<f32x4*>(Gs + gdst[u]) = rg[u];
@@ -2072,6 +2122,33 @@ __global__ __launch_bounds__(256 * WI, WI == 1 ? 2 : 1) void wgrad3x3_bf16_kerne
   }
 #undef C2D_W3B_LOAD
 
+  // K-groups 1 .. KG-1 hand their nine accumulators to group 0 through LDS, three taps per round
+  if constexpr (KG > 1) {
+    float* const red = reinterpret_cast<float*>(smem);
+    static_assert((KG - 1) * 4 * WI * 48 * 64 * 4 <= KG * (AS_BYTES + GS_BYTES), "reduction staging");
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      __syncthreads();
+      if (kg > 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[(((kg - 1) * 4 * WI + wave) * 48 + q * 16 + r) * 64 + lane] = acc[3 * c + q][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[3 * c + q][r] += red[(((g - 1) * 4 * WI + wave) * 48 + q * 16 + r) * 64 + lane];
+      }
+    }
+    if (kg > 0) return;
+  }
   if (wave_on) {
     const int jj = j0 + wj * 32 + li;
     const bool part = a.part_stride > 0;     // (see wgrad_tn_bf16_kernel)
@@ -2745,10 +2822,15 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     // ONE round of resident blocks (see the fp32 form below), and fewer of them than fit: at
     // bf16 rates the split-K atomics (1.3 TB/s chip-wide) are 40 % of the launch, so half the
     // workgroups (half the atomic bytes) win over the extra latency hiding (tools/bench_wgrad_bf16.py)
-    int splits = wgrad_bf16_slots(wi != 1 ? 256 : iw == 4 ? 256 : 384) / b.tiles;
+    // K-groups per block (wgrad3x3_bf16_kernel): two groups of four waves sharing an output tile
+    // measured 2-6 % faster alone and 1 % slower inside the step (4.177 against 4.127 ms): off.
+    // C2D_TUNE=1 C2D_WGRAD3_KG=1|2.
+    static const int kg_env = (getenv("C2D_TUNE") && getenv("C2D_WGRAD3_KG")) ? atoi(getenv("C2D_WGRAD3_KG")) : 0;
+    const int kg = wi != 1 ? 1 : (kg_env == 1 || kg_env == 2) ? kg_env : 1;
+    int splits = wgrad_bf16_slots(wi != 1 || kg != 1 ? 256 : iw == 4 ? 256 : 384) / b.tiles;
     if (splits < 1) splits = 1;
-    if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
-    b.rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
+    if (splits > nslabs / (4 * kg)) splits = nslabs / (4 * kg) > 0 ? nslabs / (4 * kg) : 1;
+    b.rows_per_split = c2d_ceil_div(nslabs, splits * kg) * kg * slab;
     b.splits = c2d_ceil_div(b.M, b.rows_per_split);
     if (splits_out) *splits_out = b.splits;
     if (splits_only) return C2D_OK;
@@ -2756,11 +2838,13 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     if (partial) b.dW = partial;
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
-    dispatch_note("wgrad3x3_bf16_kernel<%d, %d, %d>", iw, iw == 4 ? 8 : 2, wi);
-    if (iw == 4 && wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 1>), grid, dim3(256), 0, st, b);
-    else if (iw == 4) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 2>), grid, dim3(512), 0, st, b);
-    else if (wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 1>), grid, dim3(256), 0, st, b);
-    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 2>), grid, dim3(512), 0, st, b);
+    dispatch_note("wgrad3x3_bf16_kernel<%d, %d, %d, %d>", iw, iw == 4 ? 8 : 2, wi, kg);
+    if (iw == 4 && wi == 1 && kg == 2) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 1, 2>), grid, dim3(512), 0, st, b);
+    else if (iw == 4 && wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 1, 1>), grid, dim3(256), 0, st, b);
+    else if (iw == 4) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<4, 8, 2, 1>), grid, dim3(512), 0, st, b);
+    else if (wi == 1 && kg == 2) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 1, 2>), grid, dim3(512), 0, st, b);
+    else if (wi == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 1, 1>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 2, 1>), grid, dim3(512), 0, st, b);
     return c2d_launch_status();
   }
   if (kh == 3 && kw == 3 && stride == 1 && ih == iw && (iw == 4 || iw == 7) && cin % 32 == 0 &&
@@ -2837,17 +2921,38 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   hipStream_t st = (hipStream_t)stream;
   a.part_stride = 0;
   if (bf16_mfma) {
-    a.rows_per_split = c2d_ceil_div(a.rows_per_split, WB_KB) * WB_KB;
+    // K-groups per block (see wgrad_tn_bf16_kernel): 256 blocks of 2 groups = the waves of 512
+    // one-group blocks at half their atomic traffic.  Measured (tools/bench_wgrad_bf16.py, the
+    // seven per-tap shapes of the second stage): alone 384 us with one group, 359 with two, 321
+    // with four; INSIDE the training step, where these launches share the CUs with the input-
+    // gradient GEMMs of the main stream, 4.127 / 4.113 / 4.166 ms per step — the 1024-thread,
+    // 80-KiB blocks of four groups no longer fit beside a GEMM block.  C2D_TUNE=1 C2D_WGRAD_KG=1|2|4.
+    static const int kg_env = (getenv("C2D_TUNE") && getenv("C2D_WGRAD_KG")) ? atoi(getenv("C2D_WGRAD_KG")) : 0;
+    const int kg = kg_env == 1 || kg_env == 2 || kg_env == 4 ? kg_env : 2;
+    if (kg > 1) {
+      splits = wgrad_bf16_slots(256) / tiles;
+      if (splits > max_splits) splits = max_splits;
+      if (splits < 1) splits = 1;
+    }
+    const int unit = kg * WB_KB;
+    a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), unit) * unit;
     a.nsplits = c2d_ceil_div(a.M, a.rows_per_split);
     if (splits_out) *splits_out = a.nsplits;
     if (splits_only) return C2D_OK;
     if (partial) { a.part_stride = dw_numel; a.dW = partial; }
     grid.x = a.tiles_x * a.tiles_y * a.nsplits;
-    dispatch_note(plain ? "wgrad_tn_bf16_kernel<%d, true>" : "wgrad_tn_bf16_kernel<%d, false>", narrow ? 1 : 2);
-    if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, true>), grid, dim3(256), 0, st, a);
-    else if (narrow) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, false>), grid, dim3(256), 0, st, a);
-    else if (plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, false>), grid, dim3(256), 0, st, a);
+    dispatch_note(plain ? "wgrad_tn_bf16_kernel<%d, true, %d>" : "wgrad_tn_bf16_kernel<%d, false, %d>",
+                  narrow ? 1 : 2, kg);
+#define C2D_WB_LAUNCH(KG_)                                                                      \
+  {                                                                                            \
+    const dim3 blockdim(256 * KG_);                                                            \
+    if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, true, KG_>), grid, blockdim, 0, st, a);   \
+    else if (narrow) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, false, KG_>), grid, blockdim, 0, st, a);      \
+    else if (plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, true, KG_>), grid, blockdim, 0, st, a);        \
+    else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, false, KG_>), grid, blockdim, 0, st, a);                  \
+  }
+    if (kg == 4) C2D_WB_LAUNCH(4) else if (kg == 2) C2D_WB_LAUNCH(2) else C2D_WB_LAUNCH(1)
+#undef C2D_WB_LAUNCH
     return c2d_launch_status();
   }
   if (splits_out) *splits_out = a.nsplits;

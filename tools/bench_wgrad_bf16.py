@@ -1,7 +1,7 @@
 """Filter-gradient kernels on the second-stage conv shapes: fp32 operands (fp32 MFMA) next to bf16
 operands (bf16 MFMA; with C2D_TUNE=1 C2D_WGRAD_BF16_MFMA=0: the widening fp32-MFMA kernels)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cap2det_amd import hip_ops as ops
 dev = "cuda:0"
 SHAPES = [(2000, 7, 576, 128, 1, 1), (2000, 7, 576, 192, 1, 1), (2000, 7, 192, 256, 3, 1),
@@ -20,7 +20,7 @@ for (n, ih, cin, cout, k, st) in SHAPES:
     oh = -(-ih // st)
     fl = 2.0 * n * oh * oh * cin * cout * k * k
     res = []
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in ((torch.bfloat16,) if os.environ.get("C2D_BENCH_BF16_ONLY") else (torch.float32, torch.bfloat16)):
         x = torch.randn(n * ih * ih, cin, device=dev).to(dt)
         dy = torch.randn(n * oh * oh, cout, device=dev).to(dt)
         dw = torch.zeros(k * k, cin, cout, device=dev)
