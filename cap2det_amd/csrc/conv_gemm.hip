@@ -203,6 +203,13 @@ struct IgemmArgs {
   int seg_lda[4], seg_off[4], segK[4];   // (every segment's A has a_rows rows)
   int total_slabs;
   int es;                   // operand / output element size: 4 (fp32) or 2 (bf16)
+  // Fused BatchNorm/ReLU backward of the layer that PRODUCED this convolution's input (input-
+  // gradient launches only, fy != null): the epilogue turns dx into dc = dx * (y > 0) * fscale
+  // and block (m-tile) mt stores the column sums of dz = dx * (y > 0) and dz * (y - beta) / gamma
+  // over its rows at fpart[(fpart_row0 + mt) * 2 * N ..] (layout of c2d_bn_relu_bwd_partial).
+  const void* fy; int fldy, fyoff;
+  const float* fscale; const float* fbeta; const float* fgamma;
+  float* fpart; int fpart_row0;
   int dbg;                  // ablation bits (C2D_TUNE=1 C2D_IGEMM_DBG): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no epilogue
   ConvGeom g;
 #ifdef C2D_TRACE
@@ -235,6 +242,53 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
 // that draws the last ticket acquires, sums all slabs IN PIECE ORDER (bitwise reproducible) and
 // runs the epilogue.  Nobody ever waits, so no residency or dispatch-order assumption is made.
 constexpr int SK_MAX_PERIOD = 64;
+// ---- fused BN/ReLU backward in the input-gradient epilogue (IgemmArgs::fy) -------------------
+template <int ES>
+__device__ __forceinline__ f32x4 load_act4(const void* base, size_t idx) {
+  if constexpr (ES == 4) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+  } else {
+    const bf16x4 o = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx);
+    return f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+  }
+}
+// one epilogue item: v = four input-gradient values of a row, yv = the producer's outputs there
+__device__ __forceinline__ f32x4 fused_bn_item(f32x4 v, f32x4 yv, f32x4 sc, f32x4 be, f32x4 ig,
+                                               f32x4& sb, f32x4& sg) {
+  f32x4 dz;
+  dz.x = yv.x > 0.f ? v.x : 0.f; dz.y = yv.y > 0.f ? v.y : 0.f;
+  dz.z = yv.z > 0.f ? v.z : 0.f; dz.w = yv.w > 0.f ? v.w : 0.f;
+  sb += dz;
+  sg.x += dz.x * (yv.x - be.x) * ig.x; sg.y += dz.y * (yv.y - be.y) * ig.y;
+  sg.z += dz.z * (yv.z - be.z) * ig.z; sg.w += dz.w * (yv.w - be.w) * ig.w;
+  return dz * sc;
+}
+// Column sums of a block: lane sums -> LDS -> fixed-order sums over the lanes / waves that share
+// a column -> the block's row of the partials (no atomics: bitwise reproducible).
+template <int WM, int WN, int SCOLS, int RPP>
+__device__ __forceinline__ void fused_bn_finish(float* red, const float* dummy, float* fpart,
+                                                int fpart_row0, int N, const f32x4& sb,
+                                                const f32x4& sg, int tid, int wave, int ec4, int er,
+                                                bool lane_on, int n0, int mt) {
+  constexpr int BN = WN * SCOLS, NTHREADS = WM * WN * 64;
+  (void)dummy;
+  __syncthreads();            // every wave is done with its epilogue staging slice
+  if (lane_on) {
+    float* p = red + ((wave * RPP + er) * 2) * SCOLS + ec4 * 4;
+    *reinterpret_cast<f32x4*>(p) = sb;
+    *reinterpret_cast<f32x4*>(p + SCOLS) = sg;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * BN; idx += NTHREADS) {
+    const int k = idx / BN, c = idx - k * BN;
+    const int wn_c = c / SCOLS, cl = c - wn_c * SCOLS;
+    float t = 0.f;
+    for (int wm = 0; wm < WM; ++wm)
+      for (int e = 0; e < RPP; ++e) t += red[(((wm * WN + wn_c) * RPP + e) * 2 + k) * SCOLS + cl];
+    if (n0 + c < N) fpart[((size_t)(fpart_row0 + mt) * 2 + k) * N + n0 + c] = t;
+  }
+}
+
 struct SkPlan {
   int enabled;
   int period;                       // block rows after which the tile costs repeat
@@ -248,7 +302,7 @@ struct SkPlan {
 };
 
 struct IgemmSkArgs {
-  IgemmArgs a;
+  IgemmArgs a = {};
   SkPlan sk;
 };
 
@@ -710,6 +764,18 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
       const bool ncol_ok = ncol < a.N;       // N is a multiple of 4
       if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
       if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+      // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
+      const bool fused = MODE == 1 && !SK && a.fy != nullptr;
+      f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
+      if (fused && ncol_ok) {
+        fsc = *reinterpret_cast<const f32x4*>(a.fscale + ncol);
+        if (a.fgamma) {
+          fbe = *reinterpret_cast<const f32x4*>(a.fbeta + ncol);
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(a.fgamma + ncol);
+          fig = f32x4{ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
+                      ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f};
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -738,6 +804,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
             if (a.relu) {
               v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
+            if (fused)
+              v = fused_bn_item(v, load_act4<ES>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc,
+                                fbe, fig, fsb, fsg);
             if constexpr (ES == 4) {
               f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
               if (a.accumulate) v += *dst;
@@ -757,6 +826,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
         }
         __builtin_amdgcn_wave_barrier();
       }
+      if (fused)      // (block-uniform)
+        fused_bn_finish<WM, WN, SCOLS, RPP>(smem, nullptr, a.fpart, a.fpart_row0, a.N, fsb, fsg, tid,
+                                            wave, ec4, er, er < RPP, n0, mt);
     }
 
     if (!SK) break;
@@ -1137,6 +1209,18 @@ void igemm_bf16_kernel(IgemmArgs a) {
   const bool ncol_ok = ncol < a.N && lane_on;
   if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
   if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+  // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
+  const bool fused = MODE == 1 && a.fy != nullptr;
+  f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
+  if (fused && ncol_ok) {
+    fsc = *reinterpret_cast<const f32x4*>(a.fscale + ncol);
+    if (a.fgamma) {
+      fbe = *reinterpret_cast<const f32x4*>(a.fbeta + ncol);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(a.fgamma + ncol);
+      fig = f32x4{ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
+                  ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f};
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -1171,6 +1255,9 @@ void igemm_bf16_kernel(IgemmArgs a) {
           if (a.relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           }
+          if (fused)
+            v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
+                              fig, fsb, fsg);
           bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
                                                   (size_t)drow * a.ldc + a.c_off + ncol);
           if (a.accumulate) {
@@ -1185,6 +1272,10 @@ void igemm_bf16_kernel(IgemmArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
   }
+  if (fused)      // (block-uniform)
+    fused_bn_finish<WM, WN, SCOLS, RPP>(reinterpret_cast<float*>(smem), nullptr, a.fpart,
+                                        a.fpart_row0, a.N, fsb, fsg, tid, wave, ec4, er, lane_on,
+                                        n0, mt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2281,11 +2372,18 @@ bool sk_disabled_by_env() {
   return e && e[0] == '0';
 }
 
+// Row blocks (m-tiles) of the launch run_igemm chose: recorded for the fused BN/ReLU backward
+// (the caller sizes / offsets the partial-sum rows with it); g_tile_query: record only, no launch.
+static thread_local int g_last_m_tiles = 0;
+static thread_local bool g_tile_query = false;
+
 template <int MODE, int WM, int WN, int MT, int NT, int BKT, bool PM, int ES>
 int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   a.m_tiles = c2d_ceil_div(a.M, BM);
   a.n_tiles = c2d_ceil_div(a.N, BN);
+  g_last_m_tiles = a.m_tiles;
+  if (g_tile_query) return C2D_OK;
   if (a.nseg > 1) {
     a.total_slabs = 0;
     for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], BKT);
@@ -2339,6 +2437,8 @@ int launch_igemm_bf16(IgemmArgs a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   a.m_tiles = c2d_ceil_div(a.M, BM);
   a.n_tiles = c2d_ceil_div(a.N, BN);
+  g_last_m_tiles = a.m_tiles;
+  if (g_tile_query) return C2D_OK;
   if (a.nseg > 1) {
     a.total_slabs = 0;
     for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], 64);
@@ -2409,7 +2509,7 @@ static thread_local SmallCollect* g_collect = nullptr;
 
 int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{nullptr, 0}) {
   IgemmArgs a = a_in;
-  if (a.M <= 0 || a.N <= 0) return g_collect ? C2D_ERR_UNSUPPORTED : C2D_OK;
+  if (a.M <= 0 || a.N <= 0) { g_last_m_tiles = 0; return g_collect ? C2D_ERR_UNSUPPORTED : C2D_OK; }
   // Pixel-major rows for multi-tap convolutions over small per-ROI maps (see decompose<true>).
   const int hw = a.g.rh * a.g.rw;
   // Tuning hooks for tools/sweep_igemm.py (read only when C2D_TUNE is set at load time):
@@ -2465,7 +2565,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   }
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
-  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && a.es == 4) {
+  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && a.es == 4 && !a.fy) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);
@@ -2542,7 +2642,7 @@ static int conv_fwd_impl(const float* x, int ldx, int xoff, const float* wt,
   dispatch_reset();
   C2D_CHECK_ARG(x && wt && y && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cin % 16 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
-  IgemmArgs a;
+  IgemmArgs a = {};
   int rc = fill_geom(&a.g, ih, iw, kh, kw, stride, 0);
   if (rc) return rc;
   a.A = x; a.lda = ldx; a.a_off = xoff; a.Bt = wt; a.C = y; a.ldc = ldy; a.c_off = yoff;
@@ -2572,14 +2672,26 @@ extern "C" int c2d_conv_fwd_ws(const float* x, int ldx, int xoff, const float* w
                        stride, relu, IgemmWs{workspace, workspace_bytes}, stream);
 }
 
+// The BN/ReLU backward fused into an input-gradient launch (IgemmArgs::fy ...); blocks_out: the
+// number of partial-sum rows the launch(es) wrote.  query: count the rows only, launch nothing.
+struct FusedBn {
+  const void* y; int ldy, yoff;
+  const float* scale; const float* beta; const float* gamma;
+  float* part;
+  int* blocks_out;
+  bool query;
+};
+
 static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, float* dx,
                            int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
                            int kh, int kw, int stride, int accumulate, IgemmWs ws, void* stream,
-                           int es = 4) {
+                           int es = 4, const FusedBn* fb = nullptr) {
   dispatch_reset();
+  const bool query = fb && fb->query;
+  if (query) { dc = w = reinterpret_cast<const float*>(16); dx = reinterpret_cast<float*>(16); }
   C2D_CHECK_ARG(dc && w && dx && n > 0 && cin > 0 && cout > 0);
   C2D_CHECK_ARG(cout % 16 == 0 && ldc % 4 == 0 && coff % 4 == 0);
-  IgemmArgs a;
+  IgemmArgs a = {};
   int rc = fill_geom(&a.g, ih, iw, kh, kw, stride, 1);
   if (rc) return rc;
   a.A = dc; a.lda = ldc; a.a_off = coff; a.Bt = w; a.C = dx; a.ldc = lddx; a.c_off = dxoff;
@@ -2588,9 +2700,27 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
   a.a_rows = (long long)n * a.g.oh * a.g.ow;
   C2D_CHECK_ARG(kh * kw <= 64 && (es == 4 || (ldc % 8 == 0 && coff % 8 == 0)));
   C2D_CHECK_ARG(a.a_rows * ldc * 4 < (long long)OOB_OFFSET && (long long)kh * kw * cin * cout * 4 < (long long)OOB_OFFSET);
+  int blocks = 0;
+  if (fb) {
+    C2D_CHECK_ARG(!accumulate && cin % 4 == 0);
+    C2D_CHECK_ARG(query || (fb->y && fb->scale && fb->part && fb->ldy % 4 == 0 && fb->yoff % 4 == 0 &&
+                            (!fb->gamma || fb->beta)));
+    // (any non-null pointer in a query: only the tile choice is evaluated)
+    a.fy = query ? reinterpret_cast<const void*>(16) : fb->y;
+    a.fldy = fb->ldy; a.fyoff = fb->yoff;
+    a.fscale = fb->scale; a.fbeta = fb->beta; a.fgamma = fb->gamma; a.fpart = fb->part;
+    ws = IgemmWs{nullptr, 0};          // one tile per block: every block owns whole columns sums
+  }
+  struct QueryScope {                  // (run_igemm only records the tile choice while this is set)
+    bool on;
+    explicit QueryScope(bool q) : on(q) { if (on) g_tile_query = true; }
+    ~QueryScope() { if (on) g_tile_query = false; }
+  } scope(query);
   if (stride == 1) {
     a.M = n * ih * iw;
-    return run_igemm(a, (hipStream_t)stream, ws);
+    rc = run_igemm(a, (hipStream_t)stream, ws);
+    if (fb && fb->blocks_out) *fb->blocks_out = g_last_m_tiles;
+    return rc;
   }
   // stride 2: one launch per parity class (py, px) of the input pixel; a pixel of the class
   // only meets the taps with ky = (py + pad_t) mod 2 (+2, ...), i.e. 2.25 taps per pixel on
@@ -2608,10 +2738,62 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
       if (b.g.nky == 0 || b.g.nkx == 0) { b.g.nky = 0; b.g.nkx = 0; }
       set_magic(&b.g);
       b.M = n * b.g.rh * b.g.rw;
+      b.fpart_row0 = blocks;                        // (fused: each class owns its rows of partials)
       rc = run_igemm(b, (hipStream_t)stream, ws);   // (launches of one stream run in order: the
       if (rc) return rc;                             //  four classes share the workspace)
+      blocks += g_last_m_tiles;
     }
+  if (fb && fb->blocks_out) *fb->blocks_out = blocks;
   return C2D_OK;
+}
+
+// Fused forms: dc_out [n*ih*iw, cin] dense (row stride cin) = the dc of the producer layer.
+template <typename T>
+static int conv_dgrad_bn_relu_impl(const T* dc, int ldc, int coff, const T* w, const T* y, int ldy,
+                                   int yoff, const float* scale, const float* beta,
+                                   const float* gamma, T* dc_out, float* partials, int n, int ih,
+                                   int iw, int cin, int cout, int kh, int kw, int stride,
+                                   void* stream, int* blocks_out, bool query) {
+  FusedBn fb = {y, ldy, yoff, scale, beta, gamma, partials, blocks_out, query};
+  return conv_dgrad_impl(reinterpret_cast<const float*>(dc), ldc, coff,
+                         reinterpret_cast<const float*>(w), reinterpret_cast<float*>(dc_out), cin, 0,
+                         n, ih, iw, cin, cout, kh, kw, stride, 0, IgemmWs{nullptr, 0}, stream,
+                         (int)sizeof(T), &fb);
+}
+
+extern "C" int c2d_conv_dgrad_bn_relu(const float* dc, int ldc, int coff, const float* w,
+                                      const float* y, int ldy, int yoff, const float* scale,
+                                      const float* beta, const float* gamma, float* dc_out,
+                                      float* partials, int n, int ih, int iw, int cin, int cout,
+                                      int kh, int kw, int stride, void* stream) {
+  return conv_dgrad_bn_relu_impl<float>(dc, ldc, coff, w, y, ldy, yoff, scale, beta, gamma, dc_out,
+                                        partials, n, ih, iw, cin, cout, kh, kw, stride, stream,
+                                        nullptr, false);
+}
+
+extern "C" int c2d_conv_dgrad_bn_relu_bf16(const void* dc, int ldc, int coff, const void* w,
+                                           const void* y, int ldy, int yoff, const float* scale,
+                                           const float* beta, const float* gamma, void* dc_out,
+                                           float* partials, int n, int ih, int iw, int cin,
+                                           int cout, int kh, int kw, int stride, void* stream) {
+  return conv_dgrad_bn_relu_impl<c2d_bf16>((const c2d_bf16*)dc, ldc, coff, (const c2d_bf16*)w,
+                                           (const c2d_bf16*)y, ldy, yoff, scale, beta, gamma,
+                                           (c2d_bf16*)dc_out, partials, n, ih, iw, cin, cout, kh, kw,
+                                           stride, stream, nullptr, false);
+}
+
+extern "C" int c2d_conv_dgrad_bn_relu_partial_blocks(int elem_size, int n, int ih, int iw, int cin,
+                                                     int cout, int kh, int kw, int stride) {
+  int blocks = 0, rc;
+  if (elem_size == 2)
+    rc = conv_dgrad_bn_relu_impl<c2d_bf16>(nullptr, cout, 0, nullptr, nullptr, cin, 0, nullptr,
+                                           nullptr, nullptr, nullptr, nullptr, n, ih, iw, cin, cout,
+                                           kh, kw, stride, nullptr, &blocks, true);
+  else
+    rc = conv_dgrad_bn_relu_impl<float>(nullptr, cout, 0, nullptr, nullptr, cin, 0, nullptr, nullptr,
+                                        nullptr, nullptr, nullptr, n, ih, iw, cin, cout, kh, kw,
+                                        stride, nullptr, &blocks, true);
+  return rc == C2D_OK ? blocks : -1;
 }
 
 extern "C" int c2d_conv_dgrad(const float* dc, int ldc, int coff, const float* w, float* dx,
@@ -2638,7 +2820,7 @@ static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
   dispatch_reset();
   C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && dcs && ldcs && coffs && ws && couts && dx);
   C2D_CHECK_ARG(rows > 0 && cin > 0 && cin % 4 == 0 && lddx % 4 == 0 && dxoff % 4 == 0);
-  IgemmArgs a;
+  IgemmArgs a = {};
   int rc = fill_geom(&a.g, 1, 1, 1, 1, 1, 1);
   if (rc) return rc;
   a.total_slabs = 0;

@@ -224,6 +224,22 @@ def bn_relu_bwd(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dg
             _p(gamma), _p(dc), _p(dbeta), _p(dgamma), rows, c, _stream())
 
 
+def conv_dgrad_bn_relu_blocks(dtype, n, ih, iw, cin, cout, kh, kw, stride):
+  """Row blocks of partial sums c2d_conv_dgrad_bn_relu writes for this shape (-1: unsupported)."""
+  es = 2 if dtype == torch.bfloat16 else 4
+  return int(_lib.load().c2d_conv_dgrad_bn_relu_partial_blocks(es, n, ih, iw, cin, cout, kh, kw, stride))
+
+
+def conv_dgrad_bn_relu(dc, ldc, coff, w, y, ldy, yoff, scale, beta, gamma, dc_out, partials, n, ih,
+                       iw, cin, cout, kh, kw, stride):
+  """Input gradient of a convolution + BN/ReLU backward of the layer that produced its input."""
+  fn = "c2d_conv_dgrad_bn_relu_bf16" if dc.dtype == torch.bfloat16 else "c2d_conv_dgrad_bn_relu"
+  assert w.dtype == dc.dtype and y.dtype == dc.dtype and dc_out.dtype == dc.dtype
+  _lib.call(fn, _p(dc), ldc, coff, _p(w), _p(y), ldy, yoff, _p(scale), _p(beta),
+            _p(gamma) if gamma is not None else None, _p(dc_out), _p(partials), n, ih, iw, cin,
+            cout, kh, kw, stride, _stream())
+
+
 def bn_relu_bwd_partial_blocks(rows, c):
   return int(_lib.load().c2d_bn_relu_bwd_partial_blocks(rows, c))
 

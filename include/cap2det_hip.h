@@ -215,6 +215,24 @@ int c2d_bn_relu_bwd_partial(const float* dy, int lddy, int dyoff, const float* y
 int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks, const float* ws,
                                    float* grads, void* stream);
 
+/* c2d_conv_dgrad fused with the c2d_bn_relu_bwd_partial of the layer that PRODUCED the
+ * convolution's input (two consecutive slim.conv2d of an Inception branch, reference
+ * nets/inception_v2 via models/utils.py:108-188; TF computes the ReLU and FusedBatchNorm gradients
+ * between the two Conv2DBackpropInput ops): instead of storing dx and reading it back,
+ * the GEMM epilogue applies the producer's ReLU mask and folded BN scale,
+ *   dc_out[n*ih*iw][cin] (dense) = dx * (y > 0) * scale[cin],
+ * and every row block of the launch stores its column sums of dz = dx * (y > 0) and of
+ * dz * (y - beta) / gamma at partials[block][2][cin] (gamma NULL: the second half is zero) for
+ * c2d_bn_partials_reduce_batched.  y: the producer's forward output (rows of ldy, offset yoff).
+ * c2d_conv_dgrad_bn_relu_partial_blocks(elem_size 4|2, shape) = number of row blocks the launch
+ * (stride 2: its four parity-class launches) writes; -1 for an unsupported shape. */
+int c2d_conv_dgrad_bn_relu_partial_blocks(int elem_size, int n, int ih, int iw, int cin, int cout,
+                                          int kh, int kw, int stride);
+int c2d_conv_dgrad_bn_relu(const float* dc, int ldc, int coff, const float* w, const float* y,
+                           int ldy, int yoff, const float* scale, const float* beta,
+                           const float* gamma, float* dc_out, float* partials, int n, int ih,
+                           int iw, int cin, int cout, int kh, int kw, int stride, void* stream);
+
 /* out[j] += sum_rows x[row][xoff+j]  (bias gradients). */
 int c2d_col_sum(const float* x, int ldx, int xoff, float* out, int rows, int ncols,
                 void* stream);
@@ -415,6 +433,11 @@ int c2d_bn_relu_bwd_partial_bf16(const void* dy, int lddy, int dyoff, const void
                                  int yoff, const float* scale, const float* beta,
                                  const float* gamma, void* dc, float* partials, int rows, int c,
                                  void* stream);
+int c2d_conv_dgrad_bn_relu_bf16(const void* dc, int ldc, int coff, const void* w, const void* y,
+                                int ldy, int yoff, const float* scale, const float* beta,
+                                const float* gamma, void* dc_out, float* partials, int n, int ih,
+                                int iw, int cin, int cout, int kh, int kw, int stride,
+                                void* stream);
 int c2d_spatial_mean_dropout_fwd_bf16(const void* x, float* y, const uint8_t* mask, int rows,
                                       int spatial, int c, float keep_prob, void* stream);
 int c2d_spatial_mean_dropout_bwd_bf16(const float* dy, int lddy, int dyoff, void* dx,

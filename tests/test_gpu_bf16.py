@@ -70,6 +70,43 @@ def test_conv_fwd_dgrad_bf16(case):
   _check(dx2, want_dx, "dgrad")
 
 
+FUSED_CASES = [(70, 4, 4, 48, 96, 3, 1), (900, 7, 7, 64, 96, 1, 1), (100, 7, 7, 32, 64, 3, 2),
+               (70, 4, 4, 320, 64, 3, 1), (300, 7, 7, 160, 64, 3, 1), (40, 4, 4, 80, 32, 1, 1)]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_dgrad_bn_relu_bf16(case):
+  """bf16 form of the fused input gradient + BN/ReLU backward (the full-width 128 x 320 tile of
+  the (70, 4, 4, 320, ...) case included): dc within one bf16 rounding of the float64 oracle on
+  the same bf16 operands, the fp32 column sums to 1e-3 of their scale."""
+  from cap2det_amd import hip_ops as ops
+  n, ih, iw, cin, cout, k, s = case
+  rng = np.random.default_rng(sum(case) + 1)
+  w, w64 = _bf(rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin))
+  oh, ow = -(-ih // s), -(-iw // s)
+  dc, dc64 = _bf(rng.standard_normal((n, oh, ow, cout)))
+  y, y64 = _bf(np.maximum(rng.standard_normal((n, ih, iw, cin)), 0))
+  scale = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+  beta = (0.1 * rng.standard_normal(cin)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+  x64 = np.zeros((n, ih, iw, cin))
+  dx, _ = ref_ops.conv2d_backward(x64, w64, dc64, s)
+  dz = dx * (y64 > 0)
+  nb = ops.conv_dgrad_bn_relu_blocks(torch.bfloat16, n, ih, iw, cin, cout, k, k, s)
+  assert nb >= 1
+  out = torch.full((n * ih * iw, cin), 9.0, device=DEV, dtype=torch.bfloat16)
+  part = torch.full((nb, 2, cin), 7.0, device=DEV)
+  t = lambda a: torch.from_numpy(a).to(DEV)
+  ops.conv_dgrad_bn_relu(dc, cout, 0, w.view(k * k, cin, cout), y, cin, 0, t(scale), t(beta), t(gamma),
+                         out, part, n, ih, iw, cin, cout, k, k, s)
+  _check(out.view(n, ih, iw, cin), dz * scale, "fused dc")
+  sums = part.double().sum(0).cpu().numpy()
+  want_db = dz.reshape(-1, cin).sum(0)
+  want_dg = (dz * (y64 - beta) / gamma).reshape(-1, cin).sum(0)
+  for got, want, what in ((sums[0], want_db, "dbeta"), (sums[1], want_dg, "dgamma")):
+    assert np.abs(got - want).max() <= 1e-3 * max(np.abs(want).max(), 1.0), what
+
+
 def test_conv1x1_dgrad_multi_bf16():
   from cap2det_amd import hip_ops as ops
   rng = np.random.default_rng(5)

@@ -181,6 +181,67 @@ def test_conv_dgrad_wgrad(ops, case, conv_mode):
   np.testing.assert_allclose(_n(dw), want_dw, rtol=1e-4, atol=1e-5 * scale + 1e-5)
 
 
+FUSED_CASES = [
+    (3, 7, 7, 32, 64, 1, 1),      # few rows: 64x64 tiles
+    (70, 4, 4, 48, 96, 3, 1),     # pixel-major rows, ragged last group of 32 images
+    (900, 7, 7, 64, 96, 1, 1),    # row-major, many row blocks
+    (100, 7, 7, 32, 64, 3, 2),    # stride 2: four parity-class launches share the partials
+    (261, 7, 7, 32, 160, 3, 2),   # odd image count
+    (300, 7, 7, 160, 64, 3, 1),   # N = cin = 160
+]
+
+
+def _fused_reference(rng, n, ih, iw, cin, cout, k, s, with_gamma, quantize=None):
+  """Inputs + float64 expectations of c2d_conv_dgrad_bn_relu: dx of the convolution, then the
+  producer's ReLU mask / BN scale and the beta / gamma column sums."""
+  q = quantize or (lambda a: a.astype(np.float32))
+  x, w = _conv_inputs(rng, n, ih, iw, cin, cout, k)
+  w = q(w)
+  oh, ow = -(-ih // s), -(-iw // s)
+  dc = q(rng.standard_normal((n, oh, ow, cout)).astype(np.float32))
+  y = q(np.maximum(rng.standard_normal((n, ih, iw, cin)), 0).astype(np.float32))   # ties at 0
+  scale = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+  beta = (0.1 * rng.standard_normal(cin)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, cin).astype(np.float32) if with_gamma else None
+  dx, _ = ref_ops.conv2d_backward(x.astype(np.float64), w.astype(np.float64), dc.astype(np.float64), s)
+  dz = dx * (y > 0)
+  want_dc = dz * scale
+  want_db = dz.reshape(-1, cin).sum(0)
+  want_dg = ((dz * (y.astype(np.float64) - beta) / gamma).reshape(-1, cin).sum(0)
+             if with_gamma else np.zeros(cin))
+  return w, dc, y, scale, beta, gamma, want_dc, want_db, want_dg
+
+
+@pytest.mark.parametrize("with_gamma", [True, False], ids=["gamma", "nogamma"])
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_dgrad_bn_relu(ops, case, with_gamma):
+  """Input gradient fused with the producer layer's BN/ReLU backward against conv2d_backward +
+  the bn_relu_bwd formulas of the oracle; the partial sums are reproducible (no atomics)."""
+  n, ih, iw, cin, cout, k, s = case
+  rng = np.random.default_rng(29)
+  w, dc, y, scale, beta, gamma, want_dc, want_db, want_dg = _fused_reference(
+      rng, n, ih, iw, cin, cout, k, s, with_gamma)
+  nb = ops.conv_dgrad_bn_relu_blocks(torch.float32, n, ih, iw, cin, cout, k, k, s)
+  assert nb >= 1
+  # y lives in a wider concat-style buffer
+  ldy, yoff = cin + 8, 4
+  yb = np.zeros((n, ih, iw, ldy), np.float32); yb[..., yoff:yoff + cin] = y
+  outs = []
+  for _ in range(2):
+    out = torch.full((n * ih * iw, cin), 9.0, device=DEV)
+    part = torch.full((nb, 2, cin), 7.0, device=DEV)
+    ops.conv_dgrad_bn_relu(_t(dc), cout, 0, _t(w), _t(yb), ldy, yoff, _t(scale), _t(beta),
+                           _t(gamma) if with_gamma else None, out, part, n, ih, iw, cin, cout, k, k, s)
+    outs.append((_n(out), _n(part)))
+  got_dc, got_part = outs[0]
+  sc = np.abs(want_dc).max()
+  np.testing.assert_allclose(got_dc.reshape(want_dc.shape), want_dc, rtol=1e-4, atol=1e-5 * sc + 1e-6)
+  sums = got_part.astype(np.float64).sum(0)
+  np.testing.assert_allclose(sums[0], want_db, rtol=1e-4, atol=1e-4 * np.abs(want_db).max() + 1e-5)
+  np.testing.assert_allclose(sums[1], want_dg, rtol=1e-4, atol=1e-4 * max(np.abs(want_dg).max(), 1.0))
+  assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("mode,stride", [(0, 1), (0, 2), (1, 1)])
 @pytest.mark.parametrize("ih,iw,n", [(7, 7, 6), (4, 4, 6), (9, 5, 6), (7, 7, 70), (4, 4, 70)])
 def test_pool3x3(ops, mode, stride, ih, iw, n):

@@ -249,10 +249,14 @@ def test_mixed_4e_entry_group(ops):
     _scale_close(_n(y), want, 2e-5, "grouped 1x1")
 
 
-def test_second_stage_fwd_bwd_dm1_n128():
+@pytest.mark.parametrize("fuse_bn_bwd", ["1", "0"], ids=["fused_bn_bwd", "separate_bn_bwd"])
+def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd):
   """The whole second stage (Mixed_5a-c, depth multiplier 1.0) forward + backward on 128 ROIs
   through the engine's launch plan against ref_model.net_forward / net_backward in float64:
-  output map, input gradient and every filter / BatchNorm gradient."""
+  output map, input gradient and every filter / BatchNorm gradient.  Both backward plans: the
+  BN/ReLU backward of the inner convolutions fused into their consumers' input-gradient GEMMs
+  (c2d_conv_dgrad_bn_relu; nine producer layers here) and as separate launches."""
+  monkeypatch.setenv("C2D_FUSE_BN_BWD", fuse_bn_bwd)
   from cap2det_amd import hip_ops
   from cap2det_amd.models.frcnn_engine import SECOND_SCOPE, SECOND_STAGE, DerivedStore, Net, Ref, VariableStore
   n, hw, cin = 128, 7, 576
@@ -309,6 +313,9 @@ def test_second_stage_fwd_bwd_dm1_n128():
   store.grads.zero_()
   net.backward(plan, xin, 0, dx)
   torch.cuda.synchronize()
+  fused = sum(1 for st in plan["steps"] if st["kind"] == "block" for b in st["branches"] for op in b
+              if "fused_blocks" in op)
+  assert fused == (9 if fuse_bn_bwd == "1" else 0)
   want_dx, grads = ref_model.net_backward(ref_model.SECOND_STAGE, tape, dy.astype(np.float64), P64,
                                           ref_model.SECOND_SCOPE, 0, True)
   _scale_close(_n(dx.t).reshape(want_dx.shape), want_dx, 5e-5, "second stage input gradient")
