@@ -207,8 +207,12 @@ struct IgemmArgs {
   // gradient launches only, fy != null): the epilogue turns dx into dc = dx * (y > 0) * fscale
   // and block (m-tile) mt stores the column sums of dz = dx * (y > 0) and dz * (y - beta) / gamma
   // over its rows at fpart[(fpart_row0 + mt) * 2 * N ..] (layout of c2d_bn_relu_bwd_partial).
+  // The columns may belong to up to four producers (the branches feeding a concat buffer):
+  // producer p owns columns [fseg_end[p-1], fseg_end[p]), its vectors are indexed from its first
+  // column; fident[p]: a pooling branch (no BN/ReLU: the gradient passes unchanged, sums zero).
   const void* fy; int fldy, fyoff;
-  const float* fscale; const float* fbeta; const float* fgamma;
+  int fnprod; int fseg_end[4]; int fident[4];
+  const float* fscale[4]; const float* fbeta[4]; const float* fgamma[4];
   float* fpart; int fpart_row0;
   int dbg;                  // ablation bits (C2D_TUNE=1 C2D_IGEMM_DBG): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no epilogue
   ConvGeom g;
@@ -251,6 +255,23 @@ __device__ __forceinline__ f32x4 load_act4(const void* base, size_t idx) {
     const bf16x4 o = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx);
     return f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
   }
+}
+// the producer parameters of the four columns starting at ncol (all inside one producer)
+__device__ __forceinline__ bool fused_bn_params(const IgemmArgs& a, int ncol, f32x4& sc, f32x4& be,
+                                                f32x4& ig) {
+  int p = 0, lo = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (q + 1 < a.fnprod && ncol >= a.fseg_end[q]) { p = q + 1; lo = a.fseg_end[q]; }
+  if (a.fident[p]) return true;
+  sc = *reinterpret_cast<const f32x4*>(a.fscale[p] + (ncol - lo));
+  if (a.fgamma[p]) {
+    be = *reinterpret_cast<const f32x4*>(a.fbeta[p] + (ncol - lo));
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(a.fgamma[p] + (ncol - lo));
+    ig = f32x4{ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
+               ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f};
+  }
+  return false;
 }
 // one epilogue item: v = four input-gradient values of a row, yv = the producer's outputs there
 __device__ __forceinline__ f32x4 fused_bn_item(f32x4 v, f32x4 yv, f32x4 sc, f32x4 be, f32x4 ig,
@@ -767,15 +788,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
       // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
       const bool fused = MODE == 1 && !SK && a.fy != nullptr;
       f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
-      if (fused && ncol_ok) {
-        fsc = *reinterpret_cast<const f32x4*>(a.fscale + ncol);
-        if (a.fgamma) {
-          fbe = *reinterpret_cast<const f32x4*>(a.fbeta + ncol);
-          const f32x4 ga = *reinterpret_cast<const f32x4*>(a.fgamma + ncol);
-          fig = f32x4{ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
-                      ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f};
-        }
-      }
+      bool fpass = false;      // columns of a pooling branch: plain gradient
+      if (fused && ncol_ok) fpass = fused_bn_params(a, ncol, fsc, fbe, fig);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -804,12 +818,12 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
             if (a.relu) {
               v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            if (fused)
-              v = fused_bn_item(v, load_act4<ES>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc,
-                                fbe, fig, fsb, fsg);
             if constexpr (ES == 4) {
               f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
               if (a.accumulate) v += *dst;
+              if (fused && !fpass)     // (on the complete gradient: after the accumulation)
+                v = fused_bn_item(v, load_act4<ES>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol),
+                                  fsc, fbe, fig, fsb, fsg);
               *dst = v;
             } else {                                  // 4 bf16 = 8 B per lane
               bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
@@ -818,6 +832,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
                 const bf16x4 o = *dst;
                 v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
               }
+              if (fused && !fpass)
+                v = fused_bn_item(v, load_act4<ES>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol),
+                                  fsc, fbe, fig, fsb, fsg);
               bf16x4 o;
               o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
               *dst = o;
@@ -1212,15 +1229,8 @@ void igemm_bf16_kernel(IgemmArgs a) {
   // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
   const bool fused = MODE == 1 && a.fy != nullptr;
   f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
-  if (fused && ncol_ok) {
-    fsc = *reinterpret_cast<const f32x4*>(a.fscale + ncol);
-    if (a.fgamma) {
-      fbe = *reinterpret_cast<const f32x4*>(a.fbeta + ncol);
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(a.fgamma + ncol);
-      fig = f32x4{ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
-                  ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f};
-    }
-  }
+  bool fpass = false;      // columns of a pooling branch: plain gradient
+  if (fused && ncol_ok) fpass = fused_bn_params(a, ncol, fsc, fbe, fig);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -1255,15 +1265,15 @@ void igemm_bf16_kernel(IgemmArgs a) {
           if (a.relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           }
-          if (fused)
-            v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
-                              fig, fsb, fsg);
           bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
                                                   (size_t)drow * a.ldc + a.c_off + ncol);
           if (a.accumulate) {
             const bf16x4 o = *dst;
             v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
           }
+          if (fused && !fpass)
+            v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
+                              fig, fsb, fsg);
           bf16x4 o;
           o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
           *dst = o;
@@ -2676,11 +2686,28 @@ extern "C" int c2d_conv_fwd_ws(const float* x, int ldx, int xoff, const float* w
 // number of partial-sum rows the launch(es) wrote.  query: count the rows only, launch nothing.
 struct FusedBn {
   const void* y; int ldy, yoff;
-  const float* scale; const float* beta; const float* gamma;
+  int nprod; int seg_end[4]; int ident[4];
+  const float* scale[4]; const float* beta[4]; const float* gamma[4];
   float* part;
   int* blocks_out;
   bool query;
 };
+
+static int fused_bn_fill(IgemmArgs* a, const FusedBn* fb, int ncols) {
+  const bool query = fb->query;
+  C2D_CHECK_ARG(fb->nprod >= 1 && fb->nprod <= 4 && fb->seg_end[fb->nprod - 1] == ncols);
+  C2D_CHECK_ARG(query || (fb->y && fb->part && fb->ldy % 4 == 0 && fb->yoff % 4 == 0));
+  // (any non-null pointer in a query: only the tile choice is evaluated)
+  a->fy = query ? reinterpret_cast<const void*>(16) : fb->y;
+  a->fldy = fb->ldy; a->fyoff = fb->yoff; a->fnprod = fb->nprod; a->fpart = fb->part;
+  for (int p = 0; p < fb->nprod; ++p) {
+    C2D_CHECK_ARG(fb->seg_end[p] % 4 == 0 && fb->seg_end[p] > (p ? fb->seg_end[p - 1] : 0));
+    C2D_CHECK_ARG(query || fb->ident[p] || (fb->scale[p] && (!fb->gamma[p] || fb->beta[p])));
+    a->fseg_end[p] = fb->seg_end[p]; a->fident[p] = fb->ident[p];
+    a->fscale[p] = fb->scale[p]; a->fbeta[p] = fb->beta[p]; a->fgamma[p] = fb->gamma[p];
+  }
+  return C2D_OK;
+}
 
 static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, float* dx,
                            int lddx, int dxoff, int n, int ih, int iw, int cin, int cout,
@@ -2703,13 +2730,9 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
   int blocks = 0;
   if (fb) {
     C2D_CHECK_ARG(!accumulate && cin % 4 == 0);
-    C2D_CHECK_ARG(query || (fb->y && fb->scale && fb->part && fb->ldy % 4 == 0 && fb->yoff % 4 == 0 &&
-                            (!fb->gamma || fb->beta)));
-    // (any non-null pointer in a query: only the tile choice is evaluated)
-    a.fy = query ? reinterpret_cast<const void*>(16) : fb->y;
-    a.fldy = fb->ldy; a.fyoff = fb->yoff;
-    a.fscale = fb->scale; a.fbeta = fb->beta; a.fgamma = fb->gamma; a.fpart = fb->part;
-    ws = IgemmWs{nullptr, 0};          // one tile per block: every block owns whole columns sums
+    rc = fused_bn_fill(&a, fb, cin);
+    if (rc) return rc;
+    ws = IgemmWs{nullptr, 0};          // one tile per block: every block owns whole column sums
   }
   struct QueryScope {                  // (run_igemm only records the tile choice while this is set)
     bool on;
@@ -2754,7 +2777,10 @@ static int conv_dgrad_bn_relu_impl(const T* dc, int ldc, int coff, const T* w, c
                                    const float* gamma, T* dc_out, float* partials, int n, int ih,
                                    int iw, int cin, int cout, int kh, int kw, int stride,
                                    void* stream, int* blocks_out, bool query) {
-  FusedBn fb = {y, ldy, yoff, scale, beta, gamma, partials, blocks_out, query};
+  FusedBn fb = {};
+  fb.y = y; fb.ldy = ldy; fb.yoff = yoff; fb.nprod = 1; fb.seg_end[0] = cin;
+  fb.scale[0] = scale; fb.beta[0] = beta; fb.gamma[0] = gamma;
+  fb.part = partials; fb.blocks_out = blocks_out; fb.query = query;
   return conv_dgrad_impl(reinterpret_cast<const float*>(dc), ldc, coff,
                          reinterpret_cast<const float*>(w), reinterpret_cast<float*>(dc_out), cin, 0,
                          n, ih, iw, cin, cout, kh, kw, stride, 0, IgemmWs{nullptr, 0}, stream,
@@ -2816,8 +2842,13 @@ static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
                             const int* coffs, const float* const* ws,
                             const int* couts, float* dx, int lddx, int dxoff,
                             int rows, int cin, int accumulate, IgemmWs wsp, void* stream,
-                            int es = 4) {
+                            int es = 4, const FusedBn* fb = nullptr) {
   dispatch_reset();
+  const float* fake_ptrs[4]; int fake_ints[4] = {0, 0, 0, 0};
+  if (fb && fb->query) {       // only the tile choice is evaluated
+    for (int i = 0; i < 4; ++i) fake_ptrs[i] = reinterpret_cast<const float*>(16);
+    dcs = ws = fake_ptrs; coffs = fake_ints; dx = reinterpret_cast<float*>(16);
+  }
   C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && dcs && ldcs && coffs && ws && couts && dx);
   C2D_CHECK_ARG(rows > 0 && cin > 0 && cin % 4 == 0 && lddx % 4 == 0 && dxoff % 4 == 0);
   IgemmArgs a = {};
@@ -2839,7 +2870,57 @@ static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
   a.C = dx; a.ldc = lddx; a.c_off = dxoff;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate;
   a.M = rows; a.N = cin;
-  return run_igemm(a, (hipStream_t)stream, wsp);
+  if (!fb) return run_igemm(a, (hipStream_t)stream, wsp);
+  rc = fused_bn_fill(&a, fb, cin);
+  if (rc) return rc;
+  if (fb->query) g_tile_query = true;
+  rc = run_igemm(a, (hipStream_t)stream, IgemmWs{nullptr, 0});
+  g_tile_query = false;
+  if (fb->blocks_out) *fb->blocks_out = g_last_m_tiles;
+  return rc;
+}
+
+static_assert(sizeof(C2dBnProducer) == 32, "C2dBnProducer layout");
+
+static int fused_from_producers(FusedBn* fb, const void* y, int ldy, int yoff, int nprod,
+                                const C2dBnProducer* prods, float* partials) {
+  C2D_CHECK_ARG(nprod >= 1 && nprod <= 4 && prods);
+  fb->y = y; fb->ldy = ldy; fb->yoff = yoff; fb->nprod = nprod; fb->part = partials;
+  int end = 0;
+  for (int p = 0; p < nprod; ++p) {
+    C2D_CHECK_ARG(prods[p].width > 0);
+    end += prods[p].width;
+    fb->seg_end[p] = end; fb->ident[p] = prods[p].identity;
+    fb->scale[p] = prods[p].scale; fb->beta[p] = prods[p].beta; fb->gamma[p] = prods[p].gamma;
+  }
+  return C2D_OK;
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi_bn_relu(int nseg, const float* const* dcs, const int* ldcs,
+                                               const int* coffs, const float* const* ws,
+                                               const int* couts, const float* y, int ldy, int yoff,
+                                               int nprod, const C2dBnProducer* prods, float* dx,
+                                               int lddx, int dxoff, float* partials, int rows,
+                                               int cin, int accumulate, void* stream) {
+  FusedBn fb = {};
+  int rc = fused_from_producers(&fb, y, ldy, yoff, nprod, prods, partials);
+  if (rc) return rc;
+  return dgrad_multi_impl(nseg, dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin, accumulate,
+                          IgemmWs{nullptr, 0}, stream, 4, &fb);
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks(int nseg, const int* couts, int rows,
+                                                              int cin) {
+  C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && couts);
+  FusedBn fb = {};
+  fb.nprod = 1; fb.seg_end[0] = cin; fb.ident[0] = 1; fb.query = true;
+  int blocks = 0;
+  fb.blocks_out = &blocks;
+  int lds[4];
+  for (int i = 0; i < nseg; ++i) lds[i] = couts[i];
+  const int rc = dgrad_multi_impl(nseg, nullptr, lds, nullptr, nullptr, couts, nullptr, cin, 0, rows,
+                                  cin, 0, IgemmWs{nullptr, 0}, nullptr, 4, &fb);
+  return rc == C2D_OK ? blocks : -1;
 }
 
 extern "C" int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs,

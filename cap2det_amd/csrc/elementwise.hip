@@ -711,7 +711,10 @@ __global__ __launch_bounds__(256) void bn_fold_batched_kernel(
 
 // Sums the per-block partial sums of bn_relu_bwd (partial form) into the flat gradient buffer.
 // One workgroup per (layer, 64-channel chunk): 16 float4 channel lanes x 16 block lanes.
-struct BnPartDesc { long long ws_off, dbeta_off, dgamma_off; int nblocks, c, begin, pad; };
+// wide: 0, or the width W of the partial rows when the layer's c columns are a slice of rows
+// [2][W] written for a whole concat buffer (c2d_conv1x1_dgrad_multi_bn_relu): ws_off then points
+// at the layer's first column of block 0's beta half.
+struct BnPartDesc { long long ws_off, dbeta_off, dgamma_off; int nblocks, c, begin, wide; };
 
 __global__ __launch_bounds__(256) void bn_partials_reduce_kernel(
     const BnPartDesc* __restrict__ desc, int num, const float* __restrict__ ws,
@@ -729,10 +732,11 @@ __global__ __launch_bounds__(256) void bn_partials_reduce_kernel(
   float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
   if (active) {
     const float* base = ws + d.ws_off + c;
-    const size_t bstride = (size_t)2 * d.c;
+    const int half = d.wide > 0 ? d.wide : d.c;
+    const size_t bstride = (size_t)2 * half;
     for (int b = ty; b < d.nblocks; b += 16) {
       const float4 vb = *reinterpret_cast<const float4*>(base + b * bstride);
-      const float4 vg = *reinterpret_cast<const float4*>(base + b * bstride + d.c);
+      const float4 vg = *reinterpret_cast<const float4*>(base + b * bstride + half);
       sb.x += vb.x; sb.y += vb.y; sb.z += vb.z; sb.w += vb.w;
       sg.x += vg.x; sg.y += vg.y; sg.z += vg.z; sg.w += vg.w;
     }

@@ -240,6 +240,42 @@ def conv_dgrad_bn_relu(dc, ldc, coff, w, y, ldy, yoff, scale, beta, gamma, dc_ou
             cout, kh, kw, stride, _stream())
 
 
+class BnProducer(ctypes.Structure):
+  """C2dBnProducer of include/cap2det_hip.h."""
+  _fields_ = [("scale", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
+              ("width", ctypes.c_int), ("identity", ctypes.c_int)]
+
+
+def conv1x1_dgrad_multi_bn_relu_blocks(couts, rows, cin):
+  arr = (ctypes.c_int * len(couts))(*couts)
+  return int(_lib.load().c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks(len(couts), arr, rows, cin))
+
+
+def bn_producers(prods):
+  """[(scale, beta, gamma, width) or (None, None, None, width) for a pooling branch] -> array."""
+  arr = (BnProducer * len(prods))()
+  for i, (sc, be, ga, width) in enumerate(prods):
+    arr[i].scale = _p(sc) if sc is not None else None
+    arr[i].beta = _p(be) if be is not None else None
+    arr[i].gamma = _p(ga) if ga is not None else None
+    arr[i].width = width
+    arr[i].identity = 1 if sc is None else 0
+  return arr
+
+
+def conv1x1_dgrad_multi_bn_relu(dcs, ldcs, coffs, ws, couts, y, ldy, yoff, prods, dx, lddx, dxoff,
+                                partials, rows, cin, accumulate):
+  """c2d_conv1x1_dgrad_multi as the last writer of a block-input gradient, fused with the
+  BN/ReLU backward of the producers of the block input (fp32).  prods: bn_producers(...)."""
+  n = len(dcs)
+  assert dcs[0].dtype == torch.float32
+  pa = (ctypes.c_void_p * n)(*[_p(t) for t in dcs])
+  pw = (ctypes.c_void_p * n)(*[_p(t) for t in ws])
+  il = (ctypes.c_int * n)(*ldcs); io = (ctypes.c_int * n)(*coffs); ic = (ctypes.c_int * n)(*couts)
+  _lib.call("c2d_conv1x1_dgrad_multi_bn_relu", n, pa, il, io, pw, ic, _p(y), ldy, yoff, len(prods),
+            prods, _p(dx), lddx, dxoff, _p(partials), rows, cin, int(accumulate), _stream())
+
+
 def bn_relu_bwd_partial_blocks(rows, c):
   return int(_lib.load().c2d_bn_relu_bwd_partial_blocks(rows, c))
 

@@ -518,8 +518,43 @@ class Net(object):
               prod["fused_blocks"] = nb
               if "dc_entry" in prod:        # (entry convolution of the fused multi-segment dgrad)
                 prod["dc_entry"] = prod["gy"].t
+      # The same at a block boundary (fp32): the summed input gradient of a block whose input is
+      # the concat buffer of the block in front is written last by the multi-segment GEMM of its
+      # 1x1 entry convolutions (c2d_conv1x1_dgrad_multi_bn_relu) — it applies the BN/ReLU backward
+      # of the LAST op of every branch of the block in front, per column range.
+      for i in range(first_idx + 1, len(steps)):
+        cur, prev = steps[i], steps[i - 1]
+        if not (cur["kind"] == "block" and prev["kind"] == "block" and cur["n"] >= 64 and
+                self.dtype == torch.float32):
+          continue
+        entry = [b[0] for b in cur["branches"] if "dc_entry" in b[0]]
+        lasts = [b[-1] for b in prev["branches"]]
+        if len(entry) < 2 or not all(p["kind"] == "pool" or p["layer"].trainable for p in lasts):
+          continue
+        rows = cur["n"] * cur["ih"] * cur["iw"]
+        nb = ops.conv1x1_dgrad_multi_bn_relu_blocks([b["layer"].cout for b in entry], rows, cur["cin"])
+        if nb <= 0:
+          continue
+        owner = dict(nb=nb, ctot=cur["cin"], keep=[])
+        prods, off = [], 0
+        for p in lasts:
+          width = p["y"].c
+          if p["kind"] == "conv":
+            Lp = p["layer"]
+            sc, be = Lp.scale, self.store.var[Lp.name + "/BatchNorm/beta"]
+            ga = self.store.var.get(Lp.name + "/BatchNorm/gamma")
+            owner["keep"] += [sc, be, ga]
+            prods.append((sc, be, ga, width))
+            p["fused_blocks"] = nb
+            p["fused_wide"] = (owner, off)
+          else:
+            prods.append((None, None, None, width))
+          off += width
+        assert off == cur["cin"]
+        owner["prods"] = ops.bn_producers(prods)
+        cur["fuse_out"] = owner
     ddt = np.dtype([("ws", "<i8"), ("dbeta", "<i8"), ("dgamma", "<i8"), ("nblocks", "<i4"),
-                    ("c", "<i4"), ("begin", "<i4"), ("pad", "<i4")])
+                    ("c", "<i4"), ("begin", "<i4"), ("wide", "<i4")])
     recs, ws_size, chunks = [], 0, 0
     voff = self.store.offset
     for st in convs:
@@ -527,9 +562,21 @@ class Net(object):
       if not L.trainable:
         continue
       rows = st["n"] * st["oh"] * st["ow"]
+      g = voff[L.name + "/BatchNorm/gamma"][0] if L.bn_scale else -1
+      if "fused_wide" in st:
+        # this layer's sums are a column range of the [block][2][concat width] rows written for
+        # the whole block boundary (one region per boundary, shared by its producers)
+        owner, coloff = st["fused_wide"]
+        if "ws_off" not in owner:
+          owner["ws_off"] = ws_size
+          ws_size += owner["nb"] * 2 * owner["ctot"]
+        st["bn_part"] = (owner["ws_off"], owner["nb"] * 2 * owner["ctot"])
+        recs.append((owner["ws_off"] + coloff, voff[L.name + "/BatchNorm/beta"][0], g, owner["nb"],
+                     L.cout, chunks, owner["ctot"]))
+        chunks += -(-L.cout // 64)
+        continue
       nb = st.get("fused_blocks") or ops.bn_relu_bwd_partial_blocks(rows, L.cout)
       st["bn_part"] = (ws_size, nb * 2 * L.cout)
-      g = voff[L.name + "/BatchNorm/gamma"][0] if L.bn_scale else -1
       recs.append((ws_size, voff[L.name + "/BatchNorm/beta"][0], g, nb, L.cout, chunks, 0))
       ws_size += nb * 2 * L.cout
       chunks += -(-L.cout // 64)
@@ -597,16 +644,16 @@ class Net(object):
       ops.bn_partials_reduce_batched(plan["bn_desc"], plan["bn_num"], plan["bn_chunks"],
                                      plan["bn_ws"], self.store.grads)
 
-  def _wgrad(self, plan, st, x, dc):
+  def _wgrad(self, plan, st, x, dc, dcld, dcoff):
     L = st["layer"]
     part = st.get("wpart")
     if part is not None:
       off, size, (desc, num, chunks) = part
-      ops.conv_wgrad_partial(x.t, x.ld, x.off, dc, L.cout, 0, plan["wpart_ws"][off:off + size],
+      ops.conv_wgrad_partial(x.t, x.ld, x.off, dc, dcld, dcoff, plan["wpart_ws"][off:off + size],
                              st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
       ops.wgrad_reduce_batched(desc, num, chunks, plan["wpart_ws"], self.store.grads)
     else:
-      ops.conv_wgrad(x.t, x.ld, x.off, dc, L.cout, 0, self.store.grad[L.name + "/weights"],
+      ops.conv_wgrad(x.t, x.ld, x.off, dc, dcld, dcoff, self.store.grad[L.name + "/weights"],
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
 
   def _conv_bwd(self, plan, st, x, gx, accumulate, dc=None):
@@ -616,9 +663,11 @@ class Net(object):
     rows = st["n"] * st["oh"] * st["ow"]
     side = self.side if (L.trainable and plan.get("dc_alt") is not None) else None
     slot = None
+    dcld, dcoff = L.cout, 0
     if "fused_blocks" in st:
       # the consumer's fused input-gradient launch left this layer's dc in its gradient buffer
-      dc = gy.t.view(rows, L.cout)
+      # (an inner layer's own dense buffer, or its columns of a concat gradient)
+      dc, dcld, dcoff = gy.t, gy.ld, gy.off
     if dc is None:
       buf = plan["dc"]
       if side is not None:
@@ -654,27 +703,36 @@ class Net(object):
       ready.record()
       side.wait_event(ready)
       with torch.cuda.stream(side):
-        self._wgrad(plan, st, x, dc)
+        self._wgrad(plan, st, x, dc, dcld, dcoff)
         if slot is not None:
           plan["dc_events"][slot] = torch.cuda.Event()
           plan["dc_events"][slot].record()
       plan["side_pending"] = True
     elif tr:
-      self._wgrad(plan, st, x, dc)
+      self._wgrad(plan, st, x, dc, dcld, dcoff)
     prod = st.get("fuse_prev")
     if prod is not None and gx is not None:
       # gx is the producer's (dense) gradient buffer: it receives the producer's dc directly
       assert not accumulate and gx.off == 0 and gx.ld == L.cin
       Lp, yp = prod["layer"], prod["y"]
       off, size = prod["bn_part"]
-      ops.conv_dgrad_bn_relu(dc, L.cout, 0, L.w_for(self.dtype), yp.t, yp.ld, yp.off, Lp.scale,
+      ops.conv_dgrad_bn_relu(dc, dcld, dcoff, L.w_for(self.dtype), yp.t, yp.ld, yp.off, Lp.scale,
                              self.store.var[Lp.name + "/BatchNorm/beta"],
                              self.store.var.get(Lp.name + "/BatchNorm/gamma"), gx.t,
                              plan["bn_ws"][off:off + size], st["n"], st["ih"], st["iw"], L.cin,
                              L.cout, L.k, L.k, L.stride)
     elif gx is not None:
-      ops.conv_dgrad(dc, L.cout, 0, L.w_for(self.dtype), gx.t, gx.ld, gx.off,
+      ops.conv_dgrad(dc, dcld, dcoff, L.w_for(self.dtype), gx.t, gx.ld, gx.off,
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
+
+  @staticmethod
+  def _entry_dc(b):
+    """(tensor, row stride, column offset) of an entry convolution's dc for the multi-segment
+    input-gradient GEMM: its own buffer, or — a one-convolution branch whose BN/ReLU backward the
+    NEXT block's boundary launch applied — its columns of the concat gradient."""
+    if "fused_wide" in b:
+      return b["gy"].t, b["gy"].ld, b["gy"].off
+    return b["dc_entry"], b["layer"].cout, 0
 
   def _bwd_step(self, plan, st, x, gx, accumulate):
     kind = st["kind"]
@@ -698,12 +756,33 @@ class Net(object):
       fused = [b for b in firsts if gx is not None and b["kind"] == "conv" and
                b["layer"].k == 1 and b["layer"].stride == 1 and "dc_entry" in b]
       written = False
+      owner = st.get("fuse_out")
+      if owner is not None and gx is not None and len(fused) >= 2:
+        # block boundary fusion (see _prepare_backward): the other first ops (the pooling branch)
+        # write the block-input gradient first, the multi-segment GEMM accumulates onto it and —
+        # last writer — applies the BN/ReLU backward of the producers of the block input
+        for b in firsts:
+          if not any(b is f for f in fused):
+            self._bwd_step(plan, b, x, gx, written)
+            written = True
+        for b in fused:
+          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"])
+        rows = st["n"] * st["ih"] * st["iw"]
+        ws0 = owner["ws_off"]
+        segs = [self._entry_dc(b) for b in fused]
+        ops.conv1x1_dgrad_multi_bn_relu(
+            [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],
+            [b["layer"].w_for(self.dtype) for b in fused], [b["layer"].cout for b in fused],
+            x.t, x.ld, x.off, owner["prods"], gx.t, gx.ld, gx.off,
+            plan["bn_ws"][ws0:ws0 + owner["nb"] * 2 * owner["ctot"]], rows, st["cin"], written)
+        return
       if len(fused) >= 2:
         for b in fused:
           self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"])
         rows = st["n"] * st["ih"] * st["iw"]
+        segs = [self._entry_dc(b) for b in fused]
         ops.conv1x1_dgrad_multi(
-            [b["dc_entry"] for b in fused], [b["layer"].cout for b in fused], [0] * len(fused),
+            [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],
             [b["layer"].w_for(self.dtype) for b in fused],
             [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off, rows, st["cin"], False)
         written = True

@@ -206,8 +206,11 @@ int c2d_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ld
  * gradients become bitwise reproducible and the kernel keeps >= 1000 row blocks in flight.
  * c2d_bn_relu_bwd_partial_blocks(rows, c) = number of row blocks (size the workspace with it).
  * desc: DEVICE array of struct { int64 ws_off, dbeta_off, dgamma_off (-1: none); int32 nblocks,
- * c, chunk_begin, pad; } sorted by chunk_begin = running count of ceil(c/64) channel chunks;
- * ws_off indexes `ws`, dbeta_off/dgamma_off index `grads` (floats). */
+ * c, chunk_begin, wide; } sorted by chunk_begin = running count of ceil(c/64) channel chunks;
+ * ws_off indexes `ws`, dbeta_off/dgamma_off index `grads` (floats).  wide = 0, or the width W of
+ * the partial rows when the layer's c columns are a slice of rows [2][W] written for a whole
+ * concat buffer (c2d_conv1x1_dgrad_multi_bn_relu): ws_off then addresses the layer's first
+ * column in block 0's first half. */
 int c2d_bn_relu_bwd_partial_blocks(int rows, int c);
 int c2d_bn_relu_bwd_partial(const float* dy, int lddy, int dyoff, const float* y, int ldy,
                             int yoff, const float* scale, const float* beta, const float* gamma,
@@ -228,6 +231,28 @@ int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks, 
  * (stride 2: its four parity-class launches) writes; -1 for an unsupported shape. */
 int c2d_conv_dgrad_bn_relu_partial_blocks(int elem_size, int n, int ih, int iw, int cin, int cout,
                                           int kh, int kw, int stride);
+/* The same fusion for the summed input gradient of an Inception block (c2d_conv1x1_dgrad_multi)
+ * whose input is the concat buffer of the block in front: the columns belong to up to four
+ * PRODUCERS (the last op of each branch of that block), in column order.  identity != 0: a
+ * pooling branch (no BatchNorm / ReLU: its columns keep the plain gradient, sums stay zero).
+ * accumulate != 0: dx already holds the other contributions to the block-input gradient (the
+ * pooling branch of THIS block) and the mask / scale / sums apply to the complete sum, which is
+ * why this launch has to be the last writer of dx.  partials[block][2][cin]; the producers'
+ * halves are the column ranges of each row. */
+typedef struct C2dBnProducer {
+  const float* scale;   /* [width] folded BN scale (NULL when identity) */
+  const float* beta;    /* [width] or NULL (no gamma sums) */
+  const float* gamma;   /* [width] or NULL */
+  int width;            /* columns of this producer (multiple of 4) */
+  int identity;
+} C2dBnProducer;
+int c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks(int nseg, const int* couts, int rows, int cin);
+int c2d_conv1x1_dgrad_multi_bn_relu(int nseg, const float* const* dcs, const int* ldcs,
+                                    const int* coffs, const float* const* ws, const int* couts,
+                                    const float* y, int ldy, int yoff, int nprod,
+                                    const C2dBnProducer* prods, float* dx, int lddx, int dxoff,
+                                    float* partials, int rows, int cin, int accumulate,
+                                    void* stream);
 int c2d_conv_dgrad_bn_relu(const float* dc, int ldc, int coff, const float* w, const float* y,
                            int ldy, int yoff, const float* scale, const float* beta,
                            const float* gamma, float* dc_out, float* partials, int n, int ih,

@@ -242,6 +242,61 @@ def test_conv_dgrad_bn_relu(ops, case, with_gamma):
   assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("accumulate", [False, True], ids=["overwrite", "accumulate"])
+@pytest.mark.parametrize("rows,cin,couts,widths", [
+    (2000, 64, (32, 48), (24, 40)),                    # two producers
+    (3333, 256, (96, 64, 32), (96, 32, 128)),          # the middle one a pooling branch
+    (5000, 1024, (352, 192, 160), (352, 320, 224, 128)),   # Mixed_5b -> Mixed_5c widths
+])
+def test_conv1x1_dgrad_multi_bn_relu(ops, rows, cin, couts, widths, accumulate):
+  """Summed 1x1 input gradient of a block as the last writer of the block-input gradient, with
+  the BN/ReLU backward of the producers of the block input per column range; the second of three
+  producers is a pooling branch (plain gradient, zero sums)."""
+  rng = np.random.default_rng(31)
+  assert sum(widths) == cin
+  dcs = [rng.standard_normal((rows, c)).astype(np.float32) for c in couts]
+  wsn = [(rng.standard_normal((cin, c)) / np.sqrt(c)).astype(np.float32) for c in couts]
+  y = np.maximum(rng.standard_normal((rows, cin)), 0).astype(np.float32)
+  base = rng.standard_normal((rows, cin)).astype(np.float32)
+  dx = sum(d.astype(np.float64) @ w.astype(np.float64).T for d, w in zip(dcs, wsn))
+  if accumulate:
+    dx = dx + base
+  identity = [len(widths) == 3 and i == 1 for i in range(len(widths))]
+  want, prods, keep, off = np.empty_like(dx), [], [], 0
+  want_sums = np.zeros((2, cin))
+  for width, ident in zip(widths, identity):
+    sl = slice(off, off + width)
+    if ident:
+      want[:, sl] = dx[:, sl]
+      prods.append((None, None, None, width))
+    else:
+      scale = rng.uniform(0.5, 1.5, width).astype(np.float32)
+      beta = (0.1 * rng.standard_normal(width)).astype(np.float32)
+      gamma = rng.uniform(0.5, 1.5, width).astype(np.float32)
+      dz = dx[:, sl] * (y[:, sl] > 0)
+      want[:, sl] = dz * scale
+      want_sums[0, sl] = dz.sum(0)
+      want_sums[1, sl] = (dz * (y[:, sl].astype(np.float64) - beta) / gamma).sum(0)
+      t = (_t(scale), _t(beta), _t(gamma))
+      keep.append(t)
+      prods.append(t + (width,))
+    off += width
+  nb = ops.conv1x1_dgrad_multi_bn_relu_blocks(list(couts), rows, cin)
+  assert nb >= 1
+  out = _t(base).clone() if accumulate else torch.full((rows, cin), 5.0, device=DEV)
+  part = torch.full((nb, 2, cin), 7.0, device=DEV)
+  wts = [_t(w) for w in wsn]                       # [cin][cout], as c2d_conv1x1_dgrad_multi
+  ops.conv1x1_dgrad_multi_bn_relu([_t(d) for d in dcs], list(couts), [0] * len(couts), wts,
+                                  list(couts), _t(y), cin, 0, ops.bn_producers(prods), out, cin, 0,
+                                  part, rows, cin, accumulate)
+  sc = np.abs(want).max()
+  np.testing.assert_allclose(_n(out), want, rtol=1e-4, atol=1e-5 * sc + 1e-6)
+  sums = _n(part).astype(np.float64).sum(0)
+  for k in range(2):
+    np.testing.assert_allclose(sums[k], want_sums[k], rtol=1e-4,
+                               atol=1e-4 * max(np.abs(want_sums[k]).max(), 1.0))
+
+
 @pytest.mark.parametrize("mode,stride", [(0, 1), (0, 2), (1, 1)])
 @pytest.mark.parametrize("ih,iw,n", [(7, 7, 6), (4, 4, 6), (9, 5, 6), (7, 7, 70), (4, 4, 70)])
 def test_pool3x3(ops, mode, stride, ih, iw, n):

@@ -255,7 +255,8 @@ def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd):
   through the engine's launch plan against ref_model.net_forward / net_backward in float64:
   output map, input gradient and every filter / BatchNorm gradient.  Both backward plans: the
   BN/ReLU backward of the inner convolutions fused into their consumers' input-gradient GEMMs
-  (c2d_conv_dgrad_bn_relu; nine producer layers here) and as separate launches."""
+  (c2d_conv_dgrad_bn_relu, nine producer layers here; c2d_conv1x1_dgrad_multi_bn_relu at the two
+  block boundaries, six more) and as separate launches."""
   monkeypatch.setenv("C2D_FUSE_BN_BWD", fuse_bn_bwd)
   from cap2det_amd import hip_ops
   from cap2det_amd.models.frcnn_engine import SECOND_SCOPE, SECOND_STAGE, DerivedStore, Net, Ref, VariableStore
@@ -313,9 +314,12 @@ def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd):
   store.grads.zero_()
   net.backward(plan, xin, 0, dx)
   torch.cuda.synchronize()
-  fused = sum(1 for st in plan["steps"] if st["kind"] == "block" for b in st["branches"] for op in b
-              if "fused_blocks" in op)
-  assert fused == (9 if fuse_bn_bwd == "1" else 0)
+  ops_ = [op for st in plan["steps"] if st["kind"] == "block" for b in st["branches"] for op in b]
+  inner = sum(1 for op in ops_ if "fused_blocks" in op and "fused_wide" not in op)
+  boundary = sum(1 for op in ops_ if "fused_wide" in op)
+  # nine inner producers; at the two block boundaries the last convolutions of Mixed_5a (2, its
+  # third branch is the max pool) and of Mixed_5b (4)
+  assert (inner, boundary) == ((9, 6) if fuse_bn_bwd == "1" else (0, 0))
   want_dx, grads = ref_model.net_backward(ref_model.SECOND_STAGE, tape, dy.astype(np.float64), P64,
                                           ref_model.SECOND_SCOPE, 0, True)
   _scale_close(_n(dx.t).reshape(want_dx.shape), want_dx, 5e-5, "second stage input gradient")
