@@ -295,13 +295,39 @@ __global__ __launch_bounds__(256) void pool3x3_map_bwd_kernel(
 // dc = dy * (y > 0) * scale[c];  dbeta[c] += sum dz;  dgamma[c] += sum dz * (y - beta)/gamma
 // where dz = dy * (y > 0).  (y = gamma*xhat + beta wherever y > 0, so xhat = (y-beta)/gamma.)
 // Block: TX lanes over float4 channel groups x TY row lanes; LDS reduce over TY.
-template <int TX, typename T>
+// HEAD: dy is not read but derived from the gradient of the spatially averaged (and dropped-out)
+// features, dy[r][c] = dmean[r / spatial][c] * mask[r / spatial][c] * mul — the backward of
+// c2d_spatial_mean_dropout_fwd folded into this kernel (c2d_bn_relu_bwd_partial_head).
+struct HeadGrad {
+  const float* dmean; int ld, off;
+  const uint8_t* mask; int mask_ld, mask_off;
+  int spatial; float mul;
+};
+
+template <bool HEAD, typename T>
+__device__ __forceinline__ float4 bn_bwd_dy(const T* dy, int lddy, int dyoff, const HeadGrad& hg,
+                                            int r, int c) {
+  if constexpr (HEAD) {
+    const int rr = r / hg.spatial;
+    float4 g = *reinterpret_cast<const float4*>(hg.dmean + (size_t)rr * hg.ld + hg.off + c);
+    float4 m = make_float4(hg.mul, hg.mul, hg.mul, hg.mul);
+    if (hg.mask) {
+      const uchar4 k = *reinterpret_cast<const uchar4*>(hg.mask + (size_t)rr * hg.mask_ld + hg.mask_off + c);
+      m.x *= (float)k.x; m.y *= (float)k.y; m.z *= (float)k.z; m.w *= (float)k.w;
+    }
+    return make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);
+  } else {
+    return c2d_ld4(dy + (size_t)r * lddy + dyoff + c);
+  }
+}
+
+template <int TX, typename T, bool HEAD = false>
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
     const T* __restrict__ dy, int lddy, int dyoff, const T* __restrict__ y, int ldy,
     int yoff, const float* __restrict__ scale, const float* __restrict__ beta,
     const float* __restrict__ gamma, T* __restrict__ dc, float* __restrict__ dbeta,
     float* __restrict__ dgamma, float* __restrict__ partials, int M, int c4n,
-    int rows_per_block) {
+    int rows_per_block, HeadGrad hg) {
   constexpr int TY = 256 / TX;
   __shared__ float4 red[2][TY][TX];
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -327,7 +353,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
         float4 g[4], v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          g[u] = c2d_ld4(dy + (size_t)(r + u * TY) * lddy + dyoff + c);
+          g[u] = bn_bwd_dy<HEAD>(dy, lddy, dyoff, hg, r + u * TY, c);
           v[u] = c2d_ld4(y + (size_t)(r + u * TY) * ldy + yoff + c);
         }
 #pragma unroll
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
         }
       }
       for (; r < r1; r += TY) {
-        const float4 g = c2d_ld4(dy + (size_t)r * lddy + dyoff + c);
+        const float4 g = bn_bwd_dy<HEAD>(dy, lddy, dyoff, hg, r, c);
         const float4 v = c2d_ld4(y + (size_t)r * ldy + yoff + c);
         float4 dz;
         dz.x = v.x > 0.f ? g.x : 0.f; dz.y = v.y > 0.f ? g.y : 0.f;
@@ -776,17 +802,25 @@ template <typename T>
 int launch_bn_relu_bwd(const T* dy, int lddy, int dyoff, const T* y, int ldy, int yoff,
                        const float* scale, const float* beta, const float* gamma, T* dc,
                        float* dbeta, float* dgamma, float* partials, int rows, int c,
-                       int rows_per_block, hipStream_t s) {
+                       int rows_per_block, hipStream_t s, const HeadGrad* head = nullptr) {
   const int c4n = c / 4;
   const int blocks = c2d_ceil_div(rows, rows_per_block);
+  const HeadGrad hg = head ? *head : HeadGrad{nullptr, 0, 0, nullptr, 0, 0, 1, 1.0f};
 #define C2D_BNB(TX)                                                                          \
-  hipLaunchKernelGGL((bn_relu_bwd_kernel<TX, T>), dim3(blocks), dim3(256), 0, s, dy, lddy, dyoff, \
-                     y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, partials, rows, c4n, \
-                     rows_per_block)
-  if (c4n <= 16) C2D_BNB(16);
-  else if (c4n <= 32) C2D_BNB(32);
-  else if (c4n <= 64) C2D_BNB(64);
-  else C2D_BNB(128);
+  {                                                                                          \
+    if (head)                                                                                \
+      hipLaunchKernelGGL((bn_relu_bwd_kernel<TX, T, true>), dim3(blocks), dim3(256), 0, s, dy, lddy, \
+                         dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, partials, rows, \
+                         c4n, rows_per_block, hg);                                           \
+    else                                                                                     \
+      hipLaunchKernelGGL((bn_relu_bwd_kernel<TX, T, false>), dim3(blocks), dim3(256), 0, s, dy, lddy, \
+                         dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, partials, rows, \
+                         c4n, rows_per_block, hg);                                           \
+  }
+  if (c4n <= 16) C2D_BNB(16)
+  else if (c4n <= 32) C2D_BNB(32)
+  else if (c4n <= 64) C2D_BNB(64)
+  else C2D_BNB(128)
 #undef C2D_BNB
   return c2d_launch_status();
 }
@@ -914,6 +948,45 @@ extern "C" int c2d_bn_relu_bwd_partial_bf16(const void* dy, int lddy, int dyoff,
                                       yoff, scale, beta, gamma, (c2d_bf16*)dc, nullptr, nullptr,
                                       partials, rows, c, bn_rows_per_block(rows),
                                       (hipStream_t)stream);
+}
+
+// Head form: the gradient of the spatially averaged features instead of a dy buffer (HeadGrad).
+template <typename T>
+static int bn_relu_bwd_partial_head_impl(const float* dmean, int ldd, int doff, const uint8_t* mask,
+                                         int mask_ld, int mask_off, int spatial, float keep_prob,
+                                         const T* y, int ldy, int yoff, const float* scale,
+                                         const float* beta, const float* gamma, T* dc,
+                                         float* partials, int rows, int c, void* stream) {
+  C2D_CHECK_ARG(dmean && y && scale && beta && dc && partials && rows > 0 && c > 0 && c % 4 == 0);
+  C2D_CHECK_ARG(ldd % 4 == 0 && doff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0 && spatial > 0 &&
+                rows % spatial == 0 && keep_prob > 0.f && (!mask || (mask_ld % 4 == 0 && mask_off % 4 == 0)));
+  const HeadGrad hg = {dmean, ldd, doff, mask, mask_ld, mask_off, spatial,
+                       (mask ? 1.0f / keep_prob : 1.0f) / (float)spatial};
+  return launch_bn_relu_bwd<T>(nullptr, 0, 0, y, ldy, yoff, scale, beta, gamma, dc, nullptr, nullptr,
+                               partials, rows, c, bn_rows_per_block(rows), (hipStream_t)stream, &hg);
+}
+
+extern "C" int c2d_bn_relu_bwd_partial_head(const float* dmean, int ldd, int doff,
+                                            const uint8_t* mask, int mask_ld, int mask_off,
+                                            int spatial, float keep_prob, const float* y, int ldy,
+                                            int yoff, const float* scale, const float* beta,
+                                            const float* gamma, float* dc, float* partials,
+                                            int rows, int c, void* stream) {
+  return bn_relu_bwd_partial_head_impl<float>(dmean, ldd, doff, mask, mask_ld, mask_off, spatial,
+                                              keep_prob, y, ldy, yoff, scale, beta, gamma, dc,
+                                              partials, rows, c, stream);
+}
+
+extern "C" int c2d_bn_relu_bwd_partial_head_bf16(const float* dmean, int ldd, int doff,
+                                                 const uint8_t* mask, int mask_ld, int mask_off,
+                                                 int spatial, float keep_prob, const void* y,
+                                                 int ldy, int yoff, const float* scale,
+                                                 const float* beta, const float* gamma, void* dc,
+                                                 float* partials, int rows, int c, void* stream) {
+  return bn_relu_bwd_partial_head_impl<c2d_bf16>(dmean, ldd, doff, mask, mask_ld, mask_off, spatial,
+                                                 keep_prob, (const c2d_bf16*)y, ldy, yoff, scale,
+                                                 beta, gamma, (c2d_bf16*)dc, partials, rows, c,
+                                                 stream);
 }
 
 extern "C" int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks,

@@ -240,6 +240,16 @@ def conv_dgrad_bn_relu(dc, ldc, coff, w, y, ldy, yoff, scale, beta, gamma, dc_ou
             cout, kh, kw, stride, _stream())
 
 
+def bn_relu_bwd_partial_head(dmean, ldd, doff, mask, mask_ld, mask_off, spatial, keep_prob, y, ldy,
+                             yoff, scale, beta, gamma, dc, partials, rows, c):
+  """bn_relu_bwd_partial with dy derived from the gradient of the averaged features."""
+  fn = "c2d_bn_relu_bwd_partial_head_bf16" if y.dtype == torch.bfloat16 else "c2d_bn_relu_bwd_partial_head"
+  assert dmean.dtype == torch.float32 and dc.dtype == y.dtype
+  _lib.call(fn, _p(dmean), ldd, doff, _p(mask) if mask is not None else None, mask_ld, mask_off,
+            spatial, float(keep_prob), _p(y), ldy, yoff, _p(scale), _p(beta),
+            _p(gamma) if gamma is not None else None, _p(dc), _p(partials), rows, c, _stream())
+
+
 class BnProducer(ctypes.Structure):
   """C2dBnProducer of include/cap2det_hip.h."""
   _fields_ = [("scale", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("gamma", ctypes.c_void_p),

@@ -553,6 +553,16 @@ class Net(object):
         assert off == cur["cin"]
         owner["prods"] = ops.bn_producers(prods)
         cur["fuse_out"] = owner
+    # The last block's last convolutions write the network output: when every branch ends in a
+    # trainable convolution over per-ROI maps, their BN/ReLU backward can take the gradient of
+    # the averaged features directly (plan["head_grad"], set by the caller of backward()).
+    last = steps[-1]
+    plan["head_ok"] = False
+    if (os.environ.get("C2D_FUSE_BN_BWD", "1") != "0" and last["kind"] == "block" and last["n"] >= 64 and
+        all(b[-1]["kind"] == "conv" and b[-1]["layer"].trainable for b in last["branches"])):
+      plan["head_ok"] = True
+      for b in last["branches"]:
+        b[-1]["head_producer"] = True
     ddt = np.dtype([("ws", "<i8"), ("dbeta", "<i8"), ("dgamma", "<i8"), ("nblocks", "<i4"),
                     ("c", "<i4"), ("begin", "<i4"), ("wide", "<i4")])
     recs, ws_size, chunks = [], 0, 0
@@ -682,8 +692,17 @@ class Net(object):
     gamma = self.store.var.get(L.name + "/BatchNorm/gamma")
     beta = self.store.var[L.name + "/BatchNorm/beta"]
     tr = L.trainable
+    head = plan.get("head_grad") if st.get("head_producer") else None
     if "fused_blocks" in st:
       pass            # dc was written by the consumer's fused input-gradient launch
+    elif head is not None and tr and "bn_part" in st:
+      # a convolution that writes the network output: its dy is a function of the gradient of the
+      # averaged features (c2d_bn_relu_bwd_partial_head), the gradient map is never stored
+      off, size = st["bn_part"]
+      ops.bn_relu_bwd_partial_head(head["dmean"], head["ld"], head["off"] + y.off, head["mask"],
+                                   head["mask_ld"], y.off, head["spatial"], head["keep_prob"],
+                                   y.t, y.ld, y.off, L.scale, beta, gamma, dc,
+                                   plan["bn_ws"][off:off + size], rows, L.cout)
     elif tr and "bn_part" in st:
       off, size = st["bn_part"]
       ops.bn_relu_bwd_partial(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
@@ -1154,9 +1173,16 @@ class FrcnnEngine(object):
     bufs, b, n = ctx["bufs"], ctx["b"], ctx["n"]
     plan2 = bufs["plan2"]
     gnet = self.second.out_grad(plan2, 0)
-    ops.spatial_mean_dropout_bwd(dfeatures, lddf, dfoff, gnet.t, ctx["mask"], b * n,
-                                 bufs["spatial"], self.feature_dims,
-                                 self.keep_prob if ctx["mask"] is not None else 1.0)
+    if plan2.get("head_ok"):
+      # the output convolutions' BN/ReLU backward derives its dy from dfeatures (Net._conv_bwd)
+      plan2["head_grad"] = dict(dmean=dfeatures, ld=lddf, off=dfoff, mask=ctx["mask"],
+                                mask_ld=self.feature_dims, spatial=bufs["spatial"],
+                                keep_prob=self.keep_prob if ctx["mask"] is not None else 1.0)
+    else:
+      plan2["head_grad"] = None
+      ops.spatial_mean_dropout_bwd(dfeatures, lddf, dfoff, gnet.t, ctx["mask"], b * n,
+                                   bufs["spatial"], self.feature_dims,
+                                   self.keep_prob if ctx["mask"] is not None else 1.0)
     need_first = self.first_trainable_idx is not None
     dpooled = None
     if need_first:

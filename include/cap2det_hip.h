@@ -217,6 +217,17 @@ int c2d_bn_relu_bwd_partial(const float* dy, int lddy, int dyoff, const float* y
                             float* dc, float* partials, int rows, int c, void* stream);
 int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks, const float* ws,
                                    float* grads, void* stream);
+/* c2d_bn_relu_bwd_partial for the convolutions that write the network OUTPUT, with the backward of
+ * c2d_spatial_mean_dropout_fwd folded in: instead of a dy buffer the kernel takes the gradient of
+ * the averaged features, dy[r][c] = dmean[r / spatial][doff + c] * mask[r / spatial][mask_off + c]
+ * / keep_prob / spatial (mask NULL: no dropout) — models/utils.py:183-188 (reduce_mean over the
+ * map, slim.dropout) differentiated; the per-pixel gradient map is never materialised.
+ * rows = ROIs * spatial (rows of y / dc); same row blocks as c2d_bn_relu_bwd_partial_blocks. */
+int c2d_bn_relu_bwd_partial_head(const float* dmean, int ldd, int doff, const uint8_t* mask,
+                                 int mask_ld, int mask_off, int spatial, float keep_prob,
+                                 const float* y, int ldy, int yoff, const float* scale,
+                                 const float* beta, const float* gamma, float* dc,
+                                 float* partials, int rows, int c, void* stream);
 
 /* c2d_conv_dgrad fused with the c2d_bn_relu_bwd_partial of the layer that PRODUCED the
  * convolution's input (two consecutive slim.conv2d of an Inception branch, reference
@@ -458,6 +469,11 @@ int c2d_bn_relu_bwd_partial_bf16(const void* dy, int lddy, int dyoff, const void
                                  int yoff, const float* scale, const float* beta,
                                  const float* gamma, void* dc, float* partials, int rows, int c,
                                  void* stream);
+int c2d_bn_relu_bwd_partial_head_bf16(const float* dmean, int ldd, int doff, const uint8_t* mask,
+                                      int mask_ld, int mask_off, int spatial, float keep_prob,
+                                      const void* y, int ldy, int yoff, const float* scale,
+                                      const float* beta, const float* gamma, void* dc,
+                                      float* partials, int rows, int c, void* stream);
 int c2d_conv_dgrad_bn_relu_bf16(const void* dc, int ldc, int coff, const void* w, const void* y,
                                 int ldy, int yoff, const float* scale, const float* beta,
                                 const float* gamma, void* dc_out, float* partials, int n, int ih,

@@ -109,9 +109,15 @@ def _check_train_step(pipeline, dm, hw, n, nums, make_labels, extra_examples=Non
   return trainer
 
 
-@pytest.mark.parametrize("dm,hw,n,nums", [(1.0, (64, 48), 6, [6, 4]), (0.5, (40, 72), 9, [9, 0])])
+@pytest.mark.parametrize("dm,hw,n,nums", [(1.0, (64, 48), 6, [6, 4]), (0.5, (40, 72), 9, [9, 0]),
+                                          (0.5, (40, 56), 32, [32, 20])])
 def test_train_step_matches_oracle(dm, hw, n, nums):
-  """BASELINE configs[0]/[1]: voc07_groundtruth (20 classes, labels from object_texts)."""
+  """BASELINE configs[0]/[1]: voc07_groundtruth (20 classes, labels from object_texts).
+  The third case has 64 per-ROI maps: the second stage then runs the launch plan of the
+  benchmark size (pixel-major GEMM rows, nine-tap filter gradients of >= 256-image batches
+  excepted) with the BN/ReLU backward fused into the input-gradient GEMMs, at the block
+  boundaries and into the head (c2d_conv_dgrad_bn_relu, c2d_conv1x1_dgrad_multi_bn_relu,
+  c2d_bn_relu_bwd_partial_head)."""
   _check_train_step(util_model.load_pipeline(), dm, hw, n, nums,
                     lambda ex, classes: ref_labels.groundtruth_extract(ex["object_texts"], classes))
 

@@ -356,6 +356,41 @@ def test_bn_relu_bwd(ops):
 
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rois,spatial,c,coff,ctot,with_mask", [
+    (70, 16, 96, 32, 160, True), (300, 16, 352, 0, 1024, True), (129, 4, 64, 64, 128, False)])
+def test_bn_relu_bwd_partial_head(ops, rois, spatial, c, coff, ctot, with_mask, dtype):
+  """BN/ReLU backward of an output convolution with the backward of the spatial mean + dropout
+  folded in (dy is never stored) against the two formulas applied one after the other."""
+  rng = np.random.default_rng(37)
+  rows = rois * spatial
+  dmean = rng.standard_normal((rois, ctot + 8)).astype(np.float32)      # columns [4, 4 + ctot)
+  mask = (rng.uniform(size=(rois, ctot)) < 0.5).astype(np.uint8) if with_mask else None
+  keep = 0.5 if with_mask else 1.0
+  yt = _t(np.maximum(rng.standard_normal((rows, ctot)), 0).astype(np.float32)).to(dtype)
+  y = yt.float().cpu().numpy()[:, coff:coff + c]
+  scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  g = dmean[:, 4 + coff:4 + coff + c].astype(np.float64)
+  if with_mask:
+    g = g * mask[:, coff:coff + c] / keep
+  dy = np.repeat(g / spatial, spatial, axis=0)
+  dz = dy * (y > 0)
+  nb = ops.bn_relu_bwd_partial_blocks(rows, c)
+  dc = torch.full((rows, c), 3.0, device=DEV, dtype=dtype)
+  part = torch.full((nb, 2, c), 7.0, device=DEV)
+  ops.bn_relu_bwd_partial_head(_t(dmean), ctot + 8, 4 + coff, _t(mask) if with_mask else None, ctot,
+                               coff, spatial, keep, yt, ctot, coff, _t(scale), _t(beta), _t(gamma),
+                               dc, part, rows, c)
+  tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+  np.testing.assert_allclose(dc.float().cpu().numpy(), dz * scale, rtol=tol, atol=tol * np.abs(dz).max())
+  sums = part.double().sum(0).cpu().numpy()
+  np.testing.assert_allclose(sums[0], dz.sum(0), rtol=1e-4, atol=1e-4 * np.abs(dz.sum(0)).max())
+  want_g = (dz * (y.astype(np.float64) - beta) / gamma).sum(0)
+  np.testing.assert_allclose(sums[1], want_g, rtol=1e-4, atol=1e-4 * max(np.abs(want_g).max(), 1.0))
+
+
 @pytest.mark.parametrize("rows,c,with_gamma", [(1000, 96, True), (70001, 352, True), (3136, 128, False)])
 def test_bn_relu_bwd_partial_form_is_reproducible(ops, rows, c, with_gamma):
   """Atomic-free form used by the training step: per-row-block partial sums + ONE batched
