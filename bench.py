@@ -111,6 +111,23 @@ class KernelTimer(object):
       # conv1x1_dgrad_multi(dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin, accumulate)
       return 2.0 * args[8] * args[9] * sum(args[4])
 
+    def fused_dgrad_work(args):
+      # conv_dgrad_bn_relu(dc, ldc, coff, w, y, ldy, yoff, scale, beta, gamma, dc_out, partials,
+      #                    n, ih, iw, cin, cout, kh, kw, stride)
+      n, ih, iw, cin, cout, kh, kw, stride = args[12:20]
+      oh, ow = -(-ih // stride), -(-iw // stride)
+      return 2.0 * n * oh * ow * cin * cout * kh * kw
+
+    def fused_multi_work(args):
+      # conv1x1_dgrad_multi_bn_relu(dcs, ldcs, coffs, ws, couts, y, ldy, yoff, prods, dx, lddx,
+      #                             dxoff, partials, rows, cin, accumulate)
+      return 2.0 * args[13] * args[14] * sum(args[4])
+
+    # (the input-gradient GEMMs with the producer layer's BN/ReLU backward in their epilogue are
+    # the same kernels: same family, the GEMM's FLOPs as algorithmic work)
+    ops.conv_dgrad_bn_relu = timed(ops.conv_dgrad_bn_relu, "igemm_nt", fused_dgrad_work)
+    ops.conv1x1_dgrad_multi_bn_relu = timed(ops.conv1x1_dgrad_multi_bn_relu, "igemm_nt",
+                                            fused_multi_work)
     ops.conv1x1_dgrad_multi = timed(ops.conv1x1_dgrad_multi, "igemm_nt", multi_work)
     ops.conv_fwd = timed(ops.conv_fwd, "igemm_nt", conv_work("fwd"))
     ops.conv_fwd_grouped = timed(ops.conv_fwd_grouped, "igemm_nt", lambda args: args[0][2])

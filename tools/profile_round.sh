@@ -31,6 +31,8 @@ for CFG in c1 c2; do
     if [ -n "$f" ]; then cp "$f" $O/${T}_summaries/${T}_bench_kernel_stats_${CFG}$( [ $K = serial_stats ] && echo _serial ).csv; fi
   done
 done
+# (bench.py quotes the PMC summaries of the SAME build: put them where it reads them)
+cp $O/${T}_summaries/${T}_traffic_c*.json $O/${T}_summaries/${T}_mfma_c*.json $R/profiles/
 find $O -name "*kernel_trace.csv" -path "*${T}_c*" -delete
 find $O -name "*counter_collection.csv" -path "*${T}_c*" -delete
 timeout 400 python bench.py > $O/${T}_summaries/${T}_bench_c1.json 2> $O/${T}_bench_c1.err
