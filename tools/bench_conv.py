@@ -1,6 +1,6 @@
 """Micro-benchmark of the conv kernels on the second-stage shapes (N=2000 ROIs)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cap2det_amd import hip_ops as ops
 dev = "cuda:0"
 SHAPES = [  # n, ih, cin, cout, k, stride
