@@ -30,7 +30,7 @@ __host__ __device__ inline PoolGeom make_pool_geom(int ih, int iw, int stride) {
 template <typename T>
 __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(
     const T* __restrict__ x, int ldx, int xoff, T* __restrict__ y, int ldy, int yoff,
-    uint8_t* __restrict__ arg, int n, int c4n, PoolGeom g, int mode) {
+    uint8_t* __restrict__ arg, int n, int c4n, PoolGeom g, int mode, int relu) {
   const long long total = (long long)n * g.oh * g.ow * c4n;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void pool3x3_fwd_kernel(
       const float d = (float)cnt;
       out = make_float4(sum.x / d, sum.y / d, sum.z / d, sum.w / d);
     }
+    if (relu) out = make_float4(fmaxf(out.x, 0.f), fmaxf(out.y, 0.f), fmaxf(out.z, 0.f), fmaxf(out.w, 0.f));
     c2d_st4(y + (size_t)row * ldy + yoff + c4 * 4, out);
   }
 }
@@ -84,7 +85,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(
     const T* __restrict__ dy, int lddy, int dyoff, const uint8_t* __restrict__ arg,
     T* __restrict__ dx, int lddx, int dxoff, int n, int c4n, PoolGeom g, int mode,
-    int accumulate) {
+    int accumulate, const T* __restrict__ ymask, int ldym, int ymoff) {
   const long long total = (long long)n * g.ih * g.iw * c4n;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -107,7 +108,12 @@ __global__ __launch_bounds__(256) void pool3x3_bwd_kernel(
         const int ox = tx / g.stride;
         if (ox >= g.ow) continue;
         const size_t orow = (size_t)(img * g.oh + oy) * g.ow + ox;
-        const float4 gy = c2d_ld4(dy + orow * lddy + dyoff + c4 * 4);
+        float4 gy = c2d_ld4(dy + orow * lddy + dyoff + c4 * 4);
+        if (ymask) {       // the pool's output went through a ReLU: its gradient passes where y > 0
+          const float4 yv = c2d_ld4(ymask + orow * ldym + ymoff + c4 * 4);
+          gy.x = yv.x > 0.f ? gy.x : 0.f; gy.y = yv.y > 0.f ? gy.y : 0.f;
+          gy.z = yv.z > 0.f ? gy.z : 0.f; gy.w = yv.w > 0.f ? gy.w : 0.f;
+        }
         if (mode == 0) {
           const uchar4 am = *reinterpret_cast<const uchar4*>(arg + orow * c4n * 4 + c4 * 4);
           const unsigned char k = (unsigned char)(ky * 3 + kx);
@@ -302,6 +308,7 @@ struct HeadGrad {
   const float* dmean; int ld, off;
   const uint8_t* mask; int mask_ld, mask_off;
   int spatial; float mul;
+  int norelu;      // 1: the layer has no ReLU behind its BatchNorm (c2d_bn_bwd_partial): dz = dy
 };
 
 template <bool HEAD, typename T>
@@ -359,8 +366,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           float4 dz;
-          dz.x = v[u].x > 0.f ? g[u].x : 0.f; dz.y = v[u].y > 0.f ? g[u].y : 0.f;
-          dz.z = v[u].z > 0.f ? g[u].z : 0.f; dz.w = v[u].w > 0.f ? g[u].w : 0.f;
+          dz.x = (v[u].x > 0.f || hg.norelu) ? g[u].x : 0.f; dz.y = (v[u].y > 0.f || hg.norelu) ? g[u].y : 0.f;
+          dz.z = (v[u].z > 0.f || hg.norelu) ? g[u].z : 0.f; dz.w = (v[u].w > 0.f || hg.norelu) ? g[u].w : 0.f;
           sb.x += dz.x; sb.y += dz.y; sb.z += dz.z; sb.w += dz.w;
           sg.x += dz.x * (v[u].x - be.x) * ig.x; sg.y += dz.y * (v[u].y - be.y) * ig.y;
           sg.z += dz.z * (v[u].z - be.z) * ig.z; sg.w += dz.w * (v[u].w - be.w) * ig.w;
@@ -372,8 +379,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(
         const float4 g = bn_bwd_dy<HEAD>(dy, lddy, dyoff, hg, r, c);
         const float4 v = c2d_ld4(y + (size_t)r * ldy + yoff + c);
         float4 dz;
-        dz.x = v.x > 0.f ? g.x : 0.f; dz.y = v.y > 0.f ? g.y : 0.f;
-        dz.z = v.z > 0.f ? g.z : 0.f; dz.w = v.w > 0.f ? g.w : 0.f;
+        dz.x = (v.x > 0.f || hg.norelu) ? g.x : 0.f; dz.y = (v.y > 0.f || hg.norelu) ? g.y : 0.f;
+        dz.z = (v.z > 0.f || hg.norelu) ? g.z : 0.f; dz.w = (v.w > 0.f || hg.norelu) ? g.w : 0.f;
         sb.x += dz.x; sb.y += dz.y; sb.z += dz.z; sb.w += dz.w;
         sg.x += dz.x * (v.x - be.x) * ig.x; sg.y += dz.y * (v.y - be.y) * ig.y;
         sg.z += dz.z * (v.z - be.z) * ig.z; sg.w += dz.w * (v.w - be.w) * ig.w;
@@ -805,10 +812,10 @@ int launch_bn_relu_bwd(const T* dy, int lddy, int dyoff, const T* y, int ldy, in
                        int rows_per_block, hipStream_t s, const HeadGrad* head = nullptr) {
   const int c4n = c / 4;
   const int blocks = c2d_ceil_div(rows, rows_per_block);
-  const HeadGrad hg = head ? *head : HeadGrad{nullptr, 0, 0, nullptr, 0, 0, 1, 1.0f};
+  const HeadGrad hg = head ? *head : HeadGrad{nullptr, 0, 0, nullptr, 0, 0, 1, 1.0f, 0};
 #define C2D_BNB(TX)                                                                          \
   {                                                                                          \
-    if (head)                                                                                \
+    if (head && head->dmean)                                                                 \
       hipLaunchKernelGGL((bn_relu_bwd_kernel<TX, T, true>), dim3(blocks), dim3(256), 0, s, dy, lddy, \
                          dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, partials, rows, \
                          c4n, rows_per_block, hg);                                           \
@@ -829,13 +836,13 @@ int launch_bn_relu_bwd(const T* dy, int lddy, int dyoff, const T* y, int ldy, in
 
 template <typename T>
 int pool3x3_fwd_impl(const T* x, int ldx, int xoff, T* y, int ldy, int yoff, uint8_t* argmax, int n,
-                     int ih, int iw, int c, int stride, int mode, void* stream) {
+                     int ih, int iw, int c, int stride, int mode, void* stream, int relu = 0) {
   C2D_CHECK_ARG(x && y && n > 0 && ih > 0 && iw > 0 && c > 0 && c % 4 == 0);
   C2D_CHECK_ARG((stride == 1 || stride == 2) && (mode == 0 || mode == 1));
   C2D_CHECK_ARG(ldx % 4 == 0 && xoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
   const PoolGeom g = make_pool_geom(ih, iw, stride);
   const long long total = (long long)n * g.oh * g.ow * (c / 4);
-  if (n >= 64 && ih == iw && ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
+  if (!relu && n >= 64 && ih == iw && ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
     // per-ROI maps of the second stage: whole-map kernel, every input element fetched once
     const dim3 grid(grid_for((long long)n * (c / 4))), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -849,21 +856,21 @@ int pool3x3_fwd_impl(const T* x, int ldx, int xoff, T* y, int ldy, int yoff, uin
     return c2d_launch_status();
   }
   hipLaunchKernelGGL(pool3x3_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
-                     (hipStream_t)stream, x, ldx, xoff, y, ldy, yoff, argmax, n, c / 4, g, mode);
+                     (hipStream_t)stream, x, ldx, xoff, y, ldy, yoff, argmax, n, c / 4, g, mode, relu);
   return c2d_launch_status();
 }
 
 template <typename T>
 int pool3x3_bwd_impl(const T* dy, int lddy, int dyoff, const uint8_t* argmax, T* dx, int lddx,
                      int dxoff, int n, int ih, int iw, int c, int stride, int mode, int accumulate,
-                     void* stream) {
+                     void* stream, const T* ymask = nullptr, int ldym = 0, int ymoff = 0) {
   C2D_CHECK_ARG(dy && dx && n > 0 && ih > 0 && iw > 0 && c > 0 && c % 4 == 0);
   C2D_CHECK_ARG((stride == 1 || stride == 2) && (mode == 0 || mode == 1));
   C2D_CHECK_ARG(mode == 1 || argmax);
   C2D_CHECK_ARG(lddx % 4 == 0 && dxoff % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0);
   const PoolGeom g = make_pool_geom(ih, iw, stride);
   const long long total = (long long)n * ih * iw * (c / 4);
-  if (n >= 64 && ih == iw && ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
+  if (!ymask && n >= 64 && ih == iw && ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
     const dim3 grid(grid_for((long long)n * (c / 4))), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define C2D_POOL_B(IH, S, MD)                                                                     \
@@ -877,7 +884,7 @@ int pool3x3_bwd_impl(const T* dy, int lddy, int dyoff, const uint8_t* argmax, T*
   }
   hipLaunchKernelGGL(pool3x3_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
                      (hipStream_t)stream, dy, lddy, dyoff, argmax, dx, lddx, dxoff, n, c / 4, g,
-                     mode, accumulate);
+                     mode, accumulate, ymask, ldym, ymoff);
   return c2d_launch_status();
 }
 
@@ -907,6 +914,37 @@ extern "C" int c2d_pool3x3_bwd_bf16(const void* dy, int lddy, int dyoff, const u
                                     int stride, int mode, int accumulate, void* stream) {
   return pool3x3_bwd_impl<c2d_bf16>((const c2d_bf16*)dy, lddy, dyoff, argmax, (c2d_bf16*)dx, lddx,
                                     dxoff, n, ih, iw, c, stride, mode, accumulate, stream);
+}
+
+// relu(avg_pool3x3(x)) and its gradient dx (+)= avg_pool3x3_bwd(dy * (y > 0)): the two halves of
+// an average-pooling branch commuted behind its 1x1 convolution (include/cap2det_hip.h).
+extern "C" int c2d_avgpool3x3_relu_fwd(const float* x, int ldx, int xoff, float* y, int ldy,
+                                       int yoff, int n, int ih, int iw, int c, int stride,
+                                       void* stream) {
+  return pool3x3_fwd_impl<float>(x, ldx, xoff, y, ldy, yoff, nullptr, n, ih, iw, c, stride, 1, stream, 1);
+}
+extern "C" int c2d_avgpool3x3_relu_fwd_bf16(const void* x, int ldx, int xoff, void* y, int ldy,
+                                            int yoff, int n, int ih, int iw, int c, int stride,
+                                            void* stream) {
+  return pool3x3_fwd_impl<c2d_bf16>((const c2d_bf16*)x, ldx, xoff, (c2d_bf16*)y, ldy, yoff, nullptr,
+                                    n, ih, iw, c, stride, 1, stream, 1);
+}
+extern "C" int c2d_avgpool3x3_relu_bwd(const float* dy, int lddy, int dyoff, const float* y,
+                                       int ldy, int yoff, float* dx, int lddx, int dxoff, int n,
+                                       int ih, int iw, int c, int stride, int accumulate,
+                                       void* stream) {
+  C2D_CHECK_ARG(y && ldy % 4 == 0 && yoff % 4 == 0);
+  return pool3x3_bwd_impl<float>(dy, lddy, dyoff, nullptr, dx, lddx, dxoff, n, ih, iw, c, stride, 1,
+                                 accumulate, stream, y, ldy, yoff);
+}
+extern "C" int c2d_avgpool3x3_relu_bwd_bf16(const void* dy, int lddy, int dyoff, const void* y,
+                                            int ldy, int yoff, void* dx, int lddx, int dxoff,
+                                            int n, int ih, int iw, int c, int stride,
+                                            int accumulate, void* stream) {
+  C2D_CHECK_ARG(y && ldy % 4 == 0 && yoff % 4 == 0);
+  return pool3x3_bwd_impl<c2d_bf16>((const c2d_bf16*)dy, lddy, dyoff, nullptr, (c2d_bf16*)dx, lddx,
+                                    dxoff, n, ih, iw, c, stride, 1, accumulate, stream,
+                                    (const c2d_bf16*)y, ldy, yoff);
 }
 
 extern "C" int c2d_bn_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ldy,
@@ -961,7 +999,7 @@ static int bn_relu_bwd_partial_head_impl(const float* dmean, int ldd, int doff, 
   C2D_CHECK_ARG(ldd % 4 == 0 && doff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0 && spatial > 0 &&
                 rows % spatial == 0 && keep_prob > 0.f && (!mask || (mask_ld % 4 == 0 && mask_off % 4 == 0)));
   const HeadGrad hg = {dmean, ldd, doff, mask, mask_ld, mask_off, spatial,
-                       (mask ? 1.0f / keep_prob : 1.0f) / (float)spatial};
+                       (mask ? 1.0f / keep_prob : 1.0f) / (float)spatial, 0};
   return launch_bn_relu_bwd<T>(nullptr, 0, 0, y, ldy, yoff, scale, beta, gamma, dc, nullptr, nullptr,
                                partials, rows, c, bn_rows_per_block(rows), (hipStream_t)stream, &hg);
 }
@@ -987,6 +1025,34 @@ extern "C" int c2d_bn_relu_bwd_partial_head_bf16(const float* dmean, int ldd, in
                                                  keep_prob, (const c2d_bf16*)y, ldy, yoff, scale,
                                                  beta, gamma, (c2d_bf16*)dc, partials, rows, c,
                                                  stream);
+}
+
+// BatchNorm backward of a layer WITHOUT a ReLU behind it (the 1x1 convolution of a commuted
+// average-pooling branch): dc = dy * scale, sums of dy and dy * (y - beta) / gamma.
+template <typename T>
+static int bn_bwd_partial_impl(const T* dy, int lddy, int dyoff, const T* y, int ldy, int yoff,
+                               const float* scale, const float* beta, const float* gamma, T* dc,
+                               float* partials, int rows, int c, void* stream) {
+  C2D_CHECK_ARG(dy && y && scale && dc && partials && rows > 0 && c > 0 && c % 4 == 0);
+  C2D_CHECK_ARG(!gamma || beta);
+  C2D_CHECK_ARG(lddy % 4 == 0 && dyoff % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0);
+  const HeadGrad hg = {nullptr, 0, 0, nullptr, 0, 0, 1, 1.0f, 1};
+  return launch_bn_relu_bwd<T>(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, nullptr, nullptr,
+                               partials, rows, c, bn_rows_per_block(rows), (hipStream_t)stream, &hg);
+}
+extern "C" int c2d_bn_bwd_partial(const float* dy, int lddy, int dyoff, const float* y, int ldy,
+                                  int yoff, const float* scale, const float* beta,
+                                  const float* gamma, float* dc, float* partials, int rows, int c,
+                                  void* stream) {
+  return bn_bwd_partial_impl<float>(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, partials,
+                                    rows, c, stream);
+}
+extern "C" int c2d_bn_bwd_partial_bf16(const void* dy, int lddy, int dyoff, const void* y, int ldy,
+                                       int yoff, const float* scale, const float* beta,
+                                       const float* gamma, void* dc, float* partials, int rows,
+                                       int c, void* stream) {
+  return bn_bwd_partial_impl<c2d_bf16>((const c2d_bf16*)dy, lddy, dyoff, (const c2d_bf16*)y, ldy, yoff,
+                                       scale, beta, gamma, (c2d_bf16*)dc, partials, rows, c, stream);
 }
 
 extern "C" int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks,

@@ -240,6 +240,24 @@ def conv_dgrad_bn_relu(dc, ldc, coff, w, y, ldy, yoff, scale, beta, gamma, dc_ou
             cout, kh, kw, stride, _stream())
 
 
+def avgpool3x3_relu_fwd(x, ldx, xoff, y, ldy, yoff, n, ih, iw, c, stride):
+  fn = "c2d_avgpool3x3_relu_fwd_bf16" if x.dtype == torch.bfloat16 else "c2d_avgpool3x3_relu_fwd"
+  _lib.call(fn, _p(x), ldx, xoff, _p(y), ldy, yoff, n, ih, iw, c, stride, _stream())
+
+
+def avgpool3x3_relu_bwd(dy, lddy, dyoff, y, ldy, yoff, dx, lddx, dxoff, n, ih, iw, c, stride, accumulate):
+  fn = "c2d_avgpool3x3_relu_bwd_bf16" if dy.dtype == torch.bfloat16 else "c2d_avgpool3x3_relu_bwd"
+  _lib.call(fn, _p(dy), lddy, dyoff, _p(y), ldy, yoff, _p(dx), lddx, dxoff, n, ih, iw, c, stride,
+            int(accumulate), _stream())
+
+
+def bn_bwd_partial(dy, lddy, dyoff, y, ldy, yoff, scale, beta, gamma, dc, partials, rows, c):
+  """BatchNorm backward without a ReLU (see c2d_bn_bwd_partial)."""
+  fn = "c2d_bn_bwd_partial_bf16" if dy.dtype == torch.bfloat16 else "c2d_bn_bwd_partial"
+  _lib.call(fn, _p(dy), lddy, dyoff, _p(y), ldy, yoff, _p(scale), _p(beta),
+            _p(gamma) if gamma is not None else None, _p(dc), _p(partials), rows, c, _stream())
+
+
 def bn_relu_bwd_partial_head(dmean, ldd, doff, mask, mask_ld, mask_off, spatial, keep_prob, y, ldy,
                              yoff, scale, beta, gamma, dc, partials, rows, c):
   """bn_relu_bwd_partial with dy derived from the gradient of the averaged features."""

@@ -324,6 +324,14 @@ class Net(object):
       self._plans[key] = self._build_plan(n, ih, iw, training)
     return self._plans[key]
 
+  def _commutes(self, branch, block, n):
+    """An average-pooling branch whose pool can run behind its 1x1 convolution (per-ROI maps)."""
+    if not (n >= 64 and len(branch) == 2 and branch[0][0] == "avg" and branch[0][2] == 1 and
+            branch[1][0] == "conv" and os.environ.get("C2D_COMMUTE_AVGPOOL", "1") != "0"):
+      return False
+    layer = self.layers[self.scope + block + "/" + branch[1][1]]
+    return layer.k == 1 and layer.stride == 1
+
   def _new(self, rows, c, dtype=None):
     return torch.empty(rows, c, device=self.store.device, dtype=dtype or self.dtype)
 
@@ -369,6 +377,22 @@ class Net(object):
         for branch, wdt in zip(op[2], widths):
           bsteps = []
           bx, bh, bw, bc = x, h, w, c
+          if self._commutes(branch, op[1], n):
+            # avg_pool 3x3 -> 1x1 conv -> BN -> ReLU over per-ROI maps, run as 1x1 conv -> BN ->
+            # avg_pool -> ReLU (c2d_avgpool3x3_relu_fwd: same function up to rounding): the pool
+            # and its gradient touch cout channels instead of cin, and the convolution becomes
+            # one more 1x1 entry convolution of the block (its input gradient joins the
+            # multi-segment GEMM instead of a pooled pass over the whole block input).
+            layer = self.layers[self.scope + op[1] + "/" + branch[1][1]]
+            z = Ref(self._new(n * h * w, layer.cout), layer.cout, 0, layer.cout)
+            bsteps.append(dict(kind="conv", layer=layer, x=bx, y=z, n=n, ih=h, iw=w, oh=h, ow=w,
+                               relu=False, commuted=True))
+            bsteps.append(dict(kind="pool", mode=1, stride=1, x=z, y=Ref(ybuf, ctot, off, layer.cout),
+                               arg=None, n=n, ih=h, iw=w, oh=h, ow=w, c=layer.cout, relu=True))
+            scratch_rows_c = max(scratch_rows_c, n * h * w * layer.cout)
+            branches.append(bsteps)
+            off += wdt
+            continue
           for i, bop in enumerate(branch):
             last = i == len(branch) - 1
             if bop[0] == "conv":
@@ -417,7 +441,10 @@ class Net(object):
     if kind == "conv":
       L = st["layer"]
       ops.conv_fwd(x.t, x.ld, x.off, L.wt_for(self.dtype), L.scale, L.shift, st["y"].t, st["y"].ld, st["y"].off,
-                   st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, True)
+                   st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, st.get("relu", True))
+    elif kind == "pool" and st.get("relu"):
+      ops.avgpool3x3_relu_fwd(x.t, x.ld, x.off, st["y"].t, st["y"].ld, st["y"].off, st["n"],
+                              st["ih"], st["iw"], st["c"], st["stride"])
     elif kind == "pool":
       ops.pool3x3_fwd(x.t, x.ld, x.off, st["y"].t, st["y"].ld, st["y"].off, st["arg"], st["n"],
                       st["ih"], st["iw"], st["c"], st["stride"], st["mode"])
@@ -441,7 +468,7 @@ class Net(object):
               L = b["layer"]
               calls.append((bx.t, bx.ld, bx.off, L.wt_for(self.dtype), L.scale, L.shift, b["y"].t,
                             b["y"].ld, b["y"].off, b["n"], b["ih"], b["iw"], L.cin, L.cout, L.k,
-                            L.k, L.stride, True))
+                            L.k, L.stride, b.get("relu", True)))
             group = st["groups"][key] = ops.conv_group(calls)
           ops.conv_fwd_grouped(group)
         for b in level:
@@ -703,6 +730,10 @@ class Net(object):
                                    head["mask_ld"], y.off, head["spatial"], head["keep_prob"],
                                    y.t, y.ld, y.off, L.scale, beta, gamma, dc,
                                    plan["bn_ws"][off:off + size], rows, L.cout)
+    elif tr and "bn_part" in st and st.get("commuted"):
+      off, size = st["bn_part"]          # (the ReLU sits behind the pool: see _build_plan)
+      ops.bn_bwd_partial(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
+                         plan["bn_ws"][off:off + size], rows, L.cout)
     elif tr and "bn_part" in st:
       off, size = st["bn_part"]
       ops.bn_relu_bwd_partial(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
@@ -758,7 +789,11 @@ class Net(object):
     if kind == "conv":
       self._conv_bwd(plan, st, x, gx, accumulate)
     elif kind == "pool":
-      if gx is not None:
+      if gx is not None and st.get("relu"):
+        gy, y = st["gy"], st["y"]
+        ops.avgpool3x3_relu_bwd(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, gx.t, gx.ld, gx.off, st["n"],
+                                st["ih"], st["iw"], st["c"], st["stride"], accumulate)
+      elif gx is not None:
         gy = st["gy"]
         ops.pool3x3_bwd(gy.t, gy.ld, gy.off, st["arg"], gx.t, gx.ld, gx.off, st["n"], st["ih"],
                         st["iw"], st["c"], st["stride"], st["mode"], accumulate)

@@ -223,6 +223,24 @@ int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks, 
  * / keep_prob / spatial (mask NULL: no dropout) — models/utils.py:183-188 (reduce_mean over the
  * map, slim.dropout) differentiated; the per-pixel gradient map is never materialised.
  * rows = ROIs * spatial (rows of y / dc); same row blocks as c2d_bn_relu_bwd_partial_blocks. */
+/* An average-pooling branch commuted behind its 1x1 convolution (Inception `Branch_3`:
+ * avg_pool2d 3x3 -> conv2d 1x1 -> BN -> ReLU, nets/inception_v2 via models/utils.py:165-167):
+ * pooling and the 1x1 convolution are both linear and act on different axes, and the average of
+ * a constant over the VALID cells of a SAME window is that constant, so
+ *   relu(bn(conv(avgpool(x)))) == relu(avgpool(bn(conv(x))))
+ * up to fp rounding — and the pool then runs over cout channels instead of cin (128 instead
+ * of 1024).  Forward: c2d_conv_fwd(relu = 0) then c2d_avgpool3x3_relu_fwd; backward:
+ * c2d_avgpool3x3_relu_bwd (dx (+)= avgpool_bwd(dy * (y > 0)), y = the pool's output), then
+ * c2d_bn_bwd_partial on the convolution's output (BatchNorm backward without a ReLU: dc = dy *
+ * scale, partial sums of dy and dy * (y - beta) / gamma as c2d_bn_relu_bwd_partial). */
+int c2d_avgpool3x3_relu_fwd(const float* x, int ldx, int xoff, float* y, int ldy, int yoff, int n,
+                            int ih, int iw, int c, int stride, void* stream);
+int c2d_avgpool3x3_relu_bwd(const float* dy, int lddy, int dyoff, const float* y, int ldy,
+                            int yoff, float* dx, int lddx, int dxoff, int n, int ih, int iw, int c,
+                            int stride, int accumulate, void* stream);
+int c2d_bn_bwd_partial(const float* dy, int lddy, int dyoff, const float* y, int ldy, int yoff,
+                       const float* scale, const float* beta, const float* gamma, float* dc,
+                       float* partials, int rows, int c, void* stream);
 int c2d_bn_relu_bwd_partial_head(const float* dmean, int ldd, int doff, const uint8_t* mask,
                                  int mask_ld, int mask_off, int spatial, float keep_prob,
                                  const float* y, int ldy, int yoff, const float* scale,
@@ -469,6 +487,14 @@ int c2d_bn_relu_bwd_partial_bf16(const void* dy, int lddy, int dyoff, const void
                                  int yoff, const float* scale, const float* beta,
                                  const float* gamma, void* dc, float* partials, int rows, int c,
                                  void* stream);
+int c2d_avgpool3x3_relu_fwd_bf16(const void* x, int ldx, int xoff, void* y, int ldy, int yoff,
+                                 int n, int ih, int iw, int c, int stride, void* stream);
+int c2d_avgpool3x3_relu_bwd_bf16(const void* dy, int lddy, int dyoff, const void* y, int ldy,
+                                 int yoff, void* dx, int lddx, int dxoff, int n, int ih, int iw,
+                                 int c, int stride, int accumulate, void* stream);
+int c2d_bn_bwd_partial_bf16(const void* dy, int lddy, int dyoff, const void* y, int ldy, int yoff,
+                            const float* scale, const float* beta, const float* gamma, void* dc,
+                            float* partials, int rows, int c, void* stream);
 int c2d_bn_relu_bwd_partial_head_bf16(const float* dmean, int ldd, int doff, const uint8_t* mask,
                                       int mask_ld, int mask_off, int spatial, float keep_prob,
                                       const void* y, int ldy, int yoff, const float* scale,

@@ -335,6 +335,48 @@ def test_pool3x3(ops, mode, stride, ih, iw, n):
   assert float(dxw[..., :4].max()) == 1.0 and float(dxw[..., 4 + c:].min()) == 1.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("ih,iw,n,accumulate", [(4, 4, 70, False), (7, 7, 6, True), (9, 5, 3, False)])
+def test_avgpool3x3_relu_and_bn_bwd_without_relu(ops, ih, iw, n, accumulate, dtype):
+  """The three pieces of an average-pooling branch commuted behind its 1x1 convolution:
+  y = relu(avg_pool(z)), dz (+)= avg_pool_bwd(dy * (y > 0)), and the BatchNorm backward of a
+  layer without a ReLU (dc = dz * scale, sums of dz and dz * (z - beta) / gamma)."""
+  rng = np.random.default_rng(41)
+  c = 24
+  zt = _t(rng.standard_normal((n, ih, iw, c)).astype(np.float32)).to(dtype)
+  z = zt.float().cpu().numpy()
+  want_y = np.maximum(ref_ops.avg_pool_same(z.astype(np.float64), 3), 0)
+  y = torch.full((n, ih, iw, c + 8), 7.0, device=DEV, dtype=dtype)
+  ops.avgpool3x3_relu_fwd(zt, c, 0, y, c + 8, 4, n, ih, iw, c, 1)
+  tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+  np.testing.assert_allclose(y[..., 4:4 + c].float().cpu().numpy(), want_y, rtol=tol, atol=tol)
+  assert float(y[..., :4].float().min()) == 7.0 and float(y[..., 4 + c:].float().min()) == 7.0
+  dyt = _t(rng.standard_normal((n, ih, iw, c)).astype(np.float32)).to(dtype)
+  dy = dyt.float().cpu().numpy().astype(np.float64)
+  ymask = y[..., 4:4 + c].float().cpu().numpy() > 0
+  want_dz = ref_ops.avg_pool_same_backward(z.shape, dy * ymask, 3)
+  base = _t(rng.standard_normal((n, ih, iw, c)).astype(np.float32)).to(dtype)
+  dz = base.clone()
+  ops.avgpool3x3_relu_bwd(dyt, c, 0, y, c + 8, 4, dz, c, 0, n, ih, iw, c, 1, accumulate)
+  want = want_dz + (base.float().cpu().numpy() if accumulate else 0.0)
+  np.testing.assert_allclose(dz.float().cpu().numpy(), want, rtol=4 * tol, atol=4 * tol)
+  # BatchNorm backward without a ReLU on z (rows = n * ih * iw)
+  rows = n * ih * iw
+  scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+  gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  g = dz.float().cpu().numpy().reshape(rows, c).astype(np.float64)
+  nb = ops.bn_relu_bwd_partial_blocks(rows, c)
+  dc = torch.empty(rows, c, device=DEV, dtype=dtype)
+  part = torch.full((nb, 2, c), 7.0, device=DEV)
+  ops.bn_bwd_partial(dz, c, 0, zt, c, 0, _t(scale), _t(beta), _t(gamma), dc, part, rows, c)
+  np.testing.assert_allclose(dc.float().cpu().numpy(), g * scale, rtol=tol, atol=tol * np.abs(g).max())
+  sums = part.double().sum(0).cpu().numpy()
+  np.testing.assert_allclose(sums[0], g.sum(0), rtol=1e-4, atol=1e-4 * np.abs(g.sum(0)).max() + 1e-5)
+  want_g = (g * (z.reshape(rows, c).astype(np.float64) - beta) / gamma).sum(0)
+  np.testing.assert_allclose(sums[1], want_g, rtol=1e-4, atol=1e-4 * max(np.abs(want_g).max(), 1.0))
+
+
 def test_bn_relu_bwd(ops):
   rng = np.random.default_rng(19)
   rows, c = 1000, 96

@@ -249,8 +249,9 @@ def test_mixed_4e_entry_group(ops):
     _scale_close(_n(y), want, 2e-5, "grouped 1x1")
 
 
-@pytest.mark.parametrize("fuse_bn_bwd", ["1", "0"], ids=["fused_bn_bwd", "separate_bn_bwd"])
-def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd):
+@pytest.mark.parametrize("fuse_bn_bwd,commute", [("1", "1"), ("0", "1"), ("1", "0")],
+                         ids=["fused_bn_bwd", "separate_bn_bwd", "fused_pool_not_commuted"])
+def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd, commute):
   """The whole second stage (Mixed_5a-c, depth multiplier 1.0) forward + backward on 128 ROIs
   through the engine's launch plan against ref_model.net_forward / net_backward in float64:
   output map, input gradient and every filter / BatchNorm gradient.  Both backward plans: the
@@ -258,6 +259,8 @@ def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd):
   (c2d_conv_dgrad_bn_relu, nine producer layers here; c2d_conv1x1_dgrad_multi_bn_relu at the two
   block boundaries, six more) and as separate launches."""
   monkeypatch.setenv("C2D_FUSE_BN_BWD", fuse_bn_bwd)
+  # (Mixed_5b's average-pooling branch runs as 1x1 conv -> BN -> pool -> ReLU unless switched off)
+  monkeypatch.setenv("C2D_COMMUTE_AVGPOOL", commute)
   from cap2det_amd import hip_ops
   from cap2det_amd.models.frcnn_engine import SECOND_SCOPE, SECOND_STAGE, DerivedStore, Net, Ref, VariableStore
   n, hw, cin = 128, 7, 576
@@ -298,6 +301,15 @@ def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd):
   for st, saved in zip(plan["steps"], tape):
     assert st["kind"] == "block"
     for bsteps, btape in zip(st["branches"], saved[0]):
+      if bsteps[0].get("commuted"):
+        # engine: conv (BN, no ReLU) -> pool + ReLU; oracle: pool -> conv + BN + ReLU.  The
+        # convolution re-runs on the oracle-valued block input, the oracle's branch output (the
+        # ReLU whose mask the backward pass branches on) goes into the pool's output
+        assert commute == "1" and [b["kind"] for b in bsteps] == ["conv", "pool"]
+        net._fwd_step(bsteps[0], block_in)
+        ref = bsteps[1]["y"]
+        ref.t[:, ref.off:ref.off + ref.c].copy_(_t(btape[1][2].reshape(-1, ref.c).astype(np.float32)))
+        continue
       for bst, sv in zip(bsteps, btape):
         ref = bst["y"]
         if bst["kind"] == "conv":
@@ -319,7 +331,9 @@ def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd):
   boundary = sum(1 for op in ops_ if "fused_wide" in op)
   # nine inner producers; at the two block boundaries the last convolutions of Mixed_5a (2, its
   # third branch is the max pool) and of Mixed_5b (4)
-  assert (inner, boundary) == ((9, 6) if fuse_bn_bwd == "1" else (0, 0))
+  # (5 with the commuted branch: its last op is the pool, whose columns pass through)
+  assert (inner, boundary) == ((9, 5 if commute == "1" else 6) if fuse_bn_bwd == "1" else (0, 0))
+  assert sum(1 for op in ops_ if op.get("commuted")) == (1 if commute == "1" else 0)
   want_dx, grads = ref_model.net_backward(ref_model.SECOND_STAGE, tape, dy.astype(np.float64), P64,
                                           ref_model.SECOND_SCOPE, 0, True)
   _scale_close(_n(dx.t).reshape(want_dx.shape), want_dx, 5e-5, "second stage input gradient")
