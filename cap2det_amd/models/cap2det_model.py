@@ -425,6 +425,8 @@ class Model(ModelBase):
     labels = kwargs.get("labels")
     if labels is None:
       labels = self._label_extractor.extract_labels(examples)
+    elif kwargs.get("labels_ready") is not None:     # extracted on another stream (Trainer)
+      torch.cuda.current_stream().wait_event(kwargs["labels_ready"])
     ctx["labels"] = labels
     losses = self._losses
     losses.zero_()
