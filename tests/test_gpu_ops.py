@@ -188,6 +188,8 @@ FUSED_CASES = [
     (100, 7, 7, 32, 64, 3, 2),    # stride 2: four parity-class launches share the partials
     (261, 7, 7, 32, 160, 3, 2),   # odd image count
     (300, 7, 7, 160, 64, 3, 1),   # N = cin = 160
+    (70, 4, 4, 36, 48, 3, 1),     # N = 36: a ragged last 32-column tile, pixel-major
+    (300, 7, 7, 100, 64, 1, 1),   # N = 100, row-major
 ]
 
 
