@@ -128,6 +128,11 @@ class KernelTimer(object):
     ops.conv_dgrad_bn_relu = timed(ops.conv_dgrad_bn_relu, "igemm_nt", fused_dgrad_work)
     ops.conv1x1_dgrad_multi_bn_relu = timed(ops.conv1x1_dgrad_multi_bn_relu, "igemm_nt",
                                             fused_multi_work)
+    def fwd_multi_work(args):
+      # conv1x1_fwd_multi(x, ldx, xoff, outs, rows, cin): outs = (array, count, dtype)
+      return 2.0 * args[4] * args[5] * sum(o.cout for o in args[3][0])
+
+    ops.conv1x1_fwd_multi = timed(ops.conv1x1_fwd_multi, "igemm_nt", fwd_multi_work)
     ops.conv1x1_dgrad_multi = timed(ops.conv1x1_dgrad_multi, "igemm_nt", multi_work)
     ops.conv_fwd = timed(ops.conv_fwd, "igemm_nt", conv_work("fwd"))
     ops.conv_fwd_grouped = timed(ops.conv_fwd_grouped, "igemm_nt", lambda args: args[0][2])

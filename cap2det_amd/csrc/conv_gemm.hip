@@ -214,6 +214,14 @@ struct IgemmArgs {
   int fnprod; int fseg_end[4]; int fident[4];
   const float* fscale[4]; const float* fbeta[4]; const float* fgamma[4];
   float* fpart; int fpart_row0;
+  // Several 1x1 convolutions of the SAME input as one GEMM (forward launches only, mo_n > 0):
+  // output columns [mo_end[s-1], mo_end[s]) belong to convolution s — its weight rows start
+  // mo_boff[s] elements behind Bt (all of them inside mo_bbytes bytes), its BN scale / shift
+  // vectors, destination (pointer, row stride, column offset) and ReLU flag are its own.
+  int mo_n; int mo_end[4]; int mo_relu[4];
+  long long mo_boff[4]; long long mo_bbytes;
+  float* mo_C[4]; int mo_ldc[4], mo_coff[4];
+  const float* mo_scale[4]; const float* mo_shift[4];
   int dbg;                  // ablation bits (C2D_TUNE=1 C2D_IGEMM_DBG): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no epilogue
   ConvGeom g;
 #ifdef C2D_TRACE
@@ -246,6 +254,24 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
 // that draws the last ticket acquires, sums all slabs IN PIECE ORDER (bitwise reproducible) and
 // runs the epilogue.  Nobody ever waits, so no residency or dispatch-order assumption is made.
 constexpr int SK_MAX_PERIOD = 64;
+// ---- several 1x1 convolutions of one input as one GEMM (IgemmArgs::mo_n) ---------------------
+// element offset (relative to Bt) of the weight row of output column n
+__device__ __forceinline__ int mo_weight_row(const IgemmArgs& a, int n) {
+  int s = 0, lo = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (q + 1 < a.mo_n && n >= a.mo_end[q]) { s = q + 1; lo = a.mo_end[q]; }
+  return (int)a.mo_boff[s] + (n - lo) * a.K;      // (host: every weight row within 2^31 elements of Bt)
+}
+struct MoOut { float* C; int ldc, coff, lo, relu; const float* scale; const float* shift; };
+__device__ __forceinline__ MoOut mo_output(const IgemmArgs& a, int ncol) {
+  int s = 0, lo = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (q + 1 < a.mo_n && ncol >= a.mo_end[q]) { s = q + 1; lo = a.mo_end[q]; }
+  return MoOut{a.mo_C[s], a.mo_ldc[s], a.mo_coff[s], lo, a.mo_relu[s], a.mo_scale[s], a.mo_shift[s]};
+}
+
 // ---- fused BN/ReLU backward in the input-gradient epilogue (IgemmArgs::fy) -------------------
 template <int ES>
 __device__ __forceinline__ f32x4 load_act4(const void* base, size_t idx) {
@@ -425,7 +451,12 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * ES,
                                              (a.a_rows * a.lda - a.a_off) * ES);
     __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
-        a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * ES);
+        a.Bt, a.mo_n ? a.mo_bbytes
+                     : (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * ES);
+    int brow_base[B_LOADS];            // element offset of the staged weight row inside a tap's plane
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      brow_base[i] = a.mo_n ? mo_weight_row(a, brow_off[i]) : brow_off[i] * a.K;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -539,7 +570,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
                       : OOB_OFFSET;                                                            \
     const int toff = __builtin_amdgcn_readlane(tab_toff, tap);                                 \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        boff[i] = (unsigned)(brow_off[i] * Kc + toff + q4) * (unsigned)ES;                     \
+        boff[i] = (unsigned)((a.nseg > 1 ? brow_off[i] * Kc : brow_base[i]) + toff + q4) *    \
+                  (unsigned)ES;                                                                \
     if (PM)                                                                                    \
       tv_load = ((unsigned)__builtin_amdgcn_readlane((int)tab_tv, tap) >> (wm * MT)) &         \
                 ((1u << MT) - 1u);                                                             \
@@ -785,6 +817,14 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
       const bool ncol_ok = ncol < a.N;       // N is a multiple of 4
       if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
       if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+      // several convolutions in one GEMM: this lane's four columns belong to one of them
+      float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol, orelu = a.relu;
+      if (MODE == 0 && a.mo_n && ncol_ok) {
+        const MoOut o = mo_output(a, ncol);
+        oC = o.C; oldc = o.ldc; ocoff = o.coff + (ncol - o.lo); orelu = o.relu;
+        esc = *reinterpret_cast<const f32x4*>(o.scale + (ncol - o.lo));
+        esh = *reinterpret_cast<const f32x4*>(o.shift + (ncol - o.lo));
+      }
       // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
       const bool fused = MODE == 1 && !SK && a.fy != nullptr;
       f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
@@ -815,19 +855,19 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
           }
           if (row_ok && ncol_ok) {
             v = v * esc + esh;
-            if (a.relu) {
+            if (orelu) {
               v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
             if constexpr (ES == 4) {
-              f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + ncol);
+              f32x4* dst = reinterpret_cast<f32x4*>(oC + (size_t)drow * oldc + ocoff);
               if (a.accumulate) v += *dst;
               if (fused && !fpass)     // (on the complete gradient: after the accumulation)
                 v = fused_bn_item(v, load_act4<ES>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol),
                                   fsc, fbe, fig, fsb, fsg);
               *dst = v;
             } else {                                  // 4 bf16 = 8 B per lane
-              bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
-                                                      (size_t)drow * a.ldc + a.c_off + ncol);
+              bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
+                                                      (size_t)drow * oldc + ocoff);
               if (a.accumulate) {
                 const bf16x4 o = *dst;
                 v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
@@ -1026,7 +1066,12 @@ void igemm_bf16_kernel(IgemmArgs a) {
   __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
                                            (a.a_rows * a.lda - a.a_off) * 2);
   __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
-      a.Bt, (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
+      a.Bt, a.mo_n ? a.mo_bbytes
+                   : (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
+  int brow_base[B_LOADS];              // element offset of the staged weight row inside a tap's plane
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i)
+    brow_base[i] = a.mo_n ? mo_weight_row(a, brow_off[i]) : brow_off[i] * a.K;
   unsigned tv_load = ~0u;
   unsigned tvq = ~0u;       // tap validity bits (8 per activation buffer) of the slabs in the ring
   unsigned aoff[A_LOADS], boff[B_LOADS];
@@ -1046,7 +1091,7 @@ void igemm_bf16_kernel(IgemmArgs a) {
   {                                                                                            \
     const int toff = __builtin_amdgcn_readlane(tab_toff, cb.tap);                              \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        boff[i] = (unsigned)(brow_off[i] * cb.Kc + toff + q4) * 2u;                            \
+        boff[i] = (unsigned)((a.nseg > 1 ? brow_off[i] * cb.Kc : brow_base[i]) + toff + q4) * 2u; \
   }
   // DMA of the slab at a cursor into an LDS buffer (8 rows x 128 B per wave-instruction); lanes
   // past a K tail fetch zeros (never multiplied)
@@ -1226,6 +1271,14 @@ void igemm_bf16_kernel(IgemmArgs a) {
   const bool ncol_ok = ncol < a.N && lane_on;
   if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
   if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+  // several convolutions in one GEMM: this lane's four columns belong to one of them
+  float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol, orelu = a.relu;
+  if (MODE == 0 && a.mo_n && ncol_ok) {
+    const MoOut o = mo_output(a, ncol);
+    oC = o.C; oldc = o.ldc; ocoff = o.coff + (ncol - o.lo); orelu = o.relu;
+    esc = *reinterpret_cast<const f32x4*>(o.scale + (ncol - o.lo));
+    esh = *reinterpret_cast<const f32x4*>(o.shift + (ncol - o.lo));
+  }
   // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
   const bool fused = MODE == 1 && a.fy != nullptr;
   f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
@@ -1262,11 +1315,11 @@ void igemm_bf16_kernel(IgemmArgs a) {
         }
         if (row_ok && ncol_ok) {
           v = v * esc + esh;
-          if (a.relu) {
+          if (orelu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           }
-          bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) +
-                                                  (size_t)drow * a.ldc + a.c_off + ncol);
+          bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
+                                                  (size_t)drow * oldc + ocoff);
           if (a.accumulate) {
             const bf16x4 o = *dst;
             v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
@@ -2575,7 +2628,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   }
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
-  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && a.es == 4 && !a.fy) {
+  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && a.es == 4 && !a.fy && !a.mo_n) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);
@@ -2680,6 +2733,57 @@ extern "C" int c2d_conv_fwd_ws(const float* x, int ldx, int xoff, const float* w
   C2D_CHECK_ARG(workspace && workspace_bytes > 0);
   return conv_fwd_impl(x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw,
                        stride, relu, IgemmWs{workspace, workspace_bytes}, stream);
+}
+
+// Several 1x1 / stride-1 convolutions of one input as one forward GEMM (IgemmArgs::mo_n).
+static_assert(sizeof(C2dConvOut) == 48, "C2dConvOut layout");
+static int conv1x1_fwd_multi_impl(const void* x, int ldx, int xoff, int nout, const C2dConvOut* outs,
+                                  int rows, int cin, void* stream, int es) {
+  dispatch_reset();
+  C2D_CHECK_ARG(x && outs && nout >= 1 && nout <= 4 && rows > 0 && cin > 0);
+  C2D_CHECK_ARG(cin % (16 / es) == 0 && ldx % (16 / es) == 0 && xoff % (16 / es) == 0);
+  IgemmArgs a = {};
+  int rc = fill_geom(&a.g, 1, 1, 1, 1, 1, 0);
+  if (rc) return rc;
+  const char* base = nullptr; const char* top = nullptr;
+  int ntot = 0;
+  for (int s = 0; s < nout; ++s) {
+    const C2dConvOut& o = outs[s];
+    C2D_CHECK_ARG(o.wt && o.scale && o.shift && o.dst && o.cout > 0 && o.cout % 4 == 0);
+    C2D_CHECK_ARG(o.ld_dst % 4 == 0 && o.off_dst % 4 == 0);
+    const char* w = (const char*)o.wt;
+    if (!base || w < base) base = w;
+    if (!top || w + (long long)o.cout * cin * es > top) top = w + (long long)o.cout * cin * es;
+    ntot += o.cout;
+  }
+  C2D_CHECK_ARG(top - base < (long long)OOB_OFFSET);
+  a.mo_n = nout; a.mo_bbytes = top - base;
+  int end = 0;
+  for (int s = 0; s < nout; ++s) {
+    const C2dConvOut& o = outs[s];
+    C2D_CHECK_ARG(((const char*)o.wt - base) % es == 0);
+    end += o.cout;
+    a.mo_end[s] = end; a.mo_relu[s] = o.relu;
+    a.mo_boff[s] = ((const char*)o.wt - base) / es;
+    a.mo_C[s] = (float*)o.dst; a.mo_ldc[s] = o.ld_dst; a.mo_coff[s] = o.off_dst;
+    a.mo_scale[s] = o.scale; a.mo_shift[s] = o.shift;
+  }
+  a.A = (const float*)x; a.lda = ldx; a.a_off = xoff; a.a_rows = rows;
+  a.Bt = (const float*)base;
+  a.C = (float*)outs[0].dst; a.ldc = outs[0].ld_dst; a.c_off = outs[0].off_dst;
+  a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = 0; a.nseg = 1;
+  a.M = rows; a.N = ntot; a.K = cin; a.g.nimg = rows; a.es = es;
+  C2D_CHECK_ARG((long long)rows * ldx * es < (long long)OOB_OFFSET);
+  return run_igemm(a, (hipStream_t)stream, IgemmWs{nullptr, 0});
+}
+
+extern "C" int c2d_conv1x1_fwd_multi(const float* x, int ldx, int xoff, int nout,
+                                     const C2dConvOut* outs, int rows, int cin, void* stream) {
+  return conv1x1_fwd_multi_impl(x, ldx, xoff, nout, outs, rows, cin, stream, 4);
+}
+extern "C" int c2d_conv1x1_fwd_multi_bf16(const void* x, int ldx, int xoff, int nout,
+                                          const C2dConvOut* outs, int rows, int cin, void* stream) {
+  return conv1x1_fwd_multi_impl(x, ldx, xoff, nout, outs, rows, cin, stream, 2);
 }
 
 // The BN/ReLU backward fused into an input-gradient launch (IgemmArgs::fy ...); blocks_out: the

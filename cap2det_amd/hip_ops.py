@@ -268,6 +268,30 @@ def bn_relu_bwd_partial_head(dmean, ldd, doff, mask, mask_ld, mask_off, spatial,
             _p(gamma) if gamma is not None else None, _p(dc), _p(partials), rows, c, _stream())
 
 
+class ConvOut(ctypes.Structure):
+  """C2dConvOut of include/cap2det_hip.h."""
+  _fields_ = [("wt", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+              ("dst", ctypes.c_void_p), ("ld_dst", ctypes.c_int), ("off_dst", ctypes.c_int),
+              ("cout", ctypes.c_int), ("relu", ctypes.c_int)]
+
+
+def conv_outs(outs):
+  """[(wt, scale, shift, dst, ld_dst, off_dst, cout, relu)] -> (C2dConvOut array, count, dtype)."""
+  arr = (ConvOut * len(outs))()
+  for d, (wt, scale, shift, dst, ld, off, cout, relu) in zip(arr, outs):
+    d.wt, d.scale, d.shift, d.dst = _p(wt), _p(scale), _p(shift), _p(dst)
+    d.ld_dst, d.off_dst, d.cout, d.relu = ld, off, cout, int(relu)
+  return arr, len(outs), outs[0][0].dtype
+
+
+def conv1x1_fwd_multi(x, ldx, xoff, outs, rows, cin):
+  """Several 1x1 convolutions of one input as one GEMM (c2d_conv1x1_fwd_multi); outs: conv_outs()."""
+  arr, n, dtype = outs
+  assert x.dtype == dtype
+  fn = "c2d_conv1x1_fwd_multi_bf16" if dtype == torch.bfloat16 else "c2d_conv1x1_fwd_multi"
+  _lib.call(fn, _p(x), ldx, xoff, n, arr, rows, cin, _stream())
+
+
 class BnProducer(ctypes.Structure):
   """C2dBnProducer of include/cap2det_hip.h."""
   _fields_ = [("scale", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("gamma", ctypes.c_void_p),

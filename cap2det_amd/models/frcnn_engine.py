@@ -449,8 +449,27 @@ class Net(object):
       ops.pool3x3_fwd(x.t, x.ld, x.off, st["y"].t, st["y"].ld, st["y"].off, st["arg"], st["n"],
                       st["ih"], st["iw"], st["c"], st["stride"], st["mode"])
     elif self.dtype != torch.float32 or st["n"] * st["ih"] * st["iw"] > GROUP_MAX_ROWS:
-      for bsteps in st["branches"]:
-        for bst in bsteps:
+      # The 1x1 / stride-1 convolutions that open the branches all read the block input: ONE GEMM
+      # over the sum of their output channels (c2d_conv1x1_fwd_multi: the input streams from HBM
+      # once, wider tiles; every output element is the same K-ordered sum, bitwise equal results).
+      fused = ()
+      if os.environ.get("C2D_FUSE_ENTRY_FWD", "1") != "0":
+        entry = [(bi, b[0]) for bi, b in enumerate(st["branches"])
+                 if b[0]["kind"] == "conv" and b[0]["layer"].k == 1 and b[0]["layer"].stride == 1]
+        if 2 <= len(entry) <= 4:
+          cache = st.setdefault("entry_fwd", {})
+          key = (x.t.data_ptr(), x.ld, x.off)
+          if key not in cache:
+            keep = [(b["layer"].wt_for(self.dtype), b["layer"].scale, b["layer"].shift, b["y"].t,
+                     b["y"].ld, b["y"].off, b["layer"].cout, b.get("relu", True)) for _, b in entry]
+            cache[key] = (ops.conv_outs(keep), keep)
+          ops.conv1x1_fwd_multi(x.t, x.ld, x.off, cache[key][0], st["n"] * st["ih"] * st["iw"],
+                                st["cin"])
+          fused = tuple(bi for bi, _ in entry)
+      for bi, bsteps in enumerate(st["branches"]):
+        for j, bst in enumerate(bsteps):
+          if j == 0 and bi in fused:
+            continue
           self._fwd_step(bst, x)
     else:
       # few rows (the single-image first stage): each convolution alone is a launch of 30-250

@@ -260,6 +260,25 @@ int c2d_bn_relu_bwd_partial_head(const float* dmean, int ldd, int doff, const ui
  * (stride 2: its four parity-class launches) writes; -1 for an unsupported shape. */
 int c2d_conv_dgrad_bn_relu_partial_blocks(int elem_size, int n, int ih, int iw, int cin, int cout,
                                           int kh, int kw, int stride);
+/* Several 1x1 / stride-1 convolutions of the SAME input as ONE GEMM (the entry convolutions of
+ * the branches of an Inception block, nets/inception_v2 via models/utils.py:165-167): the input
+ * is read once and the GEMM is N = sum(cout) wide; output s goes to its own buffer (rows of
+ * ld_dst, column offset off_dst) through its own folded-BN scale / shift and ReLU flag.  Every
+ * output element is the same K-ordered sum as c2d_conv_fwd computes: bitwise equal results.
+ * wt: [cout][cin] rows (the layout c2d_conv_fwd takes for a 1x1 convolution); all wt of a call
+ * must lie within 2 GB of each other (one allocation in practice). */
+typedef struct C2dConvOut {
+  const void* wt;
+  const float* scale;
+  const float* shift;
+  void* dst;
+  int ld_dst, off_dst;
+  int cout;             /* multiple of 4 */
+  int relu;
+} C2dConvOut;
+int c2d_conv1x1_fwd_multi(const float* x, int ldx, int xoff, int nout, const C2dConvOut* outs,
+                          int rows, int cin, void* stream);
+
 /* The same fusion for the summed input gradient of an Inception block (c2d_conv1x1_dgrad_multi)
  * whose input is the concat buffer of the block in front: the columns belong to up to four
  * PRODUCERS (the last op of each branch of that block), in column order.  identity != 0: a
@@ -500,6 +519,8 @@ int c2d_bn_relu_bwd_partial_head_bf16(const float* dmean, int ldd, int doff, con
                                       const void* y, int ldy, int yoff, const float* scale,
                                       const float* beta, const float* gamma, void* dc,
                                       float* partials, int rows, int c, void* stream);
+int c2d_conv1x1_fwd_multi_bf16(const void* x, int ldx, int xoff, int nout, const C2dConvOut* outs,
+                               int rows, int cin, void* stream);
 int c2d_conv_dgrad_bn_relu_bf16(const void* dc, int ldc, int coff, const void* w, const void* y,
                                 int ldy, int yoff, const float* scale, const float* beta,
                                 const float* gamma, void* dc_out, float* partials, int n, int ih,

@@ -181,6 +181,34 @@ def test_conv_dgrad_wgrad(ops, case, conv_mode):
   np.testing.assert_allclose(_n(dw), want_dw, rtol=1e-4, atol=1e-5 * scale + 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,cin,couts", [(20000, 64, (32, 48)), (17001, 96, (40, 64, 104)),
+                                            (32000, 1024, (352, 192, 160, 128)), (19000, 576, (128, 192))])
+def test_conv1x1_fwd_multi_equals_separate_convs(ops, rows, cin, couts, dtype):
+  """Several 1x1 convolutions of one input as one GEMM: bitwise equal to one c2d_conv_fwd per
+  convolution (same K-ordered sums; more than 16384 rows, so that the separate calls do not take
+  the split-K kernel of the single-image first stage), each output through its own scale / shift /
+  ReLU flag into its own buffer slice; the second convolution has no ReLU."""
+  rng = np.random.default_rng(43)
+  x = _t(rng.standard_normal((rows, cin + 16)).astype(np.float32)).to(dtype)
+  flat = _t((rng.standard_normal(sum(couts) * cin + 64) / np.sqrt(cin)).astype(np.float32)).to(dtype)
+  outs, wants, keep, off = [], [], [], 16            # (weights of one flat buffer, as in the engine)
+  for i, c in enumerate(couts):
+    wt = flat[off:off + c * cin].view(1, c, cin); off += c * cin
+    scale = _t(rng.uniform(0.5, 1.5, c).astype(np.float32))
+    shift = _t((0.1 * rng.standard_normal(c)).astype(np.float32))
+    relu = i != 1
+    want = torch.full((rows, c + 16), -3.0, device=DEV, dtype=dtype)
+    ops.conv_fwd(x, cin + 16, 8, wt, scale, shift, want, c + 16, 8, rows, 1, 1, cin, c, 1, 1, 1, relu)
+    got = torch.full((rows, c + 16), -3.0, device=DEV, dtype=dtype)
+    outs.append((wt, scale, shift, got, c + 16, 8, c, relu)); wants.append(want)
+  ops.conv1x1_fwd_multi(x, cin + 16, 8, ops.conv_outs(outs), rows, cin)
+  torch.cuda.synchronize()
+  for o, want in zip(outs, wants):
+    assert torch.equal(o[3], want)
+  assert float(wants[1].float().min()) < 0.0          # (the ReLU-free output really is one)
+
+
 FUSED_CASES = [
     (3, 7, 7, 32, 64, 1, 1),      # few rows: 64x64 tiles
     (70, 4, 4, 48, 96, 3, 1),     # pixel-major rows, ragged last group of 32 images
