@@ -597,7 +597,7 @@ class Net(object):
             prods.append((None, None, None, width))
           off += width
         assert off == cur["cin"]
-        owner["prods"] = ops.bn_producers(prods)
+        owner["prod_list"] = prods            # (the C2dBnProducer array is built at first use)
         cur["fuse_out"] = owner
     # The last block's last convolutions write the network output: when every branch ends in a
     # trainable convolution over per-ROI maps, their BN/ReLU backward can take the gradient of
@@ -842,6 +842,8 @@ class Net(object):
           self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"])
         rows = st["n"] * st["ih"] * st["iw"]
         ws0 = owner["ws_off"]
+        if "prods" not in owner:
+          owner["prods"] = ops.bn_producers(owner["prod_list"])
         segs = [self._entry_dc(b) for b in fused]
         ops.conv1x1_dgrad_multi_bn_relu(
             [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],

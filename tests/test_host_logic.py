@@ -84,3 +84,54 @@ def test_product_never_imports_the_oracle_or_reference():
       if f.endswith((".py", ".hip", ".h")):
         text = open(os.path.join(base, f)).read()
         assert not pat.search(text), os.path.join(base, f)
+
+
+@pytest.mark.parametrize("fuse,commute,want", [("1", "1", (9, 5, 1)), ("1", "0", (9, 6, 0)),
+                                               ("0", "1", (0, 0, 1))])
+def test_second_stage_backward_plan(monkeypatch, fuse, commute, want):
+  """The launch plan of the second stage for per-ROI maps (host logic only, no kernel runs):
+  which convolutions get their BN/ReLU backward from the consumer's input-gradient GEMM (inner:
+  9), from the next block's multi-segment GEMM (boundary: the last convolutions of Mixed_5a and
+  5b), which branch runs with its average pool commuted, and that every trainable convolution
+  owns exactly one row range of the partial-sum workspace."""
+  import torch
+  from cap2det_amd.models.frcnn_engine import SECOND_SCOPE, SECOND_STAGE, DerivedStore, Net, VariableStore
+  monkeypatch.setenv("C2D_FUSE_BN_BWD", fuse)
+  monkeypatch.setenv("C2D_COMMUTE_AVGPOOL", commute)
+  dev = torch.device("cpu")
+  store, stats = VariableStore(dev), DerivedStore(dev)
+  net = Net(store, stats, SECOND_STAGE, SECOND_SCOPE, 576, True, 1.0)
+  store.finalize(); stats.finalize()
+  for L in net.layers.values():
+    L.trainable = True
+  plan = net.plan(128, 7, 7, True)
+  net._prepare_backward(plan, 0)
+  ops_ = [op for st in plan["steps"] for b in st["branches"] for op in b]
+  inner = sum(1 for o in ops_ if "fused_blocks" in o and "fused_wide" not in o)
+  boundary = sum(1 for o in ops_ if "fused_wide" in o)
+  commuted = sum(1 for o in ops_ if o.get("commuted"))
+  assert (inner, boundary, commuted) == want
+  assert plan["head_ok"] == (fuse != "0")
+  # the commuted branch: 1x1 convolution (no ReLU) first, pool + ReLU last, both on cout channels
+  for st in plan["steps"]:
+    for b in st["branches"]:
+      if b[0].get("commuted"):
+        assert [o["kind"] for o in b] == ["conv", "pool"] and b[0]["relu"] is False
+        assert b[1]["relu"] is True and b[1]["c"] == b[0]["layer"].cout == 128
+  # partial-sum rows: one descriptor per trainable convolution, regions inside the workspace,
+  # producers of one boundary share a region and split its columns
+  convs = [o for o in ops_ if o["kind"] == "conv"]
+  assert plan["bn_num"] == len(convs) == 19
+  size = plan["bn_ws"].numel()
+  for o in convs:
+    off, n = o["bn_part"]
+    assert 0 <= off and off + n <= size
+  owners = {}
+  for o in ops_:
+    if "fused_wide" in o:
+      owner, col = o["fused_wide"]
+      owners.setdefault(id(owner), []).append((col, o["layer"].cout, owner["ctot"]))
+  for cols in owners.values():
+    cols.sort()
+    assert all(c0 + w0 <= c1 for (c0, w0, _), (c1, _, _) in zip(cols, cols[1:]))
+    assert cols[-1][0] + cols[-1][1] <= cols[0][2]
