@@ -749,10 +749,11 @@ __global__ __launch_bounds__(256) void bn_fold_batched_kernel(
 // at the layer's first column of block 0's beta half.
 struct BnPartDesc { long long ws_off, dbeta_off, dgamma_off; int nblocks, c, begin, wide; };
 
-__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(
+constexpr int BNR_TY = 64;      // row lanes per 64-channel chunk (64 instead of 16: four times the loads in flight per chunk)
+__global__ __launch_bounds__(16 * BNR_TY) void bn_partials_reduce_kernel(
     const BnPartDesc* __restrict__ desc, int num, const float* __restrict__ ws,
     float* __restrict__ grads) {
-  __shared__ float4 red[2][16][16];
+  __shared__ float4 red[2][BNR_TY][16];
   int lo = 0, hi = num - 1;          // last descriptor with begin <= blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(256) void bn_partials_reduce_kernel(
     const float* base = ws + d.ws_off + c;
     const int half = d.wide > 0 ? d.wide : d.c;
     const size_t bstride = (size_t)2 * half;
-    for (int b = ty; b < d.nblocks; b += 16) {
+    for (int b = ty; b < d.nblocks; b += BNR_TY) {
       const float4 vb = *reinterpret_cast<const float4*>(base + b * bstride);
       const float4 vg = *reinterpret_cast<const float4*>(base + b * bstride + half);
       sb.x += vb.x; sb.y += vb.y; sb.z += vb.z; sb.w += vb.w;
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(256) void bn_partials_reduce_kernel(
     const long long off = ty == 0 ? d.dbeta_off : d.dgamma_off;
     if (off >= 0) {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = 0; k < 16; ++k) {
+      for (int k = 0; k < BNR_TY; ++k) {
         const float4 v = red[ty][k][tx];
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
       }
@@ -1058,7 +1059,7 @@ extern "C" int c2d_bn_bwd_partial_bf16(const void* dy, int lddy, int dyoff, cons
 extern "C" int c2d_bn_partials_reduce_batched(const void* desc, int num, int total_chunks,
                                               const float* ws, float* grads, void* stream) {
   C2D_CHECK_ARG(desc && ws && grads && num > 0 && total_chunks > 0);
-  hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(total_chunks), dim3(256), 0,
+  hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(total_chunks), dim3(16 * BNR_TY), 0,
                      (hipStream_t)stream, (const BnPartDesc*)desc, num, ws, grads);
   return c2d_launch_status();
 }
