@@ -2741,7 +2741,7 @@ static int conv1x1_fwd_multi_impl(const void* x, int ldx, int xoff, int nout, co
                                   int rows, int cin, void* stream, int es) {
   dispatch_reset();
   C2D_CHECK_ARG(x && outs && nout >= 1 && nout <= 4 && rows > 0 && cin > 0);
-  C2D_CHECK_ARG(cin % (16 / es) == 0 && ldx % (16 / es) == 0 && xoff % (16 / es) == 0);
+  C2D_CHECK_ARG(cin % 16 == 0 && ldx % (16 / es) == 0 && xoff % (16 / es) == 0);   // (as c2d_conv_fwd)
   IgemmArgs a = {};
   int rc = fill_geom(&a.g, 1, 1, 1, 1, 1, 0);
   if (rc) return rc;
