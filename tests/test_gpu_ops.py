@@ -1,5 +1,6 @@
 """GPU parity tests, kernel by kernel: the HIP path (through the C-ABI) against the numpy oracle
 on identical seeded inputs.  Tolerances are written per test; index/byte outputs are exact."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -759,3 +760,15 @@ def test_conv_wgrad_partial_slabs(ops, case, dtype):
   got = _n(outs[0]).reshape(want.shape) - 0.5
   scale = np.abs(want).max()
   np.testing.assert_allclose(got, want, rtol=2e-4, atol=(1e-4 if dtype == torch.bfloat16 else 2e-5) * scale)
+
+
+def test_fused_entry_points_agree_with_unfused_launches_on_random_shapes():
+  """tools/fuzz_fused.py (30 random shapes per fused entry point, fp32 and bf16): the fused
+  input gradient, the multi-output 1x1 forward and the block-boundary input gradient against the
+  unfused launches they replace."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fused.py"), "30", "11"],
+                     capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+  assert "0 mismatches" in r.stdout
