@@ -324,13 +324,16 @@ class Net(object):
       self._plans[key] = self._build_plan(n, ih, iw, training)
     return self._plans[key]
 
-  def _commutes(self, branch, block, n):
-    """An average-pooling branch whose pool can run behind its 1x1 convolution (per-ROI maps)."""
+  def _commutes(self, branch, block, n, training):
+    """An average-pooling branch whose pool can run behind its 1x1 convolution (per-ROI maps).
+    In a training plan only for a TRAINABLE convolution: the backward pass of a commuted layer
+    is the no-ReLU form (c2d_bn_bwd_partial), which exists for trainable layers only — a frozen
+    layer inside the backward range keeps the reference order (pool in front)."""
     if not (n >= 64 and len(branch) == 2 and branch[0][0] == "avg" and branch[0][2] == 1 and
             branch[1][0] == "conv" and os.environ.get("C2D_COMMUTE_AVGPOOL", "1") != "0"):
       return False
     layer = self.layers[self.scope + block + "/" + branch[1][1]]
-    return layer.k == 1 and layer.stride == 1
+    return layer.k == 1 and layer.stride == 1 and (layer.trainable or not training)
 
   def _new(self, rows, c, dtype=None):
     return torch.empty(rows, c, device=self.store.device, dtype=dtype or self.dtype)
@@ -377,7 +380,7 @@ class Net(object):
         for branch, wdt in zip(op[2], widths):
           bsteps = []
           bx, bh, bw, bc = x, h, w, c
-          if self._commutes(branch, op[1], n):
+          if self._commutes(branch, op[1], n, training):
             # avg_pool 3x3 -> 1x1 conv -> BN -> ReLU over per-ROI maps, run as 1x1 conv -> BN ->
             # avg_pool -> ReLU (c2d_avgpool3x3_relu_fwd: same function up to rounding): the pool
             # and its gradient touch cout channels instead of cin, and the convolution becomes
@@ -753,6 +756,8 @@ class Net(object):
       off, size = st["bn_part"]          # (the ReLU sits behind the pool: see _build_plan)
       ops.bn_bwd_partial(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
                          plan["bn_ws"][off:off + size], rows, L.cout)
+    elif st.get("commuted"):
+      raise RuntimeError("commuted convolution %s without a trainable backward form" % L.name)
     elif tr and "bn_part" in st:
       off, size = st["bn_part"]
       ops.bn_relu_bwd_partial(gy.t, gy.ld, gy.off, y.t, y.ld, y.off, L.scale, beta, gamma, dc,
@@ -1024,6 +1029,9 @@ class FrcnnEngine(object):
     for net in (self.first, self.second):
       for layer in net.layers.values():
         layer.trainable = (layer.name + "/weights") in trainable_names
+      net._plans.clear()           # (launch plans depend on which layers train)
+    self.invalidate_prefetch()
+    self._shape_cache.clear()
     for i, names in enumerate(self.first.order):
       if any(self.first.layers[n].trainable for n in names):
         idx = i

@@ -44,6 +44,18 @@ def exponential_decay(lr, step, decay_steps, decay_rate, staircase):
   return lr * (decay_rate ** p)
 
 
+def dropout_key(seed, global_step, rank, world_size):
+  """Key of the counter-based dropout generator for one step of one worker: a splitmix64 hash of
+  (trainer seed, global step, rank), so that runs started with different seeds draw different mask
+  sequences and no two (step, rank) pairs of one run share a mask.  Kept below 2^63: the hipGraph
+  path stores it in an int64 device word."""
+  m = (1 << 64) - 1
+  x = (int(seed) * 0x9E3779B97F4A7C15 + int(global_step) * int(world_size) + int(rank)) & m
+  x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+  x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+  return (x ^ (x >> 31)) & ((1 << 63) - 1)
+
+
 class Trainer(object):
   """Owns the model, the optimiser state and the data-parallel reduction."""
 
@@ -52,6 +64,7 @@ class Trainer(object):
     pipeline_proto = unwrap(pipeline_proto)
     if not isinstance(pipeline_proto, pipeline_pb2.Pipeline):
       raise ValueError('pipeline_proto has to be an instance of Pipeline.')
+    self.seed = int(model_kwargs.get("seed", 0) or 0)
     self.pipeline = pipeline_proto
     self.train_config = pipeline_proto.train_config
     self.device = torch.device(device)
@@ -269,8 +282,8 @@ class Trainer(object):
     frozen first-stage layers are computed under this step's kernels."""
     if kwargs.get("dropout_seed") is None and kwargs.get("dropout_mask") is None:
       # slim.dropout draws a fresh mask every step on every worker (models/utils.py:171-174):
-      # the counter-based generator is keyed on (global step, rank)
-      kwargs["dropout_seed"] = self.global_step * self.world_size + self.rank
+      # the counter-based generator is keyed on (trainer seed, global step, rank)
+      kwargs["dropout_seed"] = dropout_key(self.seed, self.global_step, self.rank, self.world_size)
     if (self.use_graph and "dropout_mask" not in kwargs and
         not self.model.engine.dropout_on_feature_map):
       return self._graph_step(examples, **kwargs)

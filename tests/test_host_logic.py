@@ -135,3 +135,34 @@ def test_second_stage_backward_plan(monkeypatch, fuse, commute, want):
     cols.sort()
     assert all(c0 + w0 <= c1 for (c0, w0, _), (c1, _, _) in zip(cols, cols[1:]))
     assert cols[-1][0] + cols[-1][1] <= cols[0][2]
+
+
+def test_dropout_key_mixes_seed_step_and_rank():
+  """The default dropout key of Trainer.train_step (slim.dropout draws a fresh mask per step and
+  per worker, models/utils.py:171-174): distinct for every (seed, step, rank), int64-safe."""
+  keys = set()
+  for seed in (0, 1, 1234):
+    for step in range(50):
+      for rank in range(8):
+        k = trainer.dropout_key(seed, step, rank, 8)
+        assert 0 <= k < (1 << 63)
+        keys.add(k)
+  assert len(keys) == 3 * 50 * 8
+  assert trainer.dropout_key(7, 3, 1, 2) == trainer.dropout_key(7, 3, 1, 2)
+
+
+def test_predict_checkpoint_errors_are_typed(tmp_path):
+  """train/predict.py:583-611 polls model_dir; only an unreadable CHECKPOINT is retried (bounded),
+  any other missing file stays the FileNotFoundError it is."""
+  from cap2det_amd.train import predict
+  with pytest.raises(predict.CheckpointUnreadable):
+    predict.read_checkpoint_arrays(str(tmp_path / "model.ckpt-7"))
+  bad = tmp_path / "model.ckpt-8.npz"
+  bad.write_bytes(b"PK\x03\x04 truncated")
+  with pytest.raises(predict.CheckpointUnreadable):
+    predict.read_checkpoint_arrays(str(tmp_path / "model.ckpt-8"))
+  good = tmp_path / "model.ckpt-9.npz"
+  np.savez(str(good), __global_step=np.int64(9), __adagrad_accumulators=np.zeros(3), w=np.ones(2))
+  arrays = predict.read_checkpoint_arrays(str(tmp_path / "model.ckpt-9"))
+  assert sorted(arrays) == ["w"]
+  assert not issubclass(predict.CheckpointUnreadable, FileNotFoundError)

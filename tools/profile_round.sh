@@ -7,8 +7,9 @@
 # benchmark lines of all four BASELINE configs.  Copy the summaries you quote from gpurun_out/
 # into profiles/ (tools/summarize_pmc.py, tools/summarize_mfma.py reduce the PMC passes).
 set -x
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
+mkdir -p $O
 T=${PROFILE_TAG:-r02}
 cd /tmp; export TMPDIR=/tmp
 for CFG in c1 c2; do
