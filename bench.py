@@ -29,18 +29,20 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (n
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
-def synthetic_batch(seed, device, classes, pipeline, num_proposals=NUM_PROPOSALS):
+def synthetic_batch(seed, device, classes, pipeline, num_proposals=NUM_PROPOSALS, batch=1,
+                    image_hw=(IMAGE_HW, IMAGE_HW)):
   """SURVEY.md §8d synthetic inputs (seeded): image, proposals, object labels and — for the
   caption-driven configs — a 60-token caption over the extractor's open vocabulary."""
   import numpy as np
   import torch
   from cap2det_amd import synthetic
   rng = np.random.default_rng(seed)
-  ex = synthetic.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, num_proposals, [num_proposals], classes)
+  ex = synthetic.make_examples(rng, batch, image_hw[0], image_hw[1], num_proposals,
+                               [num_proposals] * batch, classes)
   vocab = synthetic.caption_vocabulary(pipeline)
   single = [c for c in classes if " " not in c]
   ex["concat_caption_string"] = synthetic.synthetic_captions(
-      rng, 1, vocab, tokens=60, must_contain=[single[int(rng.integers(0, len(single)))]])
+      rng, batch, vocab, tokens=60, must_contain=[single[int(rng.integers(0, len(single)))]])
   out = dict(ex)
   for k in ("image", "proposals", "number_of_proposals"):
     out[k] = torch.from_numpy(ex[k]).to(device).contiguous()
@@ -228,6 +230,13 @@ def parse_args(argv=None):
   ap.add_argument("--per-call", action="store_true",
                   help="also print one line per timed conv / ROI-crop call (stderr)")
   ap.add_argument("--graph", action="store_true", help="hipGraph replay of the step (measured: no gain over eager launches)")
+  ap.add_argument("--image-hw", type=int, nargs=2, default=None, metavar=("H", "W"),
+                  help="SECONDARY operating point (never the headline metric): image size, e.g. the "
+                       "reference's keep-aspect 1000-px training images (--image-hw 1000 1333)")
+  ap.add_argument("--batch", type=int, default=None,
+                  help="SECONDARY operating point: images per GPU per step (reference: batch_size 2)")
+  ap.add_argument("--proposals", type=int, default=None,
+                  help="SECONDARY operating point: proposals per image (reference: max_num_proposals 500)")
   ap.add_argument("--dtype", choices=["fp32", "bf16"], default=None,
                   help="override the config's precision: fp32 = exact fp32 everywhere; bf16 = ROI crop "
                        "output and second stage in bf16 storage / fp32 accumulate")
@@ -235,8 +244,8 @@ def parse_args(argv=None):
 
 
 def launch_ranks(args, argv):
-  """`python bench.py --gpus N` as a plain command: this parent never touches the GPU
-  (`torch.cuda.device_count()` does not initialise it on this image); it starts
+  """`python bench.py --gpus N` as a plain command: this parent never touches the GPU (it does
+  not even import torch: the devices are counted from the KFD topology in sysfs); it starts
   `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (no
   exec), relays its output and returns its exit code.  One process per GPU, as the reference's
   workers (train_wsod.sh:46-88).  With fewer devices than ranks (a 1-GPU box) every rank shares
@@ -247,8 +256,8 @@ def launch_ranks(args, argv):
   env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
   env.setdefault("MASTER_ADDR", "127.0.0.1")
   if env.get("C2D_BENCH_STUB") != "1" and env.get("C2D_BENCH_SAME_DEVICE") != "1":
-    import torch
-    ndev = torch.cuda.device_count()
+    from cap2det_amd.train.gpu_count import count_visible_gpus     # (sysfs only: no torch, no HIP)
+    ndev = count_visible_gpus()
     if ndev == 0:
       print("bench.py: no GPU visible (set C2D_BENCH_STUB=1 for the CPU launcher test)", file=sys.stderr)
       return 2
@@ -341,9 +350,18 @@ def main(argv=None):
   if same_device:
     local_rank = 0
   backend = None
-  if world > 1:
+  # C2D_FORCE_ALLREDUCE=1 at one rank: rehearsal of the RCCL path on a 1-GPU box — a process group
+  # of one rank over nccl, and the reducers issue their collectives (data_parallel.collectives_on)
+  forced = world == 1 and os.environ.get("C2D_FORCE_ALLREDUCE") == "1"
+  grouped = world > 1 or forced
+  if grouped:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "MASTER_PORT" not in os.environ:
+      import socket
+      with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
     torch.cuda.set_device(local_rank)
     backend = "gloo" if same_device else "nccl"
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -372,10 +390,16 @@ def main(argv=None):
     shutil.rmtree(scratch, ignore_errors=True)
   classes = trainer.model.label_extractor.classes
   assert len(classes) == spec["classes"]
-  batch, _ = synthetic_batch(1000 + rank, device, classes, pipeline)
+  # the headline workload, unless --image-hw / --batch / --proposals name a secondary point
+  image_hw = tuple(args.image_hw) if args.image_hw else (IMAGE_HW, IMAGE_HW)
+  images_per_gpu = args.batch or 1
+  num_proposals = args.proposals or NUM_PROPOSALS
+  secondary = (image_hw, images_per_gpu, num_proposals) != ((IMAGE_HW, IMAGE_HW), 1, NUM_PROPOSALS)
+  batch, _ = synthetic_batch(1000 + rank, device, classes, pipeline, num_proposals, images_per_gpu,
+                             image_hw)
 
   def sync():
-    if world > 1:
+    if grouped:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -420,15 +444,25 @@ def main(argv=None):
                     for i in range(args.steps - (0 if args.no_kernel_timing else 1)))
   timer.enabled = False
   total_loss = float(losses["total_loss"].item())
-  if world > 1:
+  ranks_counted = None
+  if grouped:
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # what the process group itself saw: its world size and a rank count summed over it
+    ones = torch.ones(1, device=device, dtype=torch.int32)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    ranks_counted = int(ones.item())
 
   if rank == 0:
-    images = world * args.steps * 1
+    images = world * args.steps * images_per_gpu
+    crop_kernel = ("roi_crop_pool2_fwd_stream_kernel (crop_and_resize 14x14 fused with 2x2 max-pool, "
+                   "source columns streamed through registers)")
     result = {
-        "metric": "images/sec (500x500, 2000 proposals), full WSOD training step",
+        "metric": ("images/sec (500x500, 2000 proposals), full WSOD training step" if not secondary else
+                   "SECONDARY operating point (not the BASELINE metric): images/sec (%dx%d, %d "
+                   "proposals, %d images per GPU), full WSOD training step"
+                   % (image_hw[0], image_hw[1], num_proposals, images_per_gpu)),
         "value": images / elapsed,
         "unit": "images/s",
         "n_gpus": world,
@@ -441,20 +475,28 @@ def main(argv=None):
         "dtype": "f32" if args.dtype == "fp32" else "bf16 storage (ROI crop output + second stage), f32 accumulate",
         "data": "synthetic",
         "config": {"workload": "%s%s: Inception-V2, %d classes, label extractor %s inside the step, "
-                               "OICR x3, Mixed_4e + second stage + heads trainable, 1 image 500x500x3 "
+                               "OICR x3, Mixed_4e + second stage + heads trainable, %d image(s) %dx%dx3 "
                                "per GPU, %d proposals, %s, Adagrad; fwd+loss+bwd+optimizer%s"
                                % (spec["title"],
                                   "" if args.dtype == spec["dtype"] else " [precision overridden]",
                                   len(classes), type(trainer.model.label_extractor).__name__,
-                                  NUM_PROPOSALS,
+                                  images_per_gpu, image_hw[0], image_hw[1], num_proposals,
                                   "fp32" if args.dtype == "fp32" else "bf16 storage / fp32 accumulate",
-                                  "+RCCL all-reduce" if world > 1 else ""),
+                                  "+RCCL all-reduce" if grouped else ""),
                    "baseline_config": args.config, "pipeline": spec["pipeline"] + ".pbtxt",
-                   "images_per_gpu": 1, "parallelism": "dp%d" % world,
+                   "images_per_gpu": images_per_gpu, "image_hw": list(image_hw),
+                   "proposals": num_proposals, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay" if args.graph else "eager"},
         "world_size": world,
         "final_total_loss": total_loss,
     }
+    if grouped:
+      result["process_group"] = {"backend": backend, "world_size": dist.get_world_size(),
+                                 "ranks_counted_by_all_reduce": ranks_counted,
+                                 "forced_at_one_rank": forced}
+    crop_path = getattr(trainer.model.engine, "last_crop_bwd", None)
+    if crop_path:
+      result["config"]["roi_crop_backward"] = crop_path
     if per_step:
       pick = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
       result["step_ms_gpu"] = {"p10": pick(0.1), "p50": pick(0.5), "p90": pick(0.9),
@@ -536,19 +578,21 @@ def main(argv=None):
       if rc:
         gbs = rc["work"] / (rc["ms"] * 1e-3) / 1e9
         result["roofline_roi_crop"] = {
-            "kernel": "roi_crop_pool2_fwd_stream_kernel (crop_and_resize 14x14 fused with 2x2 max-pool, source columns streamed through registers)",
+            "kernel": crop_kernel,
             "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": gbs / PEAK_HBM_GBPS, "traffic": traffic.get("roi_crop_pool_fwd", {}).get("hbm_bytes_per_launch"),
             "avg_launch_ms": rc["ms"] / rc["launches"],
             "algorithmic_bytes_per_launch": rc["work"] / rc["launches"]}
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not secondary:
       result["cpu_baseline"] = cpu_baseline(pipeline, classes, NUM_PROPOSALS)
+      # configs[0] (N = 300, the reference's own CPU-runnable case): the same CPU step, SURVEY §8d
+      result["cpu_baseline_c0"] = cpu_baseline(pipeline, classes, 300, budget_s=15.0)
     if world > 1:
       result["backend"] = ("gloo, all ranks on cuda:0 (C2D_BENCH_SAME_DEVICE: code-path validation, "
                            "the value is not a scaling point)" if same_device else "nccl (RCCL)")
     print(json.dumps(result))
     sys.stdout.flush()
-  if world > 1:
+  if grouped:
     dist.destroy_process_group()
 
 

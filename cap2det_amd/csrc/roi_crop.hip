@@ -709,6 +709,27 @@ extern "C" long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, in
          (long long)kRowParts * batch * hf * wf * depth * 4;
 }
 
+// Channel chunk of the strip kernel = its workgroup size: the largest of 256 / 192 / 128 that
+// divides the depth, else 64 with a ragged last chunk (576 -> 192: 768-byte segments per cell,
+// 25 KiB of LDS, six workgroups per CU) — and small enough that the byte offset of the strip's
+// spare column wf still fits the 16-bit halves of RowEntry::off0/off1: maps wider than 64 / 85
+// columns (the reference's 1000-px training images: up to ~100 x 75 feature pixels, readers/
+// cap2det_reader.py:143-172) fall back to narrower chunks, down to 64 channels at wf <= 255.
+// 0: no chunk fits (the caller falls back to the atomic kernel).
+static int strip_chunk(int depth, int wf) {
+  for (int c : {256, 192, 128})
+    if (depth % c == 0 && (long long)wf * c * 4 <= 65535) return c;
+  return (long long)wf * 64 * 4 <= 65535 ? 64 : 0;
+}
+
+extern "C" int c2d_roi_crop_pool_bwd_ws_supported(int wf, int depth, int crop, int pool_k,
+                                                  int pool_s) {
+  if (wf < 2 || depth <= 0 || depth % 16 != 0 || pool_k != 2 || pool_s <= 0 || crop <= 0 ||
+      crop > kMaxCrop || (crop - pool_k) / pool_s + 1 > 16)
+    return 0;
+  return strip_chunk(depth, wf);
+}
+
 template <typename TG>
 static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, const float* boxes,
                                      const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
@@ -721,8 +742,8 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   C2D_CHECK_ARG(boxes && box_ind && workspace && (phase == 1 || (dout && argmax && dfeat)));
   C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 16 == 0);
   C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0 && pool_s > 0);
-  if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) || wf > 64 ||
-      wf < 2 || (long long)num_boxes * ((crop - pool_k) / pool_s + 1) * ((crop - pool_k) / pool_s + 1) *
+  if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) ||
+      strip_chunk(depth, wf) == 0 || wf < 2 || (long long)num_boxes * ((crop - pool_k) / pool_s + 1) * ((crop - pool_k) / pool_s + 1) *
                         depth >= (1ll << 31))
     return C2D_ERR_UNSUPPORTED;
   if (num_boxes == 0) return C2D_OK;
@@ -745,10 +766,7 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   if (phase != 2)
   hipLaunchKernelGGL(roi_axes_kernel, dim3(c2d_ceil_div((long long)num_boxes * crop, 256)),
                      dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
-  // channel chunk = workgroup size: the largest of 256 / 192 / 128 that divides the depth, else
-  // 64 with a ragged last chunk (576 -> 192: 768-byte segments per cell, 25 KiB of LDS, six
-  // workgroups per CU)
-  const int chunk = depth % 256 == 0 ? 256 : depth % 192 == 0 ? 192 : depth % 128 == 0 ? 128 : 64;
+  const int chunk = strip_chunk(depth, wf);
   if (phase != 2)
   hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
                      box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout, crop,

@@ -59,6 +59,11 @@ def roi_crop_pool_bwd(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool_s)
   return dfeat
 
 
+def roi_crop_pool_bwd_ws_supported(wf, depth, crop, pool_k, pool_s):
+  """Channel chunk of the atomic-free ROI-crop backward for this map width, 0 = unsupported."""
+  return int(_lib.load().c2d_roi_crop_pool_bwd_ws_supported(wf, depth, crop, pool_k, pool_s))
+
+
 def roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes, crop, pool_k, pool_s):
   return int(_lib.load().c2d_roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes,
                                                                crop, pool_k, pool_s))

@@ -936,6 +936,8 @@ class FrcnnEngine(object):
       self.prefetch_stream = torch.cuda.Stream(device=store.device)
     self._shape_cache = {}
     self.first_trainable_idx = None
+    self.last_crop_bwd = None      # which ROI-crop backward the last backward() ran (bench / tests)
+    self.force_atomic_crop_bwd = False   # tests: run c2d_roi_crop_pool_bwd where the row-owner form fits
 
   # -- variables --------------------------------------------------------------------
   def finalize(self, extra_transposes=()):
@@ -1069,7 +1071,12 @@ class FrcnnEngine(object):
     return bufs
 
   def _crop_bwd_ws_ok(self, bufs, d):
-    return (self.pool_k == 2 and bufs["p"] <= 16 and 2 <= bufs["fw"] <= 64 and d % 16 == 0)
+    """The atomic-free row-owner backward covers this shape (maps up to 255 columns wide: the
+    reference's 1000-px training images give up to ~100; c2d_roi_crop_pool_bwd_ws_supported)."""
+    if "crop_ws_ok" not in bufs:
+      bufs["crop_ws_ok"] = ops.roi_crop_pool_bwd_ws_supported(bufs["fw"], d, self.crop, self.pool_k,
+                                                              self.pool_s) > 0
+    return bufs["crop_ws_ok"]
 
   def _crop_ws(self, bufs, b, n, d):
     if "crop_ws" not in bufs:
@@ -1270,7 +1277,10 @@ class FrcnnEngine(object):
       dp4 = dpooled.t.view(b * n, bufs["p"], bufs["p"], d)
       arg4 = bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], d)
       gf4 = gcrop.view(b, bufs["fh"], bufs["fw"], d)
-      if self._crop_bwd_ws_ok(bufs, d):
+      use_ws = self._crop_bwd_ws_ok(bufs, d) and not self.force_atomic_crop_bwd
+      self.last_crop_bwd = ("row-owner strips (atomic-free)" if use_ws
+                            else "atomic fallback (c2d_roi_crop_pool_bwd)")
+      if use_ws:
         # atomic-free, bitwise reproducible row-owner form (needs a workspace)
         ws = self._crop_ws(bufs, b, n, d)
         if ctx.get("crop_ready") is not None:           # lists built during the forward pass

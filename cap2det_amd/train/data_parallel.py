@@ -6,6 +6,8 @@ The reference shards records across its async workers with a hash filter
 (TF parameter server, train_wsod.sh:46-88); the synchronous mean used here is what its
 `SyncReplicasOptimizer` option computes (train/trainer.py:90-94).
 """
+import os
+
 import torch.distributed as dist
 
 
@@ -13,6 +15,20 @@ def world_info():
   if dist.is_available() and dist.is_initialized():
     return dist.get_rank(), dist.get_world_size()
   return 0, 1
+
+
+def collectives_on():
+  """True when the reducers must issue their collectives: more than one rank — or a process
+  group of ONE rank with C2D_FORCE_ALLREDUCE=1, the rehearsal of the RCCL path (communicator
+  setup, the all-reduce on RCCL's stream beside the step's compute / side / look-ahead streams,
+  the stream joins around it) on a box with a single GPU.  A one-rank sum is the identity, so
+  the step's results must not change."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  return dist.get_world_size() > 1 or os.environ.get("C2D_FORCE_ALLREDUCE") == "1"
+
+
+from cap2det_amd.train.gpu_count import count_visible_gpus  # noqa: E402,F401  (torch-free module)
 
 
 def shard_range(num_items, rank, world):
@@ -28,7 +44,7 @@ def allreduce_bucket(flat, group=None):
   """Sums `flat` (a contiguous 1-D slice of the flat gradient buffer) over all ranks in place.
   Returns the factor the optimiser must scale the sum by (1 / world size)."""
   _, world = world_info()
-  if world > 1:
+  if collectives_on():
     if not flat.is_contiguous():
       raise ValueError("gradient bucket must be contiguous")
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -44,20 +60,21 @@ class OverlappedReducer(object):
   still have ~1 ms of kernels to go: `start_tail()` launches the all-reduce of that suffix
   (>= 85 % of the bytes) asynchronously — RCCL runs it on its own stream after the gradient
   kernels already enqueued — and `finish()` reduces the small prefix and waits for both.
-  With one rank both are no-ops."""
+  With one rank both are no-ops (unless C2D_FORCE_ALLREDUCE=1: `collectives_on`)."""
 
   def __init__(self, flat, split, group=None):
     self.flat, self.split, self.group = flat, int(split), group
     self._work = None
     _, self.world = world_info()
+    self.on = collectives_on()
 
   def start_tail(self):
-    if self.world > 1 and self.split < self.flat.numel():
+    if self.on and self.split < self.flat.numel():
       self._work = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, group=self.group,
                                    async_op=True)
 
   def finish(self):
-    if self.world > 1:
+    if self.on:
       head = self.flat[:self.split] if self._work is not None else self.flat
       if head.numel():
         dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)

@@ -457,8 +457,13 @@ int c2d_clip_gradient_norms(float* grads, const float* values, const C2dClipDesc
 /* Atomic-free, bitwise-reproducible form of c2d_roi_crop_pool_bwd (same semantics: adds into
  * dfeat).  Needs a caller-owned device workspace of at least
  * c2d_roi_crop_pool_bwd_workspace_bytes(...) bytes (sampling tables + per-row cell lists);
- * returns C2D_ERR_WORKSPACE if it is too small, C2D_ERR_UNSUPPORTED unless pool_k == 2, the
- * pooled map is at most 16x16 and wf <= 64 (use c2d_roi_crop_pool_bwd then). */
+ * returns C2D_ERR_WORKSPACE if it is too small, C2D_ERR_UNSUPPORTED unless
+ * c2d_roi_crop_pool_bwd_ws_supported(...) != 0: pool_k == 2, the pooled map at most 16x16,
+ * depth % 16 == 0 and 2 <= wf <= 255 (use c2d_roi_crop_pool_bwd then).  Maps of the reference's
+ * 1000-px training images (readers/cap2det_reader.py:143-172: up to ~100 feature columns) are
+ * inside that range; the value returned is the channel chunk (= workgroup size) the strip kernel
+ * will use for (wf, depth). */
+int c2d_roi_crop_pool_bwd_ws_supported(int wf, int depth, int crop, int pool_k, int pool_s);
 long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, int wf, int depth,
                                                 int num_boxes, int crop, int pool_k, int pool_s);
 int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax, const float* boxes,

@@ -93,7 +93,8 @@ def crop_and_resize(feat, boxes, box_ind, crop):
     idx = base + yy[:, :, None] * w + xx[:, None, :]
     return rows.index_select(0, idx.reshape(-1)).view(idx.shape + (d,))
 
-  lx4, ly4 = lx[:, None, :, None], ly[:, :, None, None]
+  # (coordinates and lerp weights are float32 as in TF's kernel; the lerps run in the map's type)
+  lx4, ly4 = lx[:, None, :, None].to(feat.dtype), ly[:, :, None, None].to(feat.dtype)
   tl, tr = gather(t, l), gather(t, r)
   top = tl + (tr - tl) * lx4
   del tl, tr
@@ -107,8 +108,12 @@ def crop_and_resize(feat, boxes, box_ind, crop):
 
 def train_step(P, accum, examples, labels, options, loss_opts, multipliers, learning_rate,
                l2_weight, dropout_mask=None):
-  """Same contract as oracle.ref_model.train_step (P / accum float32, updated in place)."""
+  """Same contract as oracle.ref_model.train_step (P / accum updated in place).  The arithmetic
+  type is P's: float32 for the timed CPU baseline, float64 for the committed mid-size fixtures
+  (tests/golden/gen_step_fixture.py)."""
   K = loss_opts["oicr_iterations"]
+  dt = next(iter(P.values())).dtype.type
+  tdt = torch.float64 if dt == np.float64 else torch.float32
   trainable_names = [k for k in P if not (k.endswith("moving_mean") or
                                           k.endswith("moving_variance"))]
   mult = ref_model.resolve_gradient_multipliers(trainable_names, multipliers)
@@ -121,7 +126,7 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
       t = t.clone().requires_grad_(True)
       leaves[k] = t
     T[k] = t
-  image = examples["image"].astype(np.float32)
+  image = examples["image"].astype(dt)
   x = _nchw(image) * (2.0 / 255.0) - 1.0
   x = x.contiguous(memory_format=torch.channels_last)
   spec1 = ref_model.FIRST_STAGE
@@ -142,7 +147,7 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
   avg = net.mean(dim=(2, 3))
   if dropout_mask is not None:
     avg = avg * (1.0 / options.dropout_keep_prob) * torch.from_numpy(
-        dropout_mask.astype(np.float32)).reshape(avg.shape)
+        dropout_mask.astype(dt)).reshape(avg.shape)
   features = avg.reshape(batch, n, -1)
 
   f_np = features.detach().numpy()
@@ -159,10 +164,10 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
       loss_grads, dict(features=f_np, midn=midn_saved), P, K)
   names = list(leaves)
   gs = torch.autograd.grad(features, [leaves[k] for k in names],
-                           torch.from_numpy(np.ascontiguousarray(dfeatures, np.float32)),
+                           torch.from_numpy(np.ascontiguousarray(dfeatures, dt)).to(tdt),
                            allow_unused=True)
   for k, g in zip(names, gs):
     if g is not None:
       grads[k] = g.numpy()
-  return ref_model.finish_step(P, accum, grads, loss_dict, mult, np.float32, learning_rate,
+  return ref_model.finish_step(P, accum, grads, loss_dict, mult, dt, learning_rate,
                                l2_weight, predictions=predictions)

@@ -1,0 +1,91 @@
+"""Generates tests/golden/step_dm1_n{256,704}.npz: the FLOAT64 oracle's full training step at
+depth multiplier 1.0 — one 160x160 image, N = 256 / 704 proposals, voc07_groundtruth semantics
+(models/cap2det_model.py:152-216,274-330; models/utils.py:15-188; train/trainer.py:55-146) —
+at sizes where the numpy oracle alone would not finish in seconds: the towers, crop_and_resize and
+pooling run on torch-CPU in float64 (oracle/torch_step.py, pinned against the hand-derived numpy
+step by tests/test_oracle_vs_torch.py), heads / MIDN / OICR / Adagrad in the numpy oracle.
+
+Run in the build container:  python tests/golden/gen_step_fixture.py
+The fixtures hold EXPECTED OUTPUTS only (scores, losses, gradient norms and sampled gradient /
+updated-variable entries); tests/test_gpu_step_fixture.py regenerates the seeded inputs and
+checks their checksums against the ones stored here."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HW, DM, SEED, SAMPLES = 160, 1.0, 5, 48
+
+
+def inputs(n, classes):
+  """The seeded inputs of a fixture (shared with the GPU test)."""
+  from tests import util_model
+  rng = np.random.default_rng(1000 + n)
+  real = n - n // 8
+  ex = util_model.make_examples(rng, 1, HW, HW, n, [real], classes)
+  P32, d = util_model.oracle_state(SEED, len(classes), 3, DM)
+  mask = (rng.uniform(size=(n, d)) < 0.5).astype(np.uint8)
+  return ex, P32, mask, real
+
+
+def checksum(ex, P32, mask):
+  return np.array([float(ex["image"].astype(np.float64).sum()),
+                   float(ex["proposals"].astype(np.float64).sum()),
+                   float(sum(np.abs(v.astype(np.float64)).sum() for v in P32.values())),
+                   float(mask.sum())])
+
+
+def sample_indices(name, size):
+  """SAMPLES pseudo-random flat positions of a variable (a function of its name only)."""
+  seed = int.from_bytes(name.encode()[-8:].rjust(8, b"\0"), "little") % (2 ** 32)
+  return np.random.default_rng(seed).integers(0, size, min(SAMPLES, size))
+
+
+def main():
+  import torch
+  from oracle import ref_labels, ref_model, torch_step
+  from cap2det_amd import synthetic
+  torch.set_num_threads(8)
+  pipeline = synthetic.load_pipeline()
+  classes = synthetic.read_lines(os.path.join(synthetic.DATA, "voc_label.txt"))
+  mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
+  loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
+                   oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+  for n in (256, 704):
+    ex, P32, mask, real = inputs(n, classes)
+    P = {k: v.astype(np.float64) for k, v in P32.items()}
+    acc = {k: np.full(v.shape, 0.1) for k, v in P.items()}
+    labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
+    ex64 = dict(image=ex["image"].astype(np.float64), number_of_proposals=ex["number_of_proposals"],
+                proposals=ex["proposals"].astype(np.float64))
+    with np.errstate(over="ignore"):
+      out = torch_step.train_step(P, acc, ex64, labels, ref_model.FrcnnOptions(depth_multiplier=DM),
+                                  loss_opts, mults, 0.01, 1e-6, mask)
+    arrays = {"checksum": checksum(ex, P32, mask), "real": np.int64(real)}
+    for i in range(4):
+      arrays["scores_%d" % i] = out["predictions"]["oicr_proposal_scores_at_%d" % i]
+    arrays["midn_class_logits"] = out["predictions"]["midn_class_logits"]
+    arrays["midn_proba_r_given_c"] = out["predictions"]["midn_proba_r_given_c"]
+    for k, v in out["losses"].items():
+      arrays["loss/" + k] = np.float64(v)
+    arrays["total_loss"] = np.float64(out["total_loss"])
+    names = sorted(out["applied"])
+    arrays["grad_names"] = np.array(names)
+    arrays["grad_norm"] = np.array([np.sqrt((out["grads"][k].astype(np.float64) ** 2).sum()) for k in names])
+    arrays["grad_absmax"] = np.array([np.abs(out["grads"][k]).max() for k in names])
+    arrays["grad_samples"] = np.stack([
+        np.resize(out["grads"][k].reshape(-1)[sample_indices(k, out["grads"][k].size)], SAMPLES)
+        for k in names])
+    arrays["updated_samples"] = np.stack([
+        np.resize(P[k].reshape(-1)[sample_indices(k, P[k].size)], SAMPLES) for k in names])
+    path = os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n)
+    np.savez_compressed(path, **arrays)
+    print(path, os.path.getsize(path), "bytes; total_loss", out["total_loss"], "vars", len(names))
+
+
+if __name__ == "__main__":
+  main()

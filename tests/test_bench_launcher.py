@@ -49,3 +49,18 @@ def test_without_gpu_and_without_stub_fails_loudly():
     return
   r = _run({}, "--gpus", "2", "--steps", "1", "--warmup", "0")
   assert r.returncode != 0 and "no GPU" in r.stderr
+
+
+def test_parent_counts_gpus_without_torch():
+  """The launcher parent must stay GPU-free by construction: the device count comes from the KFD
+  topology in sysfs (cap2det_amd/train/gpu_count.py), no torch / HIP import."""
+  code = ("import sys; sys.path.insert(0, %r); "
+          "from cap2det_amd.train.gpu_count import count_visible_gpus; "
+          "n = count_visible_gpus(); assert isinstance(n, int) and n >= 0; "
+          "assert 'torch' not in sys.modules; print(n)" % ROOT)
+  r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                     text=True, timeout=60)
+  assert r.returncode == 0, r.stderr
+  env = dict(os.environ, HIP_VISIBLE_DEVICES="")
+  r2 = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, timeout=60)
+  assert r2.returncode == 0 and r2.stdout.strip() == "0"      # an empty device list hides every GPU

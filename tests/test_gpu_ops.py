@@ -97,6 +97,45 @@ def test_roi_crop_pool_bwd_workspace_form_is_exact_and_deterministic(ops):
     ops.roi_crop_pool_bwd_ws(_t(dout), _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2, small)
 
 
+
+@pytest.mark.parametrize("hf,wf,d,n,chunk", [(63, 84, 192, 300, 192),    # 1000x1333 image: 192-channel strips
+                                             (75, 100, 576, 100, 64),    # 1200x1600: 64-channel strips, 9 chunks
+                                             (75, 100, 80, 90, 64),      # ragged last chunk
+                                             (9, 255, 64, 60, 64),       # widest supported map
+                                             (32, 32, 576, 120, 192)])   # the benchmark's map
+def test_roi_crop_pool_bwd_workspace_form_on_wide_maps(ops, hf, wf, d, n, chunk):
+  """The reference trains on keep-aspect 1000-px images x {1.2, .8, .6, .4} (configs/
+  voc07_groundtruth.pbtxt:9-23, readers/cap2det_reader.py:143-172): feature maps up to ~100
+  columns wide.  The atomic-free row-owner backward covers them with narrower channel strips."""
+  from cap2det_amd import synthetic
+  assert ops.roi_crop_pool_bwd_ws_supported(wf, d, 14, 2, 2) == chunk
+  assert ops.roi_crop_pool_bwd_ws_supported(256, d, 14, 2, 2) == 0
+  rng = np.random.default_rng(hf * 1000 + wf)
+  feat = np.maximum(rng.standard_normal((2, hf, wf, d)), 0).astype(np.float32)
+  boxes = np.concatenate([_edge_boxes(rng, n // 3), synthetic.synthetic_boxes(rng, n - n // 3)]
+                         ).astype(np.float32)
+  ind = rng.integers(0, 2, n).astype(np.int32)
+  crop = ref_ops.crop_and_resize(feat, boxes, ind, 14)
+  pooled, arg = ref_ops.max_pool(crop, 2, 2, "VALID")
+  dout = rng.standard_normal(pooled.shape).astype(np.float32)
+  dcrop = ref_ops.max_pool_backward(crop.shape, arg, dout, 2, 2, "VALID")
+  want = ref_ops.crop_and_resize_grad_image(dcrop.astype(np.float64), boxes, ind, feat.shape)
+  ws = torch.empty(ops.roi_crop_pool_bwd_workspace_bytes(2, hf, wf, d, n, 14, 2, 2), dtype=torch.uint8,
+                   device=DEV)
+  outs = []
+  for _ in range(2):
+    dfeat = torch.zeros(feat.shape, device=DEV)
+    ops.roi_crop_pool_bwd_ws(_t(dout), _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2, ws)
+    outs.append(_n(dfeat))
+  scale = np.abs(want).max()
+  assert np.abs(outs[0] - want).max() <= 1e-5 * scale + 1e-5
+  np.testing.assert_array_equal(outs[0], outs[1])
+  # the atomic kernel (what maps wider than 255 columns fall back to) on the same inputs
+  dfeat = torch.zeros(feat.shape, device=DEV)
+  ops.roi_crop_pool_bwd(_t(dout), _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2)
+  assert np.abs(_n(dfeat) - want).max() <= 2e-5 * scale + 1e-5
+
+
 CONV_CASES = [
     # n, ih, iw, cin, cout, k, stride
     (3, 7, 7, 32, 64, 1, 1),

@@ -9,8 +9,8 @@ the nine-tap filter-gradient kernel, the 4-parity stride-2 input gradient and th
 trainable first-stage block Mixed_4e on its 32x32 map, and the fused heads GEMM go through
 conv_fwd / conv_dgrad / conv_wgrad / conv1x1_dgrad_multi against the float64 oracle, and
 `c2d_debug_last_dispatch` proves that the kernel instance that produced the numbers is the one
-the benchmark-size call dispatches (every instance of profiles/r01_bench_kernel_stats_s6_serial.csv
-and of its bf16 twin must be hit).
+the benchmark-size call dispatches (every instance of the newest committed
+profiles/rNN_bench_kernel_stats_c1_serial.csv and of its bf16 twin ..._c2_serial.csv must be hit).
 
 Tolerances: fp32 path 2e-5 relative to the tensor's scale (fp32 MFMA chains of up to 2304 terms
 vs float64); bf16 path compared with the oracle evaluated on the same bf16-rounded operands, one
@@ -44,19 +44,23 @@ FIRST_STAGE_LAYERS = [
     ("4e/B2/3x3a", 32, 160, 192, 3, 1), ("4e/B2/3x3b", 32, 192, 192, 3, 1),
 ]
 
-# what the round-1 benchmark profile lists (fp32, serial): every one must appear below
-R01_INSTANCES = {
-    "igemm_nt_kernel<0, 2, 2, 2, 1, 32, true, 4>", "igemm_nt_kernel<1, 2, 2, 2, 1, 32, true, 4>",
-    "igemm_nt_kernel<1, 2, 2, 2, 2, 32, false, 4>", "igemm_nt_kernel<0, 2, 2, 2, 1, 32, false, 4>",
-    "igemm_nt_kernel<1, 2, 2, 2, 1, 32, false, 4>", "igemm_nt_kernel<0, 2, 2, 2, 2, 32, false, 4>",
-    "igemm_nt_kernel<0, 2, 2, 1, 1, 32, false, 4>", "igemm_nt_kernel<1, 2, 2, 1, 1, 32, false, 4>",
-    "wgrad3x3_kernel<4, 2, 4>", "wgrad3x3_kernel<7, 1, 4>", "wgrad_tn_kernel<2, true, 4>",
-    "wgrad_tn_kernel<1, true, 4>",
-    # (round 1's "wgrad_tn_kernel<2, false, 4>" / "<1, false, 4>" were the two stride-2 layers of
-    #  Mixed_5a: they run on the stride-2 nine-tap kernel now)
-    "wgrad3x3_s2_kernel<4>",
-    "igemm_small_kernel<0>", "igemm_small_kernel<1>", "igemm_small_group_kernel<0>",
-}
+def _latest_profile_instances(cfg):
+  """igemm / wgrad template instances of the newest committed serial kernel-stats summary of
+  BASELINE config `cfg` (profiles/rNN_bench_kernel_stats_<cfg>_serial.csv): the completeness
+  assertion at the end of this file follows the profile, not a hand-kept list."""
+  import csv, glob, os, re
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_kernel_stats_%s_serial.csv" % cfg)))
+  assert files, cfg
+  out = set()
+  with open(files[-1]) as f:
+    for row in csv.DictReader(f):
+      m = re.search(r"((?:igemm|wgrad)\w*<[^>]*>)", row["Name"])
+      if m:
+        out.add(m.group(1))
+  return files[-1], out
+
+
 _seen = set()
 
 
@@ -224,6 +228,59 @@ def test_block_entry_dgrad_multi(ops, block, dtype):
   _scale_close(_n(dx), want, 1.1 * 2.0 ** -8 if low else 2e-5, "%s entry dgrad %s" % (block, inst))
 
 
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("block", ["Mixed_5a", "Mixed_5b", "Mixed_5c"])
+def test_block_entry_fwd_multi(ops, block, dtype):
+  """The 1x1 entry convolutions of an Inception block as ONE GEMM (c2d_conv1x1_fwd_multi) at the
+  real widths — 5a: 576 -> (128, 192) on 7x7; 5b: 1024 -> (352, 192, 160, 128: the commuted
+  pooling branch's convolution runs without ReLU); 5c: 1024 -> (352, 192, 192) — against the
+  float64 oracle (tests/test_gpu_ops.py compares the fused launch with the unfused launches
+  bitwise; here it meets `ref_ops.conv2d` + the folded BatchNorm affine + ReLU directly, on the
+  instance the N = 2000 call dispatches)."""
+  hw, cin, couts = {"Mixed_5a": (7, 576, [128, 192]), "Mixed_5b": (4, 1024, [352, 192, 160, 128]),
+                    "Mixed_5c": (4, 1024, [352, 192, 192])}[block]
+  low = dtype == torch.bfloat16
+  rng = np.random.default_rng(37)
+
+  def run(n):
+    rows = n * hw * hw
+    x = rng.standard_normal((rows, cin)).astype(np.float32)
+    if low:
+      x = _bf16_round(x)
+    flat = (rng.standard_normal(sum(couts) * cin) / np.sqrt(cin)).astype(np.float32)
+    if low:
+      flat = _bf16_round(flat)
+    flat_ = _t(flat).to(dtype)
+    outs, params, off = [], [], 0
+    for i, c in enumerate(couts):
+      wt = flat_[off:off + c * cin].view(1, c, cin)
+      w = flat[off:off + c * cin].reshape(c, cin)
+      off += c * cin
+      scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+      shift = (0.1 * rng.standard_normal(c)).astype(np.float32)
+      relu = not (block == "Mixed_5b" and i == 3)
+      y = torch.empty(rows, c, device=DEV, dtype=dtype)
+      outs.append((wt, _t(scale), _t(shift), y, c, 0, c, relu))
+      params.append((w, scale, shift, relu))
+    ops.conv1x1_fwd_multi(_t(x).to(dtype), cin, 0, ops.conv_outs(outs), rows, cin)
+    return x, outs, params, ops.last_dispatch()
+
+  _, _, _, want_inst = run(N_BENCH)
+  for n in (256, 704, N_BENCH):
+    x, outs, params, inst = run(n)
+    if inst == want_inst:
+      break
+  assert inst == want_inst
+  _seen.update(inst)
+  x64 = x.astype(np.float64)
+  for (w, scale, shift, relu), o in zip(params, outs):
+    want = (x64 @ w.astype(np.float64).T) * scale + shift
+    if relu:
+      want = np.maximum(want, 0)
+    _scale_close(_n(o[3]), want, 1.1 * 2.0 ** -8 if low else 2e-5, "%s entry fwd %s" % (block, inst))
+
+
 def test_mixed_4e_entry_group(ops):
   """The three 1x1 entry convolutions of Mixed_4e (576 -> 96 / 128 / 160 on the 32x32 map) as ONE
   grouped launch (c2d_conv_fwd_grouped -> igemm_small_group_kernel), each against the oracle."""
@@ -345,9 +402,13 @@ def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd, commute):
 
 def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   """Runs last in this file: the union of the instances the layer tests dispatched (and compared)
-  covers every igemm / wgrad instance of the round-1 benchmark profile, plus the bf16 twins."""
-  missing = R01_INSTANCES - _seen
-  assert not missing, "never dispatched by a parity test: %s" % sorted(missing)
+  covers every igemm / wgrad instance of the newest committed benchmark profiles (fp32 configs[1] and
+  bf16 configs[2])."""
+  for cfg in ("c1", "c2"):
+    path, want = _latest_profile_instances(cfg)
+    assert len(want) >= 12, path
+    missing = want - _seen
+    assert not missing, "%s: never dispatched by a parity test: %s" % (path, sorted(missing))
   bf16 = {k for k in _seen if k.endswith(", 2>") or "bf16" in k}
   assert any(k.startswith("wgrad3x3_bf16_kernel<4") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad3x3_bf16_kernel<7") for k in bf16), sorted(bf16)

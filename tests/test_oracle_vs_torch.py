@@ -303,6 +303,45 @@ def test_torch_cpu_step_equals_numpy_oracle_step():
       np.testing.assert_array_equal(P1[k], P2[k])
 
 
+
+def test_torch_cpu_step_in_float64_equals_numpy_oracle_step():
+  """The float64 form of oracle/torch_step.py — what tests/golden/gen_step_fixture.py runs to make
+  the mid-size end-to-end fixtures (step_dm1_n256 / n704.npz) — against the numpy oracle's float64
+  step: same scores, losses, gradients and updated variables to float64 round-off."""
+  from oracle import ref_labels, torch_step
+  from cap2det_amd import synthetic
+  from tests import util_model
+  classes = synthetic.read_lines(synthetic.DATA + "/voc_label.txt")
+  dm, n = 0.5, 7
+  rng = np.random.default_rng(3)
+  P32, d = util_model.oracle_state(1, len(classes), 3, dm)
+  ex = synthetic.make_examples(rng, 1, 64, 80, n, [6], classes)
+  labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
+  mask = (rng.uniform(size=(n, d)) < 0.5).astype(np.uint8)
+  ex64 = dict(image=ex["image"].astype(np.float64), number_of_proposals=ex["number_of_proposals"],
+              proposals=ex["proposals"].astype(np.float64))
+  opts = ref_model.FrcnnOptions(depth_multiplier=dm)
+  loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
+                   oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+  mults = [("first_stage_feature_extraction", 0.0), ("second_stage_feature_extraction", 1.0),
+           ("first_stage_feature_extraction/InceptionV2/Mixed_4e", 1.0)]
+  P1 = {k: v.astype(np.float64) for k, v in P32.items()}
+  P2 = {k: v.copy() for k, v in P1.items()}
+  a1 = {k: np.full(v.shape, 0.1) for k, v in P1.items()}
+  a2 = {k: v.copy() for k, v in a1.items()}
+  r1 = ref_model.train_step(P1, a1, ex64, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
+  r2 = torch_step.train_step(P2, a2, ex64, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
+  np.testing.assert_allclose(r2["total_loss"], r1["total_loss"], rtol=1e-11)
+  for i in range(4):
+    key = "oicr_proposal_scores_at_%d" % i
+    np.testing.assert_allclose(r2["predictions"][key], r1["predictions"][key], rtol=1e-9, atol=1e-12)
+  assert set(r1["applied"]) == set(r2["applied"]) and len(r1["applied"]) > 60
+  for k, g in r1["applied"].items():
+    scale = max(np.abs(g).max(), 1e-30)
+    assert np.abs(g - r2["applied"][k]).max() <= 1e-9 * scale + 1e-14, k
+    assert P2[k].dtype == np.float64 and np.abs(P1[k] - P2[k]).max() <= 1e-10, k
+
+
 def test_torch_backends_of_ref_ops_match_numpy():
   rng = np.random.default_rng(1)
   try:

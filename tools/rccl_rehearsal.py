@@ -1,0 +1,134 @@
+"""Rehearsal of the RCCL gradient exchange on ONE GPU (run as a child process by
+tests/test_gpu_rccl.py; also `python tools/rccl_rehearsal.py` on a GPU box).
+
+The reference's only parallel mode is one process per GPU (/root/reference/train_wsod.sh:46-88);
+here that is `torch.distributed` over RCCL with one all-reduce of the flat gradient bucket per step
+(cap2det_amd/train/data_parallel.py).  A pool box has one GPU, so the code that a multi-GPU run
+executes — `init_process_group("nccl")`, the asynchronous all-reduce on RCCL's stream beside the
+step's compute / filter-gradient / look-ahead streams, the stream joins around it, the collective
+between the two hipGraph replays — is exercised here at world size 1 with C2D_FORCE_ALLREDUCE=1
+(a one-rank sum is the identity): three full-size eager steps and three hipGraph steps with the
+collectives must reproduce the same steps without them — bitwise in the first forward pass, to
+the order of the filter gradients' fp32 atomics in the first update.
+
+Prints one JSON line; exit code 0 = all comparisons hold."""
+import json
+import os
+import socket
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+
+def main():
+  import numpy as np
+  import torch
+  import torch.distributed as dist
+  from cap2det_amd import synthetic
+  from cap2det_amd.train import data_parallel
+  from cap2det_amd.train.trainer import Trainer
+
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  if "MASTER_PORT" not in os.environ:
+    with socket.socket() as sock:
+      sock.bind(("127.0.0.1", 0))
+      os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+  torch.cuda.set_device(0)
+  dist.init_process_group(backend="nccl", rank=0, world_size=1)
+  dev = "cuda:0"
+  size = os.environ.get("C2D_REHEARSAL_SIZE", "full")
+  hw, n = (500, 2000) if size == "full" else (96, 64)
+
+  calls = {"n": 0}
+  real_all_reduce = dist.all_reduce
+  def counting_all_reduce(*a, **k):
+    calls["n"] += 1
+    return real_all_reduce(*a, **k)
+  dist.all_reduce = counting_all_reduce
+
+  pipeline = synthetic.load_pipeline()
+  batches = None
+
+  def run(force, use_graph):
+    nonlocal batches
+    if force:
+      os.environ["C2D_FORCE_ALLREDUCE"] = "1"
+    else:
+      os.environ.pop("C2D_FORCE_ALLREDUCE", None)
+    assert data_parallel.collectives_on() == bool(force)
+    before = calls["n"]
+    trainer = Trainer(pipeline, device=dev, seed=21, use_graph=use_graph)
+    classes = trainer.model.label_extractor.classes
+    if batches is None:
+      rng = np.random.default_rng(5)
+      batches = []
+      for _ in range(2):
+        ex = synthetic.make_examples(rng, 1, hw, hw, n, [n], classes)
+        d = dict(ex)
+        for k in ("image", "proposals", "number_of_proposals"):
+          d[k] = torch.from_numpy(ex[k]).to(dev).contiguous()
+        batches.append(d)
+    out = dict(losses=[], scores0=None, after_first=None)
+    for i in range(3):
+      losses = trainer.train_step(batches[i % 2], dropout_seed=40 + i,
+                                  prefetch=None if use_graph else batches[(i + 1) % 2])
+      torch.cuda.synchronize()
+      out["losses"].append({k: float(v.item()) for k, v in losses.items()})
+      if i == 0:
+        out["scores0"] = [trainer.predictions["oicr_proposal_scores_at_%d" % j].detach().clone()
+                          for j in range(4)]
+        lo, hi = trainer.bucket
+        out["after_first"] = trainer.model.store.values[lo:hi].clone()
+    out["collectives"] = calls["n"] - before
+    out["streams"] = dict(side=trainer.model.engine.second.side is not None,
+                          lookahead=trainer.model.engine.prefetch_stream is not None)
+    return out
+
+  report = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "size": size,
+            "checks": []}
+  ok = True
+  for use_graph in (False, True):
+    ref = run(False, use_graph)
+    got = run(True, use_graph)
+    name = "graph" if use_graph else "eager"
+    chk = {"mode": name, "collectives_without": ref["collectives"], "collectives_with": got["collectives"]}
+    # without the switch a one-rank group issues nothing; with it: two per eager step (the second
+    # stage + heads suffix under the ROI-crop / Mixed_4e backward, then the Mixed_4e prefix), one
+    # per graph step (between the two replays)
+    good = ref["collectives"] == 0 and got["collectives"] == (3 if use_graph else 6)
+    if not use_graph:
+      good = good and got["streams"]["side"] and got["streams"]["lookahead"]
+    fwd_equal = all(torch.equal(a, b) for a, b in zip(ref["scores0"], got["scores0"]))
+    chk["first_forward_bitwise_equal"] = fwd_equal
+    good = good and fwd_equal
+    worst = 0.0
+    for k, v in ref["losses"][0].items():
+      worst = max(worst, abs(v - got["losses"][0][k]) / max(abs(v), 1e-12))
+    chk["first_step_loss_rel_diff"] = worst
+    good = good and worst <= 2e-6
+    a, b = ref["after_first"].double(), got["after_first"].double()
+    upd = float((a - b).abs().max() / a.abs().max())
+    chk["first_update_max_diff_of_scale"] = upd
+    good = good and upd <= 5e-5
+    finite = all(np.isfinite(v) for step in got["losses"] for v in step.values())
+    chk["all_losses_finite"] = finite
+    good = good and finite
+    chk["ok"] = bool(good)
+    ok = ok and good
+    report["checks"].append(chk)
+  # what the process group itself counts
+  ones = torch.ones(1, device=dev, dtype=torch.int32)
+  real_all_reduce(ones)
+  report["ranks_counted_by_all_reduce"] = int(ones.item())
+  report["ok"] = bool(ok and report["ranks_counted_by_all_reduce"] == 1)
+  print(json.dumps(report))
+  sys.stdout.flush()
+  dist.destroy_process_group()
+  return 0 if report["ok"] else 1
+
+
+if __name__ == "__main__":
+  sys.exit(main())
