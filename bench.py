@@ -590,6 +590,13 @@ def main(argv=None):
     if world > 1:
       result["backend"] = ("gloo, all ranks on cuda:0 (C2D_BENCH_SAME_DEVICE: code-path validation, "
                            "the value is not a scaling point)" if same_device else "nccl (RCCL)")
+    # RCCL writes its version banner to the C stdout of rank 0: flush it first, so that the JSON
+    # line is the LAST line this process prints
+    try:
+      import ctypes
+      ctypes.CDLL(None).fflush(None)
+    except Exception:
+      pass
     print(json.dumps(result))
     sys.stdout.flush()
   if grouped:

@@ -53,6 +53,11 @@ def roi_crop_pool_fwd(feat, boxes, box_ind, crop, pool_k, pool_s, out=None, argm
 
 
 def roi_crop_pool_bwd(dout, argmax, boxes, box_ind, dfeat, crop, pool_k, pool_s):
+  """The atomic form (fp32 gradients only: the bf16 storage mode runs the row-owner form, which
+  covers maps up to 255 columns wide)."""
+  if dout.dtype != torch.float32:
+    raise NotImplementedError("c2d_roi_crop_pool_bwd takes fp32 gradients; bf16 gradients need the "
+                              "workspace form (feature maps up to 255 columns wide)")
   b, hf, wf, d = dfeat.shape
   _lib.call("c2d_roi_crop_pool_bwd", _p(dout), _p(argmax), _p(boxes), _p(box_ind), _p(dfeat), b,
             hf, wf, d, boxes.shape[0], crop, pool_k, pool_s, _stream())

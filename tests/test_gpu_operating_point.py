@@ -94,12 +94,14 @@ def test_train_step_at_the_reference_operating_point(h, w, dtype):
   assert any(float(g1[k].abs().max()) > 0 for k in g1 if k.startswith(m4e))
   # ... and the Mixed_4e gradients (everything behind the ROI-crop backward) equal the ones the
   # ATOMIC ROI-crop backward gives: the wide-map strips against an independent kernel, at size
-  _, _, g3, path3 = step(force_atomic=True)
-  assert path3.startswith("atomic"), path3
-  for k in g1:
-    if k.startswith(m4e):
-      scale = float(g1[k].abs().max())
-      assert float((g1[k] - g3[k]).abs().max()) <= 2e-4 * scale + 1e-12, k
+  # (fp32 only: the atomic kernel takes fp32 gradients; the bf16 storage mode has the strips alone)
+  if dtype == "fp32":
+    _, _, g3, path3 = step(force_atomic=True)
+    assert path3.startswith("atomic"), path3
+    for k in g1:
+      if k.startswith(m4e):
+        scale = float(g1[k].abs().max())
+        assert float((g1[k] - g3[k]).abs().max()) <= 2e-4 * scale + 1e-12, k
   # which variables moved
   moved = [k for k in before if not np.array_equal(before[k], after[k])]
   assert any(k.startswith(m4e) for k in moved) and any(k.startswith("second_stage") for k in moved)

@@ -134,6 +134,17 @@ def test_roi_crop_pool_bwd_workspace_form_on_wide_maps(ops, hf, wf, d, n, chunk)
   dfeat = torch.zeros(feat.shape, device=DEV)
   ops.roi_crop_pool_bwd(_t(dout), _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2)
   assert np.abs(_n(dfeat) - want).max() <= 2e-5 * scale + 1e-5
+  if n <= 120:
+    # bf16 gradients (the bf16 storage mode, BASELINE configs[2] / [4]): same strips, fp32 sums;
+    # the oracle runs on the bf16-rounded gradient
+    dout_b = _t(dout).to(torch.bfloat16)
+    dcrop_b = ref_ops.max_pool_backward(crop.shape, arg, dout_b.float().cpu().numpy(), 2, 2, "VALID")
+    want_b = ref_ops.crop_and_resize_grad_image(dcrop_b.astype(np.float64), boxes, ind, feat.shape)
+    dfeat = torch.zeros(feat.shape, device=DEV)
+    ops.roi_crop_pool_bwd_ws(dout_b, _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2, ws)
+    assert np.abs(_n(dfeat) - want_b).max() <= 1e-5 * np.abs(want_b).max() + 1e-5
+    with pytest.raises(NotImplementedError):
+      ops.roi_crop_pool_bwd(dout_b, _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2)
 
 
 CONV_CASES = [
