@@ -1,5 +1,5 @@
-"""Generates tests/golden/step_dm1_n{256,704}.npz: the FLOAT64 oracle's full training step at
-depth multiplier 1.0 — one 160x160 image, N = 256 / 704 proposals, voc07_groundtruth semantics
+"""Generates tests/golden/step_dm1_n{256,1100}.npz: the FLOAT64 oracle's full training step at
+depth multiplier 1.0 — one 160x160 image, N = 256 / 1100 proposals, voc07_groundtruth semantics
 (models/cap2det_model.py:152-216,274-330; models/utils.py:15-188; train/trainer.py:55-146) —
 at sizes where the numpy oracle alone would not finish in seconds: the towers, crop_and_resize and
 pooling run on torch-CPU in float64 (oracle/torch_step.py, pinned against the hand-derived numpy
@@ -55,7 +55,7 @@ def main():
   mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
                    oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
-  for n in (256, 704):
+  for n in (256, 1100):
     ex, P32, mask, real = inputs(n, classes)
     P = {k: v.astype(np.float64) for k, v in P32.items()}
     acc = {k: np.full(v.shape, 0.1) for k, v in P.items()}

@@ -150,7 +150,8 @@ def test_multiscale_inference_at_the_reference_eval_sizes():
     sums = cur if sums is None else [a + c for a, c in zip(sums, cur)]
   for i in range(4):
     want = (sums[i] / 4.0).cpu().numpy()
-    assert np.abs(got[i].cpu().numpy() - want).max() <= 1e-6, i
+    # (iterations 1..K average logits of magnitude ~10: fp32 sums of four of them)
+    assert np.abs(got[i].cpu().numpy() - want).max() <= 1e-6 * max(1.0, float(np.abs(want).max())), i
     assert bool(torch.isfinite(got[i]).all())
     assert float(got[i][0, real:].abs().max()) == 0.0 or i > 0
   mid = dict(score_thresh=1e-5, iou_thresh=0.4, max_size_per_class=100, max_total_size=300)

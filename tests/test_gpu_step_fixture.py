@@ -1,8 +1,9 @@
 """End-to-end oracle parity at depth multiplier 1.0 beyond the sizes the numpy oracle finishes in
-seconds: the committed float64 fixtures tests/golden/step_dm1_n{256,704}.npz (made in the build
+seconds: the committed float64 fixtures tests/golden/step_dm1_n{256,1100}.npz (made in the build
 container by tests/golden/gen_step_fixture.py: torch-CPU float64 towers + numpy heads / MIDN /
 OICR / Adagrad, pinned against the numpy step by tests/test_oracle_vs_torch.py) are replayed on
-the HIP path: one 160x160 image, 256 / 704 proposals — the crop -> Mixed_5a-c -> heads -> losses ->
+the HIP path: one 160x160 image, 256 / 1100 proposals (1100 x 16 rows > 16384: the 4x4-map blocks take the fused
+block-entry plan of the benchmark, not the grouped small-problem launches) — the crop -> Mixed_5a-c -> heads -> losses ->
 ROI-crop backward -> Mixed_4e chain as ONE step on the launch plan of the benchmark (nine-tap
 filter gradients of >= 256-image batches, stride-2 nine-tap kernel, 128x128 pixel-major tiles,
 fused BN/ReLU backward, fused block-entry GEMMs), checked against
@@ -43,7 +44,7 @@ def profile_instances(csv_name):
   return out
 
 
-@pytest.mark.parametrize("n", [256, 704])
+@pytest.mark.parametrize("n", [256, 1100])
 def test_train_step_replays_the_float64_fixture(monkeypatch, n):
   from cap2det_amd import hip_ops
   from cap2det_amd.train.trainer import Trainer
@@ -56,12 +57,13 @@ def test_train_step_replays_the_float64_fixture(monkeypatch, n):
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   assert real == int(fix["real"])
   model.load_state_dict(P32)
-  seen = set()
+  seen = {}
   for name in CONV_ENTRY_POINTS:
     inner = getattr(hip_ops, name)
-    def wrapped(*a, _inner=inner, **k):
+    def wrapped(*a, _inner=inner, _name=name, **k):
       r = _inner(*a, **k)
-      seen.update(hip_ops.last_dispatch())
+      for inst in hip_ops.last_dispatch():
+        seen.setdefault(inst, (_name, tuple(v for v in a if isinstance(v, (int, bool)))))
       return r
     monkeypatch.setattr(hip_ops, name, wrapped)
   dev = dict(ex)
@@ -118,6 +120,8 @@ def test_fixture_steps_run_the_benchmark_kernel_instances():
     pytest.skip("replay tests did not run")
   want = profile_instances("r02_bench_kernel_stats_c1_serial.csv")
   assert len(want) >= 15
-  seen = set().union(*_dispatched.values())
-  missing = want - seen
-  assert not missing, "benchmark instances no fixture step ran: %s (ran: %s)" % (sorted(missing), sorted(seen))
+  seen = {}
+  for d in _dispatched.values():
+    seen.update(d)
+  missing = want - set(seen)
+  assert not missing, "benchmark instances no fixture step ran: %s (ran: %s)" % (sorted(missing), seen)

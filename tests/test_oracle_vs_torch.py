@@ -306,7 +306,7 @@ def test_torch_cpu_step_equals_numpy_oracle_step():
 
 def test_torch_cpu_step_in_float64_equals_numpy_oracle_step():
   """The float64 form of oracle/torch_step.py — what tests/golden/gen_step_fixture.py runs to make
-  the mid-size end-to-end fixtures (step_dm1_n256 / n704.npz) — against the numpy oracle's float64
+  the mid-size end-to-end fixtures (step_dm1_n256 / n1100.npz) — against the numpy oracle's float64
   step: same scores, losses, gradients and updated variables to float64 round-off."""
   from oracle import ref_labels, torch_step
   from cap2det_amd import synthetic
