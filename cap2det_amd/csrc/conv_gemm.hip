@@ -43,298 +43,14 @@ inline void dispatch_note(const char* fmt, int a = 0, int b = 0, int c = 0, int 
   r.p[0] = a; r.p[1] = b; r.p[2] = c; r.p[3] = d; r.p[4] = e; r.p[5] = f; r.p[6] = g; r.p[7] = h;
 }
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// Native vector type for register staging: HIP's float4 struct is copied with memcpy, which
-// keeps staged arrays in scratch memory (private segment) instead of VGPRs.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BK = 32;                // floats of K per LDS slab (one 128-B line per row)
-
-struct ConvGeom {
-  int ih, iw;      // conv input spatial size
-  int oh, ow;      // conv output spatial size
-  int kh, kw;      // taps
-  int stride;      // 1 or 2
-  int pad_t, pad_l;
-  int mode;        // 0: rows index conv OUTPUT pixels (forward / wgrad); 1: rows index conv
-                   // INPUT pixels and src() yields OUTPUT pixels (dgrad)
-  unsigned long long magic_hw, magic_w;  // ceil(2^40 / (h*w)), ceil(2^40 / w) of the ROW space
-  int rh, rw;      // row-space extent: (oh, ow) in mode 0; in mode 1 the sub-grid of input
-                   // pixels (y0 + sub*yy, x0 + sub*xx) handled by this launch
-  int sub, y0, x0; // mode 1 only: stride-2 dgrad is split into the 4 parity classes of the
-                   // input pixel, each of which sees only the taps of matching parity
-  int ky0, kx0, kstep, nky, nkx;  // tap subset: ky = ky0 + kstep*t, t < nky (same for kx)
-  int nimg;        // images (ROIs) in the batch
-  int pm;          // 1: PIXEL-MAJOR row order (small maps, see decompose<true>)
-};
-
-// Row m of the iteration space -> (image, y, x).  Exact for m * d < 2^40 (always here).
-struct RowPos {
-  int img, y, x;
-  bool valid;
-};
-
-// PM (pixel-major, used for the 3x3 convolutions over the tiny per-ROI maps): rows are ordered
-// (group of 32 images, pixel, image in group), m = ((grp * rh*rw) + pixel) * 32 + r, so every
-// aligned 32-row MFMA tile holds ONE pixel position of 32 images.  Whether a tap falls into the
-// SAME padding is then uniform over the tile and its MFMAs are skipped instead of multiplying
-// zeros (4x4 map: 100 of 144 (pixel, tap) pairs are real; 7x7: 361 of 441).
-template <bool PM = false>
-__device__ __forceinline__ RowPos decompose(int m, int M, const ConvGeom& g) {
-  RowPos p;
-  if (PM) {
-    const unsigned t = (unsigned)m >> 5, r = (unsigned)m & 31u;
-    const unsigned grp = (unsigned)(((unsigned long long)t * g.magic_hw) >> 40);
-    const unsigned px = t - grp * (unsigned)(g.rh * g.rw);
-    p.img = (int)(grp * 32u + r);
-    p.valid = m < M && p.img < g.nimg;
-    p.y = (int)(((unsigned long long)px * g.magic_w) >> 40);
-    p.x = (int)px - p.y * g.rw;
-    return p;
-  }
-  p.valid = m < M;
-  const unsigned mm = p.valid ? (unsigned)m : 0u;
-  p.img = (int)(((unsigned long long)mm * g.magic_hw) >> 40);
-  const unsigned r = mm - (unsigned)p.img * (unsigned)(g.rh * g.rw);
-  p.y = (int)(((unsigned long long)r * g.magic_w) >> 40);
-  p.x = (int)r - p.y * g.rw;
-  return p;
-}
-
-// Source row (in the A operand's row space) for iteration row `p` and tap (ky,kx); -1 if none.
-// Branch-free (bitwise predicates) so that the loads that follow can be issued back to back.
-template <int MODE>
-__device__ __forceinline__ int src_row(const ConvGeom& g, const RowPos& p, int ky, int kx) {
-  if (MODE == 0) {
-    const int iy = p.y * g.stride - g.pad_t + ky;
-    const int ix = p.x * g.stride - g.pad_l + kx;
-    const int ok = (int)p.valid & (int)(iy >= 0) & (int)(iy < g.ih) & (int)(ix >= 0) &
-                   (int)(ix < g.iw);
-    const int row = (p.img * g.ih + iy) * g.iw + ix;
-    return ok ? row : -1;
-  } else {
-    const int ty = p.y * g.sub + g.y0 + g.pad_t - ky;
-    const int tx = p.x * g.sub + g.x0 + g.pad_l - kx;
-    const int sh = g.stride - 1;  // stride is 1 or 2
-    const int oy = ty >> sh, ox = tx >> sh;
-    const int ok = (int)p.valid & (int)(ty >= 0) & (int)(tx >= 0) &
-                   (int)(((ty | tx) & sh) == 0) & (int)(oy < g.oh) & (int)(ox < g.ow);
-    const int row = (p.img * g.oh + oy) * g.ow + ox;
-    return ok ? row : -1;
-  }
-}
-
-// Does tap (ky,kx) of a row at pixel (y,x) of the row space read a real pixel?  (the image-
-// independent part of src_row)
-template <int MODE>
-__host__ __device__ __forceinline__ bool tap_ok(const ConvGeom& g, int y, int x, int ky, int kx) {
-  if (MODE == 0) {
-    const int iy = y * g.stride - g.pad_t + ky;
-    const int ix = x * g.stride - g.pad_l + kx;
-    return iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
-  } else {
-    const int ty = y * g.sub + g.y0 + g.pad_t - ky;
-    const int tx = x * g.sub + g.x0 + g.pad_l - kx;
-    const int sh = g.stride - 1;
-    return ty >= 0 && tx >= 0 && ((ty | tx) & sh) == 0 && (ty >> sh) < g.oh && (tx >> sh) < g.ow;
-  }
-}
-
-// Raw buffer descriptor over [p, p + bytes) built from wave-uniform inputs (readfirstlane makes
-// that provable to the compiler: no waterfall loop around the loads, cdna_hip_programming.md T20).
-constexpr unsigned OOB_OFFSET = 0x7FFFFF00u;   // >= any buffer size here: the load returns zeros
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long long bytes) {
-  const unsigned long long u = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-  const unsigned nb = __builtin_amdgcn_readfirstlane(
-      (unsigned)(bytes < (long long)OOB_OFFSET ? bytes : (long long)OOB_OFFSET));
-  return __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(((unsigned long long)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_b(const void* p, long long bytes) {
-  return make_rsrc((const float*)p, bytes);
-}
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0);
-  return __builtin_bit_cast(f32x4, v);
-}
-
-// four consecutive operand elements (fp32: one 16-B load; bf16: one 8-B load, widened) as fp32
-template <int ES>
-__device__ __forceinline__ f32x4 buf_load_elems4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-  if constexpr (ES == 4) {
-    return buf_load4(rs, voff, soff);
-  } else {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, soff, 0);
-    f32x4 o;   // bf16 -> fp32 = the 16 bits moved to the top half
-    o.x = __uint_as_float(v.x << 16); o.y = __uint_as_float(v.x & 0xffff0000u);
-    o.z = __uint_as_float(v.y << 16); o.w = __uint_as_float(v.y & 0xffff0000u);
-    return o;
-  }
-}
-
-__device__ __forceinline__ f32x4 mask4(f32x4 v, bool keep) {
-  v.x = keep ? v.x : 0.0f; v.y = keep ? v.y : 0.0f;
-  v.z = keep ? v.z : 0.0f; v.w = keep ? v.w : 0.0f;
-  return v;
-}
-
-struct IgemmArgs {
-  const float* A; int lda; int a_off;
-  long long a_rows;         // rows of the A operand's buffer (for the buffer-load range check)
-  const float* Bt;          // [taps][N][K]
-  float* C; int ldc; int c_off;
-  const float* scale;       // [N] or null (=1)
-  const float* shift;       // [N] or null (=0)
-  int relu;
-  int accumulate;           // C += result
-  int M, N, K;
-  int m_tiles, n_tiles;
-  // Multi-segment 1x1 mode (nseg > 1): the reduction runs over the concatenation of `nseg`
-  // (A_s [rows][lda_s] (+off_s), Bt_s [N][K_s]) pairs — one GEMM for the input gradient of an
-  // Inception block whose branches all start with a 1x1 convolution of the same input.
-  int nseg;
-  const float* segA[4]; const float* segB[4];
-  int seg_lda[4], seg_off[4], segK[4];   // (every segment's A has a_rows rows)
-  int total_slabs;
-  int es;                   // operand / output element size: 4 (fp32) or 2 (bf16)
-  // Fused BatchNorm/ReLU backward of the layer that PRODUCED this convolution's input (input-
-  // gradient launches only, fy != null): the epilogue turns dx into dc = dx * (y > 0) * fscale
-  // and block (m-tile) mt stores the column sums of dz = dx * (y > 0) and dz * (y - beta) / gamma
-  // over its rows at fpart[(fpart_row0 + mt) * 2 * N ..] (layout of c2d_bn_relu_bwd_partial).
-  // The columns may belong to up to four producers (the branches feeding a concat buffer):
-  // producer p owns columns [fseg_end[p-1], fseg_end[p]), its vectors are indexed from its first
-  // column; fident[p]: a pooling branch (no BN/ReLU: the gradient passes unchanged, sums zero).
-  const void* fy; int fldy, fyoff;
-  int fnprod; int fseg_end[4]; int fident[4];
-  const float* fscale[4]; const float* fbeta[4]; const float* fgamma[4];
-  float* fpart; int fpart_row0;
-  // Several 1x1 convolutions of the SAME input as one GEMM (forward launches only, mo_n > 0):
-  // output columns [mo_end[s-1], mo_end[s]) belong to convolution s — its weight rows start
-  // mo_boff[s] elements behind Bt (all of them inside mo_bbytes bytes), its BN scale / shift
-  // vectors, destination (pointer, row stride, column offset) and ReLU flag are its own.
-  int mo_n; int mo_end[4]; int mo_relu[4];
-  long long mo_boff[4]; long long mo_bbytes;
-  float* mo_C[4]; int mo_ldc[4], mo_coff[4];
-  const float* mo_scale[4]; const float* mo_shift[4];
-  int dbg;                  // ablation bits (C2D_TUNE=1 C2D_IGEMM_DBG): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no epilogue
-  ConvGeom g;
-#ifdef C2D_TRACE
-  unsigned long long* trace;   // diagnostic build only: 8 x u64 per block (tools/trace_igemm.py)
-#endif
-};
-
+}  // namespace
+#include "igemm_common.h"
+using namespace c2d_ig;
+namespace {
 #ifdef C2D_TRACE
 unsigned long long* g_trace = nullptr;
 #endif
 
-// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): consecutive logical tiles
-// run on one XCD, and the n-tiles of one m-tile are consecutive, so the A rows they share are
-// served by that XCD's L2.
-__device__ __forceinline__ int xcd_remap(int id, int total) {
-  const int q = total >> 3, r = total & 7;
-  const int xcd = id & 7, local = id >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-}
-
-// Stream-K plan (host-computed, passed by value).  The iteration space of a launch is the
-// concatenation, in tile order (m-tile major, n-tile minor), of every tile's slab iterations
-// (cost = visited taps x K slabs; PM tiles on the map border visit fewer taps).  `grid`
-// persistent workgroups each take `share` consecutive iterations, so all of them finish together
-// whatever the tile count is: no partial last round of tiles, no idle CUs at the end (the
-// per-block timeline of the one-tile-per-block form showed 25-35 % of a launch spent in such a
-// tail).  A tile cut by a share boundary is finished by whichever of its pieces arrives last
-// (cdna_hip_programming.md §5, in-launch split-K recipe): every piece stores its fp32
-// accumulators to its own slab, releases, and draws a ticket on the tile's counter; the piece
-// that draws the last ticket acquires, sums all slabs IN PIECE ORDER (bitwise reproducible) and
-// runs the epilogue.  Nobody ever waits, so no residency or dispatch-order assumption is made.
-constexpr int SK_MAX_PERIOD = 64;
-// ---- several 1x1 convolutions of one input as one GEMM (IgemmArgs::mo_n) ---------------------
-// element offset (relative to Bt) of the weight row of output column n
-__device__ __forceinline__ int mo_weight_row(const IgemmArgs& a, int n) {
-  int s = 0, lo = 0;
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-    if (q + 1 < a.mo_n && n >= a.mo_end[q]) { s = q + 1; lo = a.mo_end[q]; }
-  return (int)a.mo_boff[s] + (n - lo) * a.K;      // (host: every weight row within 2^31 elements of Bt)
-}
-struct MoOut { float* C; int ldc, coff, lo, relu; const float* scale; const float* shift; };
-__device__ __forceinline__ MoOut mo_output(const IgemmArgs& a, int ncol) {
-  int s = 0, lo = 0;
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-    if (q + 1 < a.mo_n && ncol >= a.mo_end[q]) { s = q + 1; lo = a.mo_end[q]; }
-  return MoOut{a.mo_C[s], a.mo_ldc[s], a.mo_coff[s], lo, a.mo_relu[s], a.mo_scale[s], a.mo_shift[s]};
-}
-
-// ---- fused BN/ReLU backward in the input-gradient epilogue (IgemmArgs::fy) -------------------
-template <int ES>
-__device__ __forceinline__ f32x4 load_act4(const void* base, size_t idx) {
-  if constexpr (ES == 4) {
-    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
-  } else {
-    const bf16x4 o = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx);
-    return f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
-  }
-}
-// the producer parameters of the four columns starting at ncol (all inside one producer)
-__device__ __forceinline__ bool fused_bn_params(const IgemmArgs& a, int ncol, f32x4& sc, f32x4& be,
-                                                f32x4& ig) {
-  int p = 0, lo = 0;
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-    if (q + 1 < a.fnprod && ncol >= a.fseg_end[q]) { p = q + 1; lo = a.fseg_end[q]; }
-  if (a.fident[p]) return true;
-  sc = *reinterpret_cast<const f32x4*>(a.fscale[p] + (ncol - lo));
-  if (a.fgamma[p]) {
-    be = *reinterpret_cast<const f32x4*>(a.fbeta[p] + (ncol - lo));
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(a.fgamma[p] + (ncol - lo));
-    ig = f32x4{ga.x != 0.f ? 1.f / ga.x : 0.f, ga.y != 0.f ? 1.f / ga.y : 0.f,
-               ga.z != 0.f ? 1.f / ga.z : 0.f, ga.w != 0.f ? 1.f / ga.w : 0.f};
-  }
-  return false;
-}
-// one epilogue item: v = four input-gradient values of a row, yv = the producer's outputs there
-__device__ __forceinline__ f32x4 fused_bn_item(f32x4 v, f32x4 yv, f32x4 sc, f32x4 be, f32x4 ig,
-                                               f32x4& sb, f32x4& sg) {
-  f32x4 dz;
-  dz.x = yv.x > 0.f ? v.x : 0.f; dz.y = yv.y > 0.f ? v.y : 0.f;
-  dz.z = yv.z > 0.f ? v.z : 0.f; dz.w = yv.w > 0.f ? v.w : 0.f;
-  sb += dz;
-  sg.x += dz.x * (yv.x - be.x) * ig.x; sg.y += dz.y * (yv.y - be.y) * ig.y;
-  sg.z += dz.z * (yv.z - be.z) * ig.z; sg.w += dz.w * (yv.w - be.w) * ig.w;
-  return dz * sc;
-}
-// Column sums of a block: lane sums -> LDS -> fixed-order sums over the lanes / waves that share
-// a column -> the block's row of the partials (no atomics: bitwise reproducible).
-template <int WM, int WN, int SCOLS, int RPP>
-__device__ __forceinline__ void fused_bn_finish(float* red, const float* dummy, float* fpart,
-                                                int fpart_row0, int N, const f32x4& sb,
-                                                const f32x4& sg, int tid, int wave, int ec4, int er,
-                                                bool lane_on, int n0, int mt) {
-  constexpr int BN = WN * SCOLS, NTHREADS = WM * WN * 64;
-  (void)dummy;
-  __syncthreads();            // every wave is done with its epilogue staging slice
-  if (lane_on) {
-    float* p = red + ((wave * RPP + er) * 2) * SCOLS + ec4 * 4;
-    *reinterpret_cast<f32x4*>(p) = sb;
-    *reinterpret_cast<f32x4*>(p + SCOLS) = sg;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 2 * BN; idx += NTHREADS) {
-    const int k = idx / BN, c = idx - k * BN;
-    const int wn_c = c / SCOLS, cl = c - wn_c * SCOLS;
-    float t = 0.f;
-    for (int wm = 0; wm < WM; ++wm)
-      for (int e = 0; e < RPP; ++e) t += red[(((wm * WN + wn_c) * RPP + e) * 2 + k) * SCOLS + cl];
-    if (n0 + c < N) fpart[((size_t)(fpart_row0 + mt) * 2 + k) * N + n0 + c] = t;
-  }
-}
 
 struct SkPlan {
   int enabled;
@@ -922,424 +638,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel
   igemm_body<MODE, WM, WN, MT, NT, BKT, PM, true, ES>(p.a, p.sk);
 }
 
-// ---------------------------------------------------------------------------------------------
-// bf16-native implicit GEMM (second stage in the bf16 storage mode, BASELINE configs[2] / [4]).
-//
-// Same iteration space, tap masks, pixel-major tile skipping, multi-segment mode and epilogue as
-// igemm_body, but the operand path is built for the bf16 MFMA rate (a 32x32x16 MFMA retires in 32
-// cycles, 16x faster than the fp32 one, so what the fp32 kernel could afford per slab — a register
-// round trip global -> VGPR -> ds_write_b128 (79 B/clk/CU), two barriers — is what bounds it):
-//   * slabs go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction:
-//     no staging VGPRs, no LDS store instructions), into TWO LDS buffers: the DMA of slab it+1
-//     flies under the MFMAs of slab it and ONE barrier per slab orders both hazards;
-//   * LDS rows are the slab's 128 unpadded bytes (an LDS-DMA image is lane-linear); the 16-byte
-//     chunk c of row r sits at position c ^ ((r >> 1) & 7) — applied to the per-lane GLOBAL address
-//     of the DMA and to the fragment reads — which makes every ds_read_b128 lane group hit 16
-//     distinct 16-byte slots (conflict-free; lane groups: MI355X_MICROARCH.md §LDS);
-//   * rows a tap sends into the SAME padding carry an out-of-range buffer offset (the DMA writes
-//     zeros), K tails (K % 64 != 0, K % 16 == 0) simply run fewer 16-deep MFMA steps.
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-struct SlabCursor {
-  int tap, kc, sgi, Kc;
-  unsigned long long taps_left;
-};
-
-template <int MODE, int WM, int WN, int MT, int NT, bool PM, int DA>
-__global__ __launch_bounds__(WM * WN * 64,
-                             (160 * 1024) / ((WM * MT * DA + WN * NT * 2) * 32 * 128) >= 3
-                                 ? 3 : ((160 * 1024) / ((WM * MT * DA + WN * NT * 2) * 32 * 128) >= 2 ? 2 : 1))
-void igemm_bf16_kernel(IgemmArgs a) {
-  constexpr int BKT = 64;                       // bf16 elements of K per slab (128 B per row)
-  constexpr int BM = WM * MT * 32;
-  constexpr int BN = WN * NT * 32;
-  constexpr int NTHREADS = WM * WN * 64;
-  constexpr int ROWS_PER_PASS = NTHREADS / 8;   // a wave-instruction stages 8 rows x 128 B
-  constexpr int A_LOADS = BM / ROWS_PER_PASS;
-  constexpr int B_LOADS = BN / ROWS_PER_PASS;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  constexpr int LDS_BYTES = DA * A_BYTES + 2 * B_BYTES;
-  static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile vs block size");
-  static_assert(DA >= 2 && DA <= 4, "activation ring depth");
-  // The weight slabs (L2 hits) are double-buffered; the activation slabs (HBM, several times
-  // the latency) go through a ring of DA buffers: DA = 2 issues both one slab ahead, DA = 3 the
-  // activation rows two slabs ahead (weights first, so that the counted wait below leaves only
-  // the newest activation pieces in flight).
-  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
-  char* const smemB = smem + DA * A_BYTES;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  // DMA: this lane fetches the chunk that belongs at LDS position lane & 7 of its row
-  const int lrow = tid >> 3;                                        // row inside a pass
-  const int kchunk = (lane & 7) ^ ((lrow >> 1) & 7);                // ((pass rows are multiples of 16))
-  const int q4 = kchunk * 8;                                        // element offset inside the slab
-
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = lb / a.n_tiles, nt = lb - mt * a.n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int ntaps = a.g.nky * a.g.nkx;
-  const int kslabs = (a.K + BKT - 1) / BKT;
-  const size_t tap_stride = (size_t)a.N * a.K;
-
-  RowPos apos[A_LOADS];
-#pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) apos[i] = decompose<PM>(m0 + lrow + i * ROWS_PER_PASS, a.M, a.g);
-  int brow_off[B_LOADS];
-#pragma unroll
-  for (int i = 0; i < B_LOADS; ++i) brow_off[i] = min(n0 + lrow + i * ROWS_PER_PASS, a.N - 1);
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  unsigned row_bits = 0;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-    if (m0 + (wm * MT + i) * 32 < a.M) row_bits |= 1u << i;
-  row_bits = __builtin_amdgcn_readfirstlane(row_bits);
-
-  // Tap table, one tap per lane (every wave holds all of it): what changes from tap to tap is
-  // computed ONCE here — the row delta of the activation rows (the source row of a tap is
-  // row_base + delta wherever the tap reads a real pixel), the offset of the tap's weight plane
-  // and (PM) which 32-row tiles of the block are real for the tap — so that a tap change in the
-  // K loop costs three v_readlane and a few VALU per staged row instead of re-deriving every
-  // source row (the re-derivation was 40 % of the 7x7 3x3 layers' time).
-  int tab_delta = 0, tab_toff = 0;
-  unsigned tab_tv = 0;
-  if (lane < ntaps) {
-    const int ty_ = lane / a.g.nkx;
-    const int ky = a.g.ky0 + a.g.kstep * ty_, kx = a.g.kx0 + a.g.kstep * (lane - ty_ * a.g.nkx);
-    tab_toff = (ky * a.g.kw + kx) * (int)tap_stride;
-    if (MODE == 0) {
-      tab_delta = (ky - a.g.pad_t) * a.g.iw + (kx - a.g.pad_l);
-    } else {
-      const int sh = a.g.stride - 1;     // (stride-2 launches hold the taps of ONE parity class)
-      tab_delta = ((a.g.y0 + a.g.pad_t - ky) >> sh) * a.g.ow + ((a.g.x0 + a.g.pad_l - kx) >> sh);
-    }
-    tab_tv = 0xffu;
-    if (PM) {
-      tab_tv = 0;
-      const int hw = a.g.rh * a.g.rw;
-#pragma unroll
-      for (int tb = 0; tb < BM / 32; ++tb) {
-        const unsigned t = (unsigned)(m0 >> 5) + tb;
-        const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
-        const unsigned px = t - grp * (unsigned)hw;
-        const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
-        const int x = (int)px - y * a.g.rw;
-        tab_tv |= (tap_ok<MODE>(a.g, y, x, ky, kx) ? 1u : 0u) << tb;
-      }
-    }
-  }
-  const unsigned long long tapmask = __ballot(lane < ntaps && tab_tv != 0);
-  int cnt = __builtin_popcountll(tapmask) * kslabs;
-  if (a.nseg > 1) cnt = a.total_slabs;
-
-  // per staged activation row: its base row in the operand and the set of taps that read a real
-  // pixel for it; per staged weight row: its offset inside a tap's plane
-  int row_base[A_LOADS];
-  unsigned long long amask[A_LOADS];
-#pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) {
-    row_base[i] = MODE == 0 ? (apos[i].img * a.g.ih + apos[i].y * a.g.stride) * a.g.iw + apos[i].x * a.g.stride
-                            : (apos[i].img * a.g.oh + apos[i].y) * a.g.ow + apos[i].x;
-    amask[i] = 0;
-    for (int ty_ = 0, tp = 0; ty_ < a.g.nky; ++ty_)
-      for (int tx_ = 0; tx_ < a.g.nkx; ++tx_, ++tp)
-        if (src_row<MODE>(a.g, apos[i], a.g.ky0 + a.g.kstep * ty_, a.g.kx0 + a.g.kstep * tx_) >= 0)
-          amask[i] |= 1ull << tp;
-  }
-
-  // Two slab cursors over the same sequence (K slabs of a tap, real taps, segments): one for the
-  // activation rows, one for the weight rows.
-  SlabCursor ca = {0, 0, 0, a.K, tapmask}, cb = ca;
-  int lda = a.lda;
-  __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
-                                           (a.a_rows * a.lda - a.a_off) * 2);
-  __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
-      a.Bt, a.mo_n ? a.mo_bbytes
-                   : (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
-  int brow_base[B_LOADS];              // element offset of the staged weight row inside a tap's plane
-#pragma unroll
-  for (int i = 0; i < B_LOADS; ++i)
-    brow_base[i] = a.mo_n ? mo_weight_row(a, brow_off[i]) : brow_off[i] * a.K;
-  unsigned tv_load = ~0u;
-  unsigned tvq = ~0u;       // tap validity bits (8 per activation buffer) of the slabs in the ring
-  unsigned aoff[A_LOADS], boff[B_LOADS];
-
-#define C2D_TAP_FROM_MASK(C) (C).tap = (C).taps_left ? __builtin_ctzll((C).taps_left) : 0;
-#define C2D_RETAP_A()                                                                          \
-  {                                                                                            \
-    const int delta = __builtin_amdgcn_readlane(tab_delta, ca.tap);                            \
-    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
-        aoff[i] = ((amask[i] >> ca.tap) & 1ull)                                                \
-                      ? (unsigned)((row_base[i] + delta) * lda + q4) * 2u : OOB_OFFSET;        \
-    if (PM)                                                                                    \
-      tv_load = ((unsigned)__builtin_amdgcn_readlane((int)tab_tv, ca.tap) >> (wm * MT)) &      \
-                ((1u << MT) - 1u);                                                             \
-  }
-#define C2D_RETAP_B()                                                                          \
-  {                                                                                            \
-    const int toff = __builtin_amdgcn_readlane(tab_toff, cb.tap);                              \
-    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        boff[i] = (unsigned)((a.nseg > 1 ? brow_off[i] * cb.Kc : brow_base[i]) + toff + q4) * 2u; \
-  }
-  // DMA of the slab at a cursor into an LDS buffer (8 rows x 128 B per wave-instruction); lanes
-  // past a K tail fetch zeros (never multiplied)
-#define C2D_ISSUE_A(SLOT)                                                                      \
-  {                                                                                            \
-    const bool in = ca.kc + q4 < ca.Kc;                                                        \
-    char* const base = smem + (SLOT) * A_BYTES + wave * 1024;                                  \
-    if (!(a.dbg & 1))                                                                          \
-    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-            rsA, (lds_void_t*)(base + i * ROWS_PER_PASS * 128), 16,                            \
-            (int)(in ? aoff[i] : OOB_OFFSET), ca.kc * 2, 0, 0);                                \
-    tvq = (tvq & ~(0xffu << (8 * (SLOT)))) | ((tv_load & 0xffu) << (8 * (SLOT)));             \
-  }
-#define C2D_ISSUE_B(SLOT)                                                                      \
-  {                                                                                            \
-    const bool in = cb.kc + q4 < cb.Kc;                                                        \
-    char* const base = smemB + (SLOT) * B_BYTES + wave * 1024;                                 \
-    if (!(a.dbg & 2))                                                                          \
-    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
-            rsB, (lds_void_t*)(base + i * ROWS_PER_PASS * 128), 16,                            \
-            (int)(in ? boff[i] : OOB_OFFSET), cb.kc * 2, 0, 0);                                \
-  }
-  // advance a cursor by one slab (next K slab, next real tap, or next segment)
-#define C2D_ADVANCE_A()                                                                        \
-  {                                                                                            \
-    ca.kc += BKT;                                                                              \
-    if (ca.kc >= ca.Kc) {                                                                      \
-      ca.kc = 0;                                                                               \
-      if (a.nseg > 1) {                                                                        \
-        ++ca.sgi;                                                                              \
-        lda = a.seg_lda[ca.sgi]; ca.Kc = a.segK[ca.sgi];                                       \
-        rsA = make_rsrc_b((const char*)a.segA[ca.sgi] + (size_t)a.seg_off[ca.sgi] * 2,        \
-                          (a.a_rows * lda - a.seg_off[ca.sgi]) * 2);                           \
-      } else {                                                                                 \
-        ca.taps_left &= ca.taps_left - 1ull;                                                   \
-        C2D_TAP_FROM_MASK(ca);                                                                 \
-      }                                                                                        \
-      C2D_RETAP_A();                                                                           \
-    }                                                                                          \
-  }
-#define C2D_ADVANCE_B()                                                                        \
-  {                                                                                            \
-    cb.kc += BKT;                                                                              \
-    if (cb.kc >= cb.Kc) {                                                                      \
-      cb.kc = 0;                                                                               \
-      if (a.nseg > 1) {                                                                        \
-        ++cb.sgi;                                                                              \
-        cb.Kc = a.segK[cb.sgi];                                                                \
-        rsB = make_rsrc_b(a.segB[cb.sgi], (long long)a.N * cb.Kc * 2);                         \
-      } else {                                                                                 \
-        cb.taps_left &= cb.taps_left - 1ull;                                                   \
-        C2D_TAP_FROM_MASK(cb);                                                                 \
-      }                                                                                        \
-      C2D_RETAP_B();                                                                           \
-    }                                                                                          \
-  }
-  // prologue: activation slabs 0 .. DA - 2 and weight slab 0; the newest pieces of every wave are
-  // those of its newest activation slab
-  int issued_a = 0, issued_b = 0;          // slabs handed to the DMA so far
-  int slot_a_in = 0;                       // activation buffer the next activation slab goes to
-  if (cnt > 0) {
-    C2D_TAP_FROM_MASK(ca);
-    cb.tap = ca.tap;
-    C2D_RETAP_A();
-    C2D_RETAP_B();
-    C2D_ISSUE_A(0);
-    issued_a = 1; slot_a_in = 1;
-#pragma unroll
-    for (int d = 1; d < DA - 2; ++d)
-      if (issued_a < cnt) {
-        C2D_ADVANCE_A();
-        C2D_ISSUE_A(d);
-        ++issued_a; slot_a_in = d + 1;
-      }
-    C2D_ISSUE_B(0);
-    issued_b = 1;
-    if (DA > 2 && issued_a < cnt) {
-      C2D_ADVANCE_A();
-      C2D_ISSUE_A(DA - 2);
-      ++issued_a; slot_a_in = DA - 1;
-    }
-  }
-  // fragment addresses inside a buffer: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
-  int arow_b[MT], brow_b[NT], asw[MT], bsw[NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int r = (wm * MT + i) * 32 + li;
-    arow_b[i] = r * 128; asw[i] = (r >> 1) & 7;
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int r = (wn * NT + j) * 32 + li;
-    brow_b[j] = r * 128; bsw[j] = (r >> 1) & 7;
-  }
-
-  int slot_a = 0, slot_b = 0;            // buffers of slab `it`
-  for (int it = 0; it < cnt; ++it) {
-    // Slab `it` has landed: a wave's DMA pieces retire in order and the weights of a slab are
-    // issued in front of the activation slab that goes out with them, so "at most the pieces of
-    // the newest activation slab outstanding" says this wave's pieces of slab `it` are done;
-    // everybody's: the barrier.  The barrier also says every wave is done reading the buffers of
-    // slab it - 1, which the DMAs issued below overwrite.
-    if (DA > 2 && issued_a > it + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (issued_b < cnt) {
-      C2D_ADVANCE_B();
-      C2D_ISSUE_B(slot_b ^ 1);
-      ++issued_b;
-    }
-    if (issued_a < cnt) {
-      C2D_ADVANCE_A();
-      C2D_ISSUE_A(slot_a_in);
-      ++issued_a;
-      if (++slot_a_in == DA) slot_a_in = 0;
-    }
-    // bit i: row tile i of this wave is inside M and (PM) real for the tap being multiplied
-    const unsigned onbits = (a.dbg & 4) ? 0u : __builtin_amdgcn_readfirstlane(row_bits & (tvq >> (8 * slot_a)));
-    const char* const bufa = smem + slot_a * A_BYTES;
-    const char* const bufb = smemB + slot_b * B_BYTES;
-    // B fragments of the whole slab, then per 32-row tile of this wave (one scalar branch each:
-    // a tile whose rows are SAME padding for this tap, or lie beyond M, costs nothing) its four A
-    // fragments and 4 x NT MFMAs in straight-line code.  Columns beyond N are computed on clamped
-    // weight rows and never stored; K tails are zeros (out-of-range DMA lanes).
-    bf16x8 bf[NT][4];
-    if (!(a.dbg & 4))
-#pragma unroll
-    for (int st = 0; st < 4; ++st)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        bf[j][st] = *reinterpret_cast<const bf16x8*>(bufb + brow_b[j] + (((2 * st + lh) ^ bsw[j]) << 4));
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if ((onbits >> i) & 1u) {
-        bf16x8 af[4];
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-          af[st] = *reinterpret_cast<const bf16x8*>(bufa + arow_b[i] + (((2 * st + lh) ^ asw[i]) << 4));
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
-      }
-    }
-    if (++slot_a == DA) slot_a = 0;
-    slot_b ^= 1;
-  }
-#undef C2D_RETAP_A
-#undef C2D_RETAP_B
-#undef C2D_ISSUE_A
-#undef C2D_ISSUE_B
-#undef C2D_ADVANCE_A
-#undef C2D_ADVANCE_B
-#undef C2D_TAP_FROM_MASK
-  __syncthreads();     // every wave is done with the slab buffers: the epilogue reuses them
-  if (a.dbg & 8) return;
-
-  // Epilogue (as igemm_body): 32-row strips transposed through a per-wave LDS slice so that the
-  // global stores are 8 B per lane (4 bf16) on contiguous row segments.
-  constexpr int SCOLS = NT * 32;
-  constexpr int SSTR = SCOLS + 4;
-  // (wide wave tiles: the 32-row strip goes through the staging slice as two halves of 16 rows)
-  constexpr int HALVES = WM * WN * 32 * SSTR * 4 <= LDS_BYTES ? 1 : 2;
-  constexpr int HROWS = 32 / HALVES;
-  static_assert(WM * WN * HROWS * SSTR * 4 <= LDS_BYTES, "epilogue staging exceeds LDS");
-  float* stage = reinterpret_cast<float*>(smem) + wave * (HROWS * SSTR);
-  constexpr int C4 = SCOLS / 4;
-  constexpr int RPP = 64 / C4;
-  static_assert(HROWS % RPP == 0, "epilogue passes vs strip rows");
-  const int ec4 = lane % C4, er = lane / C4;
-  const bool lane_on = er < RPP;                // (C4 does not divide 64: the last lanes idle)
-  const int ncol = n0 + wn * SCOLS + ec4 * 4;
-  f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
-  const bool ncol_ok = ncol < a.N && lane_on;
-  if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
-  if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
-  // several convolutions in one GEMM: this lane's four columns belong to one of them
-  float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol, orelu = a.relu;
-  if (MODE == 0 && a.mo_n && ncol_ok) {
-    const MoOut o = mo_output(a, ncol);
-    oC = o.C; oldc = o.ldc; ocoff = o.coff + (ncol - o.lo); orelu = o.relu;
-    esc = *reinterpret_cast<const f32x4*>(o.scale + (ncol - o.lo));
-    esh = *reinterpret_cast<const f32x4*>(o.shift + (ncol - o.lo));
-  }
-  // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
-  const bool fused = MODE == 1 && a.fy != nullptr;
-  f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
-  bool fpass = false;      // columns of a pooling branch: plain gradient
-  if (fused && ncol_ok) fpass = fused_bn_params(a, ncol, fsc, fbe, fig);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int h = 0; h < HALVES; ++h) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int rr = 0; rr < 16 / HALVES; ++rr) {
-          const int r = h * (16 / HALVES) + rr;
-          // accumulator register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh of the
-          // strip, i.e. row (rr & 3) + 8 * (rr >> 2) + 4 * lh of half h
-          stage[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
-        }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int pass = 0; pass < HROWS / RPP; ++pass) {
-        const int row = pass * RPP + (lane_on ? er : 0);
-        const int m = m0 + (wm * MT + i) * 32 + h * HROWS + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
-        bool row_ok = m < a.M;
-        int drow = m;
-        if (PM || (MODE == 1 && a.g.sub > 1)) {
-          const RowPos p = decompose<PM>(m, a.M, a.g);
-          row_ok = p.valid;
-          drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
-                           : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
-                                 p.x * a.g.sub + a.g.x0;
-        }
-        if (row_ok && ncol_ok) {
-          v = v * esc + esh;
-          if (orelu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          }
-          bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
-                                                  (size_t)drow * oldc + ocoff);
-          if (a.accumulate) {
-            const bf16x4 o = *dst;
-            v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
-          }
-          if (fused && !fpass)
-            v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
-                              fig, fsb, fsg);
-          bf16x4 o;
-          o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-          *dst = o;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  if (fused)      // (block-uniform)
-    fused_bn_finish<WM, WN, SCOLS, RPP>(reinterpret_cast<float*>(smem), nullptr, a.fpart,
-                                        a.fpart_row0, a.N, fsb, fsg, tid, wave, ec4, er, lane_on,
-                                        n0, mt);
-}
+// (The bf16-native implicit GEMM — direct-to-LDS operand stages, ring of 2-3 buffers — lives in
+// igemm_bf16.hip: igemm_bf16_ring_kernel.)
 
 // ---------------------------------------------------------------------------------------------
 // Small-problem kernel (first stage: one image, 32x32 .. 125x125 maps => 1k-16k rows).
@@ -2487,44 +1787,13 @@ int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
   return c2d_launch_status();
 }
 
-// C2D_TUNE=1 C2D_BF16_GLDS=0: bf16 operands through the register-staged igemm_body (A/B timing)
-bool bf16_glds_enabled() {
-  static const bool tune = getenv("C2D_TUNE") != nullptr;
-  if (!tune) return true;
-  const char* e = getenv("C2D_BF16_GLDS");
-  return !(e && e[0] == '0');
-}
-
 template <int MODE, int WM, int WN, int MT, int NT, bool PM>
 int launch_igemm_bf16(IgemmArgs a, hipStream_t s) {
-  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  a.m_tiles = c2d_ceil_div(a.M, BM);
-  a.n_tiles = c2d_ceil_div(a.N, BN);
-  g_last_m_tiles = a.m_tiles;
-  if (g_tile_query) return C2D_OK;
-  if (a.nseg > 1) {
-    a.total_slabs = 0;
-    for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], 64);
-  }
-  static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
-  a.dbg = dbg_env;
-  // C2D_TUNE=1 C2D_BF16_NBUF=2|3: depth of the activation-slab ring
-  static const int nbuf_env = (getenv("C2D_TUNE") && getenv("C2D_BF16_NBUF")) ? atoi(getenv("C2D_BF16_NBUF")) : 0;
-  constexpr bool can3 = (3 * BM + 2 * BN) * 128 <= 160 * 1024;
-  const int nbuf = (nbuf_env == 3 && can3) ? 3 : 2;
-  const dim3 grid(a.m_tiles * a.n_tiles), block(WM * WN * 64);
-  if constexpr (can3) {
-    if (nbuf == 3) {
-      dispatch_note(PM ? "igemm_bf16_kernel<%d, %d, %d, %d, %d, true, 3>"
-                       : "igemm_bf16_kernel<%d, %d, %d, %d, %d, false, 3>", MODE, WM, WN, MT, NT);
-      hipLaunchKernelGGL((igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, 3>), grid, block, 0, s, a);
-      return c2d_launch_status();
-    }
-  }
-  dispatch_note(PM ? "igemm_bf16_kernel<%d, %d, %d, %d, %d, true, 2>"
-                   : "igemm_bf16_kernel<%d, %d, %d, %d, %d, false, 2>", MODE, WM, WN, MT, NT);
-  hipLaunchKernelGGL((igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, 2>), grid, block, 0, s, a);
-  return c2d_launch_status();
+  constexpr int BM = WM * MT * 32;
+  g_last_m_tiles = c2d_ceil_div(a.M, BM);
+  a.g.mode = MODE;
+  int mtiles = 0;
+  return launch_igemm_bf16_ring(a, WM, WN, MT, NT, PM, s, &mtiles, g_tile_query);
 }
 
 // Full-width tiles: 128 rows x every output column (N <= 384, rounded up to 64) in ONE block of
@@ -2548,13 +1817,9 @@ int launch_igemm_bf16_wide(const IgemmArgs& a, hipStream_t s) {
 
 template <int WM, int WN, int MT, int NT, int BKT, bool PM = false>
 int launch_igemm(const IgemmArgs& a, hipStream_t s, const IgemmWs& ws) {
-  if (a.es == 2 && bf16_glds_enabled()) {
+  if (a.es == 2) {
     if (a.g.mode == 0) return launch_igemm_bf16<0, WM, WN, MT, NT, PM>(a, s);
     return launch_igemm_bf16<1, WM, WN, MT, NT, PM>(a, s);
-  }
-  if (a.es == 2) {   // bf16 operands: 64 elements per 128-B slab row
-    if (a.g.mode == 0) return launch_igemm_mode<0, WM, WN, MT, NT, 2 * BKT, PM, 2>(a, s, ws);
-    return launch_igemm_mode<1, WM, WN, MT, NT, 2 * BKT, PM, 2>(a, s, ws);
   }
   if (a.g.mode == 0) return launch_igemm_mode<0, WM, WN, MT, NT, BKT, PM, 4>(a, s, ws);
   return launch_igemm_mode<1, WM, WN, MT, NT, BKT, PM, 4>(a, s, ws);
@@ -2587,16 +1852,27 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     e = getenv("C2D_IGEMM_CFG");
     force = e ? atoi(e) : 0;
   }
-  // bf16 (igemm_bf16_kernel) block tile, measured per layer shape of the second stage
-  // (tools/bench_conv_bf16.py, N = 2000 ROIs): 128x256 (8 waves) for output widths of 193..256 and
-  // >= 1024 columns, 128x128 when the last 128-wide tile is more than half full, else 128x64.
-  // Output widths of 257..384 (Mixed_5b/5c: 320, 352): ONE 128-row x full-width tile per block (8
-  // waves 4 x 2), 250 blocks for 2000 4x4 maps = one round of the chip, the activations read once
-  // (192->320 3x3: 57 -> 45 us, 1024->352 1x1: 39 -> 34.5 us against 128x64 / 128x128 tiles).
-  if (!force && a.es == 2 && a.g.sub == 1)
-    force = (a.N > 256 && a.N <= 384) ? 7
-            : ((a.N > 192 && a.N <= 256) || a.N >= 1024) ? 6
-            : (a.N > 256 && (a.N % 128 == 0 || a.N % 128 > 64)) ? 3 : 2;
+  // bf16 (igemm_bf16_ring_kernel) block tile by output width, measured per GEMM call of the step
+  // (tools/bench_step_gemms.py + tools/sweep_step_gemms.sh, N = 2000 ROIs; round 3):
+  //   129..192 and 257..384 columns: ONE 128-row x full-width tile per block (8 waves 4 x 2): the
+  //     activations stream from HBM once; with three 64-column tiles the ring is 80 KiB and two
+  //     workgroups share a CU (192->256 input gradient on 7x7 maps: 130 -> 107 us, 192->320: 47 -> 46,
+  //     128->192 stride 2: 29 -> 26);
+  //   193..256 columns: 128x256 (8 waves 2 x 4);
+  //   wider (block-entry GEMMs: 736 / 832 columns forward, 576 / 1024 input gradient): 128x256 unless
+  //     the last 256-wide tile would be more than 30 % padding (576 -> 128x64);
+  //   up to 128 columns: 128x64 / 64x64 as before.
+  if (!force && a.es == 2) {
+    if (a.N > 256 && a.N <= 384) force = 7;
+    else if (a.N > 192 && a.N <= 256) force = 6;
+    else if (a.N > 128 && a.N <= 192) force = 7;
+    else if (a.N > 384) {
+      const int waste = c2d_ceil_div(a.N, 256) * 256 - a.N;
+      force = waste * 10 <= 3 * a.N ? 6 : 2;
+    } else {
+      force = 2;
+    }
+  }
   // bf16 operands: 128x64 tiles throughout (tools/bench_conv_bf16.py: 0.96 ms against 1.06 ms on
   // the second-stage shapes; the stride-2 input gradients gain most, 108 -> 66 us)
   // stride-2 input gradients (four parity-class launches of a quarter of the rows each): 128x64
@@ -2671,6 +1947,12 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
 }
 
 }  // namespace
+
+namespace c2d_ig {
+void dispatch_note_ext(const char* fmt, int a, int b, int c, int d, int e, int f, int g, int h) {
+  dispatch_note(fmt, a, b, c, d, e, f, g, h);
+}
+}  // namespace c2d_ig
 
 #ifdef C2D_TRACE
 // Diagnostic build only (make trace): per-block timeline buffer, 8 x u64 per block.

@@ -1,0 +1,530 @@
+// bf16 implicit-GEMM convolution with a DEEP LDS-DMA RING (second stage in the bf16 storage mode,
+// BASELINE configs[2] / [4]: slim.conv2d of models/utils.py:165-167 and its input gradient).
+//
+// Same iteration space, tap tables, pixel-major tile skipping, multi-segment / multi-output modes
+// and epilogue as igemm_bf16_kernel of conv_gemm.hip (round 2), which staged ONE slab ahead: a
+// workgroup then waits out the whole global -> LDS latency of a slab (~2,600 cycles under load)
+// for 512-1,400 cycles of MFMAs per slab, and issues all of a slab's DMA pieces in front of its
+// MFMAs (6-8 wave-instructions of ~100 issue cycles each, both waves of a SIMD at the same time
+// behind the barrier).  Here
+//   * operand stages go through a ring of D buffers: D - 2 stages stay in flight across the
+//     barrier (counted s_waitcnt vmcnt, raw s_barrier — never __syncthreads() with a DMA pending,
+//     cdna_hip_programming.md §5 "Pipelining across barriers");
+//   * a stage is BKT = 64 or 32 elements of K deep (128- or 64-byte rows): the 32-deep form makes
+//     a ring of three small enough for TWO workgroups per CU on the 128x256 tile.
+// What the sweeps showed (launch_tile below): deep rings lose, co-resident workgroups win.
+// LDS image of a stage: unpadded rows; 16-byte chunk c of row r sits at position c ^ swz(r) with
+// swz(r) = (r >> 1) & 7 for 128-byte rows and (r >> 2) & 3 for 64-byte rows — applied to the DMA's
+// per-lane GLOBAL address and to the fragment reads (an LDS-DMA image is lane-linear) — which puts
+// the 16 lanes of every ds_read_b128 group on 16 distinct 16-byte slots (MI355X_MICROARCH.md §LDS).
+#include "igemm_common.h"
+#include <stdlib.h>
+
+namespace c2d_ig {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct SlabCursor {
+  int tap, kc, sgi, Kc;
+  unsigned long long taps_left;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int ring_blocks_per_cu(int lds_bytes) {
+  return (160 * 1024) / lds_bytes >= 5 ? 5 : (160 * 1024) / lds_bytes;
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D>
+__global__ __launch_bounds__(WM * WN * 64,
+                             ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * 2) * (WM * WN) / 4 > 0
+                                 ? ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * 2) * (WM * WN) / 4 : 1)
+void igemm_bf16_ring_kernel(IgemmArgs a) {
+  constexpr int RB = BKT * 2;                   // bytes per staged row
+  constexpr int CPR = RB / 16;                  // 16-byte chunks per row (8 or 4)
+  constexpr int KS = BKT / 16;                  // MFMA k-steps per stage (4 or 2)
+  constexpr int BM = WM * MT * 32;
+  constexpr int BN = WN * NT * 32;
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int ROWS_PER_PASS = NTHREADS / CPR; // a wave-instruction stages 1 KiB = 1024 / RB rows
+  constexpr int A_LOADS = BM / ROWS_PER_PASS;
+  // weight rows: whole passes, plus a last partial pass that only the first waves take part in
+  // (32-deep stages of 8-wave blocks stage 128 rows per pass; BN = 192 / 320 leave half a pass)
+  constexpr int B_LOADS = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+  constexpr bool B_TAIL = BN % ROWS_PER_PASS != 0;
+  constexpr int PER = A_LOADS + B_LOADS;        // DMA wave-instructions per stage and wave (PER - 1
+                                                // for the waves outside a partial last pass)
+  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
+  constexpr int RING_BYTES = D * (A_BYTES + B_BYTES);
+  // (the epilogue stages 16-row half strips of every wave through the same memory)
+  constexpr int EPI_BYTES = WM * WN * 16 * (NT * 32 + 4) * 4;
+  constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+  static_assert(BM % ROWS_PER_PASS == 0 && BN % (1024 / RB) == 0, "tile vs block size");
+  static_assert(D >= 2 && D <= 6 && (D - 2) * PER <= 63, "ring depth vs the 6-bit vmcnt");
+  static_assert(LDS_BYTES <= 160 * 1024, "ring exceeds LDS");
+  static_assert(BKT == 64 || BKT == 32, "stage depth");
+  __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+  char* const smemB = smem + D * A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  // DMA: this lane fetches the chunk that belongs at LDS position tid % CPR of its row
+  const int lrow = tid / CPR;                                       // row inside a pass
+  const int lswz = CPR == 8 ? (lrow >> 1) & 7 : (lrow >> 2) & 3;    // (pass rows are multiples of 16)
+  const int kchunk = (tid % CPR) ^ lswz;
+  const int q4 = kchunk * 8;                                        // element offset inside the stage
+  // does this wave hold a piece of the (partial) last pass of the weight rows?
+  const bool b_last = !B_TAIL || wave * (1024 / RB) + (B_LOADS - 1) * ROWS_PER_PASS < BN;
+
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lb / a.n_tiles, nt = lb - mt * a.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ntaps = a.g.nky * a.g.nkx;
+  const int kslabs = (a.K + BKT - 1) / BKT;
+  const size_t tap_stride = (size_t)a.N * a.K;
+
+  RowPos apos[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) apos[i] = decompose<PM>(m0 + lrow + i * ROWS_PER_PASS, a.M, a.g);
+  int brow_off[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) brow_off[i] = min(n0 + lrow + i * ROWS_PER_PASS, a.N - 1);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  unsigned row_bits = 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+    if (m0 + (wm * MT + i) * 32 < a.M) row_bits |= 1u << i;
+  row_bits = __builtin_amdgcn_readfirstlane(row_bits);
+
+  // Tap table, one tap per lane (every wave holds all of it): what changes from tap to tap —
+  // the row delta of the activation rows, the offset of the tap's weight plane and (PM) which
+  // 32-row tiles of the block are real for the tap — is computed once.
+  int tab_delta = 0, tab_toff = 0;
+  unsigned tab_tv = 0;
+  if (lane < ntaps) {
+    const int ty_ = lane / a.g.nkx;
+    const int ky = a.g.ky0 + a.g.kstep * ty_, kx = a.g.kx0 + a.g.kstep * (lane - ty_ * a.g.nkx);
+    tab_toff = (ky * a.g.kw + kx) * (int)tap_stride;
+    if (MODE == 0) {
+      tab_delta = (ky - a.g.pad_t) * a.g.iw + (kx - a.g.pad_l);
+    } else {
+      const int sh = a.g.stride - 1;     // (stride-2 launches hold the taps of ONE parity class)
+      tab_delta = ((a.g.y0 + a.g.pad_t - ky) >> sh) * a.g.ow + ((a.g.x0 + a.g.pad_l - kx) >> sh);
+    }
+    tab_tv = 0xffu;
+    if (PM) {
+      tab_tv = 0;
+      const int hw = a.g.rh * a.g.rw;
+#pragma unroll
+      for (int tb = 0; tb < BM / 32; ++tb) {
+        const unsigned t = (unsigned)(m0 >> 5) + tb;
+        const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
+        const unsigned px = t - grp * (unsigned)hw;
+        const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
+        const int x = (int)px - y * a.g.rw;
+        tab_tv |= (tap_ok<MODE>(a.g, y, x, ky, kx) ? 1u : 0u) << tb;
+      }
+    }
+  }
+  const unsigned long long tapmask = __ballot(lane < ntaps && tab_tv != 0);
+  int cnt = __builtin_popcountll(tapmask) * kslabs;
+  if (a.nseg > 1) cnt = a.total_slabs;
+
+  int row_base[A_LOADS];
+  unsigned long long amask[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    row_base[i] = MODE == 0 ? (apos[i].img * a.g.ih + apos[i].y * a.g.stride) * a.g.iw + apos[i].x * a.g.stride
+                            : (apos[i].img * a.g.oh + apos[i].y) * a.g.ow + apos[i].x;
+    amask[i] = 0;
+    for (int ty_ = 0, tp = 0; ty_ < a.g.nky; ++ty_)
+      for (int tx_ = 0; tx_ < a.g.nkx; ++tx_, ++tp)
+        if (src_row<MODE>(a.g, apos[i], a.g.ky0 + a.g.kstep * ty_, a.g.kx0 + a.g.kstep * tx_) >= 0)
+          amask[i] |= 1ull << tp;
+  }
+
+  // One cursor over the stage sequence (K stages of a tap, real taps, segments).
+  SlabCursor cur = {0, 0, 0, a.K, tapmask};
+  int lda = a.lda;
+  __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
+                                           (a.a_rows * a.lda - a.a_off) * 2);
+  __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
+      a.Bt, a.mo_n ? a.mo_bbytes
+                   : (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
+  int brow_base[B_LOADS];              // element offset of the staged weight row inside a tap's plane
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i)
+    brow_base[i] = a.mo_n ? mo_weight_row(a, brow_off[i]) : brow_off[i] * a.K;
+  unsigned tv_load = ~0u;
+  unsigned tvq_lo = ~0u, tvq_hi = ~0u;   // tap validity bits (8 per ring slot) of the stages in the ring
+  unsigned aoff[A_LOADS], boff[B_LOADS];
+
+#define C2D_RETAP()                                                                            \
+  {                                                                                            \
+    const int delta = __builtin_amdgcn_readlane(tab_delta, cur.tap);                           \
+    const int toff = __builtin_amdgcn_readlane(tab_toff, cur.tap);                             \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
+        aoff[i] = ((amask[i] >> cur.tap) & 1ull)                                               \
+                      ? (unsigned)((row_base[i] + delta) * lda + q4) * 2u : OOB_OFFSET;        \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
+        boff[i] = (unsigned)((a.nseg > 1 ? brow_off[i] * cur.Kc : brow_base[i]) + toff + q4) * 2u; \
+    if (PM)                                                                                    \
+      tv_load = ((unsigned)__builtin_amdgcn_readlane((int)tab_tv, cur.tap) >> (wm * MT)) &     \
+                ((1u << MT) - 1u);                                                             \
+  }
+  // one DMA piece (8 or 16 rows x 128 / 64 B per wave-instruction); lanes past a K tail fetch zeros
+#define C2D_PIECE_A(SLOT, I)                                                                   \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                    \
+      rsA, (lds_void_t*)(smem + (SLOT) * A_BYTES + wave * 1024 + (I) * ROWS_PER_PASS * RB), 16, \
+      (int)(cur.kc + q4 < cur.Kc ? aoff[I] : OOB_OFFSET), cur.kc * 2, 0, 0);
+#define C2D_PIECE_B(SLOT, I)                                                                   \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                    \
+      rsB, (lds_void_t*)(smemB + (SLOT) * B_BYTES + wave * 1024 + (I) * ROWS_PER_PASS * RB), 16, \
+      (int)(cur.kc + q4 < cur.Kc ? boff[I] : OOB_OFFSET), cur.kc * 2, 0, 0);
+#define C2D_NOTE_TV(SLOT)                                                                      \
+  {                                                                                            \
+    if ((SLOT) < 4) tvq_lo = (tvq_lo & ~(0xffu << (8 * ((SLOT) & 3)))) | ((tv_load & 0xffu) << (8 * ((SLOT) & 3))); \
+    else tvq_hi = (tvq_hi & ~(0xffu << (8 * ((SLOT) & 3)))) | ((tv_load & 0xffu) << (8 * ((SLOT) & 3))); \
+  }
+#define C2D_ISSUE_ALL(SLOT)                                                                    \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
+      if (i + 1 < B_LOADS || b_last) { C2D_PIECE_B(SLOT, i) }                                  \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(SLOT, i) }               \
+    C2D_NOTE_TV(SLOT)                                                                          \
+  }
+  // advance the cursor by one stage (next K stage, next real tap, or next segment)
+#define C2D_ADVANCE()                                                                          \
+  {                                                                                            \
+    cur.kc += BKT;                                                                             \
+    if (cur.kc >= cur.Kc) {                                                                    \
+      cur.kc = 0;                                                                              \
+      if (a.nseg > 1) {                                                                        \
+        ++cur.sgi;                                                                             \
+        lda = a.seg_lda[cur.sgi]; cur.Kc = a.segK[cur.sgi];                                    \
+        rsA = make_rsrc_b((const char*)a.segA[cur.sgi] + (size_t)a.seg_off[cur.sgi] * 2,      \
+                          (a.a_rows * lda - a.seg_off[cur.sgi]) * 2);                          \
+        rsB = make_rsrc_b(a.segB[cur.sgi], (long long)a.N * cur.Kc * 2);                       \
+      } else {                                                                                 \
+        cur.taps_left &= cur.taps_left - 1ull;                                                 \
+        cur.tap = cur.taps_left ? __builtin_ctzll(cur.taps_left) : 0;                          \
+      }                                                                                        \
+      C2D_RETAP();                                                                             \
+    }                                                                                          \
+  }
+  // prologue: stages 0 .. D - 2
+  if (cnt > 0) {
+    cur.tap = cur.taps_left ? __builtin_ctzll(cur.taps_left) : 0;
+    C2D_RETAP();
+    C2D_ISSUE_ALL(0);
+#pragma unroll
+    for (int d = 1; d < D - 1; ++d)
+      if (d < cnt) {
+        C2D_ADVANCE();
+        C2D_ISSUE_ALL(d);
+      }
+  }
+  // fragment addresses inside a stage buffer: row r, chunk c -> r * RB + ((c ^ swz(r)) << 4)
+  int arow_b[MT], brow_b[NT], asw[MT], bsw[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int r = (wm * MT + i) * 32 + li;
+    arow_b[i] = r * RB; asw[i] = CPR == 8 ? (r >> 1) & 7 : (r >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int r = (wn * NT + j) * 32 + li;
+    brow_b[j] = r * RB; bsw[j] = CPR == 8 ? (r >> 1) & 7 : (r >> 2) & 3;
+  }
+
+  int slot = 0;                          // ring slot of stage `it`
+  int slot_in = D - 1;                   // ring slot the stage issued in iteration `it` goes to
+  for (int it = 0; it < cnt; ++it) {
+    // Stage `it` has landed: a wave's DMA pieces retire in order, so "at most the pieces of the
+    // `ahead` newest stages outstanding" says this wave's pieces of stage `it` are done;
+    // everybody's: the barrier.  The barrier also says every wave is done reading the buffer of
+    // stage it - 1, which the pieces issued below overwrite.
+    const int ahead = min(cnt, it + D - 1) - it - 1;      // stages issued beyond `it` (block-uniform)
+    if (b_last) {
+      if (D > 5 && ahead >= 4) wait_vmcnt<(D > 5 ? 4 : 0) * PER>();
+      else if (D > 4 && ahead >= 3) wait_vmcnt<(D > 4 ? 3 : 0) * PER>();
+      else if (D > 3 && ahead >= 2) wait_vmcnt<(D > 3 ? 2 : 0) * PER>();
+      else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * PER>();
+      else wait_vmcnt<0>();
+    } else {
+      if (D > 5 && ahead >= 4) wait_vmcnt<(D > 5 ? 4 : 0) * (PER - 1)>();
+      else if (D > 4 && ahead >= 3) wait_vmcnt<(D > 4 ? 3 : 0) * (PER - 1)>();
+      else if (D > 3 && ahead >= 2) wait_vmcnt<(D > 3 ? 2 : 0) * (PER - 1)>();
+      else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * (PER - 1)>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const bool more = it + D - 1 < cnt;
+    if (more) C2D_ADVANCE();
+    const unsigned tvq = slot < 4 ? tvq_lo >> (8 * (slot & 3)) : tvq_hi >> (8 * (slot & 3));
+    const unsigned onbits = (a.dbg & 4) ? 0u : __builtin_amdgcn_readfirstlane(row_bits & tvq);
+    const char* const bufa = smem + slot * A_BYTES;
+    const char* const bufb = smemB + slot * B_BYTES;
+    // B fragments of the whole stage; then, per 32-row tile of this wave (one scalar branch each:
+    // a tile whose rows are SAME padding for this tap, or lie beyond M, costs nothing) its A
+    // fragments and KS x NT MFMAs.  The DMA pieces of the stage D - 1 ahead go out between the
+    // MFMA groups of the first row tile (after the fragments are in flight).
+    bf16x8 bf[NT][KS];
+#pragma unroll
+    for (int st = 0; st < KS; ++st)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j][st] = *reinterpret_cast<const bf16x8*>(bufb + brow_b[j] + (((2 * st + lh) ^ bsw[j]) << 4));
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i)
+        if (i + 1 < B_LOADS || b_last) { C2D_PIECE_B(slot_in, i) }
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
+      C2D_NOTE_TV(slot_in)
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if ((onbits >> i) & 1u) {
+        bf16x8 af[KS];
+#pragma unroll
+        for (int st = 0; st < KS; ++st)
+          af[st] = *reinterpret_cast<const bf16x8*>(bufa + arow_b[i] + (((2 * st + lh) ^ asw[i]) << 4));
+#pragma unroll
+        for (int st = 0; st < KS; ++st)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (++slot == D) slot = 0;
+    if (++slot_in == D) slot_in = 0;
+  }
+#undef C2D_RETAP
+#undef C2D_PIECE_A
+#undef C2D_PIECE_B
+#undef C2D_NOTE_TV
+#undef C2D_ISSUE_ALL
+#undef C2D_ADVANCE
+  __syncthreads();     // every wave is done with the stage buffers: the epilogue reuses them
+  if (a.dbg & 8) return;
+
+  // Epilogue: 32-row strips transposed through a per-wave LDS slice so that the global stores
+  // are 8 B per lane (4 bf16) on contiguous row segments.
+  constexpr int SCOLS = NT * 32;
+  constexpr int SSTR = SCOLS + 4;
+  // (wide wave tiles: the 32-row strip goes through the staging slice as two halves of 16 rows)
+  constexpr int HALVES = WM * WN * 32 * SSTR * 4 <= LDS_BYTES ? 1 : 2;
+  constexpr int HROWS = 32 / HALVES;
+  static_assert(WM * WN * HROWS * SSTR * 4 <= LDS_BYTES, "epilogue staging exceeds LDS");
+  float* stage = reinterpret_cast<float*>(smem) + wave * (HROWS * SSTR);
+  constexpr int C4 = SCOLS / 4;
+  constexpr int RPP = 64 / C4;
+  static_assert(HROWS % RPP == 0, "epilogue passes vs strip rows");
+  const int ec4 = lane % C4, er = lane / C4;
+  const bool lane_on = er < RPP;                // (C4 does not divide 64: the last lanes idle)
+  const int ncol = n0 + wn * SCOLS + ec4 * 4;
+  f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+  const bool ncol_ok = ncol < a.N && lane_on;
+  if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
+  if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+  // several convolutions in one GEMM: this lane's four columns belong to one of them
+  float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol, orelu = a.relu;
+  if (MODE == 0 && a.mo_n && ncol_ok) {
+    const MoOut o = mo_output(a, ncol);
+    oC = o.C; oldc = o.ldc; ocoff = o.coff + (ncol - o.lo); orelu = o.relu;
+    esc = *reinterpret_cast<const f32x4*>(o.scale + (ncol - o.lo));
+    esh = *reinterpret_cast<const f32x4*>(o.shift + (ncol - o.lo));
+  }
+  // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
+  const bool fused = MODE == 1 && a.fy != nullptr;
+  f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
+  bool fpass = false;      // columns of a pooling branch: plain gradient
+  if (fused && ncol_ok) fpass = fused_bn_params(a, ncol, fsc, fbe, fig);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16 / HALVES; ++rr) {
+          const int r = h * (16 / HALVES) + rr;
+          // accumulator register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh of the
+          // strip, i.e. row (rr & 3) + 8 * (rr >> 2) + 4 * lh of half h
+          stage[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < HROWS / RPP; ++pass) {
+        const int row = pass * RPP + (lane_on ? er : 0);
+        const int m = m0 + (wm * MT + i) * 32 + h * HROWS + row;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
+        bool row_ok = m < a.M;
+        int drow = m;
+        if (PM || (MODE == 1 && a.g.sub > 1)) {
+          const RowPos p = decompose<PM>(m, a.M, a.g);
+          row_ok = p.valid;
+          drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
+                           : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
+                                 p.x * a.g.sub + a.g.x0;
+        }
+        if (row_ok && ncol_ok) {
+          v = v * esc + esh;
+          if (orelu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+          bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
+                                                  (size_t)drow * oldc + ocoff);
+          if (a.accumulate) {
+            const bf16x4 o = *dst;
+            v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+          }
+          if (fused && !fpass)
+            v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
+                              fig, fsb, fsg);
+          bf16x4 o;
+          o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+          *dst = o;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (fused)      // (block-uniform)
+    fused_bn_finish<WM, WN, SCOLS, RPP>(reinterpret_cast<float*>(smem), nullptr, a.fpart,
+                                        a.fpart_row0, a.N, fsb, fsg, tid, wave, ec4, er, lane_on,
+                                        n0, mt);
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+// Tuning hooks (read once, only with C2D_TUNE=1): C2D_RING_BK=32|64, C2D_RING_D=2..6 force the
+// stage depth / ring depth where an instance exists; C2D_RING=0 switches the ring kernel off
+// (the round-2 kernel of conv_gemm.hip runs instead).
+struct RingTune { int bk, d, off; };
+const RingTune& ring_tune() {
+  static const RingTune t = [] {
+    RingTune r = {0, 0, 0};
+    if (getenv("C2D_TUNE")) {
+      if (const char* e = getenv("C2D_RING_BK")) r.bk = atoi(e);
+      if (const char* e = getenv("C2D_RING_D")) r.d = atoi(e);
+      if (const char* e = getenv("C2D_RING")) r.off = e[0] == '0';
+    }
+    return r;
+  }();
+  return t;
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D>
+int launch_one(IgemmArgs a, hipStream_t s) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  a.m_tiles = c2d_ceil_div(a.M, BM);
+  a.n_tiles = c2d_ceil_div(a.N, BN);
+  if (a.nseg > 1) {
+    a.total_slabs = 0;
+    for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], BKT);
+  }
+  static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
+  a.dbg = dbg_env;
+  dispatch_note_ext(PM ? "igemm_bf16_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d>"
+                       : "igemm_bf16_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d>",
+                    MODE, WM, WN, MT, NT, BKT, D);
+  hipLaunchKernelGGL((igemm_bf16_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D>),
+                     dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
+  return c2d_launch_status();
+}
+
+// (stage depth, ring depth) of a block tile, measured per GEMM call of the step (tools/
+// sweep_step_gemms.sh, N = 2000 ROIs).  What decides is how many workgroups share a CU, not how
+// deep one workgroup prefetches: these GEMMs are short (K = 128 .. 2304: 2 - 36 stages), so a
+// workgroup spends as long in its ramp (first stages in flight) and its epilogue as in its K loop,
+// and only ANOTHER workgroup's K loop fills the matrix pipe meanwhile.  Rings of four or more
+// stages (one workgroup per CU) measured 10 - 45 % slower on every call.  So:
+//   * 128x256 (8 waves): launches of more than 1.5 rounds of the chip take 32-deep stages in a
+//     ring of three (72 KiB: TWO workgroups per CU; block-entry input gradients 109 -> 84 us,
+//     192->256 3x3 on 7x7 maps 126 -> 108 us); one-round launches (250 tiles of 4x4 maps) keep
+//     64-deep stages in two buffers;
+//   * 128x64 (4 waves): many-tile launches likewise (36 KiB: four per CU; 576-wide entry gradient
+//     142 -> 102 us);
+//   * everything else: 64-deep stages, two buffers (full-width three-tile blocks: 80 KiB, two per CU).
+#ifdef C2D_RING_SWEEP
+#define C2D_RING_COMBOS(X) X(64, 2) X(32, 3) X(64, 3) X(32, 4)
+#else
+#define C2D_RING_COMBOS(X) X(64, 2) X(32, 3)
+#endif
+template <int MODE, int WM, int WN, int MT, int NT, bool PM>
+int launch_tile(const IgemmArgs& a, hipStream_t s) {
+  constexpr int ROWS = (WM * MT + WN * NT) * 32;
+  constexpr int LDS = 160 * 1024;
+  const RingTune& t = ring_tune();
+  const long long blocks = (long long)c2d_ceil_div(a.M, WM * MT * 32) * c2d_ceil_div(a.N, WN * NT * 32);
+  int bk = 64, d = 2;
+  if (WM == 2 && WN == 4 && blocks > 384) { bk = 32; d = 3; }
+  if (WM == 2 && WN == 2 && MT == 2 && NT == 1 && blocks > 768) { bk = 32; d = 3; }
+  if (t.bk) bk = t.bk;
+  if (t.d) d = t.d;
+#define C2D_RING_CASE(BKT_, D_)                                                                \
+  if constexpr (D_ * ROWS * BKT_ * 2 <= LDS && (D_ - 2) * (ROWS * BKT_ * 2 / (WM * WN * 1024) + 1) <= 63) \
+    if (bk == BKT_ && d == D_) return launch_one<MODE, WM, WN, MT, NT, PM, BKT_, D_>(a, s);
+  C2D_RING_COMBOS(C2D_RING_CASE)
+#undef C2D_RING_CASE
+  // (a forced combination that does not exist for this tile: the default)
+  return launch_one<MODE, WM, WN, MT, NT, PM, 64, 2>(a, s);
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_shape(const IgemmArgs& a, bool pm, hipStream_t s) {
+  if (a.g.mode == 0)
+    return pm ? launch_tile<0, WM, WN, MT, NT, true>(a, s) : launch_tile<0, WM, WN, MT, NT, false>(a, s);
+  return pm ? launch_tile<1, WM, WN, MT, NT, true>(a, s) : launch_tile<1, WM, WN, MT, NT, false>(a, s);
+}
+
+}  // namespace
+
+int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
+                           hipStream_t s, int* m_tiles_out, bool query) {
+  if (ring_tune().off) return C2D_ERR_UNSUPPORTED;
+  const int bm = wm * mt * 32;
+  int rc = C2D_ERR_UNSUPPORTED;
+  const int key = ((wm * 10 + wn) * 10 + mt) * 10 + nt;
+  switch (key) {
+    case 2221: case 2422: case 4212: case 4213: case 4214: case 4215: case 4216: case 2222: case 2211:
+      break;
+    default:
+      return C2D_ERR_UNSUPPORTED;
+  }
+  if (m_tiles_out) *m_tiles_out = c2d_ceil_div(a.M, bm);
+  if (query) return C2D_OK;
+  switch (key) {
+    case 2221: rc = launch_shape<2, 2, 2, 1>(a, pm, s); break;      // 128 x 64, 4 waves
+    case 2222: rc = launch_shape<2, 2, 2, 2>(a, pm, s); break;      // 128 x 128, 4 waves
+    case 2211: rc = launch_shape<2, 2, 1, 1>(a, pm, s); break;      // 64 x 64, 4 waves
+    case 2422: rc = launch_shape<2, 4, 2, 2>(a, pm, s); break;      // 128 x 256, 8 waves (2 x 4)
+    case 4212: rc = launch_shape<4, 2, 1, 2>(a, pm, s); break;      // 128 x full width, 8 waves (4 x 2)
+    case 4213: rc = launch_shape<4, 2, 1, 3>(a, pm, s); break;
+    case 4214: rc = launch_shape<4, 2, 1, 4>(a, pm, s); break;
+    case 4215: rc = launch_shape<4, 2, 1, 5>(a, pm, s); break;
+    case 4216: rc = launch_shape<4, 2, 1, 6>(a, pm, s); break;
+  }
+  return rc;
+}
+
+}  // namespace c2d_ig

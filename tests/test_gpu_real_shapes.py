@@ -409,20 +409,22 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
     assert len(want) >= 12, path
     missing = want - _seen
     assert not missing, "%s: never dispatched by a parity test: %s" % (path, sorted(missing))
-  bf16 = {k for k in _seen if k.endswith(", 2>") or "bf16" in k}
+  bf16 = {k for k in _seen if "bf16" in k}
   assert any(k.startswith("wgrad3x3_bf16_kernel<4") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad3x3_bf16_kernel<7") for k in bf16), sorted(bf16)
   assert any(k.startswith("wgrad_tn_bf16_kernel") for k in bf16), sorted(bf16)
-  # the direct-to-LDS bf16 kernel in the block tiles the benchmark shapes dispatch (128x64,
-  # 128x256, and the full-width 128x320 / 128x384 of the 320- and 352-channel layers), row-major
-  # and pixel-major, forward and input gradient:
-  # igemm_bf16_kernel<MODE, WM, WN, MT, NT, PM, DA>
+  # the direct-to-LDS bf16 ring kernel in the block tiles the benchmark shapes dispatch (128x64,
+  # 128x256, the full-width 128x192 / 128x320 / 128x384 of the 160..192-, 320- and 352-channel
+  # layers), row-major and pixel-major, forward and input gradient, both ring forms:
+  # igemm_bf16_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D>
   import re
-  inst = [re.match(r"igemm_bf16_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d)>", k)
+  inst = [re.match(r"igemm_bf16_ring_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d+), (\d)>", k)
           for k in bf16]
   inst = [m.groups() for m in inst if m]
   for mode in ("0", "1"):
     for pm in ("true", "false"):
       assert any(g[0] == mode and g[5] == pm for g in inst), (mode, pm, sorted(bf16))
-  for tile in (("2", "2", "2", "1"), ("2", "4", "2", "2"), ("4", "2", "1", "5"), ("4", "2", "1", "6")):
+  for tile in (("2", "4", "2", "2"), ("4", "2", "1", "3"), ("4", "2", "1", "5"), ("4", "2", "1", "6")):
     assert any(g[1:5] == tile for g in inst), (tile, sorted(bf16))
+  for ring in (("64", "2"), ("32", "3")):
+    assert any(g[6:8] == ring for g in inst), (ring, sorted(bf16))
