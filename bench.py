@@ -507,10 +507,13 @@ def main(argv=None):
     # absent.  See profiles/README.md.
     traffic, mfma = {}, {}
     low_cfg = "c2" if args.dtype == "bf16" else "c1"
-    for name, into in (("r02_traffic_%s.json" % low_cfg, traffic), ("r02_mfma_%s.json" % low_cfg, mfma)):
+    import glob
+    for pattern, into in (("r*_traffic_%s.json" % low_cfg, traffic), ("r*_mfma_%s.json" % low_cfg, mfma)):
       try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))[-1]   # latest round
+        with open(newest) as f:
           into.update(json.load(f)["families"])
+        result.setdefault("pmc_summaries", []).append(os.path.basename(newest))
       except Exception:
         pass
     if not args.no_kernel_timing and args.per_call:

@@ -1265,3 +1265,56 @@ extern "C" int c2d_cast_bf16(const float* src, void* dst, long long n, void* str
                      (c2d_bf16*)dst, n / 4);
   return c2d_launch_status();
 }
+
+// ---- step-start zeroing and the loss total (round 3: no torch fill / reduce kernels in a step) ----
+namespace {
+// Zeroes up to C2D_ZERO_MAX byte ranges (each 16-byte aligned, a multiple of 16 bytes long) in ONE
+// launch: the flat gradient bucket, the loss vector, the ROI-crop gradient map ... of a training
+// step (train/trainer.py:55-61 `zero the gradients` is implicit in tf.gradients; here the
+// accumulating kernels need zeroed destinations).  Block b clears 16 KiB: the ranges' chunk
+// prefix sums come by value.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(C2dZeroRanges r) {
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < C2D_ZERO_MAX; ++q)
+    if (q < r.num && (int)blockIdx.x >= r.first_chunk[q]) k = q;
+  const long long chunk = (long long)((int)blockIdx.x - r.first_chunk[k]);
+  const long long n16 = r.bytes[k] >> 4;                // 16-byte elements of the range
+  float4* p = reinterpret_cast<float4*>(r.ptr[k]);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long i = chunk * 1024 + j * 256 + threadIdx.x;
+    if (i < n16) p[i] = z;
+  }
+}
+
+__global__ __launch_bounds__(64) void sum_small_kernel(const float* __restrict__ x, int n,
+                                                      float* __restrict__ out) {
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) v += x[i];
+  v = c2d_wave_sum(v);
+  if (threadIdx.x == 0) *out = v;
+}
+}  // namespace
+
+extern "C" int c2d_zero_ranges(const C2dZeroRanges* ranges, void* stream) {
+  C2D_CHECK_ARG(ranges && ranges->num >= 0 && ranges->num <= C2D_ZERO_MAX);
+  C2dZeroRanges r = *ranges;
+  int chunks = 0;
+  for (int k = 0; k < r.num; ++k) {
+    C2D_CHECK_ARG(r.ptr[k] && r.bytes[k] >= 0 && r.bytes[k] % 16 == 0 &&
+                  reinterpret_cast<unsigned long long>(r.ptr[k]) % 16 == 0);
+    r.first_chunk[k] = chunks;
+    chunks += c2d_ceil_div(r.bytes[k], 16 * 1024);
+  }
+  if (chunks == 0) return C2D_OK;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(chunks), dim3(256), 0, (hipStream_t)stream, r);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_sum_small(const float* x, int n, float* out, void* stream) {
+  C2D_CHECK_ARG(x && out && n >= 0 && n <= 4096);
+  hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, n, out);
+  return c2d_launch_status();
+}

@@ -409,6 +409,28 @@ def im2col4(x, out, n, ih, iw, kh, kw, stride, kpad):
   _lib.call("c2d_im2col4", _p(x), _p(out), n, ih, iw, kh, kw, stride, kpad, _stream())
 
 
+class ZeroRanges(ctypes.Structure):
+  """C2dZeroRanges of include/cap2det_hip.h."""
+  _fields_ = [("ptr", ctypes.c_void_p * 8), ("bytes", ctypes.c_longlong * 8),
+              ("first_chunk", ctypes.c_int * 8), ("num", ctypes.c_int)]
+
+
+def zero_ranges(tensors):
+  """Zeroes up to 8 contiguous device tensors (16-byte aligned, byte sizes multiples of 16) in
+  one launch (c2d_zero_ranges)."""
+  r = ZeroRanges()
+  r.num = len(tensors)
+  for i, t in enumerate(tensors):
+    assert t.is_contiguous()
+    r.ptr[i] = _p(t)
+    r.bytes[i] = t.numel() * t.element_size()
+  _lib.call("c2d_zero_ranges", ctypes.byref(r), _stream())
+
+
+def sum_small(x, out):
+  _lib.call("c2d_sum_small", _p(x), x.numel(), _p(out), _stream())
+
+
 # -- heads / losses ---------------------------------------------------------------------
 
 def midn_fwd(logits, ld, off_r, off_c, num_proposals, proba, class_logits, scores, batch, n, c):

@@ -80,7 +80,9 @@ class Model(ModelBase):
       self._l2_weight = reg.l2_regularizer.weight
     elif reg.WhichOneof('regularizer_oneof') == 'l1_regularizer':
       self._l1_weight = reg.l1_regularizer.weight
-    self._losses = torch.zeros(2 + k, device=self._device)   # midn, oicr_1..K, regularisation
+    # midn, oicr_1..K, regularisation | total (padded to a multiple of 4 floats: c2d_zero_ranges)
+    self._nloss = 2 + k
+    self._losses = torch.zeros(-(-(self._nloss + 1) // 4) * 4, device=self._device)
     self._cache = {}
     self._ctx = None
     self.initialize(seed)
@@ -253,19 +255,27 @@ class Model(ModelBase):
     shipped config, configs/*.pbtxt:58-72), zero biases."""
     gen = torch.Generator(device="cpu").manual_seed(seed)
     eng = self.engine
+    # (all variables are drawn into a HOST image of the flat buffer and uploaded once: a handful
+    # of copies instead of ~300 per-variable fill / copy launches)
+    host = torch.zeros(self.store.values.numel())
 
-    def fill(t, std):
-      t.copy_((torch.randn(t.shape, generator=gen) * std).to(self._device))
+    def normal(shape, std):
+      return torch.randn(shape, generator=gen) * std
+
+    def put(name, value):
+      off, numel = self.store.offset[name]
+      host[off:off + numel] = value.reshape(-1)
 
     sv = eng.stem_vars
-    fill(sv[eng.STEM + "/depthwise_weights"], math.sqrt(2.0 / 49))
-    fill(sv[eng.STEM + "/pointwise_weights"], math.sqrt(2.0 / (3 * eng.stem_mult)))
+    for key, std in ((eng.STEM + "/depthwise_weights", math.sqrt(2.0 / 49)),
+                     (eng.STEM + "/pointwise_weights", math.sqrt(2.0 / (3 * eng.stem_mult)))):
+      sv[key].copy_(normal(sv[key].shape, std).to(self._device))
     for net in (eng.first, eng.second):
       for L in net.layers.values():
-        fill(self.store.var[L.name + "/weights"], math.sqrt(2.0 / (L.k * L.k * L.cin)))
+        put(L.name + "/weights", normal((L.k, L.k, L.cin, L.cout), math.sqrt(2.0 / (L.k * L.k * L.cin))))
         if L.bn_scale:
-          self.store.var[L.name + "/BatchNorm/gamma"].fill_(1.0)
-        self.store.var[L.name + "/BatchNorm/beta"].zero_()
+          put(L.name + "/BatchNorm/gamma", torch.ones(L.cout))
+        # (beta = 0: the image starts zeroed)
     init = self._model_proto.fc_hyperparams.initializer
     which = init.WhichOneof('initializer_oneof')
     std, mean = 0.01, 0.0
@@ -276,9 +286,10 @@ class Model(ModelBase):
     w = torch.empty(self.engine.feature_dims, self._ncols)
     torch.nn.init.trunc_normal_(w, mean=mean, std=std, a=mean - 2 * std, b=mean + 2 * std,
                                 generator=gen)
-    self.store.var[HEADS_W].zero_()
-    self.store.var[HEADS_W][:, :self._ncols] = w.to(self._device)
-    self.store.var[HEADS_B].zero_()
+    hw = torch.zeros(self.store.var[HEADS_W].shape)
+    hw[:, :self._ncols] = w
+    put(HEADS_W, hw)                          # (HEADS_B = 0)
+    self.store.values.copy_(host.to(self._device))
     self.refresh()
 
   def refresh(self, only_trainable=False):
@@ -429,7 +440,8 @@ class Model(ModelBase):
       torch.cuda.current_stream().wait_event(kwargs["labels_ready"])
     ctx["labels"] = labels
     losses = self._losses
-    losses.zero_()
+    if not kwargs.get("step_zeroed"):        # (the trainer zeroes the step's buffers in one launch)
+      losses.zero_()
     num_proposals, proposals = ctx["num_proposals"], ctx["proposals"]
     ops.sigmoid_ce_fwd_bwd(bufs["class_logits"], labels, options.midn_loss_weight, losses[0:1],
                            bufs["dclass_logits"])
@@ -451,15 +463,22 @@ class Model(ModelBase):
       s0, s0_ld, s0_off = bufs["softmax"][i], c + 1, 1       # softmax(scores_1)[..., 1:] (:328)
     return loss_dict
 
-  def regularization_loss(self):
+  def regularization_loss(self, step_zeroed=False):
     """Sum of the slim L2 / L1 regularisers (FC weights only), as a 0-d tensor."""
-    out = self._losses[-1:]
-    out.zero_()
+    out = self._losses[self._nloss - 1:self._nloss]
+    if not step_zeroed:
+      out.zero_()
     if self._l2_weight > 0:
       ops.l2_loss(self.store.var[HEADS_W], self._l2_weight, out)
     if self._l1_weight > 0:
       ops.l1_loss(self.store.var[HEADS_W], self._l1_weight, out)
-    return self._losses[-1]
+    return self._losses[self._nloss - 1]
+
+  def total_loss(self):
+    """total_loss = sum of the model losses + regularisers (train/trainer.py:55-61) as a 0-d
+    device tensor (c2d_sum_small over the loss vector)."""
+    ops.sum_small(self._losses[:self._nloss], self._losses[self._nloss:self._nloss + 1])
+    return self._losses[self._nloss]
 
   def backward(self, after_second_stage=None):
     """Gradients of sum(losses) w.r.t. every trainable variable, accumulated into

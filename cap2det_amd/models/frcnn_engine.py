@@ -166,12 +166,15 @@ class DerivedStore(object):
     self._der_size += -(-n // 4) * 4
 
   def finalize(self):
-    self.stat_flat = torch.zeros(max(self._stat_size, 4), device=self.device)
+    # (initial statistics are staged on the host and uploaded ONCE: no per-layer fill launches)
+    host = torch.zeros(max(self._stat_size, 4))
+    for name, shape, off, n, fill in self._stat_specs:
+      if fill != 0.0:
+        host[off:off + n] = fill
+    self.stat_flat = host.to(self.device)
     self.der_flat = torch.zeros(max(self._der_size, 4), device=self.device)
     for name, shape, off, n, fill in self._stat_specs:
-      v = self.stat_flat[off:off + n].view(shape)
-      v.fill_(fill)
-      self._stats[name] = v
+      self._stats[name] = self.stat_flat[off:off + n].view(shape)
       self.stat_off[name] = off
     for name, shape, off, n in self._der_specs:
       self.derived[name] = self.der_flat[off:off + n].view(shape)
@@ -1150,6 +1153,17 @@ class FrcnnEngine(object):
     # to another tensor, so "same data_ptr and version" really means "same pixels")
     bufs["prefetched"] = (image, image._version, done)
 
+  def step_zero_list(self, image_shape, num_proposals):
+    """Gradient maps the coming backward pass of this input shape accumulates into (the ROI-crop
+    backward's destination), for the trainer's one-launch zeroing at the start of a step; a
+    buffer that does not exist yet (first step of a shape) is zeroed where it is created."""
+    b, h, w = int(image_shape[0]), int(image_shape[1]), int(image_shape[2])
+    bufs = self._shape_cache.get((b, h, w, int(num_proposals), True))
+    t = bufs.get("gcrop_buf") if bufs is not None else None
+    out = [t] if t is not None else []
+    self._step_zeroed = set(x.data_ptr() for x in out)
+    return out
+
   def invalidate_prefetch(self):
     for bufs in self._shape_cache.values():
       pre = bufs.pop("prefetched", None)
@@ -1273,7 +1287,10 @@ class FrcnnEngine(object):
         if "gfmap" not in bufs:
           bufs["gfmap"] = torch.empty_like(gfeat.t)
         gcrop = bufs["gfmap"]
-      gcrop.zero_()
+      if gcrop.data_ptr() not in getattr(self, "_step_zeroed", ()):
+        gcrop.zero_()
+      bufs["gcrop_buf"] = gcrop
+      self._step_zeroed = set()
       dp4 = dpooled.t.view(b * n, bufs["p"], bufs["p"], d)
       arg4 = bufs["pool_arg"].view(b * n, bufs["p"], bufs["p"], d)
       gf4 = gcrop.view(b, bufs["fh"], bufs["fw"], d)

@@ -222,7 +222,12 @@ class Trainer(object):
   def _forward_backward(self, examples, after_second_stage=None, prefetch=None, **kwargs):
     model, store = self.model, self.model.store
     lo, hi = self.bucket
-    store.grads[lo:hi].zero_()
+    # everything the step's accumulating kernels add into, cleared by ONE launch: the gradient
+    # bucket, the loss scalars, the gradient map of the ROI-crop backward
+    from cap2det_amd.core.standard_fields import InputDataFields as F
+    ops.zero_ranges([store.grads[lo:hi], model._losses] +
+                    model.engine.step_zero_list(examples[F.image].shape, examples[F.proposals].shape[1]))
+    kwargs = dict(kwargs, step_zeroed=True)
     # The labels depend on the examples only (captions -> GloVe / text classifier or string
     # matching): they are extracted on the look-ahead stream under the detector's forward pass
     # instead of between its forward pass and its losses (0.2-0.3 ms per step for the text-
@@ -244,7 +249,7 @@ class Trainer(object):
       from cap2det_amd.core.standard_fields import InputDataFields as F
       model.engine.prefetch_first_stage(prefetch[F.image], prefetch[F.proposals].shape[1], True)
     losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
-    losses['regularization_loss'] = model.regularization_loss()
+    losses['regularization_loss'] = model.regularization_loss(step_zeroed=True)
     model.backward(after_second_stage)
     return predictions, losses
 
@@ -295,7 +300,7 @@ class Trainer(object):
     scale = reducer.finish()
     self._apply_gradients(scale, self.learning_rate())
     self.global_step += 1
-    losses['total_loss'] = self.model._losses.sum()
+    losses['total_loss'] = self.model.total_loss()
     self.predictions = predictions
     return losses
 
@@ -357,7 +362,7 @@ class Trainer(object):
                                                        dropout_seed=st["seed"])
         with torch.cuda.graph(g_opt, stream=side):
           self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
-          total = self.model._losses.sum()
+          total = self.model.total_loss()
       torch.cuda.current_stream().wait_stream(side)
       losses['total_loss'] = total
       self._graphs = dict(key=key, fb=g_fb, opt=g_opt, predictions=predictions, losses=losses)

@@ -431,6 +431,23 @@ int c2d_l2_loss(const float* w, long long n, float weight, float* out, void* str
 /* *out += weight*sum(|w|)  (slim l1_regularizer, core/training_utils.py:167-168). */
 int c2d_l1_loss(const float* w, long long n, float weight, float* out, void* stream);
 
+/* Step-start zeroing: clears up to C2D_ZERO_MAX device byte ranges (16-byte aligned, lengths a
+ * multiple of 16) in ONE launch — the flat gradient bucket, the loss scalars, the gradient map
+ * the ROI-crop backward accumulates into.  TensorFlow's tf.gradients (train/trainer.py:96-103)
+ * has no such step; the accumulating kernels here (`+=` semantics above) need it.  The struct is
+ * passed by pointer on the HOST; first_chunk is filled by the callee. */
+#define C2D_ZERO_MAX 8
+typedef struct C2dZeroRanges {
+  void* ptr[C2D_ZERO_MAX];
+  long long bytes[C2D_ZERO_MAX];
+  int first_chunk[C2D_ZERO_MAX];
+  int num;
+} C2dZeroRanges;
+int c2d_zero_ranges(const C2dZeroRanges* ranges, void* stream);
+/* *out = x[0] + ... + x[n-1] (n <= 4096): `total_loss = tf.add_n(losses)` of
+ * train/trainer.py:55-61 over the loss scalars kept in one device vector. */
+int c2d_sum_small(const float* x, int n, float* out, void* stream);
+
 /* General optimiser step for the reference branches no shipped config takes:
  *   g' = m*(grad_scale*g + l2*w + l1*sign(w)),  m = mult * (col_mult ? col_mult[i % ld] : 1);
  *   elements with m <= 0 are frozen (gradient multipliers <= 0, train/trainer.py:104-125; the

@@ -30,7 +30,7 @@ from summarize_pmc import family_of  # noqa: E402
 
 
 def family(name):
-  if "igemm_bf16_kernel" in name:
+  if "igemm_bf16_kernel" in name or "igemm_bf16_ring_kernel" in name:
     return "igemm_bf16"
   if "wgrad_reduce_kernel" in name:
     return "wgrad_bf16"

@@ -39,7 +39,7 @@ def family_of(name):
   # bf16 MFMA peak
   if "wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16_kernel" in name or "wgrad_reduce_kernel" in name:
     return "wgrad_bf16"
-  if "igemm_bf16_kernel" in name:
+  if "igemm_bf16_kernel" in name or "igemm_bf16_ring_kernel" in name:
     return "igemm_bf16"
   m = re.search(r"igemm_nt_kernel<([^>]*)>", name)
   if m and len(m.group(1).split(",")) == 8 and m.group(1).split(",")[-1].strip() == "2":
