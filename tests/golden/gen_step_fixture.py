@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-HW, DM, SEED, SAMPLES = 160, 1.0, 5, 48
+HW, DM, SAMPLES, HEAD_STD = 160, 1.0, 48, 0.01    # (head std: the reference's truncated-normal 0.01, configs/*.pbtxt:58-72)
+SEEDS = {256: 6, 1100: 6}          # model seed per fixture (main() rejects seeds with near-tie arg-maxes)
 
 
 def inputs(n, classes):
@@ -27,7 +28,9 @@ def inputs(n, classes):
   rng = np.random.default_rng(1000 + n)
   real = n - n // 8
   ex = util_model.make_examples(rng, 1, HW, HW, n, [real], classes)
-  P32, d = util_model.oracle_state(SEED, len(classes), 3, DM)
+  # (the OICR arg-max over the proposals is a discrete choice: main() checks that none of them is a
+  # near tie, so that fp32 and float64 select the same boxes)
+  P32, d = util_model.oracle_state(SEEDS[n], len(classes), 3, DM, head_std=HEAD_STD)
   mask = (rng.uniform(size=(n, d)) < 0.5).astype(np.uint8)
   return ex, P32, mask, real
 
@@ -65,7 +68,24 @@ def main():
     with np.errstate(over="ignore"):
       out = torch_step.train_step(P, acc, ex64, labels, ref_model.FrcnnOptions(depth_multiplier=DM),
                                   loss_opts, mults, 0.01, 1e-6, mask)
-    arrays = {"checksum": checksum(ex, P32, mask), "real": np.int64(real)}
+    # margin of every arg-max the OICR losses take (models/utils.py:64-70 via core/utils.py:198-199):
+    # best vs second-best proposal score of each labelled class, relative to the best
+    margins = []
+    pr = out["predictions"]
+    s0 = pr["midn_proba_r_given_c"][0, :real]
+    for i in range(3):
+      for c in np.nonzero(labels[0] > 0)[0]:
+        col = np.sort(s0[:, c])[::-1]
+        margins.append((col[0] - col[1]) / max(abs(col[0]), 1e-30))
+      sc = pr["oicr_proposal_scores_at_%d" % (i + 1)][0, :real]
+      e = np.exp(sc - sc.max(1, keepdims=True))
+      s0 = (e / e.sum(1, keepdims=True))[:, 1:]
+    print("n", n, "min arg-max margin", min(margins))
+    if os.environ.get("C2D_FIXTURE_SCAN"):
+      continue
+    assert min(margins) > 1e-3, "pick another seed: an OICR arg-max is a near tie"
+    arrays = {"checksum": checksum(ex, P32, mask), "real": np.int64(real),
+              "min_argmax_margin": np.float64(min(margins))}
     for i in range(4):
       arrays["scores_%d" % i] = out["predictions"]["oicr_proposal_scores_at_%d" % i]
     arrays["midn_class_logits"] = out["predictions"]["midn_class_logits"]
