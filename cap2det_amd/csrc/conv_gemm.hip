@@ -769,34 +769,6 @@ __global__ __launch_bounds__(256) void igemm_small_group_kernel(IgemmGroupArgs g
   igemm_small_body<MODE>(g.a[p], (int)blockIdx.x - g.first[p]);
 }
 
-struct WgradArgs {
-  const float* A; int lda; int a_off;   // activations x (rows of the conv input)
-  long long a_rows;                     // rows of x
-  const float* G; int ldg; int g_off;   // dC rows (conv output rows)
-  float* dW;                            // [taps][I][J], pre-zeroed or accumulated into
-  int M;                                // conv output rows (reduction length)
-  int I, J;                             // cin, cout
-  int rows_per_split;                   // multiple of WBK
-  int tiles_x, tiles_y, nsplits;        // 1-D grid = tiles_x (tap, i-tile) * tiles_y (j-tile) * nsplits
-  long long part_stride;                // > 0: split z stores (plain) into dW + z * part_stride
-                                        // floats (its own slab) instead of adding atomically
-  ConvGeom g;                           // mode 0
-};
-
-// Block -> (x, y, split) with all tiles of one row split consecutive on ONE XCD (xcd_remap): the
-// x / dC rows of a split are then fetched into that XCD's L2 once and shared by its tiles.
-struct WgradBlock { int x, y, z; };
-__device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
-  const int txy = a.tiles_x * a.tiles_y;
-  const int logical = xcd_remap(blockIdx.x, txy * a.nsplits);
-  WgradBlock b;
-  b.z = logical / txy;
-  const int t = logical - b.z * txy;
-  b.y = t / a.tiles_x;
-  b.x = t - b.y * a.tiles_x;
-  return b;
-}
-
 constexpr int WBK = 16;             // rows of M per slab (32: the 128x128 form spills, 5 % slower overall)
 constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
 
@@ -2569,6 +2541,13 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   const bool plain = kh == 1 && kw == 1 && stride == 1;
   hipStream_t st = (hipStream_t)stream;
   a.part_stride = 0;
+  if (bf16_mfma && plain) {
+    // 1x1 / stride 1: the DMA-ring kernel of igemm_bf16.hip (round 3)
+    WgradArgs b = a;
+    if (partial) { b.part_stride = dw_numel; b.dW = partial; }
+    const int rc2 = launch_wgrad1x1_bf16_ring(b, st, splits_out, splits_only);
+    if (rc2 != C2D_ERR_UNSUPPORTED) return rc2;
+  }
   if (bf16_mfma) {
     // K-groups per block (see wgrad_tn_bf16_kernel): 256 blocks of 2 groups = the waves of 512
     // one-group blocks at half their atomic traffic.  Measured (tools/bench_wgrad_bf16.py, the

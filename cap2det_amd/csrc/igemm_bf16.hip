@@ -527,4 +527,227 @@ int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, b
   return rc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Filter gradient of a 1x1 / stride-1 convolution, bf16 operands (Conv2DBackpropFilter of the
+// block-entry and branch-closing convolutions of Mixed_5a-c, train/trainer.py:141-146):
+//   dW[i][j] += sum_m x[m][i] * dC[m][j]        (K = rows, split over workgroups)
+// Round 2's kernel (wgrad_tn_bf16_kernel) staged 32-row slabs through registers with two barriers
+// per slab and ran at ~270 TFLOP/s on these calls.  Here the same 128 x (64 | 128) output tile gets
+//   * its operand stages global -> LDS by DMA (no staging registers, no ds_write), a ring of D
+//     stages of BKT rows, ONE barrier per stage (as igemm_bf16_ring_kernel);
+//   * 64-row stages in two buffers (64 KiB: two workgroups per CU);
+//   * the row-major tiles read transposed with ds_read_b64_tr_b16 (cdna_hip_programming.md T10)
+//     from a lane-linear DMA image: the 64-byte granule g of row r sits at position g ^ (r & 3)
+//     (256-byte rows) / g ^ ((r >> 1) & 1) (128-byte rows), applied to the DMA's source address
+//     and to the reads, so that the four rows a 32-lane half reads hit four different bank groups.
+// ---------------------------------------------------------------------------------------------
+namespace {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag2(const char* lo_p, const char* hi_p) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lo_p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)hi_p);
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int NTJ, int BKT, int D>
+__global__ __launch_bounds__(256, (160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 3 ? 3
+                                  : ((160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 2 ? 2 : 1))
+void wgrad1x1_bf16_ring_kernel(WgradArgs a) {
+  constexpr int BJ = NTJ * 64;                         // output columns per block (64 or 128)
+  constexpr int A_RB = 256, G_RB = BJ * 2;             // bytes per staged row
+  constexpr int A_BYTES = BKT * A_RB, G_BYTES = BKT * G_RB;
+  constexpr int A_LOADS = A_BYTES / 4096;              // a pass = 256 lanes x 16 B = 4 KiB
+  constexpr int G_LOADS = G_BYTES / 4096;
+  constexpr int PER = A_LOADS + G_LOADS;
+  constexpr int KS = BKT / 16;
+  static_assert(A_BYTES % 4096 == 0 && G_BYTES % 4096 == 0 && D >= 2 && D <= 4, "stage geometry");
+  __shared__ __attribute__((aligned(1024))) char smem[D * (A_BYTES + G_BYTES)];
+  char* const smemG = smem + D * A_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int itiles = (a.I + 127) / 128;
+  const WgradBlock blk = wgrad_block(a);
+  const int i0 = (blk.x % itiles) * 128;
+  const int j0 = blk.y * BJ;
+  const int mbeg = blk.z * a.rows_per_split;
+  const int cnt = (min(a.rows_per_split, a.M - mbeg) + BKT - 1) / BKT;
+
+  // DMA lanes: A pass = 16 rows x 16 chunks; G pass = 16 rows x 16 chunks (BJ = 128) or 32 rows x
+  // 8 chunks (BJ = 64).  The lane at LDS position p of row r fetches source chunk p ^ swz(r).
+  const int arow = tid >> 4, apos = tid & 15;
+  const int achunk = apos ^ ((arow & 3) << 2);
+  constexpr int GCPR = G_RB / 16;                      // chunks per dC row (16 or 8)
+  const int grow = tid / GCPR, gpos = tid % GCPR;
+  const int gchunk = GCPR == 16 ? gpos ^ ((grow & 3) << 2) : gpos ^ (((grow >> 1) & 1) << 2);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
+                                                 (a.a_rows * a.lda - a.a_off) * 2);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * 2,
+                                                 ((long long)a.M * a.ldg - a.g_off) * 2);
+  // (columns beyond I / J are clamped: their products land in dW rows / columns never stored)
+  const unsigned aoff = (unsigned)(arow * a.lda + min(i0 + achunk * 8, a.I - 8)) * 2u;
+  const unsigned goff = (unsigned)(grow * a.ldg + min(j0 + gchunk * 8, a.J - 8)) * 2u;
+  constexpr int A_PASS_ROWS = 16, G_PASS_ROWS = 256 / GCPR;
+
+  f32x16 acc[2][NTJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  unsigned tile_bits = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+      if ((i0 + wm * 64 + i * 32 < a.I) && (j0 + (wn * NTJ + j) * 32 < a.J))
+        tile_bits |= 1u << (i * NTJ + j);
+  tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
+
+  // stage `st` (rows mbeg + st * BKT ...) into ring slot `slot`; rows >= M lie outside the
+  // descriptors and come back as zeros (splits end on stage boundaries: no row is counted twice)
+#define C2D_W_ISSUE(SLOT, ST)                                                                  \
+  {                                                                                            \
+    const int m0 = mbeg + (ST) * BKT;                                                          \
+    _Pragma("unroll") for (int p = 0; p < A_LOADS; ++p)                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                \
+          rsA, (lds_void_t*)(smem + (SLOT) * A_BYTES + p * 4096 + wave * 1024), 16, (int)aoff, \
+          (m0 + p * A_PASS_ROWS) * a.lda * 2, 0, 0);                                           \
+    _Pragma("unroll") for (int p = 0; p < G_LOADS; ++p)                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                \
+          rsG, (lds_void_t*)(smemG + (SLOT) * G_BYTES + p * 4096 + wave * 1024), 16, (int)goff, \
+          (m0 + p * G_PASS_ROWS) * a.ldg * 2, 0, 0);                                           \
+  }
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+    if (d < cnt) C2D_W_ISSUE(d, d)
+
+  // transposed-read addresses: k rows 16 s + 8 lh + tq (+4), 64-byte granule of the tile's columns
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  int a_lo[2], g_lo[NTJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    a_lo[i] = (8 * lh + tq) * A_RB + (((wm * 2 + i) ^ tq) << 6) + 32 * tg + 8 * tp;
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j)
+    g_lo[j] = (8 * lh + tq) * G_RB +
+              (((wn * NTJ + j) ^ (GCPR == 16 ? tq : (tq >> 1))) << 6) + 32 * tg + 8 * tp;
+
+  int slot = 0, slot_in = D - 1;
+  for (int it = 0; it < cnt; ++it) {
+    const int ahead = min(cnt, it + D - 1) - it - 1;
+    if (D > 3 && ahead >= 2) wait_vmcnt<(D > 3 ? 2 : 0) * PER>();
+    else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * PER>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (it + D - 1 < cnt) C2D_W_ISSUE(slot_in, it + D - 1)
+    const char* const As = smem + slot * A_BYTES;
+    const char* const Gs = smemG + slot * G_BYTES;
+    bf16x8 af[2][KS], bf[NTJ][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i][s] = tr_frag2(As + s * 16 * A_RB + a_lo[i], As + (s * 16 + 4) * A_RB + a_lo[i]);
+#pragma unroll
+      for (int j = 0; j < NTJ; ++j)
+        bf[j][s] = tr_frag2(Gs + s * 16 * G_RB + g_lo[j], Gs + (s * 16 + 4) * G_RB + g_lo[j]);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NTJ; ++j)
+        if ((tile_bits >> (i * NTJ + j)) & 1u) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    if (++slot == D) slot = 0;
+    if (++slot_in == D) slot_in = 0;
+  }
+#undef C2D_W_ISSUE
+
+  // split-K result: fp32 atomics into dW, or (part_stride > 0) plain stores into this split's slab
+  float* dw = a.dW + (size_t)blk.z * a.part_stride;
+  const bool part = a.part_stride > 0;
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j) {
+    const int jj = j0 + (wn * NTJ + j) * 32 + li;
+    if (jj >= a.J) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ii >= a.I) continue;
+        if (part) dw[(size_t)ii * a.J + jj] = acc[i][j][r];
+        else atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
+      }
+  }
+}
+
+struct WgradTune { int bk, d, slots, off; };
+const WgradTune& wgrad_tune() {
+  static const WgradTune t = [] {
+    WgradTune r = {0, 0, 0, 0};
+    if (getenv("C2D_TUNE")) {
+      if (const char* e = getenv("C2D_WRING_BK")) r.bk = atoi(e);
+      if (const char* e = getenv("C2D_WRING_D")) r.d = atoi(e);
+      if (const char* e = getenv("C2D_WRING_SLOTS")) r.slots = atoi(e);
+      if (const char* e = getenv("C2D_WRING")) r.off = e[0] == '0';
+    }
+    return r;
+  }();
+  return t;
+}
+}  // namespace
+
+int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool splits_only) {
+  const WgradTune& t = wgrad_tune();
+  if (t.off) return C2D_ERR_UNSUPPORTED;
+  if (a.I % 8 != 0 || a.J % 8 != 0 || a.I < 8 || a.J < 8 || a.lda % 8 != 0 || a.ldg % 8 != 0 ||
+      a.a_off % 8 != 0 || a.g_off % 8 != 0)
+    return C2D_ERR_UNSUPPORTED;
+  // Measured per call of the step (tools/sweep_wgrad.sh, N = 2000): these launches are bound by
+  // their split-K atomics as much as by staging — every workgroup adds a whole 128 x 128 fp32 tile
+  // (16.8 MB per 256 workgroups at the chip-wide 1.3 TB/s of float atomics, all at the end of the
+  // launch) — so the DMA ring only pays where the tile count keeps the splits low: output widths
+  // of 129..256 columns (576->192: 68 -> 49 us, 1024->192: 40 -> 33, 1024->160: 39 -> 30);
+  // 128- and 352-wide layers stay on the two-K-group kernel of conv_gemm.hip (30 / 49 us).
+  if (!t.bk && !t.d && !t.slots && !(a.J > 128 && a.J <= 256)) return C2D_ERR_UNSUPPORTED;
+  const bool narrow = a.J % 128 != 0 && a.J % 128 <= 64;    // 128 x 64 block tiles
+  const int bj = narrow ? 64 : 128;
+  const int bk = t.bk == 32 ? 32 : 64;
+  const int d = t.d >= 2 && t.d <= 4 ? t.d : 2;
+  a.tiles_x = c2d_ceil_div(a.I, 128);
+  a.tiles_y = c2d_ceil_div(a.J, bj);
+  const int tiles = a.tiles_x * a.tiles_y;
+  // two workgroups per CU in one round; at least 4 stages per workgroup
+  int splits = (t.slots > 0 ? t.slots : 512) / tiles;
+  const int max_splits = c2d_ceil_div(a.M, 4 * bk);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), bk) * bk;
+  a.nsplits = c2d_ceil_div(a.M, a.rows_per_split);
+  if (splits_out) *splits_out = a.nsplits;
+  if (splits_only) return C2D_OK;
+  const dim3 grid(tiles * a.nsplits), block(256);
+  dispatch_note_ext("wgrad1x1_bf16_ring_kernel<%d, %d, %d>", narrow ? 1 : 2, bk, d);
+#define C2D_WR(NTJ_, BK_, D_)                                                                   \
+  if ((narrow ? 1 : 2) == NTJ_ && bk == BK_ && d == D_) {                                      \
+    hipLaunchKernelGGL((wgrad1x1_bf16_ring_kernel<NTJ_, BK_, D_>), grid, block, 0, s, a);      \
+    return c2d_launch_status();                                                                \
+  }
+  C2D_WR(1, 64, 2) C2D_WR(2, 64, 2) C2D_WR(1, 32, 3) C2D_WR(2, 32, 3)
+#undef C2D_WR
+  return C2D_ERR_UNSUPPORTED;
+}
+
 }  // namespace c2d_ig

@@ -293,6 +293,36 @@ __device__ __forceinline__ void fused_bn_finish(float* red, const float* dummy, 
   }
 }
 
+// ---- filter gradients (per-tap TN GEMM over rows) -------------------------------------------
+struct WgradArgs {
+  const float* A; int lda; int a_off;   // activations x (rows of the conv input)
+  long long a_rows;                     // rows of x
+  const float* G; int ldg; int g_off;   // dC rows (conv output rows)
+  float* dW;                            // [taps][I][J], pre-zeroed or accumulated into
+  int M;                                // conv output rows (reduction length)
+  int I, J;                             // cin, cout
+  int rows_per_split;                   // multiple of WBK
+  int tiles_x, tiles_y, nsplits;        // 1-D grid = tiles_x (tap, i-tile) * tiles_y (j-tile) * nsplits
+  long long part_stride;                // > 0: split z stores (plain) into dW + z * part_stride
+                                        // floats (its own slab) instead of adding atomically
+  ConvGeom g;                           // mode 0
+};
+
+// Block -> (x, y, split) with all tiles of one row split consecutive on ONE XCD (xcd_remap): the
+// x / dC rows of a split are then fetched into that XCD's L2 once and shared by its tiles.
+struct WgradBlock { int x, y, z; };
+__device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
+  const int txy = a.tiles_x * a.tiles_y;
+  const int logical = xcd_remap(blockIdx.x, txy * a.nsplits);
+  WgradBlock b;
+  b.z = logical / txy;
+  const int t = logical - b.z * txy;
+  b.y = t / a.tiles_x;
+  b.x = t - b.y * a.tiles_x;
+  return b;
+}
+
+
 // ---- cross-file plumbing -----------------------------------------------------------------------
 // Dispatch record of the calling thread's last convolution entry point (conv_gemm.hip).
 void dispatch_note_ext(const char* fmt, int a = 0, int b = 0, int c = 0, int d = 0, int e = 0,
@@ -303,5 +333,9 @@ void dispatch_note_ext(const char* fmt, int a = 0, int b = 0, int c = 0, int d =
 // Returns C2D_ERR_UNSUPPORTED when no instance exists for the tile (the caller keeps its own).
 int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
                            hipStream_t s, int* m_tiles_out, bool query);
+// bf16 filter gradient of a 1x1 / stride-1 convolution (igemm_bf16.hip: wgrad1x1_bf16_ring_kernel):
+// fills the tiling fields of `a` itself.  *splits_out = row splits (slabs of a.part_stride floats
+// when a.part_stride > 0, else atomics into a.dW).  splits_only: compute the split count only.
+int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool splits_only);
 
 }  // namespace c2d_ig

@@ -4,7 +4,7 @@ convolutions, their input gradients (four parity launches for stride 2) and the 
 block-entry input gradients — each timed ALONE (20 back-to-back launches), with the kernel
 instance it dispatched.  Prints per call and per-step totals.
 
-  python tools/bench_step_gemms.py [bf16|fp32] [fwd|dgrad|all]
+  python tools/bench_step_gemms.py [bf16|fp32] [fwd|dgrad|wgrad|all]
 
 Tuning hooks (C2D_TUNE=1 ...) select variants; tools/sweep_step_gemms.sh runs them side by side."""
 import os
@@ -58,6 +58,9 @@ def add_conv(label, hw, cin, cout, k, st):
                                                        cout, k, k, st, True)))
   calls.append(("dgrad", label, fl, lambda: ops.conv_dgrad(dy, cout, 0, w, dx, cin, 0, n, hw, hw, cin,
                                                            cout, k, k, st, False)))
+  dw = torch.zeros(k * k, cin, cout, device=dev)
+  calls.append(("wgrad", label, fl, lambda: ops.conv_wgrad(x, cin, 0, dy, cout, 0, dw, n, hw, hw, cin,
+                                                           cout, k, k, st)))
 
 
 def add_entry(label, hw, cin, couts, accumulate=True):
@@ -83,6 +86,10 @@ def add_entry(label, hw, cin, couts, accumulate=True):
                                                 0, rows, cin, accumulate)))
   calls[-1][3].keep = (outs, arr)
   calls[-2][3].keep = (outs, arr)
+  for c, dc in zip(couts, dcs):          # (the engine issues one filter gradient per entry convolution)
+    dw = torch.zeros(1, cin, c, device=dev)
+    calls.append(("wgrad", label.split()[0] + " 1x1 %d->%d" % (cin, c), 2.0 * rows * cin * c,
+                  lambda dc=dc, dw=dw, c=c: ops.conv_wgrad(x, cin, 0, dc, c, 0, dw, n, hw, hw, cin, c, 1, 1, 1)))
 
 
 add_entry("5a 576->(128,192) 7x7", 7, 576, (128, 192))
