@@ -56,7 +56,7 @@ class KernelTimer(object):
   def __init__(self):
     import torch
     self.torch = torch
-    self.records = []   # (family, work, start_event, end_event)
+    self.records = []   # (family, work, start_event, end_event, algorithmic HBM bytes)
     self.shapes = []    # (entry point, integer arguments) per record, for --per-call
     self.enabled = False
 
@@ -90,6 +90,38 @@ class KernelTimer(object):
       out_bytes = 2.0 if out is not None and out.dtype == t.torch.bfloat16 else 4.0
       return out_bytes * boxes.shape[0] * p * p * feat.shape[3] + 4.0 * (feat.numel() + boxes.numel())
 
+    def esize(x):
+      first = x[0] if isinstance(x, (list, tuple)) else x
+      return 2.0 if getattr(first, "dtype", None) == t.torch.bfloat16 else 4.0
+
+    def conv_bytes(args, kind):
+      # operand + result bytes of one convolution call, each tensor once (weights included)
+      if kind == "fwd":
+        n, ih, iw, cin, cout, kh, kw, stride = args[9:17]
+      elif kind == "fused_dgrad":
+        n, ih, iw, cin, cout, kh, kw, stride = args[12:20]
+      else:
+        n, ih, iw, cin, cout, kh, kw, stride = args[7:15]
+      oh, ow = -(-ih // stride), -(-iw // stride)
+      es = esize(args[0])
+      act = es * n * (ih * iw * cin + oh * ow * cout)
+      w = (4.0 if kind == "wgrad" else es) * kh * kw * cin * cout
+      return act + w
+
+    def multi_bytes(rows, cin, couts, es):
+      return es * rows * (cin + sum(couts)) + es * cin * sum(couts)
+
+    BYTES = {
+        "conv_fwd": lambda a: conv_bytes(a, "fwd"), "conv_dgrad": lambda a: conv_bytes(a, "dgrad"),
+        "conv_wgrad": lambda a: conv_bytes(a, "wgrad"), "conv_wgrad_partial": lambda a: conv_bytes(a, "wgrad"),
+        "conv_dgrad_bn_relu": lambda a: conv_bytes(a, "fused_dgrad") + esize(a[0]) * a[12] * a[13] * a[14] * a[15],
+        "conv1x1_dgrad_multi": lambda a: multi_bytes(a[8], a[9], a[4], esize(a[0])) +
+                                         (esize(a[0]) * a[8] * a[9] if a[10] else 0.0),
+        "conv1x1_dgrad_multi_bn_relu": lambda a: multi_bytes(a[13], a[14], a[4], esize(a[0])) +
+                                                 esize(a[0]) * a[13] * a[14] * (2.0 if a[15] else 1.0),
+        "conv1x1_fwd_multi": lambda a: multi_bytes(a[4], a[5], [o.cout for o in a[3][0]], esize(a[0])),
+    }
+
     def timed(fn, family, work_fn):
       def inner(*args, **kwargs):
         if not t.enabled:
@@ -104,7 +136,11 @@ class KernelTimer(object):
         first = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
         low = (family != "roi_crop_pool_fwd" and not family.endswith("_bf16") and
                getattr(first, "dtype", None) == t.torch.bfloat16)
-        t.records.append((family + ("_bf16" if low else ""), w, s, e))
+        try:
+          nbytes = BYTES[fn.__name__](args) if fn.__name__ in BYTES else 0.0
+        except Exception:
+          nbytes = 0.0
+        t.records.append((family + ("_bf16" if low else ""), w, s, e, nbytes))
         t.shapes.append((fn.__name__, tuple(a for a in args if isinstance(a, (int, bool)))))
         return r
       return inner
@@ -153,11 +189,20 @@ class KernelTimer(object):
 
   def summary(self):
     out = {}
-    for family, work, s, e in self.records:
-      d = out.setdefault(family, dict(launches=0, work=0.0, ms=0.0))
+    for family, work, s, e, nbytes in self.records:
+      d = out.setdefault(family, dict(launches=0, work=0.0, ms=0.0, bytes=0.0, ideal_ms=0.0,
+                                      hbm_bound_calls=0))
       d["launches"] += 1
       d["work"] += work
       d["ms"] += s.elapsed_time(e)
+      d["bytes"] += nbytes
+      if not family.startswith("roi_crop") and work > 0:
+        # the roofline that binds THIS call: matrix pipe or HBM (operands and result once)
+        peak = PEAK_BF16_MFMA_TFLOPS if family.endswith("_bf16") else PEAK_FP32_MFMA_TFLOPS
+        t_mfma = work / (peak * 1e12) * 1e3
+        t_hbm = nbytes / (PEAK_HBM_GBPS * 1e9) * 1e3
+        d["ideal_ms"] += max(t_mfma, t_hbm)
+        d["hbm_bound_calls"] += int(t_hbm > t_mfma)
     return out
 
 
@@ -517,7 +562,7 @@ def main(argv=None):
       except Exception:
         pass
     if not args.no_kernel_timing and args.per_call:
-      for (family, work, s, e), (name, ints) in zip(timer.records, timer.shapes):
+      for (family, work, s, e, _nb), (name, ints) in zip(timer.records, timer.shapes):
         ms = s.elapsed_time(e)
         unit = "GB/s" if family.startswith("roi_crop") else "TFLOP/s"
         rate = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
@@ -540,6 +585,12 @@ def main(argv=None):
                 # the MFMAs actually issued — padding taps are skipped, `achieved` counts all taps
                 "mfma_busy": mfma.get(traffic_key, {}).get("mfma_busy"),
                 "calls_per_step": f["launches"], "avg_call_ms": f["ms"] / f["launches"],
+                # per call the binding roofline is max(FLOPs / matrix peak, algorithmic bytes /
+                # 8 TB/s): `binding_frac` = sum of those ideal times / measured time; short-K bf16
+                # GEMMs (1x1 block-entry convolutions, ~100-300 FLOP/B) are HBM-bound calls
+                "binding_frac": (f["ideal_ms"] / f["ms"]) if f["ms"] else None,
+                "hbm_bound_calls": f["hbm_bound_calls"],
+                "algorithmic_gb_per_step": f["bytes"] / 1e9,
                 "family_ms_per_step": f["ms"], "algorithmic_gflop_per_step": f["work"] / 1e9,
                 "timed_with": "HIP events around every launch of the last timed step, which runs "
                               "all kernels on one stream (the other steps overlap the filter "
