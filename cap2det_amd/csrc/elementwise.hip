@@ -1318,3 +1318,73 @@ extern "C" int c2d_sum_small(const float* x, int n, float* out, void* stream) {
   hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, n, out);
   return c2d_launch_status();
 }
+
+// ---- the reference's other optimisers (core/training_utils.py:14-71 `build_optimizer`) ----------
+namespace {
+// TensorFlow 1.x update rules (third party: tensorflow/core/kernels/training_ops.cc), on the
+// regularised / multiplied gradient g' of c2d_adagrad_step_ex:
+//   SGD       w -= lr g'
+//   MOMENTUM  a = mu a + g';  w -= lr a            (Nesterov: w -= lr (g' + mu a))
+//   ADAM      m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  w -= lr_t m / (sqrt(v) + eps)
+//             lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), computed by the caller (p3)
+//   RMSPROP   ms = rho ms + (1-rho) g'^2  [centered: mg = rho mg + (1-rho) g']
+//             mom = mu mom + lr g' / sqrt(ms [- mg^2] + eps);  w -= mom
+__global__ __launch_bounds__(256) void optimizer_kernel(
+    int kind, int flags, float* __restrict__ w, const float* __restrict__ g,
+    float* __restrict__ s0, float* __restrict__ s1, float* __restrict__ s2, long long n, float lr,
+    const float* __restrict__ lr_dev, float p0, float p1, float p2, float p3, float l1, float l2,
+    float mult, float grad_scale, const float* __restrict__ col_mult, int ld) {
+  float lr_scale = 1.0f;
+  if (lr_dev) { lr_scale = lr != 0.f ? lr_dev[0] / lr : 0.f; }
+  const float lre = lr * lr_scale;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float m = col_mult ? mult * col_mult[i % ld] : mult;
+    if (!(m > 0.f)) continue;
+    const float wi = w[i];
+    const float sg = wi > 0.f ? 1.f : (wi < 0.f ? -1.f : 0.f);
+    const float gi = m * (g[i] * grad_scale + l2 * wi + l1 * sg);
+    if (kind == C2D_OPT_SGD) {
+      w[i] = wi - lre * gi;
+    } else if (kind == C2D_OPT_MOMENTUM) {
+      const float a = p0 * s0[i] + gi;
+      s0[i] = a;
+      w[i] = (flags & 1) ? wi - lre * (gi + p0 * a) : wi - lre * a;
+    } else if (kind == C2D_OPT_ADAM) {
+      const float mm = p0 * s0[i] + (1.f - p0) * gi;
+      const float vv = p1 * s1[i] + (1.f - p1) * gi * gi;
+      s0[i] = mm; s1[i] = vv;
+      w[i] = wi - (p3 * lr_scale) * mm / (sqrtf(vv) + p2);
+    } else {   // RMSPROP: s0 = ms, s1 = mom, s2 = mg (centered)
+      const float ms = p0 * s0[i] + (1.f - p0) * gi * gi;
+      s0[i] = ms;
+      float denom = ms;
+      if (flags & 2) {
+        const float mg = p0 * s2[i] + (1.f - p0) * gi;
+        s2[i] = mg;
+        denom = ms - mg * mg;
+      }
+      const float mom = p1 * s1[i] + lre * gi / sqrtf(denom + p2);
+      s1[i] = mom;
+      w[i] = wi - mom;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int c2d_optimizer_step(int kind, int flags, float* w, const float* g, float* s0,
+                                  float* s1, float* s2, long long n, float lr,
+                                  const float* lr_dev, float p0, float p1, float p2, float p3,
+                                  float l1, float l2, float mult, float grad_scale,
+                                  const float* col_mult, int ld, void* stream) {
+  C2D_CHECK_ARG(w && g && n >= 0 && kind >= C2D_OPT_SGD && kind <= C2D_OPT_RMSPROP);
+  C2D_CHECK_ARG(kind == C2D_OPT_SGD || s0);
+  C2D_CHECK_ARG((kind != C2D_OPT_ADAM && kind != C2D_OPT_RMSPROP) || s1);
+  C2D_CHECK_ARG(!(kind == C2D_OPT_RMSPROP && (flags & 2)) || s2);
+  C2D_CHECK_ARG(!col_mult || ld > 0);
+  if (n == 0) return C2D_OK;
+  hipLaunchKernelGGL(optimizer_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, kind,
+                     flags, w, g, s0, s1, s2, n, lr, lr_dev, p0, p1, p2, p3, l1, l2, mult,
+                     grad_scale, col_mult, ld);
+  return c2d_launch_status();
+}

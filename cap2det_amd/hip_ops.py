@@ -586,6 +586,20 @@ def adagrad_step_ex(w, g, acc, lr, l1=0.0, l2=0.0, mult=1.0, grad_scale=1.0, col
             float(l1), float(l2), float(mult), float(grad_scale), _p(col_mult), int(ld), _stream())
 
 
+OPT_KINDS = {"sgd": 0, "momentum": 1, "adam": 2, "rmsprop": 3}
+
+
+def optimizer_step(kind, w, g, slots, lr, p=(0.0, 0.0, 0.0, 0.0), flags=0, l1=0.0, l2=0.0, mult=1.0,
+                   grad_scale=1.0, col_mult=None, ld=0, lr_dev=None):
+  """c2d_optimizer_step: sgd / momentum / adam / rmsprop (TF 1.x rules) on a flat segment.
+  slots: up to three state tensors of w's size (None where the rule has none)."""
+  s = list(slots) + [None] * (3 - len(slots))
+  _lib.call("c2d_optimizer_step", OPT_KINDS[kind], int(flags), _p(w), _p(g), _p(s[0]), _p(s[1]),
+            _p(s[2]), w.numel(), float(lr), _p(lr_dev), float(p[0]), float(p[1]), float(p[2]),
+            float(p[3]), float(l1), float(l2), float(mult), float(grad_scale), _p(col_mult), int(ld),
+            _stream())
+
+
 class ClipDesc(ctypes.Structure):
   """C2dClipDesc of include/cap2det_hip.h."""
   _fields_ = [("offset", ctypes.c_longlong), ("rows", ctypes.c_int), ("cols", ctypes.c_int),

@@ -30,7 +30,8 @@ def read_checkpoint_arrays(checkpoint_path):
   try:
     if os.path.exists(checkpoint_path + ".npz"):
       arrays = dict(np.load(checkpoint_path + ".npz"))
-      arrays.pop("__global_step", None); arrays.pop("__adagrad_accumulators", None)
+      for k in [k for k in arrays if k.startswith("__")]:     # step counter, optimiser slots
+        arrays.pop(k)
       return arrays
     return tf_checkpoint.read_checkpoint(checkpoint_path)
   except (FileNotFoundError, EOFError, zipfile.BadZipFile) as e:

@@ -70,13 +70,31 @@ class Trainer(object):
     self.device = torch.device(device)
     self.model = model if model is not None else builder.build(
         pipeline_proto.model, is_training=True, device=device, **model_kwargs)
+    # core/training_utils.py:14-71 `build_optimizer`: sgd, momentum, adagrad (every shipped
+    # config), adam, rmsprop — TensorFlow 1.x update rules (c2d_adagrad_step / c2d_optimizer_step)
     opt = self.train_config.optimizer.WhichOneof('optimizer')
-    if opt != 'adagrad':
-      raise ValueError('Invalid optimizer: {}.'.format(opt) if opt is None else
-                       'optimizer %s is not implemented on the HIP path (configs use adagrad)' % opt)
+    if opt not in ('sgd', 'momentum', 'adagrad', 'adam', 'rmsprop'):
+      raise ValueError('Invalid optimizer: {}.'.format(opt))
+    self.opt_kind = opt
+    self.opt_options = getattr(self.train_config.optimizer, opt)
+    if use_graph and opt == 'adam':
+      raise ValueError('hipGraph replay freezes Adam\'s bias correction: use_graph=False with adam')
     self.global_step = 0
     store = self.model.store
-    store.accum.fill_(self.train_config.optimizer.adagrad.initial_accumulator_value)
+    # slot buffers (flat, mirroring the variables): `accum` is slot 0
+    store.slots = [store.accum]
+    if opt == 'adagrad':
+      store.accum.fill_(self.opt_options.initial_accumulator_value)
+    elif opt == 'momentum':
+      store.accum.zero_()
+    elif opt == 'adam':
+      store.accum.zero_()
+      store.slots.append(torch.zeros_like(store.accum))                 # m, v
+    elif opt == 'rmsprop':
+      store.accum.fill_(1.0)                                            # TF: "rms" slot = ones
+      store.slots.append(torch.zeros_like(store.accum))                 # momentum
+      if self.opt_options.centered:
+        store.slots.append(torch.zeros_like(store.accum))               # mg
     # gradient multipliers on the reference variable names (train/trainer.py:104-125)
     names = self.model.get_variables_to_train()
     mult = resolve_gradient_multipliers(names, self.train_config.gradient_multiplier)
@@ -173,8 +191,10 @@ class Trainer(object):
     # (train/predict.py) or a resume after a crash never sees a half-written file
     tmp = path + ".tmp-%d.npz" % os.getpid()
     with open(tmp, "wb") as f:
+      extra = {"__optimizer_slot%d" % i: sl.detach().cpu().numpy()
+               for i, sl in enumerate(store.slots) if i > 0}
       np.savez(f, __global_step=np.int64(self.global_step),
-               __adagrad_accumulators=store.accum.detach().cpu().numpy(), **state)
+               __adagrad_accumulators=store.accum.detach().cpu().numpy(), **extra, **state)
       f.flush()
       os.fsync(f.fileno())
     os.replace(tmp, path + ".npz")
@@ -207,8 +227,11 @@ class Trainer(object):
     arrays = dict(np.load(path if path.endswith(".npz") else path + ".npz"))
     self.global_step = int(arrays.pop("__global_step"))
     accum = arrays.pop("__adagrad_accumulators")
+    extra = {k: arrays.pop(k) for k in list(arrays) if k.startswith("__optimizer_slot")}
     self.model.load_state_dict(arrays)
     self.model.store.accum.copy_(torch.from_numpy(accum).to(self.device))
+    for k, a in extra.items():
+      self.model.store.slots[int(k[len("__optimizer_slot"):])].copy_(torch.from_numpy(a).to(self.device))
     self._graphs = None
 
   def learning_rate(self):
@@ -264,6 +287,10 @@ class Trainer(object):
     if clipped:
       desc, num, max_norm = self._clip
       ops.clip_gradient_norms(g, v, desc, num, scale, max_norm)    # g <- final clipped gradient
+    if self.opt_kind != 'adagrad':
+      self._apply_other_optimizer(scale, lr, lr_dev, clipped)
+      self.model.refresh(only_trainable=True)
+      return
     for off, end, m, l1, l2, cols, mask in self.segments:
       if clipped:
         # the descriptors applied scale / regularisers / multipliers; what is left is the
@@ -279,6 +306,29 @@ class Trainer(object):
         ops.adagrad_step_ex(v[off:end], g[off:end], a[off:end], lr, l1, l2, m, scale, cols,
                             0 if cols is None else cols.numel(), lr_dev)
     self.model.refresh(only_trainable=True)
+
+  def _apply_other_optimizer(self, scale, lr, lr_dev, clipped):
+    """sgd / momentum / adam / rmsprop over the trainable segments (c2d_optimizer_step)."""
+    store, o, kind = self.model.store, self.opt_options, self.opt_kind
+    v, g = store.values, store.grads
+    flags, p = 0, (0.0, 0.0, 0.0, 0.0)
+    if kind == 'momentum':
+      p = (o.momentum, 0.0, 0.0, 0.0)
+      flags = 1 if o.use_nesterov else 0
+    elif kind == 'adam':
+      t = self.global_step + 1
+      p = (o.beta1, o.beta2, o.epsilon, lr * math.sqrt(1.0 - o.beta2 ** t) / (1.0 - o.beta1 ** t))
+    elif kind == 'rmsprop':
+      p = (o.decay, o.momentum, o.epsilon, 0.0)
+      flags = 2 if o.centered else 0
+    for off, end, m, l1, l2, cols, mask in self.segments:
+      slots = [] if kind == 'sgd' else [sl[off:end] for sl in store.slots]
+      if clipped:     # (the descriptors applied scale / regularisers / multipliers)
+        ops.optimizer_step(kind, v[off:end], g[off:end], slots, lr, p, flags, 0.0, 0.0, 1.0, 1.0,
+                           mask, 0 if mask is None else mask.numel(), lr_dev)
+      else:
+        ops.optimizer_step(kind, v[off:end], g[off:end], slots, lr, p, flags, l1, l2, m, scale,
+                           cols, 0 if cols is None else cols.numel(), lr_dev)
 
   def train_step(self, examples, prefetch=None, **kwargs):
     """One synchronous step; returns {loss name: 0-d device tensor} (+ 'total_loss',

@@ -458,6 +458,27 @@ int c2d_adagrad_step_ex(float* w, const float* g, float* acc, long long n, float
                         const float* lr_dev, float l1, float l2, float mult, float grad_scale,
                         const float* col_mult, int ld, void* stream);
 
+/* The reference's other optimisers (core/training_utils.py:14-71 `build_optimizer`: sgd, momentum,
+ * adam, rmsprop; every shipped config uses adagrad), TensorFlow 1.x update rules on the gradient
+ * g' of c2d_adagrad_step_ex (same grad_scale / l1 / l2 / mult / col_mult / lr_dev meaning):
+ *   C2D_OPT_SGD       w -= lr g'
+ *   C2D_OPT_MOMENTUM  s0 = p0 s0 + g';  w -= lr s0   (flags & 1, use_nesterov: w -= lr (g' + p0 s0))
+ *   C2D_OPT_ADAM      s0 = p0 s0 + (1-p0) g';  s1 = p1 s1 + (1-p1) g'^2;  w -= p3 s0 / (sqrt(s1) + p2)
+ *                     with p0 = beta1, p1 = beta2, p2 = epsilon and p3 = lr sqrt(1-beta2^t)/(1-beta1^t)
+ *                     computed by the caller for step t = 1, 2, ...
+ *   C2D_OPT_RMSPROP   s0 = p0 s0 + (1-p0) g'^2  [flags & 2, centered: s2 = p0 s2 + (1-p0) g'];
+ *                     s1 = p1 s1 + lr g' / sqrt(s0 [- s2^2] + p2);  w -= s1
+ *                     with p0 = decay, p1 = momentum, p2 = epsilon (TF initialises s0 to ONES).
+ * s0 / s1 / s2: caller-owned slot buffers of n floats (NULL where the rule has none). */
+#define C2D_OPT_SGD 0
+#define C2D_OPT_MOMENTUM 1
+#define C2D_OPT_ADAM 2
+#define C2D_OPT_RMSPROP 3
+int c2d_optimizer_step(int kind, int flags, float* w, const float* g, float* s0, float* s1,
+                       float* s2, long long n, float lr, const float* lr_dev, float p0, float p1,
+                       float p2, float p3, float l1, float l2, float mult, float grad_scale,
+                       const float* col_mult, int ld, void* stream);
+
 /* One variable = a [rows][cols] window (row stride ld) at `offset` of the flat buffers. */
 typedef struct C2dClipDesc {
   long long offset;

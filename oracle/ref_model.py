@@ -540,7 +540,7 @@ def first_trainable_index(multipliers_resolved):
 
 def train_step(P, accum, examples, labels, options, loss_opts, multipliers, learning_rate,
                l2_weight, dropout_mask=None, feature_map_dropout_mask=None, l1_weight=0.0,
-               max_gradient_norm=None):
+               max_gradient_norm=None, optimizer=None):
   """One step of train/trainer.py:_model_fn in TRAIN mode with Adagrad
   (core/training_utils.py:45-50; tf.train.AdagradOptimizer: acc += g^2; w -= lr*g*rsqrt(acc)).
 
@@ -556,11 +556,67 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
   first_from = first_trainable_index(mult)
   grads.update(extract_frcnn_feature_backward(dfeatures, saved["frcnn"], P, options, first_from))
   return finish_step(P, accum, grads, loss_dict, mult, dfeatures.dtype.type, learning_rate,
-                     l2_weight, l1_weight, max_gradient_norm, predictions)
+                     l2_weight, l1_weight, max_gradient_norm, predictions, optimizer)
+
+
+def optimizer_update(kind, opts, w, g, slots, lr, step, dt):
+  """TensorFlow 1.x update rules of core/training_utils.py:14-71's optimisers (third party:
+  tensorflow/core/kernels/training_ops.cc; parity unpinned, formulas as documented by TF).
+  slots: list of state arrays, updated in place; w updated in place.  step: 1-based step count."""
+  if kind == "sgd":
+    w -= dt(lr) * g
+  elif kind == "momentum":
+    a = slots[0]
+    a[...] = dt(opts["momentum"]) * a + g
+    if opts.get("use_nesterov"):
+      w -= dt(lr) * (g + dt(opts["momentum"]) * a)
+    else:
+      w -= dt(lr) * a
+  elif kind == "adagrad":
+    slots[0] += g * g
+    w -= dt(lr) * g / np.sqrt(slots[0])
+  elif kind == "adam":
+    b1, b2, eps = dt(opts["beta1"]), dt(opts["beta2"]), dt(opts["epsilon"])
+    m, v = slots
+    m[...] = b1 * m + (dt(1) - b1) * g
+    v[...] = b2 * v + (dt(1) - b2) * g * g
+    lr_t = dt(lr) * np.sqrt(dt(1) - b2 ** step) / (dt(1) - b1 ** step)
+    w -= lr_t * m / (np.sqrt(v) + eps)
+  elif kind == "rmsprop":
+    rho, mu, eps = dt(opts["decay"]), dt(opts["momentum"]), dt(opts["epsilon"])
+    ms, mom = slots[0], slots[1]
+    ms[...] = rho * ms + (dt(1) - rho) * g * g
+    denom = ms
+    if opts.get("centered"):
+      mg = slots[2]
+      mg[...] = rho * mg + (dt(1) - rho) * g
+      denom = ms - mg * mg
+    mom[...] = mu * mom + dt(lr) * g / np.sqrt(denom + eps)
+    w -= mom
+  else:
+    raise ValueError("Invalid optimizer: {}.".format(kind))
+
+
+def init_optimizer_slots(kind, opts, P):
+  """Initial slot values as TensorFlow creates them (Adagrad: initial_accumulator_value,
+  RMSProp: rms = 1, everything else 0)."""
+  out = {}
+  for k, v in P.items():
+    if kind == "adagrad":
+      out[k] = [np.full(v.shape, opts.get("initial_accumulator_value", 0.1), v.dtype)]
+    elif kind == "momentum":
+      out[k] = [np.zeros_like(v)]
+    elif kind == "adam":
+      out[k] = [np.zeros_like(v), np.zeros_like(v)]
+    elif kind == "rmsprop":
+      out[k] = [np.ones_like(v), np.zeros_like(v)] + ([np.zeros_like(v)] if opts.get("centered") else [])
+    else:
+      out[k] = []
+  return out
 
 
 def finish_step(P, accum, grads, loss_dict, mult, dt, learning_rate, l2_weight, l1_weight=0.0,
-                max_gradient_norm=None, predictions=None):
+                max_gradient_norm=None, predictions=None, optimizer=None):
   """Tail of `train_step`: regularisers, gradient multipliers, per-variable norm clipping,
   Adagrad (shared with oracle/torch_step.py, bench.py's timed CPU baseline)."""
   reg = {}
@@ -582,8 +638,13 @@ def finish_step(P, accum, grads, loss_dict, mult, dt, learning_rate, l2_weight, 
       # every gradient on its own L2 norm, after the multipliers
       norm = np.sqrt(np.sum(g * g))
       g = g * dt(max_gradient_norm) / np.maximum(norm, dt(max_gradient_norm))
-    accum[name] += g * g
-    P[name] -= dt(learning_rate) * g / np.sqrt(accum[name])
+    if optimizer is None:
+      accum[name] += g * g
+      P[name] -= dt(learning_rate) * g / np.sqrt(accum[name])
+    else:
+      # optimizer = dict(kind, opts, slots {name: [arrays]}, step): accum is unused
+      optimizer_update(optimizer["kind"], optimizer["opts"], P[name], g, optimizer["slots"][name],
+                       learning_rate, optimizer["step"], dt)
     applied[name] = g
   return dict(losses=loss_dict, reg_losses=reg, total_loss=total, grads=grads, applied=applied,
               predictions=predictions)

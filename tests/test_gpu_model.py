@@ -635,6 +635,96 @@ def test_reference_branches_no_shipped_config_takes():
   assert (m1 != m2).float().mean().item() > 0.3
 
 
+@pytest.mark.parametrize("kind,opts", [
+    ("sgd", {}), ("momentum", dict(momentum=0.9, use_nesterov=True)),
+    ("adam", dict(beta1=0.9, beta2=0.999, epsilon=1e-8)),
+    ("rmsprop", dict(decay=0.9, momentum=0.5, epsilon=1e-10, centered=True))])
+def test_train_steps_with_the_other_optimizers(kind, opts):
+  """core/training_utils.py:14-71 `build_optimizer`: every optimiser the reference's Optimizer
+  proto names (no shipped config selects them).  Two full training steps of the HIP path against
+  the float64 oracle with TensorFlow 1.x's update rules: same losses, every trainable variable
+  within the gradient tolerance after each step, frozen variables untouched, checkpoint round trip
+  of the slot buffers."""
+  from cap2det_amd.train.trainer import Trainer
+  dm, hw, n, nums, k = 0.5, (48, 40), 6, [6, 4], 3
+  lr = 0.001 if kind in ("adam", "rmsprop") else 0.01
+  pipeline = util_model.load_pipeline()
+  tc = pipeline.train_config
+  sub = getattr(tc.optimizer, kind)
+  if not opts:
+    sub.use_locking = False                       # (selects the oneof member)
+  for key, v in opts.items():
+    setattr(sub, key, v)
+  tc.learning_rate = lr
+  assert tc.optimizer.WhichOneof("optimizer") == kind
+  trainer = Trainer(pipeline, device=DEV, depth_multiplier=dm)
+  model = trainer.model
+  classes = model.label_extractor.classes
+  P32, d = util_model.oracle_state(7, len(classes), k, dm)
+  model.load_state_dict(P32)
+  rng = np.random.default_rng(5)
+  P = {kk: v.astype(np.float64) for kk, v in P32.items()}
+  slots = ref_model.init_optimizer_slots(kind, opts, P)
+  mults = [(g.scope, g.multiplier) for g in tc.gradient_multiplier]
+  loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=k,
+                   oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
+  for step in (1, 2):
+    ex = util_model.make_examples(rng, 2, hw[0], hw[1], n, nums, classes)
+    mask = (rng.uniform(size=(2 * n, d)) < 0.5).astype(np.uint8)
+    labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
+    ex64 = dict(image=ex["image"].astype(np.float64), number_of_proposals=ex["number_of_proposals"],
+                proposals=ex["proposals"].astype(np.float64))
+    P_before = {kk: v.copy() for kk, v in P.items()}
+    want = ref_model.train_step(P, {}, ex64, labels, ref_model.FrcnnOptions(depth_multiplier=dm),
+                                loss_opts, mults, lr, 1e-6, mask,
+                                optimizer=dict(kind=kind, opts=opts, slots=slots, step=step))
+    losses = trainer.train_step(_to_dev(ex), dropout_mask=torch.from_numpy(mask).to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses["total_loss"].item(), want["total_loss"], rtol=2e-4)
+    state = model.state_dict()
+    moved = 0
+    for name in P:
+      if name in want["applied"]:
+        # the update is a bounded function of the gradient: compare the step taken with the
+        # oracle's, relative to the largest step of the tensor
+        stepped = P[name] - P_before[name]
+        got = state[name].astype(np.float64) - P_before[name]
+        scale = max(np.abs(stepped).max(), 1e-12)
+        if kind in ("adam", "rmsprop"):
+          # g / (sqrt(v) + eps) is ill-conditioned where |g| is of the order of the fp32 noise of
+          # the gradient (Adam's first step is lr * g / (|g| + 1e-8)): compare the elements whose
+          # gradient is well above that noise, bound the step of the others by the largest step
+          g = np.abs(want["applied"][name])
+          if g.max() < 1e-6:
+            # an analytically zero gradient (the bias of the shift-invariant proposal softmax):
+            # fp32 round-off of O(1e-8) over (|g| + 1e-8) is an O(lr) step, bounded by lr
+            assert np.abs(got).max() <= 1.05 * lr, (step, name)
+            moved += 1
+            continue
+          well = g > 1e-3 * g.max()
+          assert well.any(), name
+          assert np.abs(got - stepped)[well].max() <= 2e-2 * scale + 1e-9, (step, name)
+          assert np.abs(got).max() <= 1.05 * scale + 1e-9, (step, name)
+        else:
+          assert np.abs(got - stepped).max() <= 2e-3 * scale + 1e-9, (step, name)
+        moved += 1
+      elif step == 1:
+        np.testing.assert_array_equal(state[name], P32[name], err_msg="frozen " + name)
+    assert moved > 60
+    # (re-synchronise the HIP state with the oracle so that step 2 tests the SLOTS, not drift)
+    model.load_state_dict({kk: v.astype(np.float32) for kk, v in P.items()})
+    for kk in list(P):
+      P[kk] = P[kk].astype(np.float32).astype(np.float64)
+  import tempfile
+  with tempfile.TemporaryDirectory() as tmp:
+    path = trainer.save_checkpoint(tmp)
+    other = Trainer(pipeline, device=DEV, depth_multiplier=dm)
+    other.load_checkpoint(path)
+    assert other.global_step == 2 and len(other.model.store.slots) == len(trainer.model.store.slots)
+    for a, b in zip(other.model.store.slots, trainer.model.store.slots):
+      assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("config,dtype", [("c2", "fp32"), ("c2", "bf16"), ("c3", "fp32"),
                                           ("c4", "bf16")])
 def test_full_size_caption_configs(tmp_path, config, dtype):

@@ -726,6 +726,51 @@ def test_adagrad_and_l2(ops):
   np.testing.assert_allclose(_n(out)[0], 0.5e-2 * (w.astype(np.float64) ** 2).sum(), rtol=1e-5)
 
 
+
+@pytest.mark.parametrize("kind,opts,flags", [
+    ("sgd", {}, 0), ("momentum", dict(momentum=0.9), 0), ("momentum", dict(momentum=0.9, use_nesterov=True), 1),
+    ("adam", dict(beta1=0.9, beta2=0.999, epsilon=1e-8), 0),
+    ("rmsprop", dict(decay=0.9, momentum=0.0, epsilon=1e-10), 0),
+    ("rmsprop", dict(decay=0.9, momentum=0.5, epsilon=1e-10, centered=True), 2)])
+def test_optimizer_step_kinds(ops, kind, opts, flags):
+  """c2d_optimizer_step (core/training_utils.py:14-71's sgd / momentum / adam / rmsprop) against
+  the oracle's TensorFlow 1.x rules over three steps, with L2 / L1 regularisers, a gradient
+  multiplier, the 1/world gradient scale and per-column multipliers incl. a frozen column."""
+  rng = np.random.default_rng(11)
+  rows, ld = 37, 12
+  n = rows * ld
+  w0 = rng.standard_normal(n).astype(np.float32)
+  col = np.array([1.0, 0.5, 0.0, 2.0] * 3, np.float32)
+  lr, l1, l2, mult, scale = 0.05, 1e-3, 1e-2, 0.5, 0.25
+  w = _t(w0)
+  nslots = {"sgd": 0, "momentum": 1, "adam": 2, "rmsprop": 3 if opts.get("centered") else 2}[kind]
+  slots = [torch.zeros(n, device=DEV) for _ in range(nslots)]
+  if kind == "rmsprop":
+    slots[0].fill_(1.0)
+  w64 = w0.astype(np.float64)
+  sl64 = ref_model.init_optimizer_slots(kind, opts, {"w": w64})["w"]
+  m_el = (mult * np.tile(col, rows)).astype(np.float64)
+  for step in range(1, 4):
+    g = rng.standard_normal(n).astype(np.float32)
+    p = {"sgd": (0, 0, 0, 0), "momentum": (opts.get("momentum", 0), 0, 0, 0),
+         "adam": (opts.get("beta1", 0), opts.get("beta2", 0), opts.get("epsilon", 0),
+                  lr * np.sqrt(1 - opts.get("beta2", 0) ** step) / (1 - opts.get("beta1", 0.5) ** step)),
+         "rmsprop": (opts.get("decay", 0), opts.get("momentum", 0), opts.get("epsilon", 0), 0)}[kind]
+    ops.optimizer_step(kind, w, _t(g), slots, lr, p, flags, l1, l2, mult, scale, _t(col), ld)
+    gp = m_el * (scale * g.astype(np.float64) + l2 * w64 + l1 * np.sign(w64))
+    live = m_el > 0
+    wl, sll = w64[live].copy(), [a[live].copy() for a in sl64]
+    ref_model.optimizer_update(kind, opts, wl, gp[live], sll, lr, step, np.float64)
+    w64[live] = wl
+    for a, b in zip(sl64, sll):
+      a[live] = b
+    np.testing.assert_allclose(_n(w), w64, rtol=2e-5, atol=2e-6, err_msg="step %d" % step)
+  frozen = np.tile(col, rows) == 0
+  np.testing.assert_array_equal(_n(w)[frozen], w0[frozen])
+  for a, b in zip(slots, sl64):
+    np.testing.assert_allclose(_n(a), b, rtol=2e-5, atol=2e-6)
+
+
 def test_conv_fwd_grouped_matches_single_calls():
   """c2d_conv_fwd_grouped: independent convolutions of one Inception level in ONE launch (all
   small) or one launch each (a large one in the group): bit-identical to c2d_conv_fwd."""

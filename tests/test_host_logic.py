@@ -166,3 +166,45 @@ def test_predict_checkpoint_errors_are_typed(tmp_path):
   arrays = predict.read_checkpoint_arrays(str(tmp_path / "model.ckpt-9"))
   assert sorted(arrays) == ["w"]
   assert not issubclass(predict.CheckpointUnreadable, FileNotFoundError)
+
+
+def test_oracle_optimizer_rules_known_answers():
+  """Hand-computed steps of the TensorFlow 1.x rules behind core/training_utils.py:14-71's
+  `build_optimizer` (oracle/ref_model.optimizer_update; the GPU kernel is tested against it)."""
+  f = np.float64
+  g = np.array([0.5, -2.0, 0.0])
+  # Adam, step 1: m_hat / (sqrt(v_hat) + eps) = sign(g) up to eps  ->  w -= lr * sign(g)
+  w = np.ones(3)
+  sl = ref_model.init_optimizer_slots("adam", {}, {"w": w})["w"]
+  ref_model.optimizer_update("adam", dict(beta1=0.9, beta2=0.999, epsilon=1e-8), w, g, sl, 0.1, 1, f)
+  np.testing.assert_allclose(w, [0.9, 1.1, 1.0], atol=1e-7)
+  np.testing.assert_allclose(sl[0], 0.1 * g)
+  np.testing.assert_allclose(sl[1], 0.001 * g * g)
+  # momentum 0.5, two steps of the same gradient: a = g, then 1.5 g;  w -= lr a each step
+  w = np.zeros(3)
+  sl = ref_model.init_optimizer_slots("momentum", {}, {"w": w})["w"]
+  for _ in range(2):
+    ref_model.optimizer_update("momentum", dict(momentum=0.5), w, g, sl, 0.1, 1, f)
+  np.testing.assert_allclose(w, -0.1 * (1.0 + 1.5) * g)
+  # Nesterov, first step: a = g, w -= lr (g + mu a) = lr * 1.5 g
+  w = np.zeros(3)
+  sl = ref_model.init_optimizer_slots("momentum", {}, {"w": w})["w"]
+  ref_model.optimizer_update("momentum", dict(momentum=0.5, use_nesterov=True), w, g, sl, 0.1, 1, f)
+  np.testing.assert_allclose(w, -0.1 * 1.5 * g)
+  # RMSProp (rms slot starts at ONE), centered, momentum 0.5: worked by hand for g = 0.5
+  w = np.ones(1)
+  sl = ref_model.init_optimizer_slots("rmsprop", dict(centered=True), {"w": w})["w"]
+  ref_model.optimizer_update("rmsprop", dict(decay=0.9, momentum=0.5, epsilon=1e-10, centered=True),
+                             w, np.array([0.5]), sl, 0.1, 1, f)
+  ms, mg = 0.9 + 0.1 * 0.25, 0.1 * 0.5
+  np.testing.assert_allclose(w, [1.0 - 0.1 * 0.5 / np.sqrt(ms - mg * mg + 1e-10)], rtol=1e-12)
+  # SGD and Adagrad (accumulator 0.1)
+  w = np.ones(3)
+  ref_model.optimizer_update("sgd", {}, w, g, [], 0.1, 1, f)
+  np.testing.assert_allclose(w, 1.0 - 0.1 * g)
+  w = np.ones(3)
+  sl = ref_model.init_optimizer_slots("adagrad", dict(initial_accumulator_value=0.1), {"w": w})["w"]
+  ref_model.optimizer_update("adagrad", {}, w, g, sl, 0.1, 1, f)
+  np.testing.assert_allclose(w, 1.0 - 0.1 * g / np.sqrt(0.1 + g * g))
+  with pytest.raises(ValueError):
+    ref_model.optimizer_update("lamb", {}, w, g, [], 0.1, 1, f)
