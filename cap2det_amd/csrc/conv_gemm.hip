@@ -639,7 +639,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel
 }
 
 // (The bf16-native implicit GEMM — direct-to-LDS operand stages, ring of 2-3 buffers — lives in
-// igemm_bf16.hip: igemm_bf16_ring_kernel.)
+// igemm_bf16.hip: igemm_ring_kernel.)
 
 // ---------------------------------------------------------------------------------------------
 // Small-problem kernel (first stage: one image, 32x32 .. 125x125 maps => 1k-16k rows).
@@ -1718,6 +1718,14 @@ int launch_igemm_mode(IgemmArgs a, hipStream_t s, const IgemmWs& ws) {
   a.m_tiles = c2d_ceil_div(a.M, BM);
   a.n_tiles = c2d_ceil_div(a.N, BN);
   g_last_m_tiles = a.m_tiles;
+  if (ES == 4 && !ws.ptr) {
+    // the DMA-ring kernel of igemm_bf16.hip on fp32 operands, where enabled (round 3)
+    IgemmArgs b = a;
+    b.g.mode = MODE;
+    int mtiles = 0;
+    const int rc = launch_igemm_f32_ring(b, WM, WN, MT, NT, PM, s, &mtiles, g_tile_query);
+    if (rc != C2D_ERR_UNSUPPORTED) return rc;
+  }
   if (g_tile_query) return C2D_OK;
   if (a.nseg > 1) {
     a.total_slabs = 0;
@@ -1824,7 +1832,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     e = getenv("C2D_IGEMM_CFG");
     force = e ? atoi(e) : 0;
   }
-  // bf16 (igemm_bf16_ring_kernel) block tile by output width, measured per GEMM call of the step
+  // bf16 (igemm_ring_kernel<..., 2>) block tile by output width, measured per GEMM call of the step
   // (tools/bench_step_gemms.py + tools/sweep_step_gemms.sh, N = 2000 ROIs; round 3):
   //   129..192 and 257..384 columns: ONE 128-row x full-width tile per block (8 waves 4 x 2): the
   //     activations stream from HBM once; with three 64-column tiles the ring is 80 KiB and two

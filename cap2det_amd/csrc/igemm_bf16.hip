@@ -19,6 +19,7 @@
 // the 16 lanes of every ds_read_b128 group on 16 distinct 16-byte slots (MI355X_MICROARCH.md §LDS).
 #include "igemm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace c2d_ig {
 namespace {
@@ -39,14 +40,20 @@ constexpr int ring_blocks_per_cu(int lds_bytes) {
   return (160 * 1024) / lds_bytes >= 5 ? 5 : (160 * 1024) / lds_bytes;
 }
 
-template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D>
+// ES = operand / result element size: 2 = bf16 on v_mfma_f32_32x32x16_bf16; 4 = fp32 on
+// v_mfma_f32_32x32x2_f32 (exact fp32; round 3: the same ring with 16- or 32-float stages, i.e. the
+// same 64- / 128-byte rows — the register-staged igemm_nt_kernel of conv_gemm.hip spends 11 % of
+// its launches on operand staging and needs a second barrier per slab).
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES>
 __global__ __launch_bounds__(WM * WN * 64,
-                             ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * 2) * (WM * WN) / 4 > 0
-                                 ? ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * 2) * (WM * WN) / 4 : 1)
-void igemm_bf16_ring_kernel(IgemmArgs a) {
-  constexpr int RB = BKT * 2;                   // bytes per staged row
+                             ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 > 0
+                                 ? ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 : 1)
+void igemm_ring_kernel(IgemmArgs a) {
+  constexpr int RB = BKT * ES;                  // bytes per staged row (128 or 64)
   constexpr int CPR = RB / 16;                  // 16-byte chunks per row (8 or 4)
-  constexpr int KS = BKT / 16;                  // MFMA k-steps per stage (4 or 2)
+  constexpr int KS = ES == 2 ? BKT / 16 : CPR / 2;   // bf16: MFMA k-steps per stage; fp32: 16-byte
+                                                     // chunks per lane and stage (4 MFMAs each)
+  constexpr int EPC = 16 / ES;                  // elements per 16-byte chunk
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
   constexpr int NTHREADS = WM * WN * 64;
@@ -66,7 +73,7 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
   static_assert(BM % ROWS_PER_PASS == 0 && BN % (1024 / RB) == 0, "tile vs block size");
   static_assert(D >= 2 && D <= 6 && (D - 2) * PER <= 63, "ring depth vs the 6-bit vmcnt");
   static_assert(LDS_BYTES <= 160 * 1024, "ring exceeds LDS");
-  static_assert(BKT == 64 || BKT == 32, "stage depth");
+  static_assert(RB == 128 || RB == 64, "stage depth");
   __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
   char* const smemB = smem + D * A_BYTES;
 
@@ -79,7 +86,7 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
   const int lrow = tid / CPR;                                       // row inside a pass
   const int lswz = CPR == 8 ? (lrow >> 1) & 7 : (lrow >> 2) & 3;    // (pass rows are multiples of 16)
   const int kchunk = (tid % CPR) ^ lswz;
-  const int q4 = kchunk * 8;                                        // element offset inside the stage
+  const int q4 = kchunk * EPC;                                      // element offset inside the stage
   // does this wave hold a piece of the (partial) last pass of the weight rows?
   const bool b_last = !B_TAIL || wave * (1024 / RB) + (B_LOADS - 1) * ROWS_PER_PASS < BN;
 
@@ -161,11 +168,11 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
   // One cursor over the stage sequence (K stages of a tap, real taps, segments).
   SlabCursor cur = {0, 0, 0, a.K, tapmask};
   int lda = a.lda;
-  __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 2,
-                                           (a.a_rows * a.lda - a.a_off) * 2);
+  __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * ES,
+                                           (a.a_rows * a.lda - a.a_off) * ES);
   __amdgpu_buffer_rsrc_t rsB = make_rsrc_b(
       a.Bt, a.mo_n ? a.mo_bbytes
-                   : (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * 2);
+                   : (a.nseg > 1 ? (long long)a.N * a.K : (long long)a.g.kh * a.g.kw * a.N * a.K) * ES);
   int brow_base[B_LOADS];              // element offset of the staged weight row inside a tap's plane
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i)
@@ -180,9 +187,9 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
     const int toff = __builtin_amdgcn_readlane(tab_toff, cur.tap);                             \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
         aoff[i] = ((amask[i] >> cur.tap) & 1ull)                                               \
-                      ? (unsigned)((row_base[i] + delta) * lda + q4) * 2u : OOB_OFFSET;        \
+                      ? (unsigned)((row_base[i] + delta) * lda + q4) * (unsigned)ES : OOB_OFFSET; \
     _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                        \
-        boff[i] = (unsigned)((a.nseg > 1 ? brow_off[i] * cur.Kc : brow_base[i]) + toff + q4) * 2u; \
+        boff[i] = (unsigned)((a.nseg > 1 ? brow_off[i] * cur.Kc : brow_base[i]) + toff + q4) * (unsigned)ES; \
     if (PM)                                                                                    \
       tv_load = ((unsigned)__builtin_amdgcn_readlane((int)tab_tv, cur.tap) >> (wm * MT)) &     \
                 ((1u << MT) - 1u);                                                             \
@@ -191,11 +198,11 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
 #define C2D_PIECE_A(SLOT, I)                                                                   \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                    \
       rsA, (lds_void_t*)(smem + (SLOT) * A_BYTES + wave * 1024 + (I) * ROWS_PER_PASS * RB), 16, \
-      (int)(cur.kc + q4 < cur.Kc ? aoff[I] : OOB_OFFSET), cur.kc * 2, 0, 0);
+      (int)(cur.kc + q4 < cur.Kc ? aoff[I] : OOB_OFFSET), cur.kc * ES, 0, 0);
 #define C2D_PIECE_B(SLOT, I)                                                                   \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                    \
       rsB, (lds_void_t*)(smemB + (SLOT) * B_BYTES + wave * 1024 + (I) * ROWS_PER_PASS * RB), 16, \
-      (int)(cur.kc + q4 < cur.Kc ? boff[I] : OOB_OFFSET), cur.kc * 2, 0, 0);
+      (int)(cur.kc + q4 < cur.Kc ? boff[I] : OOB_OFFSET), cur.kc * ES, 0, 0);
 #define C2D_NOTE_TV(SLOT)                                                                      \
   {                                                                                            \
     if ((SLOT) < 4) tvq_lo = (tvq_lo & ~(0xffu << (8 * ((SLOT) & 3)))) | ((tv_load & 0xffu) << (8 * ((SLOT) & 3))); \
@@ -217,9 +224,9 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
       if (a.nseg > 1) {                                                                        \
         ++cur.sgi;                                                                             \
         lda = a.seg_lda[cur.sgi]; cur.Kc = a.segK[cur.sgi];                                    \
-        rsA = make_rsrc_b((const char*)a.segA[cur.sgi] + (size_t)a.seg_off[cur.sgi] * 2,      \
-                          (a.a_rows * lda - a.seg_off[cur.sgi]) * 2);                          \
-        rsB = make_rsrc_b(a.segB[cur.sgi], (long long)a.N * cur.Kc * 2);                       \
+        rsA = make_rsrc_b((const char*)a.segA[cur.sgi] + (size_t)a.seg_off[cur.sgi] * ES,     \
+                          (a.a_rows * lda - a.seg_off[cur.sgi]) * ES);                         \
+        rsB = make_rsrc_b(a.segB[cur.sgi], (long long)a.N * cur.Kc * ES);                      \
       } else {                                                                                 \
         cur.taps_left &= cur.taps_left - 1ull;                                                 \
         cur.tap = cur.taps_left ? __builtin_ctzll(cur.taps_left) : 0;                          \
@@ -284,12 +291,16 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
     // a tile whose rows are SAME padding for this tap, or lie beyond M, costs nothing) its A
     // fragments and KS x NT MFMAs.  The DMA pieces of the stage D - 1 ahead go out between the
     // MFMA groups of the first row tile (after the fragments are in flight).
-    bf16x8 bf[NT][KS];
+    // (fp32: lane half lh takes the chunks lh * KS .. of a row — a permutation of the k order common
+    //  to both operands — and feeds four v_mfma_f32_32x32x2_f32 from every 16-byte chunk)
+    typedef typename std::conditional<ES == 2, bf16x8, f32x4>::type frag_t;
+    frag_t bf[NT][KS];
 #pragma unroll
     for (int st = 0; st < KS; ++st)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        bf[j][st] = *reinterpret_cast<const bf16x8*>(bufb + brow_b[j] + (((2 * st + lh) ^ bsw[j]) << 4));
+        bf[j][st] = *reinterpret_cast<const frag_t*>(
+            bufb + brow_b[j] + (((ES == 2 ? 2 * st + lh : lh * KS + st) ^ bsw[j]) << 4));
     if (more) {
 #pragma unroll
       for (int i = 0; i < B_LOADS; ++i)
@@ -302,15 +313,23 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if ((onbits >> i) & 1u) {
-        bf16x8 af[KS];
+        frag_t af[KS];
 #pragma unroll
         for (int st = 0; st < KS; ++st)
-          af[st] = *reinterpret_cast<const bf16x8*>(bufa + arow_b[i] + (((2 * st + lh) ^ asw[i]) << 4));
+          af[st] = *reinterpret_cast<const frag_t*>(
+              bufa + arow_b[i] + (((ES == 2 ? 2 * st + lh : lh * KS + st) ^ asw[i]) << 4));
 #pragma unroll
         for (int st = 0; st < KS; ++st)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) {
+            if constexpr (ES == 2) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st][e], bf[j][st][e], acc[i][j], 0, 0, 0);
+            }
+          }
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -392,18 +411,27 @@ void igemm_bf16_ring_kernel(IgemmArgs a) {
           if (orelu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           }
-          bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
-                                                  (size_t)drow * oldc + ocoff);
-          if (a.accumulate) {
-            const bf16x4 o = *dst;
-            v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+          if constexpr (ES == 2) {
+            bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
+                                                    (size_t)drow * oldc + ocoff);
+            if (a.accumulate) {
+              const bf16x4 o = *dst;
+              v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+            }
+            if (fused && !fpass)
+              v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
+                                fig, fsb, fsg);
+            bf16x4 o;
+            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+            *dst = o;
+          } else {
+            f32x4* dst = reinterpret_cast<f32x4*>(oC + (size_t)drow * oldc + ocoff);
+            if (a.accumulate) v += *dst;
+            if (fused && !fpass)
+              v = fused_bn_item(v, load_act4<4>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
+                                fig, fsb, fsg);
+            *dst = v;
           }
-          if (fused && !fpass)
-            v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
-                              fig, fsb, fsg);
-          bf16x4 o;
-          o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-          *dst = o;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -433,7 +461,7 @@ const RingTune& ring_tune() {
   return t;
 }
 
-template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D>
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES = 2>
 int launch_one(IgemmArgs a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   a.m_tiles = c2d_ceil_div(a.M, BM);
@@ -444,10 +472,10 @@ int launch_one(IgemmArgs a, hipStream_t s) {
   }
   static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
   a.dbg = dbg_env;
-  dispatch_note_ext(PM ? "igemm_bf16_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d>"
-                       : "igemm_bf16_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d>",
-                    MODE, WM, WN, MT, NT, BKT, D);
-  hipLaunchKernelGGL((igemm_bf16_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D>),
+  dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d>"
+                       : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d>",
+                    MODE, WM, WN, MT, NT, BKT, D, ES);
+  hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES>),
                      dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
   return c2d_launch_status();
 }
@@ -497,6 +525,78 @@ int launch_shape(const IgemmArgs& a, bool pm, hipStream_t s) {
   return pm ? launch_tile<1, WM, WN, MT, NT, true>(a, s) : launch_tile<1, WM, WN, MT, NT, false>(a, s);
 }
 
+// fp32 operands on the same ring.  Swept on the step's 26 forward / input-gradient calls (tools/
+// bench_step_gemms.py fp32; 16- / 32-float stages, rings of 2-4): the register-staged
+// igemm_nt_kernel of conv_gemm.hip stays ahead by 3-6 % overall (3.66 + 3.57 ms against 3.77 + 3.79
+// with the best ring) — at 64 cycles per fp32 MFMA the staging instructions of a workgroup sit
+// under the MFMAs of the three others on its CU — with ONE exception the default takes: the 3x3
+// forward convolutions with 257..384 output columns on the per-ROI maps (192->320 of Mixed_5b/5c:
+// five 64-column tiles per row block), 284 -> 234 us per call with 16-float stages in two buffers
+// (24 KiB: five workgroups per CU).  C2D_TUNE=1 C2D_RING_FP32=1|0 forces the ring on (all tiles,
+// sweep build) / off; C2D_RINGF_BK = 16 | 32, C2D_RINGF_D = ring depth (sweep build).
+struct RingF32Tune { int on, bk, d; };
+const RingF32Tune& ringf_tune() {
+  static const RingF32Tune t = [] {
+    RingF32Tune r = {-1, 0, 0};
+    if (getenv("C2D_TUNE")) {
+      if (const char* e = getenv("C2D_RING_FP32")) r.on = atoi(e);
+      if (const char* e = getenv("C2D_RINGF_BK")) r.bk = atoi(e);
+      if (const char* e = getenv("C2D_RINGF_D")) r.d = atoi(e);
+    }
+    return r;
+  }();
+  return t;
+}
+
+#ifdef C2D_RING_SWEEP
+template <int MODE, int WM, int WN, int MT, int NT, bool PM>
+int launch_tile_f32(const IgemmArgs& a, hipStream_t s) {
+  const RingF32Tune& t = ringf_tune();
+  const int bk = t.bk == 32 ? 32 : 16;
+  const int d = t.d >= 2 && t.d <= 4 ? t.d : 2;
+  if (bk == 16 && d == 3) return launch_one<MODE, WM, WN, MT, NT, PM, 16, 3, 4>(a, s);
+  if (bk == 16 && d == 4) return launch_one<MODE, WM, WN, MT, NT, PM, 16, 4, 4>(a, s);
+  if (bk == 16 && d == 2) return launch_one<MODE, WM, WN, MT, NT, PM, 16, 2, 4>(a, s);
+  if (bk == 32 && d == 3) return launch_one<MODE, WM, WN, MT, NT, PM, 32, 3, 4>(a, s);
+  return launch_one<MODE, WM, WN, MT, NT, PM, 32, 2, 4>(a, s);
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_shape_f32(const IgemmArgs& a, bool pm, hipStream_t s) {
+  if (a.g.mode == 0)
+    return pm ? launch_tile_f32<0, WM, WN, MT, NT, true>(a, s) : launch_tile_f32<0, WM, WN, MT, NT, false>(a, s);
+  return pm ? launch_tile_f32<1, WM, WN, MT, NT, true>(a, s) : launch_tile_f32<1, WM, WN, MT, NT, false>(a, s);
+}
+#endif
+
+}  // namespace
+
+int launch_igemm_f32_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
+                          hipStream_t s, int* m_tiles_out, bool query) {
+  const int on = ringf_tune().on;
+  if (on == 0) return C2D_ERR_UNSUPPORTED;
+  const int key = ((wm * 10 + wn) * 10 + mt) * 10 + nt;
+  const bool pick = key == 2221 && pm && a.g.mode == 0 && a.N > 256 && a.N <= 384 && !a.fy && !a.mo_n &&
+                    a.nseg == 1;
+#ifdef C2D_RING_SWEEP
+  if (on == 1) {
+    if (key != 2221 && key != 2222 && key != 2211) return C2D_ERR_UNSUPPORTED;
+    if (m_tiles_out) *m_tiles_out = c2d_ceil_div(a.M, wm * mt * 32);
+    if (query) return C2D_OK;
+    switch (key) {
+      case 2221: return launch_shape_f32<2, 2, 2, 1>(a, pm, s);      // 128 x 64
+      case 2222: return launch_shape_f32<2, 2, 2, 2>(a, pm, s);      // 128 x 128
+      default: return launch_shape_f32<2, 2, 1, 1>(a, pm, s);        // 64 x 64
+    }
+  }
+#endif
+  if (!pick) return C2D_ERR_UNSUPPORTED;
+  if (m_tiles_out) *m_tiles_out = c2d_ceil_div(a.M, wm * mt * 32);
+  if (query) return C2D_OK;
+  return launch_one<0, 2, 2, 2, 1, true, 16, 2, 4>(a, s);
+}
+
+namespace {
 }  // namespace
 
 int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
@@ -535,7 +635,7 @@ int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, b
 // Round 2's kernel (wgrad_tn_bf16_kernel) staged 32-row slabs through registers with two barriers
 // per slab and ran at ~270 TFLOP/s on these calls.  Here the same 128 x (64 | 128) output tile gets
 //   * its operand stages global -> LDS by DMA (no staging registers, no ds_write), a ring of D
-//     stages of BKT rows, ONE barrier per stage (as igemm_bf16_ring_kernel);
+//     stages of BKT rows, ONE barrier per stage (as igemm_ring_kernel);
 //   * 64-row stages in two buffers (64 KiB: two workgroups per CU);
 //   * the row-major tiles read transposed with ds_read_b64_tr_b16 (cdna_hip_programming.md T10)
 //     from a lane-linear DMA image: the 64-byte granule g of row r sits at position g ^ (r & 3)

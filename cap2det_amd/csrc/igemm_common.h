@@ -333,6 +333,10 @@ void dispatch_note_ext(const char* fmt, int a = 0, int b = 0, int c = 0, int d =
 // Returns C2D_ERR_UNSUPPORTED when no instance exists for the tile (the caller keeps its own).
 int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
                            hipStream_t s, int* m_tiles_out, bool query);
+// The same ring on fp32 operands (v_mfma_f32_32x32x2_f32); C2D_ERR_UNSUPPORTED unless enabled / an
+// instance exists for the tile.
+int launch_igemm_f32_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
+                          hipStream_t s, int* m_tiles_out, bool query);
 // bf16 filter gradient of a 1x1 / stride-1 convolution (igemm_bf16.hip: wgrad1x1_bf16_ring_kernel):
 // fills the tiling fields of `a` itself.  *splits_out = row splits (slabs of a.part_stride floats
 // when a.part_stride > 0, else atomics into a.dW).  splits_only: compute the split count only.

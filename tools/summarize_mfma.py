@@ -19,6 +19,7 @@ fall into the SAME padding (100 of 144 (pixel, tap) pairs are real on a 4x4 map)
 spent.  On the other side it is not diluted by the clock: the chip holds ~2.1 GHz under this load,
 the nominal peaks assume 2.4."""
 import collections
+import re
 import csv
 import glob
 import json
@@ -30,7 +31,7 @@ from summarize_pmc import family_of  # noqa: E402
 
 
 def family(name):
-  if "igemm_bf16_kernel" in name or "igemm_bf16_ring_kernel" in name:
+  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring_kernel<[^>]*, 2>", name):
     return "igemm_bf16"
   if "wgrad_reduce_kernel" in name:
     return "wgrad_bf16"

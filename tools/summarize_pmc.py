@@ -21,6 +21,7 @@ import sys
 FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
     ("igemm", "igemm_nt_kernel"),
     ("igemm", "igemm_small_kernel"),
+    ("igemm", "igemm_ring_kernel"),      # (fp32 instances: the bf16 ones are matched first)
     ("wgrad", "wgrad_tn_kernel"),
     ("wgrad", "wgrad3x3_kernel"),
     ("roi_crop_pool_fwd", "roi_crop_pool_fwd_kernel"),
@@ -39,7 +40,7 @@ def family_of(name):
   # bf16 MFMA peak
   if "wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16_kernel" in name or "wgrad_reduce_kernel" in name:
     return "wgrad_bf16"
-  if "igemm_bf16_kernel" in name or "igemm_bf16_ring_kernel" in name:
+  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring_kernel<[^>]*, 2>", name):
     return "igemm_bf16"
   m = re.search(r"igemm_nt_kernel<([^>]*)>", name)
   if m and len(m.group(1).split(",")) == 8 and m.group(1).split(",")[-1].strip() == "2":
