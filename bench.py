@@ -617,13 +617,13 @@ def main(argv=None):
       else:
         # second stage on bf16 operands (MFMA 32x32x16 bf16, fp32 accumulate); the frozen /
         # Mixed_4e first stage and the heads stay on the fp32 kernels
-        ig16 = mfma_family("igemm_nt_bf16", "igemm_bf16_kernel<*> (implicit-GEMM conv fwd + dgrad of "
+        ig16 = mfma_family("igemm_nt_bf16", "igemm_ring_kernel<*, 2> (implicit-GEMM conv fwd + dgrad of "
                            "the second stage, bf16 MFMA 32x32x16, fp32 accumulate, direct-to-LDS "
-                           "operand slabs)", "igemm_bf16",
+                           "operand stages in a ring of 2-3)", "igemm_bf16",
                            PEAK_BF16_MFMA_TFLOPS)
-        wg16 = mfma_family("wgrad_tn_bf16", "wgrad_tn_bf16_kernel<*> + wgrad3x3_bf16_kernel<*> (conv "
-                           "filter gradient, bf16 MFMA 32x32x16 through ds_read_b64_tr_b16, split-K "
-                           "slabs) + wgrad_reduce_kernel (their batched reduction)",
+        wg16 = mfma_family("wgrad_tn_bf16", "wgrad_tn_bf16_kernel<*> + wgrad1x1_bf16_ring_kernel<*> + "
+                           "wgrad3x3_bf16_kernel<*> (conv filter gradient, bf16 MFMA 32x32x16 through "
+                           "ds_read_b64_tr_b16, split-K atomics)",
                            "wgrad_bf16", PEAK_BF16_MFMA_TFLOPS)
         if ig16: result["roofline"] = ig16
         if wg16: result["roofline_wgrad"] = wg16

@@ -2,7 +2,7 @@
 // BASELINE configs[2] / [4]: slim.conv2d of models/utils.py:165-167 and its input gradient).
 //
 // Same iteration space, tap tables, pixel-major tile skipping, multi-segment / multi-output modes
-// and epilogue as igemm_bf16_kernel of conv_gemm.hip (round 2), which staged ONE slab ahead: a
+// and epilogue as round 2's igemm_bf16_kernel (which this kernel replaces), which staged ONE slab ahead: a
 // workgroup then waits out the whole global -> LDS latency of a slab (~2,600 cycles under load)
 // for 512-1,400 cycles of MFMAs per slab, and issues all of a slab's DMA pieces in front of its
 // MFMAs (6-8 wave-instructions of ~100 issue cycles each, both waves of a SIMD at the same time
@@ -287,10 +287,10 @@ void igemm_ring_kernel(IgemmArgs a) {
     const unsigned onbits = (a.dbg & 4) ? 0u : __builtin_amdgcn_readfirstlane(row_bits & tvq);
     const char* const bufa = smem + slot * A_BYTES;
     const char* const bufb = smemB + slot * B_BYTES;
-    // B fragments of the whole stage; then, per 32-row tile of this wave (one scalar branch each:
-    // a tile whose rows are SAME padding for this tap, or lie beyond M, costs nothing) its A
-    // fragments and KS x NT MFMAs.  The DMA pieces of the stage D - 1 ahead go out between the
-    // MFMA groups of the first row tile (after the fragments are in flight).
+    // B fragments of the whole stage, then the DMA pieces of the stage D - 1 ahead (behind the
+    // fragment reads, so that their issue overlaps the LDS latency), then, per 32-row tile of this
+    // wave (one scalar branch each: a tile whose rows are SAME padding for this tap, or lie beyond
+    // M, costs nothing) its A fragments and KS x NT MFMAs.
     // (fp32: lane half lh takes the chunks lh * KS .. of a row — a permutation of the k order common
     //  to both operands — and feeds four v_mfma_f32_32x32x2_f32 from every 16-byte chunk)
     typedef typename std::conditional<ES == 2, bf16x8, f32x4>::type frag_t;
@@ -444,9 +444,10 @@ void igemm_ring_kernel(IgemmArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-// Tuning hooks (read once, only with C2D_TUNE=1): C2D_RING_BK=32|64, C2D_RING_D=2..6 force the
-// stage depth / ring depth where an instance exists; C2D_RING=0 switches the ring kernel off
-// (the round-2 kernel of conv_gemm.hip runs instead).
+// Tuning hooks (read once, only with C2D_TUNE=1): C2D_RING_BK=32|64, C2D_RING_D=2|3 (more in a
+// -DC2D_RING_SWEEP build) force the stage depth / ring depth where an instance exists;
+// C2D_RING=0 makes every bf16 convolution fail with C2D_ERR_UNSUPPORTED (there is no second bf16
+// GEMM: a check that nothing falls back silently).
 struct RingTune { int bk, d, off; };
 const RingTune& ring_tune() {
   static const RingTune t = [] {

@@ -1,7 +1,7 @@
 """bf16 igemm (fwd / dgrad) and filter gradient on every distinct second-stage conv shape at
 N = 2000 ROIs.  Prints per call: time, TFLOP/s, the kernel instance dispatched.  Tuning hooks
-(C2D_TUNE=1 C2D_BF16_GLDS=0|1 C2D_IGEMM_CFG=2|3|4) select the variant; tools/_sweep_bf16.sh runs
-them side by side."""
+(C2D_TUNE=1 C2D_IGEMM_CFG=2|3|6|7 block tile, C2D_RING_BK / C2D_RING_D stage and ring depth) select the
+variant; tools/sweep_ring.sh runs them side by side."""
 import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cap2det_amd import hip_ops as ops

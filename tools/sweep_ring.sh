@@ -3,7 +3,6 @@
 # (run on the GPU box from the repo root; writes gpurun_out/ring_sweep/*.log).
 O=gpurun_out/ring_sweep; mkdir -p $O
 python tools/bench_conv_bf16.py igemm > $O/default.log 2>&1
-C2D_TUNE=1 C2D_RING=0 python tools/bench_conv_bf16.py igemm > $O/r2kernel.log 2>&1
 for cfg in ${RING_CFGS:-"64 2" "64 3" "32 2" "32 3" "32 4"}; do
   set -- $cfg
   C2D_TUNE=1 C2D_RING_BK=$1 C2D_RING_D=$2 python tools/bench_conv_bf16.py igemm > $O/bk$1_d$2.log 2>&1
