@@ -1974,7 +1974,8 @@ static int conv_fwd_impl(const float* x, int ldx, int xoff, const float* wt,
   a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = 0; a.nseg = 1;
   a.M = n * a.g.oh * a.g.ow; a.N = cout; a.K = cin; a.g.nimg = n; a.es = es;
   a.a_rows = (long long)n * ih * iw;
-  C2D_CHECK_ARG(kh * kw <= 64 && (es == 4 || (ldx % 8 == 0 && xoff % 8 == 0 && ldy % 4 == 0 && yoff % 4 == 0)));
+  // (bf16: 16-byte loads and stores = 8 elements)
+  C2D_CHECK_ARG(kh * kw <= 64 && (es == 4 || (ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0 && cout % 8 == 0)));
   C2D_CHECK_ARG(a.a_rows * ldx * 4 < (long long)OOB_OFFSET && (long long)kh * kw * cin * cout * 4 < (long long)OOB_OFFSET);
   return run_igemm(a, (hipStream_t)stream, ws);
 }
@@ -2013,6 +2014,7 @@ static int conv1x1_fwd_multi_impl(const void* x, int ldx, int xoff, int nout, co
     const C2dConvOut& o = outs[s];
     C2D_CHECK_ARG(o.wt && o.scale && o.shift && o.dst && o.cout > 0 && o.cout % 4 == 0);
     C2D_CHECK_ARG(o.ld_dst % 4 == 0 && o.off_dst % 4 == 0);
+    C2D_CHECK_ARG(es == 4 || (o.cout % 8 == 0 && o.ld_dst % 8 == 0 && o.off_dst % 8 == 0));
     const char* w = (const char*)o.wt;
     if (!base || w < base) base = w;
     if (!top || w + (long long)o.cout * cin * es > top) top = w + (long long)o.cout * cin * es;
@@ -2091,7 +2093,7 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate; a.nseg = 1;
   a.N = cin; a.K = cout; a.g.nimg = n; a.es = es;
   a.a_rows = (long long)n * a.g.oh * a.g.ow;
-  C2D_CHECK_ARG(kh * kw <= 64 && (es == 4 || (ldc % 8 == 0 && coff % 8 == 0)));
+  C2D_CHECK_ARG(kh * kw <= 64 && (es == 4 || (ldc % 8 == 0 && coff % 8 == 0 && lddx % 8 == 0 && dxoff % 8 == 0 && cin % 8 == 0)));
   C2D_CHECK_ARG(a.a_rows * ldc * 4 < (long long)OOB_OFFSET && (long long)kh * kw * cin * cout * 4 < (long long)OOB_OFFSET);
   int blocks = 0;
   if (fb) {
@@ -2232,6 +2234,7 @@ static int dgrad_multi_impl(int nseg, const float* const* dcs, const int* ldcs,
   a.a_rows = rows;
   a.nseg = nseg; a.es = es;
   for (int i = 0; i < nseg && es == 2; ++i) C2D_CHECK_ARG(ldcs[i] % 8 == 0 && coffs[i] % 8 == 0);
+  C2D_CHECK_ARG(es == 4 || (cin % 8 == 0 && lddx % 8 == 0 && dxoff % 8 == 0));
   a.A = dcs[0]; a.lda = ldcs[0]; a.a_off = coffs[0]; a.Bt = ws[0]; a.K = couts[0];
   a.C = dx; a.ldc = lddx; a.c_off = dxoff;
   a.scale = nullptr; a.shift = nullptr; a.relu = 0; a.accumulate = accumulate;

@@ -68,7 +68,7 @@ void igemm_ring_kernel(IgemmArgs a) {
   constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
   constexpr int RING_BYTES = D * (A_BYTES + B_BYTES);
   // (the epilogue stages 16-row half strips of every wave through the same memory)
-  constexpr int EPI_BYTES = WM * WN * 16 * (NT * 32 + 4) * 4;
+  constexpr int EPI_BYTES = WM * WN * 16 * (NT * 32 + 4) * 4 + (BM + 3 * BN) * 4;   // (+ its row / column tables)
   constexpr int LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
   static_assert(BM % ROWS_PER_PASS == 0 && BN % (1024 / RB) == 0, "tile vs block size");
   static_assert(D >= 2 && D <= 6 && (D - 2) * PER <= 63, "ring depth vs the 6-bit vmcnt");
@@ -82,6 +82,11 @@ void igemm_ring_kernel(IgemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
+#ifdef C2D_RING_TRACE
+  // diagnostic build only (tools/trace_ring.py): per-block phase stamps of wave 0
+  const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+  unsigned long long tr_wait = 0, tr_issue = 0;
+#endif
   // DMA: this lane fetches the chunk that belongs at LDS position tid % CPR of its row
   const int lrow = tid / CPR;                                       // row inside a pass
   const int lswz = CPR == 8 ? (lrow >> 1) & 7 : (lrow >> 2) & 3;    // (pass rows are multiples of 16)
@@ -261,7 +266,13 @@ void igemm_ring_kernel(IgemmArgs a) {
 
   int slot = 0;                          // ring slot of stage `it`
   int slot_in = D - 1;                   // ring slot the stage issued in iteration `it` goes to
+#ifdef C2D_RING_TRACE
+  const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+#endif
   for (int it = 0; it < cnt; ++it) {
+#ifdef C2D_RING_TRACE
+    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
     // Stage `it` has landed: a wave's DMA pieces retire in order, so "at most the pieces of the
     // `ahead` newest stages outstanding" says this wave's pieces of stage `it` are done;
     // everybody's: the barrier.  The barrier also says every wave is done reading the buffer of
@@ -281,7 +292,11 @@ void igemm_ring_kernel(IgemmArgs a) {
       else wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
-    const bool more = it + D - 1 < cnt;
+#ifdef C2D_RING_TRACE
+    const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+    tr_wait += tw1 - tw0;
+#endif
+    const bool more = it + D - 1 < cnt && !(a.dbg & 64);
     if (more) C2D_ADVANCE();
     const unsigned tvq = slot < 4 ? tvq_lo >> (8 * (slot & 3)) : tvq_hi >> (8 * (slot & 3));
     const unsigned onbits = (a.dbg & 4) ? 0u : __builtin_amdgcn_readfirstlane(row_bits & tvq);
@@ -309,6 +324,9 @@ void igemm_ring_kernel(IgemmArgs a) {
       for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
       C2D_NOTE_TV(slot_in)
     }
+#ifdef C2D_RING_TRACE
+    tr_issue += __builtin_amdgcn_s_memtime() - tw1;
+#endif
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -342,105 +360,277 @@ void igemm_ring_kernel(IgemmArgs a) {
 #undef C2D_NOTE_TV
 #undef C2D_ISSUE_ALL
 #undef C2D_ADVANCE
+#ifdef C2D_RING_TRACE
+  const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();     // every wave is done with the stage buffers: the epilogue reuses them
+#ifdef C2D_RING_TRACE
+  const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+  unsigned long long te2 = te1, te3 = te1;
+#endif
   if (a.dbg & 8) return;
 
-  // Epilogue: 32-row strips transposed through a per-wave LDS slice so that the global stores
-  // are 8 B per lane (4 bf16) on contiguous row segments.
+  // Epilogue: every wave transposes its 32-row strips through a private LDS slice so that a lane
+  // stores 16 B (8 bf16 / 4 fp32) of ONE output row, neighbouring lanes neighbouring columns.
   constexpr int SCOLS = NT * 32;
   constexpr int SSTR = SCOLS + 4;
-  // (wide wave tiles: the 32-row strip goes through the staging slice as two halves of 16 rows)
-  constexpr int HALVES = WM * WN * 32 * SSTR * 4 <= LDS_BYTES ? 1 : 2;
-  constexpr int HROWS = 32 / HALVES;
-  static_assert(WM * WN * HROWS * SSTR * 4 <= LDS_BYTES, "epilogue staging exceeds LDS");
-  float* stage = reinterpret_cast<float*>(smem) + wave * (HROWS * SSTR);
-  constexpr int C4 = SCOLS / 4;
-  constexpr int RPP = 64 / C4;
-  static_assert(HROWS % RPP == 0, "epilogue passes vs strip rows");
-  const int ec4 = lane % C4, er = lane / C4;
-  const bool lane_on = er < RPP;                // (C4 does not divide 64: the last lanes idle)
-  const int ncol = n0 + wn * SCOLS + ec4 * 4;
-  f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
-  const bool ncol_ok = ncol < a.N && lane_on;
-  if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
-  if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
-  // several convolutions in one GEMM: this lane's four columns belong to one of them
-  float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol, orelu = a.relu;
-  if (MODE == 0 && a.mo_n && ncol_ok) {
-    const MoOut o = mo_output(a, ncol);
-    oC = o.C; oldc = o.ldc; ocoff = o.coff + (ncol - o.lo); orelu = o.relu;
-    esc = *reinterpret_cast<const f32x4*>(o.scale + (ncol - o.lo));
-    esh = *reinterpret_cast<const f32x4*>(o.shift + (ncol - o.lo));
-  }
-  // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
-  const bool fused = MODE == 1 && a.fy != nullptr;
-  f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
-  bool fpass = false;      // columns of a pooling branch: plain gradient
-  if (fused && ncol_ok) fpass = fused_bn_params(a, ncol, fsc, fbe, fig);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int h = 0; h < HALVES; ++h) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int rr = 0; rr < 16 / HALVES; ++rr) {
-          const int r = h * (16 / HALVES) + rr;
-          // accumulator register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh of the
-          // strip, i.e. row (rr & 3) + 8 * (rr >> 2) + 4 * lh of half h
-          stage[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
-        }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int pass = 0; pass < HROWS / RPP; ++pass) {
-        const int row = pass * RPP + (lane_on ? er : 0);
-        const int m = m0 + (wm * MT + i) * 32 + h * HROWS + row;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
-        bool row_ok = m < a.M;
-        int drow = m;
-        if (PM || (MODE == 1 && a.g.sub > 1)) {
-          const RowPos p = decompose<PM>(m, a.M, a.g);
-          row_ok = p.valid;
-          drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
-                           : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
-                                 p.x * a.g.sub + a.g.x0;
-        }
-        if (row_ok && ncol_ok) {
-          v = v * esc + esh;
-          if (orelu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  constexpr int FHALVES = WM * WN * 32 * SSTR * 4 <= LDS_BYTES ? 1 : 2;
+  if (MODE == 1 && a.fy != nullptr) {
+    // Fused BN/ReLU backward of the producer layer (see IgemmArgs::fy; an option of bf16
+    // networks): it sums over the rows per column, so every lane keeps FOUR fixed columns and a
+    // pass covers 64 / (SCOLS / 4) rows.
+    // (wide wave tiles: the 32-row strip goes through the staging slice as two halves of 16 rows)
+    constexpr int HALVES = FHALVES;
+    constexpr int HROWS = 32 / HALVES;
+    static_assert(WM * WN * HROWS * SSTR * 4 <= LDS_BYTES, "epilogue staging exceeds LDS");
+    float* stage = reinterpret_cast<float*>(smem) + wave * (HROWS * SSTR);
+    constexpr int C4 = SCOLS / 4;
+    constexpr int RPP = 64 / C4;
+    static_assert(HROWS % RPP == 0, "epilogue passes vs strip rows");
+    const int ec4 = lane % C4, er = lane / C4;
+    const bool lane_on = er < RPP;                // (C4 does not divide 64: the last lanes idle)
+    const int ncol = n0 + wn * SCOLS + ec4 * 4;
+    f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
+    const bool ncol_ok = ncol < a.N && lane_on;
+    if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
+    if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
+    // several convolutions in one GEMM: this lane's four columns belong to one of them
+    float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol, orelu = a.relu;
+    if (MODE == 0 && a.mo_n && ncol_ok) {
+      const MoOut o = mo_output(a, ncol);
+      oC = o.C; oldc = o.ldc; ocoff = o.coff + (ncol - o.lo); orelu = o.relu;
+      esc = *reinterpret_cast<const f32x4*>(o.scale + (ncol - o.lo));
+      esh = *reinterpret_cast<const f32x4*>(o.shift + (ncol - o.lo));
+    }
+    // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
+    const bool fused = MODE == 1 && a.fy != nullptr;
+    f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
+    bool fpass = false;      // columns of a pooling branch: plain gradient
+    if (fused && ncol_ok) fpass = fused_bn_params(a, ncol, fsc, fbe, fig);
+  #pragma unroll
+    for (int i = 0; i < MT; ++i) {
+  #pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+  #pragma unroll
+        for (int j = 0; j < NT; ++j)
+  #pragma unroll
+          for (int rr = 0; rr < 16 / HALVES; ++rr) {
+            const int r = h * (16 / HALVES) + rr;
+            // accumulator register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh of the
+            // strip, i.e. row (rr & 3) + 8 * (rr >> 2) + 4 * lh of half h
+            stage[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
           }
-          if constexpr (ES == 2) {
-            bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
-                                                    (size_t)drow * oldc + ocoff);
-            if (a.accumulate) {
-              const bf16x4 o = *dst;
-              v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+  #pragma unroll
+        for (int pass = 0; pass < HROWS / RPP; ++pass) {
+          const int row = pass * RPP + (lane_on ? er : 0);
+          const int m = m0 + (wm * MT + i) * 32 + h * HROWS + row;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
+          bool row_ok = m < a.M;
+          int drow = m;
+          if (PM || (MODE == 1 && a.g.sub > 1)) {
+            const RowPos p = decompose<PM>(m, a.M, a.g);
+            row_ok = p.valid;
+            drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
+                             : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
+                                   p.x * a.g.sub + a.g.x0;
+          }
+          if (row_ok && ncol_ok) {
+            v = v * esc + esh;
+            if (orelu) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            if (fused && !fpass)
-              v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
-                                fig, fsb, fsg);
-            bf16x4 o;
-            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-            *dst = o;
-          } else {
-            f32x4* dst = reinterpret_cast<f32x4*>(oC + (size_t)drow * oldc + ocoff);
-            if (a.accumulate) v += *dst;
-            if (fused && !fpass)
-              v = fused_bn_item(v, load_act4<4>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
-                                fig, fsb, fsg);
-            *dst = v;
+            if constexpr (ES == 2) {
+              bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
+                                                      (size_t)drow * oldc + ocoff);
+              if (a.accumulate) {
+                const bf16x4 o = *dst;
+                v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+              }
+              if (fused && !fpass)
+                v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
+                                  fig, fsb, fsg);
+              bf16x4 o;
+              o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+              *dst = o;
+            } else {
+              f32x4* dst = reinterpret_cast<f32x4*>(oC + (size_t)drow * oldc + ocoff);
+              if (a.accumulate) v += *dst;
+              if (fused && !fpass)
+                v = fused_bn_item(v, load_act4<4>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
+                                  fig, fsb, fsg);
+              *dst = v;
+            }
           }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (fused)      // (block-uniform)
+      fused_bn_finish<WM, WN, SCOLS, RPP>(reinterpret_cast<float*>(smem), nullptr, a.fpart,
+                                          a.fpart_row0, a.N, fsb, fsg, tid, wave, ec4, er, lane_on,
+                                          n0, mt);
+  } else {
+    // Round 3 (tools/trace_ring.py): the passes above cost 400 - 600 cycles each — per pass a
+    // row decomposition (two divisions for pixel-major rows), the routing of a multi-output
+    // launch from memory, 4 elements per lane — and were a sixth to a third of a launch.  Here
+    // the per-row and per-column facts are computed once per block into LDS tables and a pass
+    // handles 16 B per lane of a flat (row, 16-byte chunk) index, so no lane idles either.
+    constexpr int CW = 16 / ES;                    // columns per lane and store
+    constexpr int CPRW = SCOLS / CW;               // chunks per strip row
+    constexpr int TAB_BYTES = (BM + 3 * BN) * 4;
+    constexpr int HALVES = WM * WN * 32 * SSTR * 4 + TAB_BYTES <= LDS_BYTES ? 1 : 2;
+    constexpr int HROWS = 32 / HALVES;
+    constexpr int STAGE_BYTES = WM * WN * HROWS * SSTR * 4;
+    static_assert(STAGE_BYTES + TAB_BYTES <= LDS_BYTES, "epilogue staging exceeds LDS");
+    constexpr int NPASS = HROWS * CPRW / 64;
+    static_assert(HROWS * CPRW % 64 == 0, "epilogue chunks vs wave size");
+    constexpr int GP = NPASS <= 8 ? NPASS : NPASS / 2;   // passes whose old values are held at once
+    static_assert(NPASS % GP == 0 && GP <= 8, "epilogue pass groups");
+    float* stage = reinterpret_cast<float*>(smem) + wave * (HROWS * SSTR);
+    int* const drow_tab = reinterpret_cast<int*>(smem + STAGE_BYTES);   // output row of tile row r, or -1
+    float* const tab_sc = reinterpret_cast<float*>(drow_tab + BM);      // BN scale / shift of column c,
+    float* const tab_sh = tab_sc + BN;                                  // and the lower bound of its
+    float* const tab_lb = tab_sh + BN;                                  // activation (0 = ReLU, -inf)
+    const bool has_bn = a.scale || a.shift || a.relu || a.mo_n;         // (block-uniform)
+    for (int r = tid; r < BM; r += NTHREADS) {
+      const int m = m0 + r;
+      bool row_ok = m < a.M;
+      int drow = m;
+      if (PM || (MODE == 1 && a.g.sub > 1)) {
+        const RowPos p = decompose<PM>(m, a.M, a.g);
+        row_ok = p.valid;
+        drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
+                         : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw + p.x * a.g.sub + a.g.x0;
+      }
+      drow_tab[r] = row_ok ? drow : -1;
+    }
+    if (has_bn)
+      for (int c = tid; c < BN; c += NTHREADS) {
+        const int ncol = n0 + c;
+        float sc = 1.f, sh = 0.f;
+        int relu = a.relu;
+        if (ncol < a.N) {
+          if (MODE == 0 && a.mo_n) {
+            const MoOut o = mo_output(a, ncol);
+            sc = o.scale[ncol - o.lo]; sh = o.shift[ncol - o.lo]; relu = o.relu;
+          } else {
+            if (a.scale) sc = a.scale[ncol];
+            if (a.shift) sh = a.shift[ncol];
+          }
+        }
+        tab_sc[c] = sc; tab_sh[c] = sh; tab_lb[c] = relu ? 0.f : -__builtin_inff();
+      }
+    // (the tables' global loads are consumed by their LDS writes: no load is pending when the
+    //  first store is issued — on gfx9 stores count in vmcnt too, and a wait for a load placed
+    //  after a store would also wait for that store's acknowledgement)
+    __syncthreads();
+#ifdef C2D_RING_TRACE
+    te2 = __builtin_amdgcn_s_memtime();
+#endif
+    // where chunk `c` of strip (i, h) goes: nullptr = nowhere (row beyond M / padding, column beyond N)
+    const int mo_n = MODE == 0 ? a.mo_n : 0;
+    auto locate = [&](int i, int h, int c, int& row, int& lcol) -> char* {
+      row = c / CPRW;
+      lcol = wn * SCOLS + (c - row * CPRW) * CW;
+      const int ncol = n0 + lcol;
+      const int drow = drow_tab[(wm * MT + i) * 32 + h * HROWS + row];
+      if (drow < 0 || ncol >= a.N) return nullptr;
+      float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol;
+      if (mo_n) {      // several convolutions in one GEMM: the chunk belongs to one of them
+        oC = a.mo_C[0]; oldc = a.mo_ldc[0]; ocoff = a.mo_coff[0] + ncol;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const bool t = q + 1 < mo_n && ncol >= a.mo_end[q];
+          oC = t ? a.mo_C[q + 1] : oC; oldc = t ? a.mo_ldc[q + 1] : oldc;
+          ocoff = t ? a.mo_coff[q + 1] + ncol - a.mo_end[q] : ocoff;
         }
       }
-      __builtin_amdgcn_wave_barrier();
+      return reinterpret_cast<char*>(oC) + ((size_t)drow * oldc + ocoff) * ES;
+    };
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int rr = 0; rr < 16 / HALVES; ++rr) {
+            const int r = h * (16 / HALVES) + rr;
+            // accumulator register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh of the
+            // strip, i.e. row (rr & 3) + 8 * (rr >> 2) + 4 * lh of half h
+            stage[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
+          }
+#pragma unroll
+        for (int pg = 0; pg < NPASS / GP; ++pg) {
+          f32x4 oldv[GP];
+          if (a.accumulate) {     // the old values of GP passes in flight together, ONE wait
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+              int row, lcol;
+              const char* src = locate(i, h, (pg * GP + q) * 64 + lane, row, lcol);
+              if (src) oldv[q] = *reinterpret_cast<const f32x4*>(src);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+          }
+          if (pg == 0) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // the strip is in LDS
+            __builtin_amdgcn_wave_barrier();
+          }
+#pragma unroll
+          for (int q = 0; q < GP; ++q) {
+            int row, lcol;
+            char* dst = locate(i, h, (pg * GP + q) * 64 + lane, row, lcol);
+            float v[CW];
+#pragma unroll
+            for (int e = 0; e < CW; e += 4)
+              *reinterpret_cast<f32x4*>(&v[e]) = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + (lcol - wn * SCOLS) + e]);
+            if (has_bn) {
+#pragma unroll
+              for (int e = 0; e < CW; e += 4) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(&tab_sc[lcol + e]);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(&tab_sh[lcol + e]);
+                const f32x4 lb = *reinterpret_cast<const f32x4*>(&tab_lb[lcol + e]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[e + u] = fmaxf(v[e + u] * sc[u] + sh[u], lb[u]);
+              }
+            }
+            if (dst) {
+              if constexpr (ES == 2) {
+                if (a.accumulate) {
+                  const bf16x8 o = __builtin_bit_cast(bf16x8, oldv[q]);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x8*>(dst) = o;
+              } else {
+                f32x4 o = {v[0], v[1], v[2], v[3]};
+                if (a.accumulate) o += oldv[q];
+                *reinterpret_cast<f32x4*>(dst) = o;
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifdef C2D_RING_TRACE
+        if (i == 0 && h == 0) te3 = __builtin_amdgcn_s_memtime();
+#endif
+      }
     }
   }
-  if (fused)      // (block-uniform)
-    fused_bn_finish<WM, WN, SCOLS, RPP>(reinterpret_cast<float*>(smem), nullptr, a.fpart,
-                                        a.fpart_row0, a.N, fsb, fsg, tid, wave, ec4, er, lane_on,
-                                        n0, mt);
+#ifdef C2D_RING_TRACE
+  if (a.trace && tid == 0) {
+    const unsigned long long tr3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* t = a.trace + (size_t)blockIdx.x * 16;
+    t[0] = tr0; t[1] = tr1 - tr0; t[2] = tr2 - tr1; t[3] = tr3 - tr2; t[4] = tr_wait; t[5] = tr_issue;
+    t[6] = (unsigned long long)cnt; t[7] = __builtin_amdgcn_s_memrealtime();
+    t[8] = te1 - tr2; t[9] = te2 - te1; t[10] = te3 - te2; t[11] = tr3 - te3;
+  }
+#endif
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -448,6 +638,9 @@ void igemm_ring_kernel(IgemmArgs a) {
 // -DC2D_RING_SWEEP build) force the stage depth / ring depth where an instance exists;
 // C2D_RING=0 makes every bf16 convolution fail with C2D_ERR_UNSUPPORTED (there is no second bf16
 // GEMM: a check that nothing falls back silently).
+#ifdef C2D_RING_TRACE
+unsigned long long* g_ring_trace = nullptr;
+#endif
 struct RingTune { int bk, d, off; };
 const RingTune& ring_tune() {
   static const RingTune t = [] {
@@ -473,6 +666,9 @@ int launch_one(IgemmArgs a, hipStream_t s) {
   }
   static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
   a.dbg = dbg_env;
+#ifdef C2D_RING_TRACE
+  a.trace = g_ring_trace;
+#endif
   dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d>"
                        : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d>",
                     MODE, WM, WN, MT, NT, BKT, D, ES);
@@ -852,3 +1048,13 @@ int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool 
 }
 
 }  // namespace c2d_ig
+
+#ifdef C2D_RING_TRACE
+// Diagnostic build only (make EXTRA_CXXFLAGS=-DC2D_RING_TRACE; tools/trace_ring.py): 16 x u64 per
+// block — start, prologue, K loop, epilogue, time at wait + barrier, time issuing DMA (cycles of
+// wave 0), stages, s_memrealtime at the end.
+extern "C" int c2d_debug_set_ring_trace(void* buf) {
+  c2d_ig::g_ring_trace = (unsigned long long*)buf;
+  return C2D_OK;
+}
+#endif

@@ -153,7 +153,9 @@ int c2d_conv1x1_dgrad_multi_ws(int nseg, const float* const* dcs, const int* ldc
 
 /* bf16 storage / fp32 accumulate forms of the three convolution calls (BASELINE.json configs[2]
  * and [4]): activations, weights and outputs are bf16 (uint16 storage; leading dimensions and
- * offsets in ELEMENTS, multiples of 8), BatchNorm scale / shift stay fp32, products are
+ * offsets in ELEMENTS, multiples of 8, and so are the channel counts of the written tensor —
+ * cout forward, cin for the input gradients: every lane loads and stores 16 bytes), BatchNorm
+ * scale / shift stay fp32, products are
  * accumulated in fp32 on v_mfma_f32_32x32x16_bf16 and rounded to bf16 (nearest even) once, in
  * the epilogue.  The reference has no reduced-precision mode; tolerances are stated in
  * tests/test_gpu_bf16.py. */
@@ -273,7 +275,7 @@ typedef struct C2dConvOut {
   const float* shift;
   void* dst;
   int ld_dst, off_dst;
-  int cout;             /* multiple of 4 */
+  int cout;             /* multiple of 4 (bf16: of 8, as ld_dst and off_dst) */
   int relu;
 } C2dConvOut;
 int c2d_conv1x1_fwd_multi(const float* x, int ldx, int xoff, int nout, const C2dConvOut* outs,
