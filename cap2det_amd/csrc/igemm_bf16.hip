@@ -20,6 +20,7 @@
 #include "igemm_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace c2d_ig {
 namespace {
@@ -34,6 +35,11 @@ struct SlabCursor {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_ring(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
 }
 
 constexpr int ring_blocks_per_cu(int lds_bytes) {
@@ -264,12 +270,15 @@ void igemm_ring_kernel(IgemmArgs a) {
     brow_b[j] = r * RB; bsw[j] = CPR == 8 ? (r >> 1) & 7 : (r >> 2) & 3;
   }
 
-  int slot = 0;                          // ring slot of stage `it`
-  int slot_in = D - 1;                   // ring slot the stage issued in iteration `it` goes to
-#ifdef C2D_RING_TRACE
-  const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
-#endif
-  for (int it = 0; it < cnt; ++it) {
+  // One stage of the K loop.  `slot` / `slot_in` (ring slot of stage `it` / of the stage issued
+  // in this iteration) are plain ints in the general loop and compile-time constants in the
+  // steady-state loop below, which also knows that a further stage is issued and how many are in
+  // flight: round 3's stamps (tools/trace_ring.py) showed the ≈75 scalar / address
+  // instructions of a general stage — ring-slot arithmetic, the `ahead` / `more` cases, tuning
+  // bits — to cost as much as its MFMAs once sixteen waves share the CU's scalar issue.
+  typedef typename std::conditional<ES == 2, bf16x8, f32x4>::type frag_t;
+  auto stage = [&](auto slot, auto slot_in, auto steady_c, int it) __attribute__((always_inline)) {
+    constexpr bool STEADY = decltype(steady_c)::value;
 #ifdef C2D_RING_TRACE
     const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -277,80 +286,147 @@ void igemm_ring_kernel(IgemmArgs a) {
     // `ahead` newest stages outstanding" says this wave's pieces of stage `it` are done;
     // everybody's: the barrier.  The barrier also says every wave is done reading the buffer of
     // stage it - 1, which the pieces issued below overwrite.
-    const int ahead = min(cnt, it + D - 1) - it - 1;      // stages issued beyond `it` (block-uniform)
-    if (b_last) {
-      if (D > 5 && ahead >= 4) wait_vmcnt<(D > 5 ? 4 : 0) * PER>();
-      else if (D > 4 && ahead >= 3) wait_vmcnt<(D > 4 ? 3 : 0) * PER>();
-      else if (D > 3 && ahead >= 2) wait_vmcnt<(D > 3 ? 2 : 0) * PER>();
-      else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * PER>();
-      else wait_vmcnt<0>();
+    if constexpr (STEADY) {
+      if (b_last) wait_vmcnt<(D - 2) * PER>();
+      else wait_vmcnt<(D - 2) * (PER - 1)>();
     } else {
-      if (D > 5 && ahead >= 4) wait_vmcnt<(D > 5 ? 4 : 0) * (PER - 1)>();
-      else if (D > 4 && ahead >= 3) wait_vmcnt<(D > 4 ? 3 : 0) * (PER - 1)>();
-      else if (D > 3 && ahead >= 2) wait_vmcnt<(D > 3 ? 2 : 0) * (PER - 1)>();
-      else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * (PER - 1)>();
-      else wait_vmcnt<0>();
+      const int ahead = min(cnt, it + D - 1) - it - 1;      // stages issued beyond `it` (block-uniform)
+      if (b_last) {
+        if (D > 5 && ahead >= 4) wait_vmcnt<(D > 5 ? 4 : 0) * PER>();
+        else if (D > 4 && ahead >= 3) wait_vmcnt<(D > 4 ? 3 : 0) * PER>();
+        else if (D > 3 && ahead >= 2) wait_vmcnt<(D > 3 ? 2 : 0) * PER>();
+        else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * PER>();
+        else wait_vmcnt<0>();
+      } else {
+        if (D > 5 && ahead >= 4) wait_vmcnt<(D > 5 ? 4 : 0) * (PER - 1)>();
+        else if (D > 4 && ahead >= 3) wait_vmcnt<(D > 4 ? 3 : 0) * (PER - 1)>();
+        else if (D > 3 && ahead >= 2) wait_vmcnt<(D > 3 ? 2 : 0) * (PER - 1)>();
+        else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * (PER - 1)>();
+        else wait_vmcnt<0>();
+      }
     }
     __builtin_amdgcn_s_barrier();
 #ifdef C2D_RING_TRACE
     const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
     tr_wait += tw1 - tw0;
 #endif
-    const bool more = it + D - 1 < cnt && !(a.dbg & 64);
+    const bool more = STEADY || (it + D - 1 < cnt && !(a.dbg & 64));
     if (more) C2D_ADVANCE();
-    const unsigned tvq = slot < 4 ? tvq_lo >> (8 * (slot & 3)) : tvq_hi >> (8 * (slot & 3));
-    const unsigned onbits = (a.dbg & 4) ? 0u : __builtin_amdgcn_readfirstlane(row_bits & tvq);
+    // (row-major launches compute every 32-row tile: rows beyond M are zeros and are not stored)
+    unsigned onbits = ~0u;
+    if (PM || !STEADY) {
+      const unsigned tvq = slot < 4 ? tvq_lo >> (8 * (slot & 3)) : tvq_hi >> (8 * (slot & 3));
+      onbits = (!STEADY && (a.dbg & 4)) ? 0u : __builtin_amdgcn_readfirstlane(row_bits & tvq);
+    }
     const char* const bufa = smem + slot * A_BYTES;
     const char* const bufb = smemB + slot * B_BYTES;
     // B fragments of the whole stage, then the DMA pieces of the stage D - 1 ahead (behind the
     // fragment reads, so that their issue overlaps the LDS latency), then, per 32-row tile of this
-    // wave (one scalar branch each: a tile whose rows are SAME padding for this tap, or lie beyond
-    // M, costs nothing) its A fragments and KS x NT MFMAs.
+    // wave (pixel-major: one scalar branch each — a tile whose rows are SAME padding for this tap
+    // costs nothing) its A fragments and KS x NT MFMAs.
     // (fp32: lane half lh takes the chunks lh * KS .. of a row — a permutation of the k order common
     //  to both operands — and feeds four v_mfma_f32_32x32x2_f32 from every 16-byte chunk)
-    typedef typename std::conditional<ES == 2, bf16x8, f32x4>::type frag_t;
-    frag_t bf[NT][KS];
+    // (one-row-tile waves of many column tiles: the fragments of ONE k-step at a time — those of a
+    //  whole 64-deep stage, 12..24 B fragments, do not fit beside the accumulators at four waves
+    //  per SIMD)
+    constexpr bool PER_STEP = MT == 1 && NT * KS > 8;
+    if constexpr (PER_STEP) {
+      if (more) {
 #pragma unroll
-    for (int st = 0; st < KS; ++st)
+        for (int i = 0; i < B_LOADS; ++i)
+          if (i + 1 < B_LOADS || b_last) { C2D_PIECE_B(slot_in, i) }
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        bf[j][st] = *reinterpret_cast<const frag_t*>(
-            bufb + brow_b[j] + (((ES == 2 ? 2 * st + lh : lh * KS + st) ^ bsw[j]) << 4));
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
-        if (i + 1 < B_LOADS || b_last) { C2D_PIECE_B(slot_in, i) }
-#pragma unroll
-      for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
-      C2D_NOTE_TV(slot_in)
-    }
+        for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
+        C2D_NOTE_TV(slot_in)
+      }
 #ifdef C2D_RING_TRACE
-    tr_issue += __builtin_amdgcn_s_memtime() - tw1;
+      tr_issue += __builtin_amdgcn_s_memtime() - tw1;
 #endif
-    __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(1);
+      if ((STEADY && !PM) || (onbits & 1u)) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if ((onbits >> i) & 1u) {
-        frag_t af[KS];
+        for (int st = 0; st < KS; ++st) {
+          const int ch = ES == 2 ? 2 * st + lh : lh * KS + st;
+          const frag_t afc = *reinterpret_cast<const frag_t*>(bufa + arow_b[0] + ((ch ^ asw[0]) << 4));
+          frag_t bfc[NT];
 #pragma unroll
-        for (int st = 0; st < KS; ++st)
-          af[st] = *reinterpret_cast<const frag_t*>(
-              bufa + arow_b[i] + (((ES == 2 ? 2 * st + lh : lh * KS + st) ^ asw[i]) << 4));
-#pragma unroll
-        for (int st = 0; st < KS; ++st)
+          for (int j = 0; j < NT; ++j)
+            bfc[j] = *reinterpret_cast<const frag_t*>(bufb + brow_b[j] + ((ch ^ bsw[j]) << 4));
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             if constexpr (ES == 2) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
+              acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc, bfc[j], acc[0][j], 0, 0, 0);
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st][e], bf[j][st][e], acc[i][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(afc[e], bfc[j][e], acc[0][j], 0, 0, 0);
             }
           }
+        }
+      }
+    } else {
+      frag_t bf[NT][KS];
+  #pragma unroll
+      for (int st = 0; st < KS; ++st)
+  #pragma unroll
+        for (int j = 0; j < NT; ++j)
+          bf[j][st] = *reinterpret_cast<const frag_t*>(
+              bufb + brow_b[j] + (((ES == 2 ? 2 * st + lh : lh * KS + st) ^ bsw[j]) << 4));
+      if (more) {
+  #pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+          if (i + 1 < B_LOADS || b_last) { C2D_PIECE_B(slot_in, i) }
+  #pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
+        C2D_NOTE_TV(slot_in)
+      }
+  #ifdef C2D_RING_TRACE
+      tr_issue += __builtin_amdgcn_s_memtime() - tw1;
+  #endif
+      __builtin_amdgcn_s_setprio(1);
+  #pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if ((STEADY && !PM) || ((onbits >> i) & 1u)) {
+          frag_t af[KS];
+  #pragma unroll
+          for (int st = 0; st < KS; ++st)
+            af[st] = *reinterpret_cast<const frag_t*>(
+                bufa + arow_b[i] + (((ES == 2 ? 2 * st + lh : lh * KS + st) ^ asw[i]) << 4));
+  #pragma unroll
+          for (int st = 0; st < KS; ++st)
+  #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              if constexpr (ES == 2) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st], bf[j][st], acc[i][j], 0, 0, 0);
+              } else {
+  #pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st][e], bf[j][st][e], acc[i][j], 0, 0, 0);
+              }
+            }
+        }
       }
     }
     __builtin_amdgcn_s_setprio(0);
+  };
+
+#ifdef C2D_RING_TRACE
+  const unsigned long long tr1 = __builtin_amdgcn_s_memtime();
+#endif
+  int it = 0;
+  // steady state, D stages per trip (the stage of a trip's position d sits in ring slot d): every
+  // stage of the trip issues a further one and has D - 2 newer ones in flight
+  if (a.dbg == 0)
+    for (; it + 2 * D - 2 < cnt; it += D)
+      static_for_ring(std::make_integer_sequence<int, D>{}, [&](auto d) __attribute__((always_inline)) {
+        stage(d, std::integral_constant<int, (decltype(d)::value + D - 1) % D>{}, std::true_type{},
+              it + decltype(d)::value);
+      });
+  // the last stages (and launches run with tuning bits): the general form
+  int slot = 0;                          // (`it` is a multiple of D here) ring slot of stage `it`
+  int slot_in = D - 1;                   // ring slot the stage issued in iteration `it` goes to
+  for (; it < cnt; ++it) {
+    stage(slot, slot_in, std::false_type{}, it);
     if (++slot == D) slot = 0;
     if (++slot_in == D) slot_in = 0;
   }
