@@ -122,6 +122,26 @@ class KernelTimer(object):
         "conv1x1_fwd_multi": lambda a: multi_bytes(a[4], a[5], [o.cout for o in a[3][0]], esize(a[0])),
     }
 
+    def small_rows(name, args):
+      """rows of the GEMM <= 16384: the one-tile-per-workgroup domain (conv_gemm.hip run_igemm)"""
+      try:
+        if name == "conv_fwd":
+          n, ih, iw, stride = args[9], args[10], args[11], args[16]
+        elif name == "conv_dgrad":
+          n, ih, iw, stride = args[7], args[8], args[9], args[14]
+          stride = 1                       # (rows of an input gradient = input pixels)
+        elif name == "conv_fwd_grouped":
+          return True
+        elif name == "conv1x1_fwd_multi":
+          return args[4] <= 16384
+        elif name == "conv1x1_dgrad_multi":
+          return args[8] <= 16384
+        else:
+          return False
+        return n * (-(-ih // stride)) * (-(-iw // stride)) <= 16384
+      except Exception:
+        return False
+
     def timed(fn, family, work_fn):
       def inner(*args, **kwargs):
         if not t.enabled:
@@ -140,7 +160,12 @@ class KernelTimer(object):
           nbytes = BYTES[fn.__name__](args) if fn.__name__ in BYTES else 0.0
         except Exception:
           nbytes = 0.0
-        t.records.append((family + ("_bf16" if low else ""), w, s, e, nbytes))
+        fam = family + ("_bf16" if low else "")
+        # the bf16 step's single-image first stage runs on its own kernel (igemm_small_kernel<*, 2>:
+        # one 32x32 tile per workgroup, launch-bound): its own family, not the ring kernel's
+        if fam == "igemm_nt_bf16" and small_rows(fn.__name__, args):
+          fam = "igemm_small_bf16"
+        t.records.append((fam, w, s, e, nbytes))
         t.shapes.append((fn.__name__, tuple(a for a in args if isinstance(a, (int, bool)))))
         return r
       return inner
@@ -284,8 +309,9 @@ def parse_args(argv=None):
   ap.add_argument("--proposals", type=int, default=None,
                   help="SECONDARY operating point: proposals per image (reference: max_num_proposals 500)")
   ap.add_argument("--dtype", choices=["fp32", "bf16"], default=None,
-                  help="override the config's precision: fp32 = exact fp32 everywhere; bf16 = ROI crop "
-                       "output and second stage in bf16 storage / fp32 accumulate")
+                  help="override the config's precision: fp32 = exact fp32 everywhere; bf16 = the "
+                       "convolution towers behind the stem (first stage, ROI crop output, second stage) "
+                       "in bf16 storage / fp32 accumulate")
   return ap.parse_args(argv)
 
 
@@ -518,7 +544,7 @@ def main(argv=None):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "fp32" else "bf16 storage (ROI crop output + second stage), f32 accumulate",
+        "dtype": "f32" if args.dtype == "fp32" else "bf16 storage (convolution towers behind the stem: first stage, ROI crop output, second stage), f32 accumulate",
         "data": "synthetic",
         "config": {"workload": "%s%s: Inception-V2, %d classes, label extractor %s inside the step, "
                                "OICR x3, Mixed_4e + second stage + heads trainable, %d image(s) %dx%dx3 "
@@ -625,8 +651,13 @@ def main(argv=None):
                            "wgrad3x3_bf16_kernel<*> (conv filter gradient, bf16 MFMA 32x32x16 through "
                            "ds_read_b64_tr_b16, split-K atomics)",
                            "wgrad_bf16", PEAK_BF16_MFMA_TFLOPS)
+        sm16 = mfma_family("igemm_small_bf16", "igemm_small_kernel<*, 2> + igemm_small_group_kernel<*, 2> + "
+                           "short igemm_ring_kernel launches (the single-image first stage behind the "
+                           "stem, one 32x32 tile per workgroup with K split over its waves: "
+                           "launch-latency-bound)", "igemm_small_bf16", PEAK_BF16_MFMA_TFLOPS)
         if ig16: result["roofline"] = ig16
         if wg16: result["roofline_wgrad"] = wg16
+        if sm16: result["roofline_first_stage"] = sm16
         if ig32: result["roofline_fp32_igemm"] = ig32
         if wg32: result["roofline_fp32_wgrad"] = wg32
       rc = summ.get("roi_crop_pool_fwd")

@@ -650,7 +650,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM == 4 ? 2 : 3) void igemm_sk_kernel
 // 16-B loads of its own row: no LDS, no barrier in the loop), the next slab is prefetched into a
 // second register set, and the 4 partial tiles are summed through LDS before the epilogue.
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+// ES = 2 (round 3): bf16 operands / output on v_mfma_f32_32x32x16_bf16 — the bf16 step's first
+// stage.  Lane (i, h) feeds its MFMA operand straight from memory as well: 16 bytes are the 8
+// elements k = 16 st + 8 h .. of its row, a slab is 64 elements of K (four MFMAs), and the MFMAs
+// are 1/16 of the fp32 form's time, so the K loop is a chain of load round trips: FOUR register
+// sets in flight instead of two.
+template <int MODE, int ES = 4>
 __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int tile) {
   __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
   const int tid = threadIdx.x;
@@ -660,7 +665,8 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
   const int m0 = (tile / a.n_tiles) * 32, n0 = (tile % a.n_tiles) * 32;
   const RowPos pos = decompose(m0 + li, a.M, a.g);
   const int ncol = min(n0 + li, a.N - 1);
-  const int kslabs = (a.K + 31) / 32;
+  constexpr int SLAB = ES == 2 ? 64 : 32;        // elements of K per slab
+  const int kslabs = (a.K + SLAB - 1) / SLAB;
   const int total = a.g.nky * a.g.nkx * kslabs;
   const int sbeg = (int)((long long)total * wave / 4), send = (int)((long long)total * (wave + 1) / 4);
   const size_t tap_stride = (size_t)a.N * a.K;
@@ -669,6 +675,53 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
+  if constexpr (ES == 2) {
+    constexpr int SETS = 4;
+    bf16x8 ga[SETS][4], gb[SETS][4];
+    unsigned okb[SETS];
+    const __bf16* const A16 = reinterpret_cast<const __bf16*>(a.A);
+    const __bf16* const B16 = reinterpret_cast<const __bf16*>(a.Bt);
+#define C2D_SMB_LOAD(SLABI, SET)                                                               \
+  {                                                                                            \
+    const int tp = (SLABI) / kslabs;                                                           \
+    const int kc = ((SLABI) - tp * kslabs) * 64 + lh * 8;                                      \
+    const int ty_ = tp / a.g.nkx, tx_ = tp - ty_ * a.g.nkx;                                    \
+    const int ky = a.g.ky0 + ty_ * a.g.kstep, kx = a.g.kx0 + tx_ * a.g.kstep;                  \
+    const int sr = src_row<MODE>(a.g, pos, ky, kx);                                            \
+    const __bf16* ap = A16 + (size_t)max(sr, 0) * a.lda + a.a_off;                             \
+    const __bf16* bp = B16 + (size_t)(ky * a.g.kw + kx) * tap_stride + (size_t)ncol * a.K;     \
+    okb[SET] = 0;                                                                              \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                            \
+      const int k = kc + 16 * v;                                                               \
+      const int kk = min(k, a.K - 8);                                                          \
+      okb[SET] |= ((sr >= 0 && k < a.K) ? 1u : 0u) << v;                                       \
+      ga[SET][v] = *reinterpret_cast<const bf16x8*>(ap + kk);                                  \
+      gb[SET][v] = *reinterpret_cast<const bf16x8*>(bp + kk);                                  \
+    }                                                                                          \
+  }
+#define C2D_SMB_MMA(SET)                                                                       \
+  {                                                                                            \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                            \
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                    \
+      const bf16x8 av = ((okb[SET] >> v) & 1u) ? ga[SET][v] : __builtin_bit_cast(bf16x8, z);   \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, gb[SET][v], acc, 0, 0, 0);             \
+    }                                                                                          \
+  }
+#pragma unroll
+    for (int q = 0; q < SETS - 1; ++q)
+      if (sbeg + q < send) C2D_SMB_LOAD(sbeg + q, q);
+    for (int sl = sbeg; sl < send; sl += SETS) {
+#pragma unroll
+      for (int q = 0; q < SETS; ++q) {
+        if (sl + q < send) {
+          if (sl + q + SETS - 1 < send) C2D_SMB_LOAD(sl + q + SETS - 1, (q + SETS - 1) % SETS);
+          C2D_SMB_MMA(q);
+        }
+      }
+    }
+#undef C2D_SMB_LOAD
+#undef C2D_SMB_MMA
+  } else {
   f32x4 fa[2][4], fb[2][4];
   unsigned okm[2] = {0u, 0u};
   // slab index -> (tap, kc)
@@ -713,6 +766,7 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
   }
 #undef C2D_SM_LOAD
 #undef C2D_SM_MMA
+  }
 
   // sum the 4 partial tiles; C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -741,15 +795,26 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
       const RowPos p = decompose(m, a.M, a.g);
       drow = (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw + p.x * a.g.sub + a.g.x0;
     }
-    f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + n);
-    if (a.accumulate) v += *dst;
-    *dst = v;
+    if constexpr (ES == 2) {
+      bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) + (size_t)drow * a.ldc + a.c_off + n);
+      if (a.accumulate) {
+        const bf16x4 o = *dst;
+        v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+      }
+      bf16x4 o;
+      o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+      *dst = o;
+    } else {
+      f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)drow * a.ldc + a.c_off + n);
+      if (a.accumulate) v += *dst;
+      *dst = v;
+    }
   }
 }
 
-template <int MODE>
+template <int MODE, int ES = 4>
 __global__ __launch_bounds__(256) void igemm_small_kernel(IgemmArgs a) {
-  igemm_small_body<MODE>(a, blockIdx.x);
+  igemm_small_body<MODE, ES>(a, blockIdx.x);
 }
 
 // Several INDEPENDENT small problems in one launch (the convolutions of one dependency level of
@@ -761,12 +826,12 @@ struct IgemmGroupArgs {
   int first[SMALL_GROUP_MAX + 1];   // first workgroup of problem p; first[num] = grid size
   int num;
 };
-template <int MODE>
+template <int MODE, int ES = 4>
 __global__ __launch_bounds__(256) void igemm_small_group_kernel(IgemmGroupArgs g) {
   int p = 0;
   for (int i = 1; i < g.num; ++i)
     if ((int)blockIdx.x >= g.first[i]) p = i;
-  igemm_small_body<MODE>(g.a[p], (int)blockIdx.x - g.first[p]);
+  igemm_small_body<MODE, ES>(g.a[p], (int)blockIdx.x - g.first[p]);
 }
 
 constexpr int WBK = 16;             // rows of M per slab (32: the 128x128 form spills, 5 % slower overall)
@@ -1812,6 +1877,7 @@ struct SmallCollect {
   IgemmGroupArgs args;
   int num;
   int mode;
+  int es;
 };
 static thread_local SmallCollect* g_collect = nullptr;
 
@@ -1884,21 +1950,29 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   }
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
-  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && a.es == 4 && !a.fy && !a.mo_n) {
+  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && !a.fy && !a.mo_n) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);
     b.n_tiles = c2d_ceil_div(a.N, 32);
     if (g_collect) {          // grouped launch being assembled (run_small_group)
-      if (g_collect->num < SMALL_GROUP_MAX && (g_collect->num == 0 || g_collect->mode == a.g.mode)) {
+      if (g_collect->num < SMALL_GROUP_MAX &&
+          (g_collect->num == 0 || (g_collect->mode == a.g.mode && g_collect->es == a.es))) {
         g_collect->args.a[g_collect->num++] = b;
         g_collect->mode = a.g.mode;
+        g_collect->es = a.es;
         return C2D_OK;
       }
       return C2D_ERR_UNSUPPORTED;
     }
     const dim3 grid(b.m_tiles * b.n_tiles), block(256);
-    dispatch_note("igemm_small_kernel<%d>", a.g.mode);
+    if (a.es == 2) {
+      dispatch_note("igemm_small_kernel<%d, 2>", a.g.mode);
+      if (a.g.mode == 0) hipLaunchKernelGGL((igemm_small_kernel<0, 2>), grid, block, 0, s, b);
+      else hipLaunchKernelGGL((igemm_small_kernel<1, 2>), grid, block, 0, s, b);
+      return c2d_launch_status();
+    }
+    dispatch_note("igemm_small_kernel<%d, 4>", a.g.mode);
     if (a.g.mode == 0) hipLaunchKernelGGL(igemm_small_kernel<0>, grid, block, 0, s, b);
     else hipLaunchKernelGGL(igemm_small_kernel<1>, grid, block, 0, s, b);
     return c2d_launch_status();
@@ -2320,37 +2394,43 @@ static int launch_small_group(SmallCollect& c, hipStream_t st) {
   }
   for (int p = c.num; p <= SMALL_GROUP_MAX; ++p) c.args.first[p] = first;
   c.args.num = c.num;
-  dispatch_note("igemm_small_group_kernel<%d>", c.mode);
+  if (c.es == 2) {
+    dispatch_note("igemm_small_group_kernel<%d, 2>", c.mode);
+    if (c.mode == 0) hipLaunchKernelGGL((igemm_small_group_kernel<0, 2>), dim3(first), dim3(256), 0, st, c.args);
+    else hipLaunchKernelGGL((igemm_small_group_kernel<1, 2>), dim3(first), dim3(256), 0, st, c.args);
+    return c2d_launch_status();
+  }
+  dispatch_note("igemm_small_group_kernel<%d, 4>", c.mode);
   if (c.mode == 0) hipLaunchKernelGGL(igemm_small_group_kernel<0>, dim3(first), dim3(256), 0, st, c.args);
   else hipLaunchKernelGGL(igemm_small_group_kernel<1>, dim3(first), dim3(256), 0, st, c.args);
   return c2d_launch_status();
 }
 
-static int conv_desc_run(const C2dConvDesc& d, int dgrad, void* stream) {
+static int conv_desc_run(const C2dConvDesc& d, int dgrad, void* stream, int es) {
   if (!dgrad)
     return conv_fwd_impl(d.src, d.ld_src, d.off_src, d.weights, d.scale, d.shift, d.dst, d.ld_dst,
                          d.off_dst, d.n, d.ih, d.iw, d.cin, d.cout, d.kh, d.kw, d.stride, d.flag,
-                         IgemmWs{nullptr, 0}, stream);
+                         IgemmWs{nullptr, 0}, stream, es);
   return conv_dgrad_impl(d.src, d.ld_src, d.off_src, d.weights, d.dst, d.ld_dst, d.off_dst, d.n,
                          d.ih, d.iw, d.cin, d.cout, d.kh, d.kw, d.stride, d.flag,
-                         IgemmWs{nullptr, 0}, stream);
+                         IgemmWs{nullptr, 0}, stream, es);
 }
 
-static int conv_grouped_impl(const C2dConvDesc* descs, int num, int dgrad, void* stream) {
+static int conv_grouped_impl(const C2dConvDesc* descs, int num, int dgrad, void* stream, int es = 4) {
   dispatch_reset();
   C2D_CHECK_ARG(descs && num >= 1 && num <= 64);
   // every problem of the group is "small" (run_igemm's one-tile-per-block domain): ONE launch;
   // otherwise (or more than SMALL_GROUP_MAX sub-problems) each convolution is launched on its own
   SmallCollect c;
-  c.num = 0; c.mode = 0;
+  c.num = 0; c.mode = 0; c.es = es;
   g_collect = &c;
   int rc = C2D_OK;
-  for (int i = 0; i < num && rc == C2D_OK; ++i) rc = conv_desc_run(descs[i], dgrad, stream);
+  for (int i = 0; i < num && rc == C2D_OK; ++i) rc = conv_desc_run(descs[i], dgrad, stream, es);
   g_collect = nullptr;
   if (rc == C2D_OK) return launch_small_group(c, (hipStream_t)stream);
   if (rc != C2D_ERR_UNSUPPORTED) return rc;
   for (int i = 0; i < num; ++i) {
-    rc = conv_desc_run(descs[i], dgrad, stream);
+    rc = conv_desc_run(descs[i], dgrad, stream, es);
     if (rc) return rc;
   }
   return C2D_OK;
@@ -2362,6 +2442,14 @@ extern "C" int c2d_conv_fwd_grouped(const C2dConvDesc* descs, int num, void* str
 
 extern "C" int c2d_conv_dgrad_grouped(const C2dConvDesc* descs, int num, void* stream) {
   return conv_grouped_impl(descs, num, 1, stream);
+}
+
+extern "C" int c2d_conv_fwd_grouped_bf16(const C2dConvDesc* descs, int num, void* stream) {
+  return conv_grouped_impl(descs, num, 0, stream, 2);
+}
+
+extern "C" int c2d_conv_dgrad_grouped_bf16(const C2dConvDesc* descs, int num, void* stream) {
+  return conv_grouped_impl(descs, num, 1, stream, 2);
 }
 
 // ---- bf16 storage / fp32 accumulate forms (BASELINE configs[2] / [4]) -------------------------

@@ -1258,6 +1258,23 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void cast_f32_kernel(const c2d_bf16* __restrict__ src,
+                                                       float* __restrict__ dst, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x)
+    c2d_st4(dst + i * 4, c2d_ld4(src + i * 4));
+}
+}  // namespace
+
+extern "C" int c2d_cast_f32(const void* src, float* dst, long long n, void* stream) {
+  C2D_CHECK_ARG(src && dst && n >= 0 && n % 4 == 0);
+  if (n == 0) return C2D_OK;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const c2d_bf16*)src, dst, n / 4);
+  return c2d_launch_status();
+}
+
 extern "C" int c2d_cast_bf16(const float* src, void* dst, long long n, void* stream) {
   C2D_CHECK_ARG(src && dst && n >= 0 && n % 4 == 0);
   if (n == 0) return C2D_OK;

@@ -153,19 +153,20 @@ def conv_group(calls):
   flops = 0.0
   for d, c in zip(arr, calls):
     (x, ldx, xoff, wt, scale, shift, y, ldy, yoff, n, ih, iw, cin, cout, kh, kw, stride, relu) = c
-    assert x.dtype == torch.float32 and y.dtype == torch.float32
+    assert x.dtype == y.dtype == wt.dtype and x.dtype == calls[0][0].dtype
     d.src, d.ld_src, d.off_src, d.weights = _p(x), ldx, xoff, _p(wt)
     d.scale, d.shift = _p(scale), _p(shift)
     d.dst, d.ld_dst, d.off_dst = _p(y), ldy, yoff
     d.n, d.ih, d.iw, d.cin, d.cout, d.kh, d.kw, d.stride, d.flag = (n, ih, iw, cin, cout, kh, kw,
                                                                     stride, int(relu))
     flops += 2.0 * n * (-(-ih // stride)) * (-(-iw // stride)) * cin * cout * kh * kw
-  return arr, len(calls), flops
+  return arr, len(calls), flops, calls[0][0].dtype
 
 
 def conv_fwd_grouped(group):
   """Independent convolutions of one dependency level in one call (c2d_conv_fwd_grouped)."""
-  _lib.call("c2d_conv_fwd_grouped", ctypes.cast(group[0], ctypes.c_void_p), group[1], _stream())
+  fn = "c2d_conv_fwd_grouped_bf16" if group[3] == torch.bfloat16 else "c2d_conv_fwd_grouped"
+  _lib.call(fn, ctypes.cast(group[0], ctypes.c_void_p), group[1], _stream())
 
 
 def conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
@@ -357,6 +358,11 @@ def bn_partials_reduce_batched(desc, num, total_chunks, ws, grads):
 def cast_bf16(src, dst):
   assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
   _lib.call("c2d_cast_bf16", _p(src), _p(dst), src.numel(), _stream())
+
+
+def cast_f32(src, dst):
+  assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src.numel() == dst.numel()
+  _lib.call("c2d_cast_f32", _p(src), _p(dst), src.numel(), _stream())
 
 
 def col_sum(x, ldx, xoff, out, rows, ncols):

@@ -32,8 +32,10 @@ class Model(ModelBase):
   def __init__(self, model_proto, is_training=False, device="cuda:0", depth_multiplier=1.0,
                bn_scale=True, seed=0, compute_dtype="fp32", allow_missing_pretrained=False):
     """compute_dtype: "fp32" (BASELINE configs[0], [1], [3]: exact fp32 everywhere) or "bf16"
-    (configs[2], [4]: ROI crop output and second stage in bf16 storage with fp32 accumulation;
-    first stage, heads, losses, variables and optimiser stay fp32).
+    (configs[2], [4]: the convolution towers behind the stem — the single-image first stage, the ROI
+    crop output and the second stage — in bf16 storage with fp32 accumulation; the stem, the map
+    the ROI crop interpolates, heads, losses, variables and optimiser stay fp32;
+    C2D_FIRST_STAGE_FP32=1 keeps the first stage in fp32 as well).
     allow_missing_pretrained: keep the synthetic initial values when
     `frcnn_options.checkpoint_path` names a file that does not exist (benchmarks and tests; the
     reference's tf.train.init_from_checkpoint fails hard, models/utils.py:181-186, and so does

@@ -304,6 +304,7 @@ class Net(object):
     self._plans = {}
 
   side = None   # torch.cuda.Stream for the filter gradients, set by FrcnnEngine (eager mode only)
+  group_small = False   # bf16 nets: few-row block inputs take the grouped launches (first stage)
 
   def _depth(self, d):
     return max(int(d * self.dm), 16)
@@ -454,7 +455,8 @@ class Net(object):
     elif kind == "pool":
       ops.pool3x3_fwd(x.t, x.ld, x.off, st["y"].t, st["y"].ld, st["y"].off, st["arg"], st["n"],
                       st["ih"], st["iw"], st["c"], st["stride"], st["mode"])
-    elif self.dtype != torch.float32 or st["n"] * st["ih"] * st["iw"] > GROUP_MAX_ROWS:
+    elif st["n"] * st["ih"] * st["iw"] > GROUP_MAX_ROWS or (self.dtype != torch.float32 and
+                                                             not self.group_small):
       # The 1x1 / stride-1 convolutions that open the branches all read the block input: ONE GEMM
       # over the sum of their output channels (c2d_conv1x1_fwd_multi: the input streams from HBM
       # once, wider tiles; every output element is the same K-ordered sum, bitwise equal results).
@@ -889,12 +891,19 @@ class FrcnnEngine(object):
   STEM = FIRST_SCOPE + "Conv2d_1a_7x7"
 
   def __init__(self, store, options, bn_scale=True, depth_multiplier=1.0,
-               act_dtype=torch.float32):
+               act_dtype=torch.float32, first_stage_dtype=None):
     """options: FRCNN proto (protos/frcnn.proto:4-33).  act_dtype: storage of the per-ROI
     tensors (ROI crop output, second stage activations and gradients): fp32, or bf16 with fp32
-    accumulation; the first stage, the heads, all statistics and all variables stay fp32."""
+    accumulation.  first_stage_dtype: storage of the single-image tower behind the stem
+    convolution (default: act_dtype; C2D_FIRST_STAGE_FP32=1 keeps it fp32 in a bf16 network, as
+    rounds 2-3a ran it).  The stem, the ROI crop's input map and its gradient, the heads, all
+    statistics and all variables stay fp32."""
     self.store = store
     self.act_dtype = act_dtype
+    if first_stage_dtype is None:
+      first_stage_dtype = (torch.float32 if os.environ.get("C2D_FIRST_STAGE_FP32", "0") == "1"
+                           else act_dtype)
+    self.first_dtype = first_stage_dtype
     self.device = store.device
     self.options = options
     self.crop = options.initial_crop_size
@@ -926,7 +935,8 @@ class FrcnnEngine(object):
     self.stem_scale = torch.empty(self.stem_cout, device=dev)
     self.stem_shift = torch.empty(self.stem_cout, device=dev)
     self.first = Net(store, self.stats, FIRST_STAGE_AFTER_STEM, FIRST_SCOPE, self.stem_cout,
-                     bn_scale, dm)
+                     bn_scale, dm, dtype=first_stage_dtype)
+    self.first.group_small = True
     self.second = Net(store, self.stats, SECOND_STAGE, SECOND_SCOPE, self.first.cout, bn_scale, dm,
                       dtype=act_dtype)
     self.feature_dims = self.second.cout
@@ -1057,6 +1067,10 @@ class FrcnnEngine(object):
         stem=Ref(torch.empty(b * sh * sw, self.stem_cout, device=dev), self.stem_cout, 0,
                  self.stem_cout),
         sh=sh, sw=sw)
+    bufs["stem_in"] = bufs["stem"]          # what the first stage reads
+    if self.first_dtype != torch.float32:
+      bufs["stem_in"] = Ref(torch.empty(b * sh * sw, self.stem_cout, device=dev, dtype=self.first_dtype),
+                            self.stem_cout, 0, self.stem_cout)
     bufs["plan1"] = self.first.plan(b, sh, sw, training)
     fh, fw = bufs["plan1"]["oh"], bufs["plan1"]["ow"]
     p = (self.crop - self.pool_k) // self.pool_s + 1
@@ -1110,7 +1124,9 @@ class FrcnnEngine(object):
     ops.conv_fwd(bufs["cols"], self.stem_kpad, 0, self.stem_wt, self.stem_scale, self.stem_shift,
                  st.t, st.ld, 0, b * bufs["sh"] * bufs["sw"], 1, 1, self.stem_kpad, self.stem_cout,
                  1, 1, 1, True)
-    self.first.forward(bufs["plan1"], st, 0, upto)
+    if bufs["stem_in"] is not st:
+      ops.cast_bf16(st.t, bufs["stem_in"].t)
+    self.first.forward(bufs["plan1"], bufs["stem_in"], 0, upto)
 
   def prefetch_first_stage(self, image, num_proposals, is_training=True):
     """Starts the frozen part of the first stage for the NEXT step's image on a side stream, so
@@ -1198,10 +1214,15 @@ class FrcnnEngine(object):
     if self.prefetch_stream is not None:
       bufs["prefix_free"] = torch.cuda.Event()
       bufs["prefix_free"].record()
-    st = bufs["stem"]
-    feat = self.first.forward(bufs["plan1"], st, upto, None)
+    feat = self.first.forward(bufs["plan1"], bufs["stem_in"], upto, None)
     boxes = proposals.reshape(-1, 4)
     fmask = None
+    if feat.t.dtype != torch.float32:
+      # the ROI crop interpolates an fp32 map: the bf16 tower's output widened (exact)
+      if "feat_f32" not in bufs:
+        bufs["feat_f32"] = Ref(torch.empty(feat.t.shape, device=self.device), feat.ld, feat.off, feat.c)
+      ops.cast_f32(feat.t, bufs["feat_f32"].t)
+      feat = bufs["feat_f32"]
     crop_src = feat.t
     if self.dropout_on_feature_map and is_training and self.keep_prob < 1.0:
       if "fmap_mask" not in bufs:
@@ -1282,10 +1303,16 @@ class FrcnnEngine(object):
       plan1 = bufs["plan1"]
       gfeat = self.first.out_grad(plan1, self.first_trainable_idx)
       d = self.first.cout
-      gcrop = gfeat.t            # d(loss)/d(features_to_crop)
+      g32 = gfeat.t              # fp32 d(loss)/d(first-stage output)
+      if g32.dtype != torch.float32:
+        # the ROI-crop backward sums in fp32; a bf16 tower takes the rounded sum (cast below)
+        if "gfeat_f32" not in bufs:
+          bufs["gfeat_f32"] = torch.empty(gfeat.t.shape, device=self.device)
+        g32 = bufs["gfeat_f32"]
+      gcrop = g32                # d(loss)/d(features_to_crop)
       if ctx.get("fmask") is not None:
         if "gfmap" not in bufs:
-          bufs["gfmap"] = torch.empty_like(gfeat.t)
+          bufs["gfmap"] = torch.empty_like(g32)
         gcrop = bufs["gfmap"]
       if gcrop.data_ptr() not in getattr(self, "_step_zeroed", ()):
         gcrop.zero_()
@@ -1311,6 +1338,8 @@ class FrcnnEngine(object):
         ops.roi_crop_pool_bwd(dp4, arg4, ctx["boxes"], bufs["box_ind"], gf4, self.crop,
                               self.pool_k, self.pool_s)
       if ctx.get("fmask") is not None:          # through the feature-map dropout
-        ops.spatial_mean_dropout_bwd(gcrop, d, 0, gfeat.t, ctx["fmask"], gcrop.shape[0], 1, d,
+        ops.spatial_mean_dropout_bwd(gcrop, d, 0, g32, ctx["fmask"], gcrop.shape[0], 1, d,
                                      self.keep_prob)
-      self.first.backward(plan1, bufs["stem"], self.first_trainable_idx, None)
+      if g32 is not gfeat.t:
+        ops.cast_bf16(g32, gfeat.t)
+      self.first.backward(plan1, bufs["stem_in"], self.first_trainable_idx, None)

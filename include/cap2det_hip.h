@@ -121,6 +121,10 @@ typedef struct C2dConvDesc {
 } C2dConvDesc;
 int c2d_conv_fwd_grouped(const C2dConvDesc* descs, int num, void* stream);
 int c2d_conv_dgrad_grouped(const C2dConvDesc* descs, int num, void* stream);
+/* bf16 storage forms (src / weights / dst hold bf16; see c2d_conv_fwd_bf16): the grouped launch
+ * is igemm_small_group_kernel<*, 2> — the bf16 step's first stage. */
+int c2d_conv_fwd_grouped_bf16(const C2dConvDesc* descs, int num, void* stream);
+int c2d_conv_dgrad_grouped_bf16(const C2dConvDesc* descs, int num, void* stream);
 
 /* Debug query: the kernel template instances launched by the calling thread's LAST convolution
  * entry point (c2d_conv_fwd / _dgrad / _wgrad / c2d_conv1x1_dgrad_multi, their _bf16 / _ws /
@@ -534,6 +538,8 @@ int c2d_roi_crop_pool_bwd_run_bf16(const void* dout, const uint8_t* argmax, cons
  * BatchNorm vectors, filter gradients, the first-stage feature map and its gradient stay fp32.
  * ------------------------------------------------------------------------------------- */
 int c2d_cast_bf16(const float* src, void* dst, long long n, void* stream);   /* n % 4 == 0 */
+/* the other way (exact): the bf16 first stage's feature map in front of the fp32 ROI crop */
+int c2d_cast_f32(const void* src, float* dst, long long n, void* stream);    /* n % 4 == 0 */
 int c2d_roi_crop_pool_fwd_bf16(const float* feat, const float* boxes, const int32_t* box_ind,
                                void* out, uint8_t* argmax, int batch, int hf, int wf, int depth,
                                int num_boxes, int crop, int pool_k, int pool_s, void* stream);

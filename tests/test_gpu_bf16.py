@@ -34,7 +34,12 @@ CASES = [  # n, ih, iw, cin, cout, k, stride
     # pixel-major forward (N = 288) / input gradient (N = cin = 320, accumulating epilogue with
     # idle store lanes), row-major 1x1 forward (N = 352) / input gradient (N = 288)
     (70, 4, 4, 48, 288, 3, 1), (70, 4, 4, 320, 64, 3, 1), (700, 4, 4, 64, 352, 1, 1),
-    (700, 4, 4, 288, 64, 1, 1)]
+    (700, 4, 4, 288, 64, 1, 1),
+    # the single-image first stage (one 32x32 output tile per block, K split over the four waves,
+    # operands straight from memory: igemm_small_kernel<*, 2>), K tails of the 64-deep slabs and
+    # odd tap counts per wave included
+    (1, 32, 32, 96, 128, 3, 1), (1, 33, 31, 64, 96, 3, 2), (1, 32, 32, 576, 224, 1, 1),
+    (2, 19, 23, 80, 48, 3, 1), (1, 63, 63, 192, 64, 1, 1)]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -68,6 +73,57 @@ def test_conv_fwd_dgrad_bf16(case):
   dx2 = torch.empty_like(dx)
   ops.conv_dgrad(dc, cout, 0, w.view(k * k, cin, cout), dx2, cin, 0, n, ih, iw, cin, cout, k, k, s, False)
   _check(dx2, want_dx, "dgrad")
+
+
+def test_first_stage_shapes_take_the_small_kernel():
+  from cap2det_amd import hip_ops as ops
+  x = torch.zeros(32 * 32, 96, device=DEV, dtype=torch.bfloat16)
+  wt = torch.zeros(9, 128, 96, device=DEV, dtype=torch.bfloat16)
+  y = torch.empty(32 * 32, 128, device=DEV, dtype=torch.bfloat16)
+  ops.conv_fwd(x, 96, 0, wt, None, None, y, 128, 0, 1, 32, 32, 96, 128, 3, 3, 1, False)
+  assert ops.last_dispatch() == ["igemm_small_kernel<0, 2>"]
+  dx = torch.empty_like(x)
+  ops.conv_dgrad(y, 128, 0, wt.view(9, 96, 128), dx, 96, 0, 1, 32, 32, 96, 128, 3, 3, 1, False)
+  assert ops.last_dispatch() == ["igemm_small_kernel<1, 2>"]
+
+
+def test_conv_fwd_grouped_bf16_matches_single_calls():
+  """c2d_conv_fwd_grouped_bf16: the convolutions of one Inception level of the single-image first
+  stage in ONE launch (igemm_small_group_kernel<0, 2>), bit-identical to c2d_conv_fwd_bf16; a
+  group with a large member falls back to one launch each."""
+  from cap2det_amd import hip_ops as ops
+  rng = np.random.default_rng(12)
+  for n, hw, big in [(1, 32, False), (1, 63, False), (3, 9, False), (400, 7, True)]:
+    cin = 64
+    x = torch.from_numpy(rng.standard_normal((n * hw * hw, cin + 16)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    calls, singles = [], []
+    for (cout, k, stride) in [(96, 1, 1), (32, 3, 1), (48, 3, 2), (24, 1, 1), (64, 1, 2)]:
+      oh = -(-hw // stride)
+      wt = torch.from_numpy((rng.standard_normal((k * k, cout, cin)) / np.sqrt(k * k * cin)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+      sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(DEV)
+      sh = torch.from_numpy((0.1 * rng.standard_normal(cout)).astype(np.float32)).to(DEV)
+      y1 = torch.full((n * oh * oh, cout + 8), -3.0, device=DEV, dtype=torch.bfloat16)
+      y2 = y1.clone()
+      args = [x, cin + 16, 16, wt, sc, sh, None, cout + 8, 8, n, hw, hw, cin, cout, k, k, stride, True]
+      calls.append(tuple(args[:6] + [y1] + args[7:]))
+      singles.append((args, y2))
+    group = ops.conv_group(calls)
+    ops.conv_fwd_grouped(group)
+    inst = ops.last_dispatch()
+    assert (inst == ["igemm_small_group_kernel<0, 2>"]) == (not big), inst
+    ops.conv_fwd_grouped(group)      # descriptors are reusable
+    for (args, y2), c in zip(singles, calls):
+      ops.conv_fwd(*(args[:6] + [y2] + args[7:]))
+      assert torch.equal(c[6], y2), (n, hw, args[13:17])
+      assert float(y2[:, :8].float().max()) == -3.0
+
+
+def test_cast_f32_is_exact():
+  from cap2det_amd import hip_ops as ops
+  src = torch.randn(1024 * 576, device=DEV).to(torch.bfloat16)
+  dst = torch.empty(src.numel(), device=DEV)
+  ops.cast_f32(src, dst)
+  assert torch.equal(dst, src.float())
 
 
 FUSED_CASES = [(70, 4, 4, 48, 96, 3, 1), (900, 7, 7, 64, 96, 1, 1), (100, 7, 7, 32, 64, 3, 2),
@@ -164,13 +220,18 @@ def _rel_l2(got, want):
   return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
 
 
+@pytest.mark.parametrize("first_stage", ["bf16", "fp32"])
 @pytest.mark.parametrize("dm,hw,n,nums", [(1.0, (64, 48), 6, [6, 4]), (0.5, (40, 72), 9, [9, 0])])
-def test_train_step_bf16_tracks_the_fp64_oracle(dm, hw, n, nums):
+def test_train_step_bf16_tracks_the_fp64_oracle(monkeypatch, dm, hw, n, nums, first_stage):
+  """first_stage = "fp32": the single-image tower kept in fp32 (C2D_FIRST_STAGE_FP32=1, the bf16
+  mode of rounds 2-3a) holds the tighter bounds of TOL_FP32_FIRST."""
   from oracle import ref_labels
   from tests import util_model
+  monkeypatch.setenv("C2D_FIRST_STAGE_FP32", "1" if first_stage == "fp32" else "0")
   _check_train_step_bf16(
       util_model.load_pipeline(), dm, hw, n, nums,
-      lambda ex, classes: ref_labels.groundtruth_extract(ex["object_texts"], classes))
+      lambda ex, classes: ref_labels.groundtruth_extract(ex["object_texts"], classes),
+      tol=TOL_FP32_FIRST if first_stage == "fp32" else TOL)
 
 
 def test_train_step_bf16_coco17_extend_match(tmp_path):
@@ -201,20 +262,31 @@ def test_train_step_bf16_text_classifier_match(tmp_path):
                                    extra_examples=extra, seed=99))
 
 
-def _check_train_step_bf16(pipeline, dm, hw, n, nums, make_labels, extra_examples=None, seed=99):
-  """Full training step with compute_dtype='bf16' (ROI crop output + second stage in bf16
-  storage, fp32 accumulation) against the float64 oracle of the reference semantics.  There is no
-  bf16 reference: the stated tolerance is what ~12 bf16 roundings per path (2^-9 relative each)
-  allow — proposal scores within 2 % of the tensor's max, losses 2 % relative, every filter / head
-  gradient tensor within 10 % relative L2 error (these tiny cases sum over < 300 pixels; observed
-  max 6.6 %), the whole gradient within 3 % and at cosine >= 0.999 of the oracle's; the fp32 path (tests/test_gpu_model.py) holds 1e-4."""
+# relative bounds: proposal scores / logits (of the tensor's max), losses, a filter or head gradient
+# tensor (L2), a BatchNorm beta / gamma gradient (L2), the whole gradient (L2)
+TOL = dict(score=5e-2, loss=2e-2, grad=0.15, bn_grad=0.25, whole=5e-2)
+TOL_FP32_FIRST = dict(score=2e-2, loss=2e-2, grad=0.10, bn_grad=0.20, whole=3e-2)
+
+
+def _check_train_step_bf16(pipeline, dm, hw, n, nums, make_labels, extra_examples=None, seed=99,
+                           tol=TOL):
+  """Full training step with compute_dtype='bf16' (the convolution towers behind the stem — the
+  single-image first stage, the ROI crop output and the second stage — in bf16 storage, fp32
+  accumulation) against the float64 oracle of the reference semantics.  There is no
+  bf16 reference: the stated tolerance (TOL) is what ~25 bf16 roundings per path (2^-9 relative
+  each) allow — proposal scores within 5 % of the tensor's max (observed 3.4 %), losses 2 %
+  relative (0.7 %), every filter / head gradient tensor within 15 % relative L2 error (these tiny
+  cases sum over < 300 pixels; observed 11 %), the whole gradient within 5 % (4.0 %) and at cosine
+  >= 0.999 of the oracle's; with the first stage kept in fp32 (~12 roundings): 2 % / 2 % / 10 % /
+  3 % (TOL_FP32_FIRST).  The fp32 path (tests/test_gpu_model.py) holds 1e-4."""
   from cap2det_amd.train.trainer import Trainer
   from oracle import ref_model
   from tests import util_model
   rng = np.random.default_rng(seed)
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=dm, compute_dtype="bf16")
   model = trainer.model
-  assert model.engine.second.dtype == torch.bfloat16 and model.engine.first.dtype == torch.float32
+  assert model.engine.second.dtype == torch.bfloat16
+  assert model.engine.first.dtype == (torch.float32 if tol is TOL_FP32_FIRST else torch.bfloat16)
   classes = model.label_extractor.classes
   c, k = len(classes), 3
   P32, d = util_model.oracle_state(5, c, k, dm)
@@ -243,12 +315,16 @@ def _check_train_step_bf16(pipeline, dm, hw, n, nums, make_labels, extra_example
   torch.cuda.synchronize()
   np.testing.assert_array_equal(model._ctx["labels"].cpu().numpy(), labels)   # extractor parity
   pred, wp = trainer.predictions, want["predictions"]
+  seen = {}
   for name in ["midn_class_logits", "midn_proba_r_given_c"] + \
       ["oicr_proposal_scores_at_%d" % i for i in range(k + 1)]:
     got = pred[name].detach().float().cpu().numpy()
-    assert np.abs(got - wp[name]).max() <= 2e-2 * max(np.abs(wp[name]).max(), 1e-6), name
+    seen[name] = np.abs(got - wp[name]).max() / max(np.abs(wp[name]).max(), 1e-6)
   for name, v in want["losses"].items():
-    np.testing.assert_allclose(losses[name].item(), v, rtol=2e-2, err_msg=name)
+    seen["loss " + name] = abs(losses[name].item() - v) / abs(v)
+  print("bf16 step vs float64 oracle, relative deviations:", {kk: round(float(v), 4) for kk, v in seen.items()})
+  for name, e in seen.items():
+    assert e <= (tol["score"] if not name.startswith("loss ") else tol["loss"]), (name, e, seen)
   grads = model.grad_dict()
   worst = 0.0
   gots, wants = [], []
@@ -261,13 +337,13 @@ def _check_train_step_bf16(pipeline, dm, hw, n, nums, make_labels, extra_example
     e = _rel_l2(grads[name], w)
     worst = max(worst, e)
     # BatchNorm beta / gamma gradients are signed sums over only 96-294 pixels in this tiny case
-    # (heavy cancellation): 15 %; filter and head gradients: 6 %
-    tol = 0.20 if "/BatchNorm/" in name else 0.10
-    assert e <= tol, "grad %s: relative L2 error %.3e" % (name, e)
+    # (heavy cancellation): their own, wider bound
+    bound = tol["bn_grad"] if "/BatchNorm/" in name else tol["grad"]
+    assert e <= bound, "grad %s: relative L2 error %.3e" % (name, e)
     gots.append(np.asarray(grads[name], np.float64).ravel()); wants.append(np.asarray(w).ravel())
   assert worst > 1e-5        # (it really ran in reduced precision)
   g, w = np.concatenate(gots), np.concatenate(wants)
   cos = float(g @ w / (np.linalg.norm(g) * np.linalg.norm(w)))
   assert cos >= 0.999, "whole-gradient cosine similarity %.5f" % cos
-  assert _rel_l2(g, w) <= 3e-2
+  assert _rel_l2(g, w) <= tol["whole"], _rel_l2(g, w)
   return trainer

@@ -300,7 +300,7 @@ def test_mixed_4e_entry_group(ops):
   group = ops.conv_group(calls)
   ops.conv_fwd_grouped(group)
   inst = ops.last_dispatch()
-  assert inst == ["igemm_small_group_kernel<0>"], inst
+  assert inst == ["igemm_small_group_kernel<0, 4>"], inst
   _seen.update(inst)
   for y, want in zip(outs, wants):
     _scale_close(_n(y), want, 2e-5, "grouped 1x1")
