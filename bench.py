@@ -154,8 +154,11 @@ class KernelTimer(object):
         w = work_fn(args, kwargs) if family == "roi_crop_pool_fwd" else work_fn(args)
         # families are kept per operand type: bf16 operands run on the bf16 MFMA kernels
         first = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
+        first_dtype = getattr(first, "dtype", None)
+        if fn.__name__ == "conv_fwd_grouped":
+          first_dtype = args[0][3]           # (descriptor array, count, flops, storage type)
         low = (family != "roi_crop_pool_fwd" and not family.endswith("_bf16") and
-               getattr(first, "dtype", None) == t.torch.bfloat16)
+               first_dtype == t.torch.bfloat16)
         try:
           nbytes = BYTES[fn.__name__](args) if fn.__name__ in BYTES else 0.0
         except Exception:

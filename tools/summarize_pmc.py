@@ -42,6 +42,8 @@ def family_of(name):
     return "wgrad_bf16"
   if "igemm_bf16_kernel" in name or re.search(r"igemm_ring_kernel<[^>]*, 2>", name):
     return "igemm_bf16"
+  if re.search(r"igemm_small(_group)?_kernel<\d, 2>", name):
+    return "igemm_small_bf16"      # the bf16 step's single-image first stage
   m = re.search(r"igemm_nt_kernel<([^>]*)>", name)
   if m and len(m.group(1).split(",")) == 8 and m.group(1).split(",")[-1].strip() == "2":
     return "igemm_bf16"       # igemm_nt_kernel<MODE, WM, WN, MT, NT, BKT, PM, ES = 2>
