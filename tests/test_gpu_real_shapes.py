@@ -177,6 +177,13 @@ def test_second_stage_layer_bf16(ops, layer):
   _check_layer(ops, *layer, dtype=torch.bfloat16)
 
 
+@pytest.mark.parametrize("layer", FIRST_STAGE_LAYERS, ids=[l[0] for l in FIRST_STAGE_LAYERS])
+def test_mixed_4e_layer_bf16(ops, layer):
+  """The bf16 step's first stage: igemm_small_kernel<*, 2> forward / input gradient, the per-tap bf16
+  filter gradient, on the 32x32 map of one image."""
+  _check_layer(ops, *layer, dtype=torch.bfloat16)
+
+
 @pytest.mark.parametrize("c", [20, 80])
 def test_heads_gemm_real_size(ops, c):
   """The five heads fused in one [1024, 2C + 3(C+1)] GEMM on N = 2000 rows (103 -> 112 columns for
@@ -281,29 +288,36 @@ def test_block_entry_fwd_multi(ops, block, dtype):
     _scale_close(_n(o[3]), want, 1.1 * 2.0 ** -8 if low else 2e-5, "%s entry fwd %s" % (block, inst))
 
 
-def test_mixed_4e_entry_group(ops):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_mixed_4e_entry_group(ops, dtype):
   """The three 1x1 entry convolutions of Mixed_4e (576 -> 96 / 128 / 160 on the 32x32 map) as ONE
-  grouped launch (c2d_conv_fwd_grouped -> igemm_small_group_kernel), each against the oracle."""
+  grouped launch (c2d_conv_fwd_grouped(_bf16) -> igemm_small_group_kernel), each against the
+  oracle."""
   rng = np.random.default_rng(41)
   hw, cin = 32, 576
+  low = dtype == torch.bfloat16
   x = rng.standard_normal((1, hw, hw, cin)).astype(np.float32)
+  if low:
+    x = _bf16_round(x)
+  x_ = _t(x).view(hw * hw, cin).to(dtype)
   calls, outs, wants = [], [], []
   for cout in (96, 128, 160):
     w = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    if low:
+      w = _bf16_round(w)
     wt = torch.empty(1, cout, cin, device=DEV)
     ops.transpose_taps(_t(w), wt, 1, cin, cout)
-    y = torch.empty(hw * hw, cout, device=DEV)
-    calls.append((_t(x).view(hw * hw, cin), cin, 0, wt, None, None, y, cout, 0, 1, hw, hw, cin, cout,
-                  1, 1, 1, False))
+    y = torch.empty(hw * hw, cout, device=DEV, dtype=dtype)
+    calls.append((x_, cin, 0, wt.to(dtype), None, None, y, cout, 0, 1, hw, hw, cin, cout, 1, 1, 1, False))
     outs.append(y)
     wants.append(ref_ops.conv2d(x.astype(np.float64), w.astype(np.float64), 1).reshape(hw * hw, cout))
   group = ops.conv_group(calls)
   ops.conv_fwd_grouped(group)
   inst = ops.last_dispatch()
-  assert inst == ["igemm_small_group_kernel<0, 4>"], inst
+  assert inst == ["igemm_small_group_kernel<0, %d>" % (2 if low else 4)], inst
   _seen.update(inst)
   for y, want in zip(outs, wants):
-    _scale_close(_n(y), want, 2e-5, "grouped 1x1")
+    _scale_close(_n(y), want, 1.1 * 2.0 ** -8 if low else 2e-5, "grouped 1x1")
 
 
 @pytest.mark.parametrize("fuse_bn_bwd,commute", [("1", "1"), ("0", "1"), ("1", "0")],
