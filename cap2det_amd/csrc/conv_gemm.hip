@@ -1906,7 +1906,9 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   //     128->192 stride 2: 29 -> 26);
   //   193..256 columns: 128x256 (8 waves 2 x 4);
   //   wider (block-entry GEMMs: 736 / 832 columns forward, 576 / 1024 input gradient): 128x256 unless
-  //     the last 256-wide tile would be more than 30 % padding (576 -> 128x64);
+  //     the last 256-wide tile would be more than 35 % padding (the 576-wide entry gradient, a
+  //     third padding, reads its operand three times instead of nine: 122 -> 105 us cold, 87.5 ->
+  //     81.5 warm);
   //   up to 128 columns: 128x64 / 64x64 as before.
   if (!force && a.es == 2) {
     if (a.N > 256 && a.N <= 384) force = 7;
@@ -1914,7 +1916,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     else if (a.N > 128 && a.N <= 192) force = 7;
     else if (a.N > 384) {
       const int waste = c2d_ceil_div(a.N, 256) * 256 - a.N;
-      force = waste * 10 <= 3 * a.N ? 6 : 2;
+      force = waste * 20 <= 7 * a.N ? 6 : 2;
     } else {
       force = 2;
     }

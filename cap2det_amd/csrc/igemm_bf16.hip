@@ -754,18 +754,22 @@ int launch_one(IgemmArgs a, hipStream_t s) {
 }
 
 // (stage depth, ring depth) of a block tile, measured per GEMM call of the step (tools/
-// sweep_step_gemms.sh, N = 2000 ROIs).  What decides is how many workgroups share a CU, not how
-// deep one workgroup prefetches: these GEMMs are short (K = 128 .. 2304: 2 - 36 stages), so a
-// workgroup spends as long in its ramp (first stages in flight) and its epilogue as in its K loop,
-// and only ANOTHER workgroup's K loop fills the matrix pipe meanwhile.  Rings of four or more
-// stages (one workgroup per CU) measured 10 - 45 % slower on every call.  So:
-//   * 128x256 (8 waves): launches of more than 1.5 rounds of the chip take 32-deep stages in a
-//     ring of three (72 KiB: TWO workgroups per CU; block-entry input gradients 109 -> 84 us,
-//     192->256 3x3 on 7x7 maps 126 -> 108 us); one-round launches (250 tiles of 4x4 maps) keep
-//     64-deep stages in two buffers;
+// sweep_step_gemms.sh + tools/sweep_cold.py, N = 2000 ROIs; with the operands warm from the previous
+// repetition and, as inside a step, cold: C2D_BENCH_COLD=1).  What decides is how many workgroups
+// share a CU, not how deep one workgroup prefetches: these GEMMs are short (K = 128 .. 2304: 2 - 36
+// stages), so a workgroup spends as long in its ramp (first stages in flight) and its epilogue as
+// in its K loop, and only ANOTHER workgroup's K loop fills the matrix pipe meanwhile.  Rings of
+// four or more stages (one workgroup per CU) measured 10 - 45 % slower on every call.  So:
+//   * 128x256 (8 waves): 32-deep stages in a ring of three (72 KiB: TWO workgroups per CU) —
+//     first for launches of more than 1.5 rounds of the chip (block-entry input gradients 109 ->
+//     84 us, 192->256 3x3 on 7x7 maps 126 -> 108 us); since the steady-state loop (half the
+//     instructions per stage) also for the one-round launches of 4x4 maps (224->224 3x3 forward /
+//     input gradient 47 -> 41 / 46 -> 39 us cold, 38.6 -> 34.5 / 37.4 -> 33.2 warm);
+//   * 128x192 (8 waves, full width): the same ring for one-round launches (61 KiB: two per CU;
+//     160->224 / 192->224 input gradients 41 -> 37.5 us cold); 80 KiB of 64-deep stages otherwise;
 //   * 128x64 (4 waves): many-tile launches likewise (36 KiB: four per CU; 576-wide entry gradient
 //     142 -> 102 us);
-//   * everything else: 64-deep stages, two buffers (full-width three-tile blocks: 80 KiB, two per CU).
+//   * everything else: 64-deep stages, two buffers.
 #ifdef C2D_RING_SWEEP
 #define C2D_RING_COMBOS(X) X(64, 2) X(32, 3) X(64, 3) X(32, 4)
 #else
@@ -778,7 +782,8 @@ int launch_tile(const IgemmArgs& a, hipStream_t s) {
   const RingTune& t = ring_tune();
   const long long blocks = (long long)c2d_ceil_div(a.M, WM * MT * 32) * c2d_ceil_div(a.N, WN * NT * 32);
   int bk = 64, d = 2;
-  if (WM == 2 && WN == 4 && blocks > 384) { bk = 32; d = 3; }
+  if (WM == 2 && WN == 4) { bk = 32; d = 3; }
+  if (WM == 4 && WN == 2 && NT == 3 && blocks <= 384) { bk = 32; d = 3; }
   if (WM == 2 && WN == 2 && MT == 2 && NT == 1 && blocks > 768) { bk = 32; d = 3; }
   if (t.bk) bk = t.bk;
   if (t.d) d = t.d;
