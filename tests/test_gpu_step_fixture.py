@@ -33,8 +33,13 @@ CONV_ENTRY_POINTS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv1x1_fwd_multi"
 _dispatched = {}
 
 
-def profile_instances(csv_name):
-  """igemm / wgrad template instances of a committed rocprofv3 kernel-stats summary."""
+def profile_instances(csv_name=None):
+  """igemm / wgrad template instances of a committed rocprofv3 kernel-stats summary (default: the
+  newest fp32 one-stream summary, profiles/rNN_bench_kernel_stats_c1_serial.csv)."""
+  import glob
+  if csv_name is None:
+    csv_name = os.path.basename(sorted(glob.glob(os.path.join(
+        ROOT, "profiles", "r*_bench_kernel_stats_c1_serial.csv")))[-1])
   out = set()
   with open(os.path.join(ROOT, "profiles", csv_name)) as f:
     for row in csv.DictReader(f):
@@ -117,12 +122,12 @@ def test_train_step_replays_the_float64_fixture(monkeypatch, n):
 
 
 def test_fixture_steps_run_the_benchmark_kernel_instances():
-  """Runs after the two replays: every igemm / wgrad template instance of the committed fp32
-  benchmark profile (N = 2000, profiles/r02_bench_kernel_stats_c1_serial.csv) was dispatched by a
+  """Runs after the two replays: every igemm / wgrad template instance of the newest committed fp32
+  benchmark profile (N = 2000, profiles/rNN_bench_kernel_stats_c1_serial.csv) was dispatched by a
   fixture step, i.e. the fixtures arbitrate the kernels the benchmark times."""
   if not _dispatched:
     pytest.skip("replay tests did not run")
-  want = profile_instances("r02_bench_kernel_stats_c1_serial.csv")
+  want = profile_instances()
   assert len(want) >= 15
   seen = {}
   for d in _dispatched.values():
