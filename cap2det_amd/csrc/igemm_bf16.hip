@@ -1098,8 +1098,10 @@ int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool 
   // (16.8 MB per 256 workgroups at the chip-wide 1.3 TB/s of float atomics, all at the end of the
   // launch) — so the DMA ring only pays where the tile count keeps the splits low: output widths
   // of 129..256 columns (576->192: 68 -> 49 us, 1024->192: 40 -> 33, 1024->160: 39 -> 30);
-  // 128- and 352-wide layers stay on the two-K-group kernel of conv_gemm.hip (30 / 49 us).
-  if (!t.bk && !t.d && !t.slots && !(a.J > 128 && a.J <= 256)) return C2D_ERR_UNSUPPORTED;
+  // 128-wide layers stay on the two-K-group kernel of conv_gemm.hip (30 us); the 352-wide ones
+  // measured equal with warm operands (49 us either way) and 78 -> 65 us with cold ones
+  // (C2D_BENCH_COLD=1: what the step sees), so they take the ring as well.
+  if (!t.bk && !t.d && !t.slots && !(a.J > 128 && a.J <= 384)) return C2D_ERR_UNSUPPORTED;
   const bool narrow = a.J % 128 != 0 && a.J % 128 <= 64;    // 128 x 64 block tiles
   const int bj = narrow ? 64 : 128;
   const int bk = t.bk == 32 ? 32 : 64;
