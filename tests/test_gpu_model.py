@@ -825,21 +825,26 @@ def test_full_size_caption_configs(tmp_path, config, dtype):
   assert not any(k.endswith("moving_mean") or k.endswith("moving_variance") for k in moved)
 
 
+@pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("n,nums", [(9, [9, 4]), (32, [32, 20])])
-def test_graph_step_equals_eager_step(n, nums):
+def test_graph_step_equals_eager_step(n, nums, compute_dtype):
   """`Trainer(use_graph=True)` (hipGraph capture and replay of the step, one stream, dropout seed
   and learning rate read from device memory) against the eager step on the same inputs, state
   and dropout seed: the same losses and the same updated variables up to the fp32 atomics' order
   after ONE step (later steps see those rounding differences through the discrete OICR box
   selection and ReLU masks, so they are only required to replay and stay finite).  The second
   case has 64 per-ROI maps (the fused BN/ReLU-backward plan, commuted pooling branch and fused
-  block-entry GEMMs inside the captured graph)."""
+  block-entry GEMMs inside the captured graph).  bf16: both towers in bf16 storage (the grouped
+  bf16 first-stage launches and the casts around the ROI crop inside the graph); an atomics-order
+  difference of the filter gradients can move a bf16 rounding, so 2 % / 5 %."""
   from cap2det_amd.train.trainer import Trainer
   pipeline = util_model.load_pipeline()
   rng = np.random.default_rng(17)
   results, ex = [], None
+  ltol, stol = (1e-5, 5e-5) if compute_dtype == "fp32" else (2e-2, 5e-2)
   for use_graph in (False, True):
-    trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, use_graph=use_graph)
+    trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, use_graph=use_graph,
+                      compute_dtype=compute_dtype)
     model = trainer.model
     classes = model.label_extractor.classes
     P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
@@ -860,7 +865,7 @@ def test_graph_step_equals_eager_step(n, nums):
   (le, state_e), (lg, state_g) = results
   assert le.keys() == lg.keys()
   for k in le:
-    assert abs(le[k] - lg[k]) <= 1e-5 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    assert abs(le[k] - lg[k]) <= ltol * max(1.0, abs(le[k])), (k, le[k], lg[k])
   for k in state_e:
     a, b = state_e[k].astype(np.float64), state_g[k].astype(np.float64)
-    assert np.abs(a - b).max() <= 5e-5 * max(np.abs(a).max(), 1e-3), k
+    assert np.abs(a - b).max() <= stol * max(np.abs(a).max(), 1e-3), k
