@@ -169,6 +169,27 @@ def conv_fwd_grouped(group):
   _lib.call(fn, ctypes.cast(group[0], ctypes.c_void_p), group[1], _stream())
 
 
+def conv_dgrad_group(calls):
+  """Packs [(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride, accumulate),
+  ...] (the arguments of conv_dgrad) into a descriptor array for conv_dgrad_grouped."""
+  arr = (ConvDesc * len(calls))()
+  for d, c in zip(arr, calls):
+    (dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride, accumulate) = c
+    assert dc.dtype == dx.dtype == w.dtype and dc.dtype == calls[0][0].dtype
+    d.src, d.ld_src, d.off_src, d.weights = _p(dc), ldc, coff, _p(w)
+    d.scale, d.shift = None, None
+    d.dst, d.ld_dst, d.off_dst = _p(dx), lddx, dxoff
+    d.n, d.ih, d.iw, d.cin, d.cout, d.kh, d.kw, d.stride, d.flag = (n, ih, iw, cin, cout, kh, kw,
+                                                                    stride, int(accumulate))
+  return arr, len(calls), 0.0, calls[0][0].dtype
+
+
+def conv_dgrad_grouped(group):
+  """Independent input gradients in one call (c2d_conv_dgrad_grouped / _bf16)."""
+  fn = "c2d_conv_dgrad_grouped_bf16" if group[3] == torch.bfloat16 else "c2d_conv_dgrad_grouped"
+  _lib.call(fn, ctypes.cast(group[0], ctypes.c_void_p), group[1], _stream())
+
+
 def conv_dgrad(dc, ldc, coff, w, dx, lddx, dxoff, n, ih, iw, cin, cout, kh, kw, stride,
                accumulate):
   if dc.dtype == torch.bfloat16:

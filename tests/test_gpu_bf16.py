@@ -118,6 +118,31 @@ def test_conv_fwd_grouped_bf16_matches_single_calls():
       assert float(y2[:, :8].float().max()) == -3.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_conv_dgrad_grouped_matches_single_calls(dtype):
+  """c2d_conv_dgrad_grouped(_bf16): independent input gradients of one Inception level (single
+  image: one igemm_small_group_kernel<1, ES> launch), bit-identical to the single calls, with and
+  without accumulation into the destination."""
+  from cap2det_amd import hip_ops as ops
+  rng = np.random.default_rng(13)
+  n, hw = 1, 32
+  calls, singles = [], []
+  for (cin, cout, k, acc) in [(64, 96, 1, False), (96, 32, 3, True), (48, 64, 3, False), (80, 32, 1, True)]:
+    dc = torch.from_numpy(rng.standard_normal((n * hw * hw, cout + 8)).astype(np.float32)).to(DEV).to(dtype)
+    w = torch.from_numpy((rng.standard_normal((k * k, cin, cout)) / np.sqrt(k * k * cout)).astype(np.float32)).to(DEV).to(dtype)
+    base = torch.from_numpy(rng.standard_normal((n * hw * hw, cin + 8)).astype(np.float32)).to(DEV).to(dtype)
+    dx1, dx2 = base.clone(), base.clone()
+    args = [dc, cout + 8, 8, w, None, cin + 8, 8, n, hw, hw, cin, cout, k, k, 1, acc]
+    calls.append(tuple(args[:4] + [dx1] + args[5:]))
+    singles.append((args, dx2))
+  group = ops.conv_dgrad_group(calls)
+  ops.conv_dgrad_grouped(group)
+  assert ops.last_dispatch() == ["igemm_small_group_kernel<1, %d>" % (2 if dtype == torch.bfloat16 else 4)]
+  for (args, dx2), c in zip(singles, calls):
+    ops.conv_dgrad(*(args[:4] + [dx2] + args[5:]))
+    assert torch.equal(c[4], dx2), args[10:16]
+
+
 def test_cast_f32_is_exact():
   from cap2det_amd import hip_ops as ops
   src = torch.randn(1024 * 576, device=DEV).to(torch.bfloat16)
