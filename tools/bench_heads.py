@@ -1,3 +1,7 @@
+"""The fused heads GEMM (1024 -> 112 columns, N = 2000 rows: forward, input gradient, filter
+gradient), each timed alone with the instance it dispatches.
+
+  python tools/bench_heads.py"""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from cap2det_amd import hip_ops as ops
