@@ -157,3 +157,53 @@ def test_multiscale_inference_matches_oracle():
     np.testing.assert_allclose(pred["detection_scores_at_%d" % i].cpu().numpy(), sc, rtol=1e-5,
                                atol=1e-7)
     assert num[0] > 0
+
+
+def test_multiscale_inference_bf16_tracks_fp32():
+  """Evaluation mode with compute_dtype="bf16" (both towers in bf16 storage): the scores averaged
+  over three resolutions stay within 5 % of the tensor's maximum of the fp32 model's on the same
+  weights, and the post-processing of the model's OWN scores equals the oracle's NMS of them
+  exactly (labels, boxes, order)."""
+  from cap2det_amd.models import builder
+  pipeline = util_model.load_pipeline()
+  rng = np.random.default_rng(22)
+  dm, n = 0.5, 9
+  ex, preds = None, {}
+  for dtype in ("fp32", "bf16"):
+    model = builder.build(pipeline.model, is_training=False, device=DEV, depth_multiplier=dm,
+                          compute_dtype=dtype)
+    opt = model._model_proto
+    del opt.eval_min_dimension[:]
+    opt.eval_min_dimension.extend([48, 40, 33])
+    classes = model.label_extractor.classes
+    c, k = len(classes), 3
+    P32, d = util_model.oracle_state(5, c, k, dm, head_std=0.3)
+    model.load_state_dict(P32)
+    if ex is None:
+      ex = util_model.make_examples(rng, 1, 36, 44, n, [n], classes)
+    dev = dict(ex)
+    for key in ("image", "proposals"):
+      dev[key] = _t(ex[key])
+    dev["number_of_proposals"] = _t(ex["number_of_proposals"])
+    pred = model.build_prediction(dev)
+    torch.cuda.synchronize()
+    preds[dtype] = {kk: v.detach().float().cpu().numpy() if v.dtype.is_floating_point else v.cpu().numpy()
+                    for kk, v in pred.items() if torch.is_tensor(v)}
+    if dtype == "bf16":
+      assert model.engine.first.dtype == torch.bfloat16 and model.engine.second.dtype == torch.bfloat16
+  k = 3
+  for i in range(k + 1):
+    a, b = preds["fp32"]["oicr_proposal_scores_at_%d" % i], preds["bf16"]["oicr_proposal_scores_at_%d" % i]
+    assert np.abs(a - b).max() <= 5e-2 * np.abs(a).max(), (i, np.abs(a - b).max(), np.abs(a).max())
+  mid = dict(score_thresh=1e-5, iou_thresh=0.4, max_size_per_class=100, max_total_size=300)
+  oic = dict(mid, iou_thresh=0.3)
+  p16 = preds["bf16"]
+  for i in range(k + 1):
+    s = p16["oicr_proposal_scores_at_%d" % i]
+    if i > 0:
+      s = pp.softmax_drop_background(s.astype(np.float64)).astype(np.float32)
+    num, b, sc, cl = pp.batch_multiclass_nms(ex["proposals"], s, **(mid if i == 0 else oic))
+    np.testing.assert_array_equal(p16["num_detections_at_%d" % i], num)
+    np.testing.assert_array_equal(p16["detection_classes_at_%d" % i], cl)
+    np.testing.assert_array_equal(p16["detection_boxes_at_%d" % i], b)
+    np.testing.assert_allclose(p16["detection_scores_at_%d" % i], sc, rtol=1e-5, atol=1e-7)
