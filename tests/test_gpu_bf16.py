@@ -372,3 +372,49 @@ def _check_train_step_bf16(pipeline, dm, hw, n, nums, make_labels, extra_example
   assert cos >= 0.999, "whole-gradient cosine similarity %.5f" % cos
   assert _rel_l2(g, w) <= tol["whole"], _rel_l2(g, w)
   return trainer
+
+
+def test_feature_map_dropout_branch_bf16_tracks_fp32():
+  """`dropout_on_feature_map: true` (models/utils.py:138-142; off in every shipped config) in the
+  bf16 mode: the mask is applied to the fp32 widening of the bf16 tower's output in front of the
+  ROI crop, its backward to the fp32 crop gradient before the cast for Mixed_4e.  Same injected
+  masks in both modes: losses within 2 %, the whole gradient at cosine >= 0.995 (observed 0.9988 on
+  this tiny case: 96-pixel feature maps, half of them dropped)."""
+  from cap2det_amd.protos import cap2det_model_pb2
+  from cap2det_amd.train.trainer import Trainer
+  from tests import util_model
+  dm, hw, n, nums = 0.5, (48, 56), 7, [7, 5]
+  rng = np.random.default_rng(31)
+  out = {}
+  ex = mask = fmask = None
+  for dtype in ("fp32", "bf16"):
+    pipeline = util_model.load_pipeline()
+    m = pipeline.model.Extensions[cap2det_model_pb2.Cap2DetModel.ext]
+    m.frcnn_options.dropout_on_feature_map = True
+    trainer = Trainer(pipeline, device=DEV, depth_multiplier=dm, compute_dtype=dtype)
+    model = trainer.model
+    classes = model.label_extractor.classes
+    P32, d = util_model.oracle_state(6, len(classes), 3, dm)
+    model.load_state_dict(P32)
+    if ex is None:
+      ex = util_model.make_examples(rng, 2, hw[0], hw[1], n, nums, classes)
+      mask = (rng.uniform(size=(2 * n, d)) < 0.5).astype(np.uint8)
+    dev = dict(ex)
+    for key in ("image", "proposals"):
+      dev[key] = torch.from_numpy(ex[key]).to(DEV).contiguous()
+    dev["number_of_proposals"] = torch.from_numpy(ex["number_of_proposals"]).to(DEV)
+    if fmask is None:
+      bufs = model.engine._buffers(2, hw[0], hw[1], n, True)
+      fmask = (rng.uniform(size=(2 * bufs["fh"] * bufs["fw"], model.engine.first.cout)) < 0.5).astype(np.uint8)
+    losses = trainer.train_step(dev, dropout_mask=torch.from_numpy(mask).to(DEV),
+                                feature_map_dropout_mask=torch.from_numpy(fmask).to(DEV))
+    torch.cuda.synchronize()
+    grads = model.grad_dict()
+    out[dtype] = ({k: float(v) for k, v in losses.items()},
+                  np.concatenate([np.asarray(grads[k], np.float64).ravel() for k in sorted(grads)]))
+  (l32, g32), (l16, g16) = out["fp32"], out["bf16"]
+  for k in l32:
+    assert abs(l32[k] - l16[k]) <= 2e-2 * max(abs(l32[k]), 1e-6), (k, l32[k], l16[k])
+  cos = float(g32 @ g16 / (np.linalg.norm(g32) * np.linalg.norm(g16)))
+  assert cos >= 0.995, cos
+  assert float(np.abs(g32 - g16).max()) > 0.0
