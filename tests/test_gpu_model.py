@@ -454,19 +454,23 @@ def test_towers_restore_from_tf_checkpoint(tmp_path):
   assert float(l1["total_loss"]) == float(l2["total_loss"])  # resuming reproduces the next step
 
 
-def test_first_stage_lookahead_is_neutral():
+@pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
+def test_first_stage_lookahead_is_neutral(compute_dtype):
   """Trainer.train_step(examples, prefetch=next_examples): the frozen first-stage layers of the
   next image run one step early on a side stream.  Same losses and variables as the plain
   sequence of steps — with matching, mismatching and absent look-aheads — up to the summation
   order of the fp32 filter-gradient atomics (two plain runs differ by as much; a look-ahead that
-  was wrongly used would change the losses in the first digit)."""
+  was wrongly used would change the losses in the first digit).  bf16: the look-ahead also
+  carries the stem's cast and the bf16 tower's buffers; an atomics-order difference can move a
+  bf16 rounding in later steps, so 1 % there (first step still bitwise)."""
   from cap2det_amd.train.trainer import Trainer
   pipeline = util_model.load_pipeline()
   rng = np.random.default_rng(5)
   classes = None
   runs = []
+  ltol, vtol = (2e-6, 1e-4) if compute_dtype == "fp32" else (1e-2, 2e-2)
   for mode in ("plain", "lookahead"):
-    tr = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=3)
+    tr = Trainer(pipeline, device=DEV, depth_multiplier=0.5, seed=3, compute_dtype=compute_dtype)
     classes = tr.model.label_extractor.classes
     r = np.random.default_rng(11)
     batches = [_to_dev(util_model.make_examples(r, 1, 64, 48, 6, [6], classes)) for _ in range(4)]
@@ -482,9 +486,10 @@ def test_first_stage_lookahead_is_neutral():
     torch.cuda.synchronize()
     runs.append((losses, tr.model.state_dict()))
   assert runs[0][0][0] == runs[1][0][0]                      # first step: identical inputs, bitwise
-  np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=2e-6)
+  np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=ltol)
   for n, v in runs[0][1].items():
-    np.testing.assert_allclose(v, runs[1][1][n], rtol=1e-4, atol=2e-6, err_msg=n)
+    np.testing.assert_allclose(v, runs[1][1][n], rtol=vtol, atol=2e-6 if compute_dtype == "fp32" else 2e-4,
+                               err_msg=n)
 
 
 def test_trainer_train_loop_with_lookahead(tmp_path):
