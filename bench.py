@@ -119,6 +119,7 @@ class KernelTimer(object):
                                          (esize(a[0]) * a[8] * a[9] if a[10] else 0.0),
         "conv1x1_dgrad_multi_bn_relu": lambda a: multi_bytes(a[13], a[14], a[4], esize(a[0])) +
                                                  esize(a[0]) * a[13] * a[14] * (2.0 if a[15] else 1.0),
+        "conv1x1_wgrad_multi": lambda a: esize(a[0]) * a[8] * (a[9] + sum(a[7])) + 4.0 * a[9] * sum(a[7]),
         "conv1x1_fwd_multi": lambda a: multi_bytes(a[4], a[5], [o.cout for o in a[3][0]], esize(a[0])),
     }
 
@@ -204,6 +205,9 @@ class KernelTimer(object):
     ops.conv_fwd_grouped = timed(ops.conv_fwd_grouped, "igemm_nt", lambda args: args[0][2])
     ops.conv_dgrad = timed(ops.conv_dgrad, "igemm_nt", conv_work("dgrad"))
     ops.conv_wgrad = timed(ops.conv_wgrad, "wgrad_tn", wgrad_work)
+    # conv1x1_wgrad_multi(x, ldx, xoff, dcs, ldcs, coffs, dws, couts, rows, cin)
+    ops.conv1x1_wgrad_multi = timed(ops.conv1x1_wgrad_multi, "wgrad_tn",
+                                    lambda a: 2.0 * a[8] * a[9] * sum(a[7]))
     # bf16 mode: split-K slabs (same argument positions as conv_wgrad) + the batched reduction of
     # the slabs, whose time belongs to the filter gradients (it replaces their atomics)
     ops.conv_wgrad_partial = timed(ops.conv_wgrad_partial, "wgrad_tn", wgrad_work)

@@ -845,7 +845,7 @@ constexpr int WG_STRIDE = 128 + 4;  // floats per k-row of the [WBK][128] tiles
 // the last 128-wide j-tile would be at most half full: J = 192, 160, 320 ...).
 // PLAIN = 1x1 / stride 1 (source row = output row): the loader's offsets are slab-invariant.
 template <int NTJ, bool PLAIN, int ES>
-__global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_tn_body(const WgradArgs& a, const WgradBlock blk) {
   constexpr int BJ = 2 * NTJ * 32;
   __shared__ __attribute__((aligned(16))) float As[WBK * WG_STRIDE];
   __shared__ __attribute__((aligned(16))) float Gs[WBK * WG_STRIDE];
@@ -854,7 +854,6 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int itiles = (a.I + 127) / 128;
-  const WgradBlock blk = wgrad_block(a);
   const int tap = blk.x / itiles;
   const int i0 = (blk.x - tap * itiles) * 128;
   const int j0 = blk.y * BJ;
@@ -977,6 +976,23 @@ __global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
         else atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
       }
   }
+}
+
+template <int NTJ, bool PLAIN, int ES>
+__global__ __launch_bounds__(256, 4) void wgrad_tn_kernel(WgradArgs a) {
+  wgrad_tn_body<NTJ, PLAIN, ES>(a, wgrad_block(a));
+}
+
+// Filter gradients of SEVERAL 1x1 / stride-1 convolutions of one input in ONE launch (the entry
+// convolutions of an Inception block, c2d_conv1x1_wgrad_multi): the row splits are shared, so the
+// launch has as many splits as ALL its tiles leave room for — a third of the split-K atomics of
+// the separate launches — and the x rows of a split are fetched into the XCD's L2 once for every
+// output.  Block -> (split, problem, tile): all tiles of a split are consecutive on one XCD.
+template <int NTJ, int ES>
+__global__ __launch_bounds__(256, 4) void wgrad_tn_group_kernel(WgradGroupArgs g) {
+  int p;
+  const WgradBlock blk = wgrad_group_block(g, &p);
+  wgrad_tn_body<NTJ, true, ES>(g.a[p], blk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2709,6 +2725,76 @@ extern "C" int c2d_conv_wgrad_bf16(const void* x, int ldx, int xoff, const void*
                                    int kh, int kw, int stride, void* stream) {
   return conv_wgrad_impl<2>((const float*)x, ldx, xoff, (const float*)dc, ldc, coff, dw, n, ih, iw,
                             cin, cout, kh, kw, stride, stream);
+}
+
+// ---- several 1x1 filter gradients of one input in one launch -----------------------------------
+template <int ES>
+static int conv1x1_wgrad_multi_impl(const float* x, int ldx, int xoff, int nseg,
+                                    const float* const* dcs, const int* ldcs, const int* coffs,
+                                    float* const* dws, const int* couts, int rows, int cin,
+                                    void* stream) {
+  dispatch_reset();
+  C2D_CHECK_ARG(x && dcs && ldcs && coffs && dws && couts && nseg >= 1 && nseg <= WGRAD_GROUP_MAX);
+  C2D_CHECK_ARG(rows > 0 && cin > 0 && cin % 4 == 0 && ldx % 4 == 0 && xoff % 4 == 0);
+  C2D_CHECK_ARG((long long)rows * ldx * 4 < (long long)OOB_OFFSET);
+  WgradArgs a[WGRAD_GROUP_MAX];
+  for (int p = 0; p < nseg; ++p) {
+    C2D_CHECK_ARG(dcs[p] && dws[p] && couts[p] > 0 && couts[p] % 4 == 0 && ldcs[p] % 4 == 0 &&
+                  coffs[p] % 4 == 0 && (long long)rows * ldcs[p] * 4 < (long long)OOB_OFFSET);
+    const int rc = fill_geom(&a[p].g, 1, 1, 1, 1, 1, 0);
+    if (rc) return rc;
+    a[p].A = x; a[p].lda = ldx; a[p].a_off = xoff; a[p].G = dcs[p]; a[p].ldg = ldcs[p];
+    a[p].g_off = coffs[p]; a[p].dW = dws[p]; a[p].M = rows; a[p].I = cin; a[p].J = couts[p];
+    a[p].a_rows = rows; a[p].part_stride = 0;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (ES == 2) {
+    C2D_CHECK_ARG(cin % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0);
+    for (int p = 0; p < nseg; ++p)
+      C2D_CHECK_ARG(couts[p] % 8 == 0 && ldcs[p] % 8 == 0 && coffs[p] % 8 == 0);
+    return launch_wgrad1x1_bf16_ring_group(a, nseg, st);
+  }
+  // fp32: 128 x 64 block tiles for every output (the 32-column MFMA tiles beyond an output's
+  // width issue nothing), four workgroups per CU in one round
+  WgradGroupArgs g;
+  int tiles = 0;
+  for (int p = 0; p < nseg; ++p) {
+    a[p].tiles_x = c2d_ceil_div(cin, 128);
+    a[p].tiles_y = c2d_ceil_div(couts[p], 64);
+    g.first_tile[p] = tiles;
+    tiles += a[p].tiles_x * a[p].tiles_y;
+  }
+  for (int p = nseg; p <= WGRAD_GROUP_MAX; ++p) g.first_tile[p] = tiles;
+  int splits = 1024 / tiles;
+  const int max_splits = c2d_ceil_div(rows, 4 * WBK);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int rps = c2d_ceil_div(c2d_ceil_div(rows, splits), WBK) * WBK;
+  g.nsplits = c2d_ceil_div(rows, rps);
+  g.num = nseg;
+  for (int p = 0; p < nseg; ++p) {
+    a[p].rows_per_split = rps; a[p].nsplits = g.nsplits;
+    g.a[p] = a[p];
+  }
+  dispatch_note("wgrad_tn_group_kernel<1, %d>", ES);
+  hipLaunchKernelGGL((wgrad_tn_group_kernel<1, 4>), dim3(tiles * g.nsplits), dim3(256), 0, st, g);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_conv1x1_wgrad_multi(const float* x, int ldx, int xoff, int nseg,
+                                       const float* const* dcs, const int* ldcs, const int* coffs,
+                                       float* const* dws, const int* couts, int rows, int cin,
+                                       void* stream) {
+  return conv1x1_wgrad_multi_impl<4>(x, ldx, xoff, nseg, dcs, ldcs, coffs, dws, couts, rows, cin,
+                                     stream);
+}
+
+extern "C" int c2d_conv1x1_wgrad_multi_bf16(const void* x, int ldx, int xoff, int nseg,
+                                            const void* const* dcs, const int* ldcs,
+                                            const int* coffs, float* const* dws, const int* couts,
+                                            int rows, int cin, void* stream) {
+  return conv1x1_wgrad_multi_impl<2>((const float*)x, ldx, xoff, nseg, (const float* const*)dcs, ldcs,
+                                     coffs, dws, couts, rows, cin, stream);
 }
 
 // ---- split-K slabs instead of atomics (bf16 MFMA filter gradients) -----------------------------

@@ -931,9 +931,7 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* lo_p, const char* hi_p) {
 }
 
 template <int NTJ, int BKT, int D>
-__global__ __launch_bounds__(256, (160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 3 ? 3
-                                  : ((160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 2 ? 2 : 1))
-void wgrad1x1_bf16_ring_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad1x1_bf16_ring_body(const WgradArgs& a, const WgradBlock blk) {
   constexpr int BJ = NTJ * 64;                         // output columns per block (64 or 128)
   constexpr int A_RB = 256, G_RB = BJ * 2;             // bytes per staged row
   constexpr int A_BYTES = BKT * A_RB, G_BYTES = BKT * G_RB;
@@ -949,7 +947,6 @@ void wgrad1x1_bf16_ring_kernel(WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int itiles = (a.I + 127) / 128;
-  const WgradBlock blk = wgrad_block(a);
   const int i0 = (blk.x % itiles) * 128;
   const int j0 = blk.y * BJ;
   const int mbeg = blk.z * a.rows_per_split;
@@ -1071,6 +1068,22 @@ void wgrad1x1_bf16_ring_kernel(WgradArgs a) {
   }
 }
 
+#define C2D_WRING_BOUNDS(NTJ, BKT, D)                                                            \
+  __launch_bounds__(256, (160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 3                      \
+                             ? 3 : ((160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 2 ? 2 : 1))
+template <int NTJ, int BKT, int D>
+__global__ C2D_WRING_BOUNDS(NTJ, BKT, D) void wgrad1x1_bf16_ring_kernel(WgradArgs a) {
+  wgrad1x1_bf16_ring_body<NTJ, BKT, D>(a, wgrad_block(a));
+}
+// several filter gradients of one input in one launch (see WgradGroupArgs)
+template <int NTJ, int BKT, int D>
+__global__ C2D_WRING_BOUNDS(NTJ, BKT, D) void wgrad1x1_bf16_ring_group_kernel(WgradGroupArgs g) {
+  int p;
+  const WgradBlock blk = wgrad_group_block(g, &p);
+  wgrad1x1_bf16_ring_body<NTJ, BKT, D>(g.a[p], blk);
+}
+#undef C2D_WRING_BOUNDS
+
 struct WgradTune { int bk, d, slots, off; };
 const WgradTune& wgrad_tune() {
   static const WgradTune t = [] {
@@ -1128,6 +1141,41 @@ int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool 
   C2D_WR(1, 64, 2) C2D_WR(2, 64, 2) C2D_WR(1, 32, 3) C2D_WR(2, 32, 3)
 #undef C2D_WR
   return C2D_ERR_UNSUPPORTED;
+}
+
+
+// Grouped form (c2d_conv1x1_wgrad_multi_bf16): `num` 1x1 / stride-1 filter gradients that share
+// the activations x; 128-column tiles for every output, ONE split count from the tiles of all.
+int launch_wgrad1x1_bf16_ring_group(WgradArgs* a, int num, hipStream_t s) {
+  if (num < 1 || num > WGRAD_GROUP_MAX) return C2D_ERR_UNSUPPORTED;
+  WgradGroupArgs g;
+  int tiles = 0;
+  for (int p = 0; p < num; ++p) {
+    if (a[p].I % 8 != 0 || a[p].J % 8 != 0 || a[p].I < 8 || a[p].J < 8 || a[p].lda % 8 != 0 ||
+        a[p].ldg % 8 != 0 || a[p].a_off % 8 != 0 || a[p].g_off % 8 != 0 || a[p].M != a[0].M)
+      return C2D_ERR_UNSUPPORTED;
+    a[p].tiles_x = c2d_ceil_div(a[p].I, 128);
+    a[p].tiles_y = c2d_ceil_div(a[p].J, 128);
+    g.first_tile[p] = tiles;
+    tiles += a[p].tiles_x * a[p].tiles_y;
+  }
+  for (int p = num; p <= WGRAD_GROUP_MAX; ++p) g.first_tile[p] = tiles;
+  const WgradTune& t = wgrad_tune();
+  int splits = (t.slots > 0 ? t.slots : 512) / tiles;       // two workgroups per CU in one round
+  const int max_splits = c2d_ceil_div(a[0].M, 4 * 64);      // at least 4 stages per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int rps = c2d_ceil_div(c2d_ceil_div(a[0].M, splits), 64) * 64;
+  g.nsplits = c2d_ceil_div(a[0].M, rps);
+  g.num = num;
+  for (int p = 0; p < num; ++p) {
+    a[p].rows_per_split = rps; a[p].nsplits = g.nsplits; a[p].part_stride = 0;
+    a[p].a_rows = a[p].M;
+    g.a[p] = a[p];
+  }
+  dispatch_note_ext("wgrad1x1_bf16_ring_group_kernel<2, 64, 2>");
+  hipLaunchKernelGGL((wgrad1x1_bf16_ring_group_kernel<2, 64, 2>), dim3(tiles * g.nsplits), dim3(256), 0, s, g);
+  return c2d_launch_status();
 }
 
 }  // namespace c2d_ig

@@ -323,6 +323,30 @@ __device__ __forceinline__ WgradBlock wgrad_block(const WgradArgs& a) {
 }
 
 
+// Several 1x1 / stride-1 filter gradients of ONE input in one launch (conv_gemm.hip:
+// wgrad_tn_group_kernel, igemm_bf16.hip: wgrad1x1_bf16_ring_group_kernel).
+constexpr int WGRAD_GROUP_MAX = 4;
+struct WgradGroupArgs {
+  WgradArgs a[WGRAD_GROUP_MAX];
+  int first_tile[WGRAD_GROUP_MAX + 1];   // first tile of problem p inside a split; [num] = tiles per split
+  int num, nsplits;
+};
+__device__ __forceinline__ WgradBlock wgrad_group_block(const WgradGroupArgs& g, int* p_out) {
+  const int txy = g.first_tile[g.num];
+  const int logical = xcd_remap(blockIdx.x, txy * g.nsplits);
+  WgradBlock b;
+  b.z = logical / txy;
+  int t = logical - b.z * txy;
+  int p = 0;
+  for (int i = 1; i < g.num; ++i)
+    if (t >= g.first_tile[i]) p = i;
+  t -= g.first_tile[p];
+  b.y = t / g.a[p].tiles_x;
+  b.x = t - b.y * g.a[p].tiles_x;
+  *p_out = p;
+  return b;
+}
+
 // ---- cross-file plumbing -----------------------------------------------------------------------
 // Dispatch record of the calling thread's last convolution entry point (conv_gemm.hip).
 void dispatch_note_ext(const char* fmt, int a = 0, int b = 0, int c = 0, int d = 0, int e = 0,
@@ -341,5 +365,8 @@ int launch_igemm_f32_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bo
 // fills the tiling fields of `a` itself.  *splits_out = row splits (slabs of a.part_stride floats
 // when a.part_stride > 0, else atomics into a.dW).  splits_only: compute the split count only.
 int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool splits_only);
+// `num` (<= WGRAD_GROUP_MAX) 1x1 / stride-1 filter gradients of ONE input as one launch; fills the
+// tiling fields of a[p] itself (atomics into a[p].dW).
+int launch_wgrad1x1_bf16_ring_group(WgradArgs* a, int num, hipStream_t s);
 
 }  // namespace c2d_ig

@@ -225,6 +225,18 @@ def conv1x1_dgrad_multi(dcs, ldcs, coffs, ws, couts, dx, lddx, dxoff, rows, cin,
             int(accumulate), _stream())
 
 
+def conv1x1_wgrad_multi(x, ldx, xoff, dcs, ldcs, coffs, dws, couts, rows, cin):
+  """dws[s] += x^T . dcs[s] for up to 4 1x1 / stride-1 convolutions of ONE input in one launch
+  (c2d_conv1x1_wgrad_multi(_bf16), see include/cap2det_hip.h)."""
+  n = len(dcs)
+  ptrs = ctypes.c_void_p * n
+  ints = ctypes.c_int * n
+  assert all(t.dtype == x.dtype for t in dcs) and all(t.dtype == torch.float32 for t in dws)
+  fn = "c2d_conv1x1_wgrad_multi_bf16" if x.dtype == torch.bfloat16 else "c2d_conv1x1_wgrad_multi"
+  _lib.call(fn, _p(x), ldx, xoff, n, ptrs(*[_p(t) for t in dcs]), ints(*ldcs), ints(*coffs),
+            ptrs(*[_p(t) for t in dws]), ints(*couts), rows, cin, _stream())
+
+
 def conv_wgrad(x, ldx, xoff, dc, ldc, coff, dw, n, ih, iw, cin, cout, kh, kw, stride):
   fn = "c2d_conv_wgrad_bf16" if x.dtype == torch.bfloat16 else "c2d_conv_wgrad"
   assert x.dtype == dc.dtype and dw.dtype == torch.float32

@@ -77,6 +77,9 @@ SECOND_STAGE = [
 
 
 GROUP_MAX_ROWS = 16384   # block inputs up to this many rows use grouped launches per level
+# block inputs from this many rows on take ONE grouped filter-gradient launch for their 1x1 entry
+# convolutions (c2d_conv1x1_wgrad_multi); below, the row splits of one output already fill the chip
+WGRAD_MULTI_MIN_ROWS = int(os.environ.get("C2D_WGRAD_MULTI_MIN_ROWS", "8192"))
 
 
 def _out_hw(h, w, stride):
@@ -720,8 +723,10 @@ class Net(object):
       ops.conv_wgrad(x.t, x.ld, x.off, dc, dcld, dcoff, self.store.grad[L.name + "/weights"],
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
 
-  def _conv_bwd(self, plan, st, x, gx, accumulate, dc=None):
-    """BN/ReLU backward -> dc, filter gradient, and (when gx is given) the input gradient."""
+  def _conv_bwd(self, plan, st, x, gx, accumulate, dc=None, defer=None):
+    """BN/ReLU backward -> dc, filter gradient, and (when gx is given) the input gradient.
+    defer: list collecting (step, dc, row stride, column offset) of the filter gradients the caller
+    launches itself (_entry_wgrads: the entry convolutions of a block in ONE grouped launch)."""
     L = st["layer"]
     gy, y = st["gy"], st["y"]
     rows = st["n"] * st["oh"] * st["ow"]
@@ -775,7 +780,9 @@ class Net(object):
                       g[L.name + "/BatchNorm/beta"] if tr else None,
                       g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
                       rows, L.cout)
-    if tr and side is not None:
+    if tr and defer is not None and slot is None and st.get("wpart") is None:
+      defer.append((st, dc, dcld, dcoff))
+    elif tr and side is not None:
       # dW only meets the rest of the step at the all-reduce / optimiser: it runs on a side stream
       # beside the input-gradient GEMM of the same layer, each filling the other's partial rounds
       ready = torch.cuda.Event()
@@ -803,6 +810,39 @@ class Net(object):
     elif gx is not None:
       ops.conv_dgrad(dc, dcld, dcoff, L.w_for(self.dtype), gx.t, gx.ld, gx.off,
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
+
+  def _entry_wgrads(self, plan, x, deferred):
+    """Filter gradients of a block's 1x1 entry convolutions, which all read the block input: ONE
+    c2d_conv1x1_wgrad_multi launch (shared row splits, a third of the split atomics, the input
+    rows fetched once) on the side stream."""
+    if not deferred:
+      return
+    st0 = deferred[0][0]
+    rows = st0["n"] * st0["oh"] * st0["ow"]
+    side = self.side if plan.get("dc_alt") is not None else None
+
+    def launch():
+      if len(deferred) == 1 or rows < WGRAD_MULTI_MIN_ROWS or self.dtype == torch.float32:
+        # (fp32: the grouped launch's 1024 workgroups crowd the input-gradient GEMM it runs
+        # beside — 11.77 -> 11.91 ms per step measured — so the outputs stay separate launches)
+        for st, dc, dcld, dcoff in deferred:
+          self._wgrad(plan, st, x, dc, dcld, dcoff)
+        return
+      ops.conv1x1_wgrad_multi(
+          x.t, x.ld, x.off, [dc for _, dc, _, _ in deferred], [ld for _, _, ld, _ in deferred],
+          [off for _, _, _, off in deferred],
+          [self.store.grad[st["layer"].name + "/weights"] for st, _, _, _ in deferred],
+          [st["layer"].cout for st, _, _, _ in deferred], rows, st0["layer"].cin)
+
+    if side is not None:
+      ready = torch.cuda.Event()
+      ready.record()
+      side.wait_event(ready)
+      with torch.cuda.stream(side):
+        launch()
+      plan["side_pending"] = True
+    else:
+      launch()
 
   @staticmethod
   def _entry_dc(b):
@@ -848,8 +888,10 @@ class Net(object):
           if not any(b is f for f in fused):
             self._bwd_step(plan, b, x, gx, written)
             written = True
+        deferred = []
         for b in fused:
-          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"])
+          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"], defer=deferred)
+        self._entry_wgrads(plan, x, deferred)
         rows = st["n"] * st["ih"] * st["iw"]
         ws0 = owner["ws_off"]
         if "prods" not in owner:
@@ -862,8 +904,10 @@ class Net(object):
             plan["bn_ws"][ws0:ws0 + owner["nb"] * 2 * owner["ctot"]], rows, st["cin"], written)
         return
       if len(fused) >= 2:
+        deferred = []
         for b in fused:
-          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"])
+          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"], defer=deferred)
+        self._entry_wgrads(plan, x, deferred)
         rows = st["n"] * st["ih"] * st["iw"]
         segs = [self._entry_dc(b) for b in fused]
         ops.conv1x1_dgrad_multi(

@@ -174,6 +174,21 @@ int c2d_conv1x1_dgrad_multi_bf16(int nseg, const void* const* dcs, const int* ld
                                  void* dx, int lddx, int dxoff, int rows, int cin, int accumulate,
                                  void* stream);
 
+/* The filter gradients of SEVERAL 1x1 / stride-1 convolutions of ONE input (the entry convolutions
+ * of an Inception block: nets/inception_v2 via models/utils.py:165-167, gradients taken by
+ * train/trainer.py:141-146) in one launch: dws[s][cin][couts[s]] += x^T . dcs[s], nseg <= 4, HOST
+ * arrays of device pointers / leading dimensions / column offsets / widths.  The row splits are
+ * shared by all outputs (a third of the split-K atomics of nseg separate c2d_conv_wgrad calls,
+ * the x rows of a split fetched once); same sums up to the fp32 order of the split additions.
+ * _bf16: x and dcs hold bf16, dws stay fp32. */
+int c2d_conv1x1_wgrad_multi(const float* x, int ldx, int xoff, int nseg, const float* const* dcs,
+                            const int* ldcs, const int* coffs, float* const* dws,
+                            const int* couts, int rows, int cin, void* stream);
+int c2d_conv1x1_wgrad_multi_bf16(const void* x, int ldx, int xoff, int nseg,
+                                 const void* const* dcs, const int* ldcs, const int* coffs,
+                                 float* const* dws, const int* couts, int rows, int cin,
+                                 void* stream);
+
 /* dw[kh*kw][cin][cout] += Conv2DBackpropFilter(x, dc)  (fp32 atomics over row splits; the
  * caller zero-fills dw once per step). */
 int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, int coff,

@@ -867,3 +867,31 @@ def test_fused_entry_points_agree_with_unfused_launches_on_random_shapes():
                      capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
   assert "0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("rows,cin,couts", [(4096, 576, (128, 192)), (3000, 1024, (352, 192, 160, 128)),
+                                            (1000, 64, (32, 48, 80)), (2500, 96, (40,))])
+def test_conv1x1_wgrad_multi_matches_the_oracle(ops, rows, cin, couts, dtype):
+  """c2d_conv1x1_wgrad_multi(_bf16): the filter gradients of several 1x1 convolutions of one input
+  in ONE launch (shared row splits) against x^T . dc in float64 on the same operands, inputs and
+  gradients inside wider buffers, ACCUMULATING into non-zero dw; the instance is the grouped one."""
+  rng = np.random.default_rng(rows + cin)
+  low = dtype == torch.bfloat16
+  ldx, xoff = cin + 16, 8
+  xb = torch.from_numpy(rng.standard_normal((rows, ldx)).astype(np.float32)).to(DEV).to(dtype)
+  x64 = xb[:, xoff:xoff + cin].float().cpu().numpy().astype(np.float64)
+  dcs, ldcs, coffs, dws, wants = [], [], [], [], []
+  for c in couts:
+    ld, off = c + 24, 16
+    d = torch.from_numpy(rng.standard_normal((rows, ld)).astype(np.float32)).to(DEV).to(dtype)
+    base = rng.standard_normal((cin, c)).astype(np.float32)
+    dcs.append(d); ldcs.append(ld); coffs.append(off)
+    dws.append(torch.from_numpy(base.copy()).to(DEV))
+    wants.append(base.astype(np.float64) + x64.T @ d[:, off:off + c].float().cpu().numpy().astype(np.float64))
+  ops.conv1x1_wgrad_multi(xb, ldx, xoff, dcs, ldcs, coffs, dws, list(couts), rows, cin)
+  inst = ops.last_dispatch()
+  assert inst == (["wgrad1x1_bf16_ring_group_kernel<2, 64, 2>"] if low else ["wgrad_tn_group_kernel<1, 4>"]), inst
+  for dw, want in zip(dws, wants):
+    err = np.abs(dw.cpu().numpy().astype(np.float64) - want).max()
+    assert err <= 3e-5 * np.abs(want).max(), (err, np.abs(want).max())

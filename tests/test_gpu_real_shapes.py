@@ -238,6 +238,33 @@ def test_block_entry_dgrad_multi(ops, block, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("block", ["Mixed_5a", "Mixed_5b", "Mixed_5c"])
+def test_block_entry_wgrad_multi(ops, block, dtype):
+  """The filter gradients of a block's 1x1 entry convolutions in ONE launch (c2d_conv1x1_wgrad_multi:
+  the bf16 step's launch; shared row splits) at the real widths and 704 ROIs, the gradients at their
+  places in the step: inside the block's own buffers or (352-wide branch 0) the 1024-wide concat
+  gradient.  Against x^T . dc in float64."""
+  hw, cin, couts = {"Mixed_5a": (7, 576, [128, 192]), "Mixed_5b": (4, 1024, [352, 192, 160]),
+                    "Mixed_5c": (4, 1024, [352, 192, 192])}[block]
+  low = dtype == torch.bfloat16
+  rng = np.random.default_rng(37)
+  rows = 704 * hw * hw
+  x = rng.standard_normal((rows, cin)).astype(np.float32)
+  wide = rng.standard_normal((rows, 1024)).astype(np.float32)       # branch 0 = columns 0..c0 of it
+  dcs = [wide] + [rng.standard_normal((rows, c)).astype(np.float32) for c in couts[1:]]
+  if low:
+    x, dcs = _bf16_round(x), [_bf16_round(a) for a in dcs]
+  dws = [torch.zeros(cin, c, device=DEV) for c in couts]
+  ops.conv1x1_wgrad_multi(_t(x).to(dtype), cin, 0, [_t(a).to(dtype) for a in dcs],
+                          [1024] + couts[1:], [0] * len(couts), dws, couts, rows, cin)
+  inst = ops.last_dispatch()
+  _seen.update(inst)
+  for dw, dc, c in zip(dws, dcs, couts):
+    want = x.astype(np.float64).T @ dc[:, :c].astype(np.float64)
+    _scale_close(_n(dw), want, 2e-5, "%s entry wgrad %s" % (block, inst))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("block", ["Mixed_5a", "Mixed_5b", "Mixed_5c"])
 def test_block_entry_fwd_multi(ops, block, dtype):
   """The 1x1 entry convolutions of an Inception block as ONE GEMM (c2d_conv1x1_fwd_multi) at the
   real widths — 5a: 576 -> (128, 192) on 7x7; 5b: 1024 -> (352, 192, 160, 128: the commuted

@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CONV_ENTRY_POINTS = ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv1x1_fwd_multi", "conv1x1_dgrad_multi",
                      "conv_dgrad_bn_relu", "conv1x1_dgrad_multi_bn_relu", "conv_fwd_grouped",
-                     "conv_wgrad_partial")
+                     "conv_wgrad_partial", "conv1x1_wgrad_multi")
 _dispatched = {}
 
 
