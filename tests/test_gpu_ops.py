@@ -417,7 +417,8 @@ def test_pool3x3(ops, mode, stride, ih, iw, n):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("ih,iw,n,accumulate", [(4, 4, 70, False), (7, 7, 6, True), (9, 5, 3, False)])
+@pytest.mark.parametrize("ih,iw,n,accumulate", [(4, 4, 70, False), (4, 4, 130, True), (7, 7, 6, True),
+                                                (9, 5, 3, False)])
 def test_avgpool3x3_relu_and_bn_bwd_without_relu(ops, ih, iw, n, accumulate, dtype):
   """The three pieces of an average-pooling branch commuted behind its 1x1 convolution:
   y = relu(avg_pool(z)), dz (+)= avg_pool_bwd(dy * (y > 0)), and the BatchNorm backward of a
