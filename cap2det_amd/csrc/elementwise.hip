@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void pool3x3_map_fwd_kernel(
 // Gradient: the lane keeps the whole dy map (and arg-max map) of its ROI in registers and emits
 // each input pixel's gradient from the <= 9 outputs whose window holds it, in the generic
 // kernel's (ky, kx) order.
-template <int IH, int STRIDE, int MODE, typename T>
+template <int IH, int STRIDE, int MODE, typename T, bool YM = false>
 __global__ __launch_bounds__(256) void pool3x3_map_bwd_kernel(
     const T* __restrict__ dy, int lddy, int dyoff, const uint8_t* __restrict__ arg,
     T* __restrict__ dx, int lddx, int dxoff, int n, int c4n, int accumulate,
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void pool3x3_map_bwd_kernel(
 #pragma unroll
     for (int o = 0; o < OH * OW; ++o) {
       g[o] = c2d_ld4(gp + (size_t)o * lddy);
-      if (ymask) {         // the pool's output went through a ReLU: its gradient passes where y > 0
+      if (YM) {            // the pool's output went through a ReLU: its gradient passes where y > 0
         const float4 yv = c2d_ld4(ymask + ((size_t)img * (OH * OW) + o) * ldym + ymoff + c4 * 4);
         g[o].x = yv.x > 0.f ? g[o].x : 0.f; g[o].y = yv.y > 0.f ? g[o].y : 0.f;
         g[o].z = yv.z > 0.f ? g[o].z : 0.f; g[o].w = yv.w > 0.f ? g[o].w : 0.f;
@@ -877,15 +877,17 @@ int pool3x3_bwd_impl(const T* dy, int lddy, int dyoff, const uint8_t* argmax, T*
   C2D_CHECK_ARG(lddx % 4 == 0 && dxoff % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0);
   const PoolGeom g = make_pool_geom(ih, iw, stride);
   const long long total = (long long)n * ih * iw * (c / 4);
-  if (n >= 64 && ih == iw && ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
+  if (n >= 64 && ih == iw && (!ymask || mode == 1) &&
+      ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
     const dim3 grid(grid_for((long long)n * (c / 4))), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define C2D_POOL_B(IH, S, MD)                                                                     \
-  hipLaunchKernelGGL((pool3x3_map_bwd_kernel<IH, S, MD, T>), grid, block, 0, st, dy, lddy, dyoff,  \
-                     argmax, dx, lddx, dxoff, n, c / 4, accumulate, ymask, ldym, ymoff)
-    if (ih == 4 && mode == 0) C2D_POOL_B(4, 1, 0);
-    else if (ih == 4) C2D_POOL_B(4, 1, 1);
-    else C2D_POOL_B(7, 2, 0);
+#define C2D_POOL_B(IH, S, MD, YM)                                                                 \
+  hipLaunchKernelGGL((pool3x3_map_bwd_kernel<IH, S, MD, T, YM>), grid, block, 0, st, dy, lddy,     \
+                     dyoff, argmax, dx, lddx, dxoff, n, c / 4, accumulate, ymask, ldym, ymoff)
+    if (ih == 4 && mode == 0) C2D_POOL_B(4, 1, 0, false);
+    else if (ih == 4 && ymask) C2D_POOL_B(4, 1, 1, true);
+    else if (ih == 4) C2D_POOL_B(4, 1, 1, false);
+    else C2D_POOL_B(7, 2, 0, false);
 #undef C2D_POOL_B
     return c2d_launch_status();
   }
