@@ -47,6 +47,7 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // grid (C, B).  logits: [B*N][ld], r|c logits at column off_r / off_c.
+constexpr int kMidnCache = 8;        // proposals per thread held in registers (N <= 2048)
 __global__ __launch_bounds__(256) void midn_fwd_kernel(
     const float* __restrict__ logits, int ld, int off_r, int off_c,
     const int32_t* __restrict__ num_proposals, float* __restrict__ proba,
@@ -55,6 +56,54 @@ __global__ __launch_bounds__(256) void midn_fwd_kernel(
   const int c = blockIdx.x, b = blockIdx.y;
   const int nb = num_proposals[b];
   const float* L = logits + (size_t)b * N * ld;
+  if (N <= kMidnCache * 256) {
+    // The class's two logit columns live in registers (proposal r = tid + 256 j): every strided
+    // column load of the block is in flight at once instead of four dependent sweeps.  Same
+    // values, same per-thread summation order, same block reductions as the sweeps below.
+    float u[kMidnCache], lc[kMidnCache];
+#pragma unroll
+    for (int j = 0; j < kMidnCache; ++j) {
+      const int r = threadIdx.x + 256 * j;
+      const float m = r < nb ? 1.0f : 0.0f;
+      const bool in = r < N;
+      const float lr = in ? L[(size_t)r * ld + off_r + c] : 0.f;
+      lc[j] = in ? L[(size_t)r * ld + off_c + c] : 0.f;
+      u[j] = m * lr - kBig * (1.0f - m);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kMidnCache; ++j)
+      if (threadIdx.x + 256 * j < N) mx = fmaxf(mx, u[j]);
+    mx = block_max(mx, red);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMidnCache; ++j)
+      if (threadIdx.x + 256 * j < N) se += expf(u[j] - mx);
+    se = block_sum(se, red);
+    float cl = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMidnCache; ++j) {
+      const int r = threadIdx.x + 256 * j;
+      if (r < N) {
+        const float m = r < nb ? 1.0f : 0.0f;
+        u[j] = m * (expf(u[j] - mx) / se);             // (u now holds the probability)
+        cl += m * (lc[j] * u[j]);
+      }
+    }
+    cl = block_sum(cl, red);
+    if (threadIdx.x == 0) class_logits[b * C + c] = cl;
+    const float sg = sigmoidf(cl);
+#pragma unroll
+    for (int j = 0; j < kMidnCache; ++j) {
+      const int r = threadIdx.x + 256 * j;
+      if (r < N) {
+        const size_t i = ((size_t)b * N + r) * C + c;
+        proba[i] = u[j];
+        scores[i] = sg * u[j];
+      }
+    }
+    return;
+  }
   // u_r = mask*Lr - 1e10*(1-mask)   (models/cap2det_model.py:92-93, core/utils.py:183-184)
   float mx = -INFINITY;
   for (int r = threadIdx.x; r < N; r += blockDim.x) {

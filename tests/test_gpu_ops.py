@@ -725,6 +725,11 @@ def test_adagrad_and_l2(ops):
   out = torch.zeros(1, device=DEV)
   ops.l2_loss(_t(w), 1e-2, out)
   np.testing.assert_allclose(_n(out)[0], 0.5e-2 * (w.astype(np.float64) ** 2).sum(), rtol=1e-5)
+  # a variable that starts at an odd float of the flat buffer (no 16-byte loads), accumulating
+  tw1 = _t(w)[1:]
+  ops.l2_loss(tw1, 1e-2, out)
+  np.testing.assert_allclose(_n(out)[0], 0.5e-2 * ((w.astype(np.float64) ** 2).sum() +
+                                                   (w[1:].astype(np.float64) ** 2).sum()), rtol=1e-5)
 
 
 
