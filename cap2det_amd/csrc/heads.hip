@@ -186,13 +186,33 @@ __global__ __launch_bounds__(256) void oicr_select_kernel(
   const int nb = num_proposals[b];
   const float* S = s0 + (size_t)b * N * ld + off + c;
   float mn = INFINITY;
-  for (int r = threadIdx.x; r < N; r += blockDim.x) mn = fminf(mn, S[(size_t)r * ld]);
-  mn = block_min(mn, red);
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int r = threadIdx.x; r < N; r += blockDim.x) {
-    const float v = (S[(size_t)r * ld] - mn) * (r < nb ? 1.0f : 0.0f);
-    if (v > best) { best = v; bi = r; }   // r ascending per thread: keeps the first
+  if (N <= kMidnCache * 256) {
+    // the class column in registers (proposal r = tid + 256 j): one strided sweep instead of two
+    float sv[kMidnCache];
+#pragma unroll
+    for (int j = 0; j < kMidnCache; ++j) {
+      const int r = threadIdx.x + 256 * j;
+      sv[j] = r < N ? S[(size_t)r * ld] : INFINITY;
+      mn = fminf(mn, sv[j]);
+    }
+    mn = block_min(mn, red);
+#pragma unroll
+    for (int j = 0; j < kMidnCache; ++j) {
+      const int r = threadIdx.x + 256 * j;
+      if (r < N) {
+        const float v = (sv[j] - mn) * (r < nb ? 1.0f : 0.0f);
+        if (v > best) { best = v; bi = r; }   // r ascending per thread: keeps the first
+      }
+    }
+  } else {
+    for (int r = threadIdx.x; r < N; r += blockDim.x) mn = fminf(mn, S[(size_t)r * ld]);
+    mn = block_min(mn, red);
+    for (int r = threadIdx.x; r < N; r += blockDim.x) {
+      const float v = (S[(size_t)r * ld] - mn) * (r < nb ? 1.0f : 0.0f);
+      if (v > best) { best = v; bi = r; }   // r ascending per thread: keeps the first
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
