@@ -675,7 +675,10 @@ def main(argv=None):
             "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": gbs / PEAK_HBM_GBPS, "traffic": traffic.get("roi_crop_pool_fwd", {}).get("hbm_bytes_per_launch"),
             "avg_launch_ms": rc["ms"] / rc["launches"],
-            "algorithmic_bytes_per_launch": rc["work"] / rc["launches"]}
+            "algorithmic_bytes_per_launch": rc["work"] / rc["launches"],
+            # (the metric prices it against HBM; the counters say what actually limits it)
+            "limiter": "vector ALU busy 87 % of the launch (profiles/r03_crop_counters.json, "
+                       "DESIGN.md section 3): not HBM-bound"}
     if not args.no_cpu_baseline and world == 1 and not secondary:
       result["cpu_baseline"] = cpu_baseline(pipeline, classes, NUM_PROPOSALS)
       # configs[0] (N = 300, the reference's own CPU-runnable case): the same CPU step, SURVEY §8d
