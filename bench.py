@@ -677,8 +677,8 @@ def main(argv=None):
             "avg_launch_ms": rc["ms"] / rc["launches"],
             "algorithmic_bytes_per_launch": rc["work"] / rc["launches"],
             # (the metric prices it against HBM; the counters say what actually limits it)
-            "limiter": "vector ALU busy 87 % of the launch (profiles/r03_crop_counters.json, "
-                       "DESIGN.md section 3): not HBM-bound"}
+            "limiter": "vector ALU (busy 87 % of the launch before round 3's instruction diet, "
+                       "profiles/r03_crop_counters.json, DESIGN.md section 3): not HBM-bound"}
     if not args.no_cpu_baseline and world == 1 and not secondary:
       result["cpu_baseline"] = cpu_baseline(pipeline, classes, NUM_PROPOSALS)
       # configs[0] (N = 300, the reference's own CPU-runnable case): the same CPU step, SURVEY §8d

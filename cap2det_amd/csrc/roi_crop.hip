@@ -47,13 +47,25 @@ __device__ __forceinline__ SampleAxis sample_axis(float a1, float a2, int n, int
 }
 
 __device__ __forceinline__ float4 lerp4(float4 a, float4 b, float t) {
-  // a + (b - a) * t, unfused, per component (TF order).
-  float4 r;
-  r.x = __fadd_rn(a.x, __fmul_rn(__fsub_rn(b.x, a.x), t));
-  r.y = __fadd_rn(a.y, __fmul_rn(__fsub_rn(b.y, a.y), t));
-  r.z = __fadd_rn(a.z, __fmul_rn(__fsub_rn(b.z, a.z), t));
-  r.w = __fadd_rn(a.w, __fmul_rn(__fsub_rn(b.w, a.w), t));
-  return r;
+  // a + (b - a) * t, unfused, per component (TF order; the file is compiled with
+  // -ffp-contract=off).  Written on two-element vectors so that the three operations are the
+  // packed v_pk_add_f32 / v_pk_mul_f32 forms: 6 instructions per float4, exactly rounded each.
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
+  const f2 tt = {t, t};
+  const f2 rlo = alo + (blo - alo) * tt;
+  const f2 rhi = ahi + (bhi - ahi) * tt;
+  return make_float4(rlo.x, rlo.y, rhi.x, rhi.y);
+}
+
+// float4 copy as two v_mov_b64 (volatile: stays where it is written)
+__device__ __forceinline__ float4 mov4(float4 s) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 lo = {s.x, s.y}, hi = {s.z, s.w};
+  f2 dlo, dhi;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(dlo) : "v"(lo));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(dhi) : "v"(hi));
+  return make_float4(dlo.x, dlo.y, dhi.x, dhi.y);
 }
 
 // Bilinear sample of float4 channel group `d4` at (sy, sx); zeros when out of range.
@@ -152,69 +164,91 @@ __global__ __launch_bounds__(256) void roi_crop_pool_fwd_kernel(
 template <typename TO>
 __device__ __forceinline__ void crop_pool2_stream_body(
     const float4* __restrict__ img, const SampleAxis* ys, const SampleAxis* xs,
-    TO* __restrict__ out, uchar4* __restrict__ argmax, size_t obase, int wf, int d4n, int pout,
-    int part, int splits) {
+    TO* __restrict__ out, uchar4* __restrict__ argmax, size_t obase, int hf, int wf, int d4n,
+    int pout, int part, int splits) {
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   const int total = pout * d4n;
+  // The kernel is vector-ALU-bound (87 % busy), so the walk is written for few
+  // instructions: raw buffer loads (descriptor over the image, the lane's four row offsets in
+  // VGPRs, the source column's offset as the scalar operand: no address arithmetic per load),
+  // two crop columns per trip (the even column's samples stay in their registers until the odd
+  // column completes the pooling window), output pointers advanced per pooled cell, and the
+  // zeroing of out-of-range crop rows only in waves that have one.
+  const unsigned long long ub = (unsigned long long)img;
+  const unsigned ub_lo = __builtin_amdgcn_readfirstlane((unsigned)ub);
+  const unsigned ub_hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(((unsigned long long)ub_hi << 32) | ub_lo), (short)0,
+      __builtin_amdgcn_readfirstlane(hf * wf * d4n * 16), 0x00020000);
+  auto ld = [&](unsigned voff, int soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
+  };
   for (int idx = part * blockDim.x + threadIdx.x; idx < total; idx += splits * blockDim.x) {
     const int d4 = idx % d4n;
     const int py = idx / d4n;
     const SampleAxis y0 = ys[2 * py], y1 = ys[2 * py + 1];
-    // row base pointers of the four source rows (clamped when the crop row is out of range: its
+    // byte offsets of the four source rows (clamped when the crop row is out of range: its
     // samples are zeroed below, the loads only need a valid address)
-    const float4* r0 = img + (size_t)max(y0.lo, 0) * wf * d4n + d4;
-    const float4* r1 = img + (size_t)max(y0.hi, 0) * wf * d4n + d4;
-    const float4* r2 = img + (size_t)max(y1.lo, 0) * wf * d4n + d4;
-    const float4* r3 = img + (size_t)max(y1.hi, 0) * wf * d4n + d4;
+    const unsigned r0 = (unsigned)((max(y0.lo, 0) * wf) * d4n + d4) * 16u;
+    const unsigned r1 = (unsigned)((max(y0.hi, 0) * wf) * d4n + d4) * 16u;
+    const unsigned r2 = (unsigned)((max(y1.lo, 0) * wf) * d4n + d4) * 16u;
+    const unsigned r3 = (unsigned)((max(y1.hi, 0) * wf) * d4n + d4) * 16u;
+    const bool wave_rows_ok = __ballot(y0.lo < 0 || y1.lo < 0) == 0ull;
     float4 a0 = zero, a1 = zero, a2 = zero, a3 = zero;   // rows at source column acol
     float4 b0 = zero, b1 = zero, b2 = zero, b3 = zero;   // rows at source column bcol
     int acol = -1, bcol = -1;
-    float4 c0 = zero, c2 = zero;
-    for (int x = 0; x < 2 * pout; ++x) {
+    // one crop column: the two samples (crop rows 2 py, 2 py + 1) at crop column x
+    auto column = [&](int x, float4& v0, float4& v1) {
       const SampleAxis sx = xs[x];                        // uniform over the workgroup
-      float4 v0 = zero, v1 = zero;
-      if (sx.lo >= 0) {
-        if (acol != sx.lo) {
-          if (bcol == sx.lo) { a0 = b0; a1 = b1; a2 = b2; a3 = b3; }
-          else {
-            const size_t o = (size_t)sx.lo * d4n;
-            a0 = r0[o]; a1 = r1[o]; a2 = r2[o]; a3 = r3[o];
-          }
-          acol = sx.lo;
+      if (sx.lo < 0) { v0 = zero; v1 = zero; return; }
+      if (acol != sx.lo) {
+        // (the walk advanced by one source column: the old right column is the new left one;
+        // eight 64-bit moves that the compiler may neither split nor hoist above this branch)
+        if (bcol == sx.lo) { a0 = mov4(b0); a1 = mov4(b1); a2 = mov4(b2); a3 = mov4(b3); }
+        else {
+          const int o = sx.lo * d4n * 16;
+          a0 = ld(r0, o); a1 = ld(r1, o); a2 = ld(r2, o); a3 = ld(r3, o);
         }
-        if (bcol != sx.hi) {
-          if (sx.hi == acol) { b0 = a0; b1 = a1; b2 = a2; b3 = a3; }
-          else {
-            const size_t o = (size_t)sx.hi * d4n;
-            b0 = r0[o]; b1 = r1[o]; b2 = r2[o]; b3 = r3[o];
-          }
-          bcol = sx.hi;
-        }
-        if (y0.lo >= 0) v0 = lerp4(lerp4(a0, b0, sx.lerp), lerp4(a1, b1, sx.lerp), y0.lerp);
-        if (y1.lo >= 0) v1 = lerp4(lerp4(a2, b2, sx.lerp), lerp4(a3, b3, sx.lerp), y1.lerp);
+        acol = sx.lo;
       }
-      if ((x & 1) == 0) {
-        c0 = v0; c2 = v1;                                 // window samples k = 0 and k = 2
-      } else {
-        // k = 0, 1, 2, 3 in order; strict '>' keeps the FIRST maximum (TF MaxPoolGrad tie rule)
-        float4 best = c0;
-        uchar4 arg = make_uchar4(0, 0, 0, 0);
-        if (v0.x > best.x) { best.x = v0.x; arg.x = 1; }
-        if (v0.y > best.y) { best.y = v0.y; arg.y = 1; }
-        if (v0.z > best.z) { best.z = v0.z; arg.z = 1; }
-        if (v0.w > best.w) { best.w = v0.w; arg.w = 1; }
-        if (c2.x > best.x) { best.x = c2.x; arg.x = 2; }
-        if (c2.y > best.y) { best.y = c2.y; arg.y = 2; }
-        if (c2.z > best.z) { best.z = c2.z; arg.z = 2; }
-        if (c2.w > best.w) { best.w = c2.w; arg.w = 2; }
-        if (v1.x > best.x) { best.x = v1.x; arg.x = 3; }
-        if (v1.y > best.y) { best.y = v1.y; arg.y = 3; }
-        if (v1.z > best.z) { best.z = v1.z; arg.z = 3; }
-        if (v1.w > best.w) { best.w = v1.w; arg.w = 3; }
-        const size_t o = obase + (size_t)(py * pout + (x >> 1)) * d4n + d4;
-        c2d_st4(out + o * 4, best);
-        if (argmax) argmax[o] = arg;
+      if (bcol != sx.hi) {
+        // (right = left on an integer sampling coordinate: fetched again rather than copied — a
+        // copy here became sixteen speculative moves in front of EVERY right-column fetch)
+        const int o = sx.hi * d4n * 16;
+        b0 = ld(r0, o); b1 = ld(r1, o); b2 = ld(r2, o); b3 = ld(r3, o);
+        bcol = sx.hi;
       }
+      v0 = lerp4(lerp4(a0, b0, sx.lerp), lerp4(a1, b1, sx.lerp), y0.lerp);
+      v1 = lerp4(lerp4(a2, b2, sx.lerp), lerp4(a3, b3, sx.lerp), y1.lerp);
+      if (!wave_rows_ok) {
+        if (y0.lo < 0) v0 = zero;
+        if (y1.lo < 0) v1 = zero;
+      }
+    };
+    TO* op = out + (obase + (size_t)py * pout * d4n + d4) * 4;
+    uchar4* ap = argmax ? argmax + obase + (size_t)py * pout * d4n + d4 : nullptr;
+    for (int px = 0; px < pout; ++px) {
+      float4 c0, c2, v0, v1;
+      column(2 * px, c0, c2);                             // window samples k = 0 and k = 2
+      column(2 * px + 1, v0, v1);                         // k = 1 and k = 3
+      // k = 0, 1, 2, 3 in order; strict '>' keeps the FIRST maximum (TF MaxPoolGrad tie rule)
+      float4 best = c0;
+      uchar4 arg = make_uchar4(0, 0, 0, 0);
+      if (v0.x > best.x) { best.x = v0.x; arg.x = 1; }
+      if (v0.y > best.y) { best.y = v0.y; arg.y = 1; }
+      if (v0.z > best.z) { best.z = v0.z; arg.z = 1; }
+      if (v0.w > best.w) { best.w = v0.w; arg.w = 1; }
+      if (c2.x > best.x) { best.x = c2.x; arg.x = 2; }
+      if (c2.y > best.y) { best.y = c2.y; arg.y = 2; }
+      if (c2.z > best.z) { best.z = c2.z; arg.z = 2; }
+      if (c2.w > best.w) { best.w = c2.w; arg.w = 2; }
+      if (v1.x > best.x) { best.x = v1.x; arg.x = 3; }
+      if (v1.y > best.y) { best.y = v1.y; arg.y = 3; }
+      if (v1.z > best.z) { best.z = v1.z; arg.z = 3; }
+      if (v1.w > best.w) { best.w = v1.w; arg.w = 3; }
+      c2d_st4(op, best);
+      op += (size_t)d4n * 4;
+      if (ap) { *ap = arg; ap += d4n; }
     }
   }
 }
@@ -571,7 +605,7 @@ __global__ __launch_bounds__(256) void roi_crop_pool2_fwd_stream_kernel(
   if (b < 0 || b >= batch) return;
   load_axes(ys, xs, boxes, roi, hf, wf, crop);
   crop_pool2_stream_body<TO>(feat + (size_t)b * hf * wf * d4n, ys, xs, out, argmax,
-                             (size_t)roi * pout * pout * d4n, wf, d4n, pout, part, splits);
+                             (size_t)roi * pout * pout * d4n, hf, wf, d4n, pout, part, splits);
 }
 
 // (A prefetching variant — three-slot register ring over the sorted list of needed columns, the
