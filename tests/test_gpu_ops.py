@@ -806,11 +806,13 @@ def test_conv_fwd_grouped_matches_single_calls():
 
 
 @pytest.mark.parametrize("hf,wf,d,n,crop,pk,ps", [(32, 32, 64, 300, 14, 2, 2), (9, 33, 16, 60, 14, 2, 2),
+                                                   (32, 32, 576, 48, 14, 2, 2), (63, 84, 576, 24, 14, 2, 2),
                                                    (20, 20, 32, 50, 8, 2, 2), (16, 16, 32, 40, 9, 3, 3),
                                                    (16, 16, 32, 40, 14, 2, 1)])
 def test_roi_crop_pool_forms_match_oracle(hf, wf, d, n, crop, pk, ps):
-  """The column-streaming 2x2/stride-2 kernel (first three cases) and the generic kernel (other
-  poolings) against crop_and_resize + max_pool of the oracle, bit for bit incl. the arg-max."""
+  """The column-streaming 2x2/stride-2 kernel (first five cases; two at the benchmark's depth 576,
+  on the 32x32 map of a 500-px image and the 63x84 map of a 1000x1333 one) and the generic kernel
+  (other poolings) against crop_and_resize + max_pool of the oracle, bit for bit incl. the arg-max."""
   from cap2det_amd import hip_ops as ops
   rng = np.random.default_rng(hf * 100 + n)
   feat = np.maximum(rng.standard_normal((2, hf, wf, d)), 0).astype(np.float32)
