@@ -307,7 +307,7 @@ def parse_args(argv=None):
   ap.add_argument("--per-call", action="store_true",
                   help="also print one line per timed conv / ROI-crop call (stderr)")
   ap.add_argument("--graph", action="store_true", help="hipGraph replay of the step on one stream (measured, profiles/r03_bench_c{1,2}_graph.json: "
-                       "12.57 vs 11.86 ms eager for c1, 4.33 vs 3.80 for c2: eager with its side streams wins)")
+                       "12.52 vs 11.80 ms eager for c1, 3.77 vs 3.42 for c2: eager with its side streams wins)")
   ap.add_argument("--image-hw", type=int, nargs=2, default=None, metavar=("H", "W"),
                   help="SECONDARY operating point (never the headline metric): image size, e.g. the "
                        "reference's keep-aspect 1000-px training images (--image-hw 1000 1333)")
