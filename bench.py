@@ -561,7 +561,7 @@ def main(argv=None):
                                   len(classes), type(trainer.model.label_extractor).__name__,
                                   images_per_gpu, image_hw[0], image_hw[1], num_proposals,
                                   "fp32" if args.dtype == "fp32" else "bf16 storage / fp32 accumulate",
-                                  "+RCCL all-reduce" if grouped else ""),
+                                  ("+gloo all-reduce (ranks share cuda:0)" if same_device else "+RCCL all-reduce") if grouped else ""),
                    "baseline_config": args.config, "pipeline": spec["pipeline"] + ".pbtxt",
                    "images_per_gpu": images_per_gpu, "image_hw": list(image_hw),
                    "proposals": num_proposals, "parallelism": "dp%d" % world,

@@ -57,6 +57,12 @@ def header_signatures():
   return sigs
 
 
+def header_abi_version():
+  """`#define C2D_ABI_VERSION n` of the header."""
+  with open(HEADER_PATH) as f:
+    return int(re.search(r"#define\s+C2D_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
 def load():
   """Loads (once) and returns the ctypes handle; raises if the extension is not built."""
   global _lib
@@ -72,6 +78,11 @@ def load():
     fn = getattr(lib, name)  # AttributeError => header/library mismatch: fail loudly
     fn.restype = restype
     fn.argtypes = argtypes
+  want = header_abi_version()
+  got = lib.c2d_version()
+  if got != want:
+    raise ImportError("cap2det_amd: %s was built for ABI %d, include/cap2det_hip.h declares %d — "
+                      "rebuild it (`make -C cap2det_amd/csrc`)" % (LIB_PATH, got, want))
   _lib = lib
   return lib
 

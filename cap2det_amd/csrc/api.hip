@@ -1,7 +1,7 @@
 // Version / error strings of the C-ABI (include/cap2det_hip.h).
 #include "c2d_common.h"
 
-extern "C" int c2d_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int c2d_version(void) { return C2D_ABI_VERSION; }
 
 extern "C" const char* c2d_error_string(int code) {
   switch (code) {

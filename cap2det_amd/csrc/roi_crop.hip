@@ -622,9 +622,13 @@ static int crop_stream_splits() {
   return v >= 1 && v <= 8 ? v : 1;
 }
 
-static int crop_stream_form(int crop, int pool_k, int pool_s, int pout) {
+static int crop_stream_form(int crop, int pool_k, int pool_s, int pout, int hf, int wf,
+                            int depth) {
   static const char* e = getenv("C2D_TUNE") ? getenv("C2D_CROP_STREAM") : nullptr;
   const int want = e ? atoi(e) : 1;
+  // the stream kernel addresses ONE image's map through a raw buffer descriptor with 32-bit byte
+  // offsets: maps of 2 GiB and more take the generic kernel (64-bit pointer arithmetic)
+  if ((long long)hf * wf * depth * 4 >= (1ll << 31)) return 0;
   return (pool_k == 2 && pool_s == 2 && crop == 2 * pout) ? want : 0;
 }
 
@@ -652,7 +656,7 @@ extern "C" int c2d_roi_crop_pool_fwd(const float* feat, const float* boxes,
   C2D_CHECK_ARG(pool_k > 0 && pool_s > 0 && pool_k <= crop && pool_k * pool_k <= 255);
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
-  const int form = crop_stream_form(crop, pool_k, pool_s, pout);
+  const int form = crop_stream_form(crop, pool_k, pool_s, pout, hf, wf, depth);
   if (form == 1)
     hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<float>,
                        dim3(num_boxes * crop_stream_splits()), dim3(256), 0,
@@ -675,7 +679,7 @@ extern "C" int c2d_roi_crop_pool_fwd_bf16(const float* feat, const float* boxes,
   C2D_CHECK_ARG(pool_k > 0 && pool_s > 0 && pool_k <= crop && pool_k * pool_k <= 255);
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
-  const int form = crop_stream_form(crop, pool_k, pool_s, pout);
+  const int form = crop_stream_form(crop, pool_k, pool_s, pout, hf, wf, depth);
   if (form == 1)
     hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<c2d_bf16>,
                        dim3(num_boxes * crop_stream_splits()), dim3(256), 0,

@@ -8,11 +8,22 @@ def count_visible_gpus():
   """Number of GPUs this process tree may use, WITHOUT touching HIP (the parent of the rank
   processes must stay GPU-free): KFD topology nodes with SIMDs (`simd_count > 0`; CPU nodes report
   0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES lists."""
+  override = os.environ.get("C2D_NUM_GPUS")
+  if override is not None:                     # explicit answer of the operator: trusted as is
+    return max(0, int(override))
   root = "/sys/class/kfd/kfd/topology/nodes"
   n = 0
   try:
     nodes = sorted(os.listdir(root))
   except OSError:
+    nodes = None
+  if nodes is None:
+    # /dev/kfd passed into a container without the KFD sysfs tree: one render node per GPU
+    # (still no HIP call: the parent stays GPU-free)
+    try:
+      n = len([e for e in os.listdir("/dev/dri") if e.startswith("renderD")])
+    except OSError:
+      n = 0
     nodes = []
   for node in nodes:
     try:
@@ -25,6 +36,14 @@ def count_visible_gpus():
   for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
     v = os.environ.get(var)
     if v is not None:
-      listed = [t for t in v.split(",") if t.strip() != ""]
+      # an index outside [0, n) ends the list (the HIP runtime ignores everything behind it);
+      # UUID entries (GPU-xxxx) cannot be checked without the runtime and count as given
+      listed = []
+      for t in (t.strip() for t in v.split(",")):
+        if t == "":
+          continue
+        if t.lstrip("-").isdigit() and not 0 <= int(t) < n:
+          break
+        listed.append(t)
       n = min(n, len(listed))
   return n

@@ -265,15 +265,19 @@ class Trainer(object):
         ready = torch.cuda.Event(); ready.record()
       labels.record_stream(main)
       kwargs = dict(kwargs, labels=labels, labels_ready=ready)
-    predictions = model.build_prediction(examples, **kwargs)
-    if prefetch is not None:
-      # look-ahead: the frozen first-stage layers of the NEXT batch's image run on a side stream
-      # under this step's second stage (FrcnnEngine.prefetch_first_stage)
-      from cap2det_amd.core.standard_fields import InputDataFields as F
-      model.engine.prefetch_first_stage(prefetch[F.image], prefetch[F.proposals].shape[1], True)
-    losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
-    losses['regularization_loss'] = model.regularization_loss(step_zeroed=True)
-    model.backward(after_second_stage)
+    try:
+      predictions = model.build_prediction(examples, **kwargs)
+      if prefetch is not None:
+        # look-ahead: the frozen first-stage layers of the NEXT batch's image run on a side stream
+        # under this step's second stage (FrcnnEngine.prefetch_first_stage)
+        model.engine.prefetch_first_stage(prefetch[F.image], prefetch[F.proposals].shape[1], True)
+      losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
+      losses['regularization_loss'] = model.regularization_loss(step_zeroed=True)
+      model.backward(after_second_stage)
+    finally:
+      # "zeroed by the step's one launch" holds for THIS backward pass only: if the forward pass or
+      # the losses raise, a later direct model.backward() must zero its gradient map itself
+      model.engine._step_zeroed = set()
     return predictions, losses
 
   def _apply_gradients(self, scale, lr, lr_dev=None):
@@ -397,11 +401,14 @@ class Trainer(object):
             "seed": torch.zeros(1, dtype=torch.int64, device=self.device)}
       ex = {F.image: st[F.image], F.proposals: st[F.proposals],
             F.num_proposals: st[F.num_proposals]}
-      state = (store.values.clone(), store.accum.clone())
+      # (every optimiser slot: rmsprop keeps momentum / mean-gradient slots beside slot 0)
+      state = (store.values.clone(), [sl.clone() for sl in store.slots])
       self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
       self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
       torch.cuda.synchronize()
-      store.values.copy_(state[0]); store.accum.copy_(state[1])   # undo the warm-up update
+      store.values.copy_(state[0])                                # undo the warm-up update
+      for sl, saved in zip(store.slots, state[1]):
+        sl.copy_(saved)
       self.model.refresh(only_trainable=True)
       side = torch.cuda.Stream()
       side.wait_stream(torch.cuda.current_stream())

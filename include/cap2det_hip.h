@@ -32,7 +32,10 @@ extern "C" {
 #define C2D_ERR_WORKSPACE (-4)
 #define C2D_ERR_DATA (-5)        /* malformed input data (record framing, protobuf, JPEG stream) */
 
-/* ABI version: major*10000 + minor*100 + patch. */
+/* ABI version, bumped whenever an entry point is added or a signature changes (round 1: 100 with
+ * 28 entry points; round 4: 400).  c2d_version() returns the value the library was built with:
+ * a host side compiled against another header must refuse to run (cap2det_amd/_lib.py does). */
+#define C2D_ABI_VERSION 400
 int c2d_version(void);
 /* Human readable message for a C2D_ERR_* code (static storage). */
 const char* c2d_error_string(int code);

@@ -64,3 +64,29 @@ def test_parent_counts_gpus_without_torch():
   env = dict(os.environ, HIP_VISIBLE_DEVICES="")
   r2 = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, timeout=60)
   assert r2.returncode == 0 and r2.stdout.strip() == "0"      # an empty device list hides every GPU
+
+
+def test_gpu_count_fallbacks(monkeypatch, tmp_path):
+  """without the KFD sysfs tree (a container with /dev/kfd passed through) the count
+  falls back to the render nodes of /dev/dri, C2D_NUM_GPUS is an explicit override, and an
+  out-of-range index in a *_VISIBLE_DEVICES list ends the list as it does in the HIP runtime."""
+  from cap2det_amd.train import gpu_count
+  real_listdir = os.listdir
+
+  def fake_listdir(path):
+    if path == "/sys/class/kfd/kfd/topology/nodes":
+      raise OSError("not mounted")
+    if path == "/dev/dri":
+      return ["card0", "card1", "renderD128", "renderD129", "renderD130", "renderD131"]
+    return real_listdir(path)
+  for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "C2D_NUM_GPUS"):
+    monkeypatch.delenv(var, raising=False)
+  monkeypatch.setattr(gpu_count.os, "listdir", fake_listdir)
+  assert gpu_count.count_visible_gpus() == 4
+  monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,7,2")
+  assert gpu_count.count_visible_gpus() == 2            # index 7 ends the list
+  monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-abc,GPU-def,GPU-123")
+  monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+  assert gpu_count.count_visible_gpus() == 2
+  monkeypatch.setenv("C2D_NUM_GPUS", "8")
+  assert gpu_count.count_visible_gpus() == 8

@@ -874,3 +874,42 @@ def test_graph_step_equals_eager_step(n, nums, compute_dtype):
   for k in state_e:
     a, b = state_e[k].astype(np.float64), state_g[k].astype(np.float64)
     assert np.abs(a - b).max() <= stol * max(np.abs(a).max(), 1e-3), k
+
+
+def test_graph_step_equals_eager_step_rmsprop_slots():
+  """the eager warm-up in front of the graph capture must be undone in EVERY optimiser
+  slot.  Centered rmsprop with momentum keeps three (rms, momentum, mean gradient): after one
+  step the graph trainer's variables and all three slots equal the eager trainer's (atomics-order
+  tolerance) — a warm-up update left in the momentum / mean-gradient slots shows as a step of
+  roughly twice the size."""
+  from cap2det_amd.train.trainer import Trainer
+  pipeline = util_model.load_pipeline()
+  sub = pipeline.train_config.optimizer.rmsprop
+  sub.decay, sub.momentum, sub.epsilon, sub.centered = 0.9, 0.5, 1e-10, True
+  pipeline.train_config.learning_rate = 0.001
+  rng = np.random.default_rng(23)
+  out, ex = [], None
+  for use_graph in (False, True):
+    trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, use_graph=use_graph)
+    model = trainer.model
+    assert len(model.store.slots) == 3
+    classes = model.label_extractor.classes
+    P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
+    model.load_state_dict(P32)
+    if ex is None:
+      ex = _to_dev(util_model.make_examples(rng, 2, 40, 56, 9, [9, 4], classes))
+    trainer.train_step(ex, dropout_seed=7)
+    torch.cuda.synchronize()
+    lo, hi = trainer.bucket
+    out.append((model.store.values[lo:hi].double().cpu().numpy().copy(),
+                [sl[lo:hi].double().cpu().numpy().copy() for sl in model.store.slots],
+                model.store.grads[lo:hi].double().cpu().numpy().copy()))
+  (ve, se, ge), (vg, sg, gg) = out
+  # the slots are functions of the gradient: rms and the mean gradient directly
+  for i, (a, b) in enumerate(zip(se, sg)):
+    assert np.abs(a - b).max() <= 1e-4 * max(np.abs(a).max(), 1e-6), "slot %d" % i
+  # g / sqrt(rms - mg^2 + eps) is ill-conditioned where |g| is at the fp32 noise of the gradient:
+  # compare the variables where the gradient is well above it
+  well = np.abs(ge) > 1e-3 * np.abs(ge).max()
+  assert well.sum() > 1000
+  assert np.abs(ve - vg)[well].max() <= 2e-2 * 0.001 * 3.2, np.abs(ve - vg)[well].max()
