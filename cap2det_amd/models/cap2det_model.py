@@ -482,7 +482,7 @@ class Model(ModelBase):
     ops.sum_small(self._losses[:self._nloss], self._losses[self._nloss:self._nloss + 1])
     return self._losses[self._nloss]
 
-  def backward(self, after_second_stage=None):
+  def backward(self, after_second_stage=None, after_block=None):
     """Gradients of sum(losses) w.r.t. every trainable variable, accumulated into
     `self.store.grads` (caller zeroes it once per step).  after_second_stage: callable invoked
     once the head and second-stage gradients are final (the data-parallel reducer starts its
@@ -497,7 +497,7 @@ class Model(ModelBase):
     ops.col_sum(bufs["dlogits"], self._npad, 0, g[HEADS_B], b * n, self._npad)
     ops.conv_dgrad(bufs["dlogits"], self._npad, 0, self.store.var[HEADS_W], bufs["dfeatures"], d, 0,
                    b * n, 1, 1, d, self._npad, 1, 1, 1, False)
-    self.engine.backward(bufs["dfeatures"], d, 0, ctx["fctx"], after_second_stage)
+    self.engine.backward(bufs["dfeatures"], d, 0, ctx["fctx"], after_second_stage, after_block)
 
   def build_evaluation(self, predictions, examples=None, **kwargs):
     """models/cap2det_model.py:332-343 returns {} in the reference."""

@@ -543,13 +543,15 @@ class Net(object):
     # partial sums into one workspace; one batched launch at the end of backward() adds them
     # into the flat gradient buffer (atomic-free, bitwise reproducible).
     import numpy as np
-    convs = []
+    convs, conv_step = [], {}
     for i in range(first_idx, len(steps)):
       st = steps[i]
       if st["kind"] == "conv":
         convs.append(st)
       elif st["kind"] == "block":
         convs.extend(b for bsteps in st["branches"] for b in bsteps if b["kind"] == "conv")
+      for c in convs:
+        conv_step.setdefault(id(c), i)
     # Consecutive convolutions of a branch over per-ROI maps: the consumer's input-gradient GEMM
     # applies the producer's BN/ReLU backward in its epilogue (c2d_conv_dgrad_bn_relu) — the
     # producer's bn_relu_bwd launch, the store of its dy and the re-read disappear.  Measured per
@@ -623,11 +625,13 @@ class Net(object):
     ddt = np.dtype([("ws", "<i8"), ("dbeta", "<i8"), ("dgamma", "<i8"), ("nblocks", "<i4"),
                     ("c", "<i4"), ("begin", "<i4"), ("wide", "<i4")])
     recs, ws_size, chunks = [], 0, 0
+    rec_step = []           # top-level step of every record (per-step reductions: backward(after_step=))
     voff = self.store.offset
     for st in convs:
       L = st["layer"]
       if not L.trainable:
         continue
+      rec_step.append(conv_step[id(st)])
       rows = st["n"] * st["oh"] * st["ow"]
       g = voff[L.name + "/BatchNorm/gamma"][0] if L.bn_scale else -1
       if "fused_wide" in st:
@@ -681,6 +685,18 @@ class Net(object):
     plan["bn_desc"] = (torch.from_numpy(np.array(recs, dtype=ddt).view(np.uint8).copy()).to(dev)
                        if recs else None)
     plan["bn_num"], plan["bn_chunks"] = len(recs), chunks
+    # the same records per top-level step (chunk indices rebased), for a backward pass that hands
+    # every step's gradients over as soon as the step is done (data_parallel.BlockReducer)
+    plan["bn_desc_steps"] = {}
+    for i in sorted(set(rec_step)):
+      sub = [list(r) for r, si in zip(recs, rec_step) if si == i]
+      base = sub[0][5]
+      for r in sub:
+        r[5] -= base
+      nch = sub[-1][5] + -(-sub[-1][4] // 64)
+      plan["bn_desc_steps"][i] = (
+          torch.from_numpy(np.array([tuple(r) for r in sub], dtype=ddt).view(np.uint8).copy()).to(dev),
+          len(sub), nch)
     plan["bwd_ready"] = True
     plan["first_idx"] = first_idx
 
@@ -689,10 +705,15 @@ class Net(object):
     self._prepare_backward(plan, first_idx)
     return plan["steps"][-1]["gy"]
 
-  def backward(self, plan, x_in, first_idx=0, dx_in=None):
+  def backward(self, plan, x_in, first_idx=0, dx_in=None, after_step=None):
     """Backpropagates plan['steps'][-1]['gy'] down to steps[first_idx]; gradients of the
     variables are ACCUMULATED into the store's flat gradient buffer (zeroed once per step by
-    the trainer).  dx_in: Ref receiving d(loss)/d(net input) (overwritten) or None."""
+    the trainer).  dx_in: Ref receiving d(loss)/d(net input) (overwritten) or None.
+    after_step(i): called when every kernel that writes the gradients of top-level step i's
+    variables has been enqueued (its BatchNorm partial sums reduced right there instead of at the
+    end); with a filter-gradient side stream the call happens INSIDE that stream, behind an event
+    of the main stream, so that work queued by the callee (the data-parallel all-reduce of the
+    step's range) is ordered behind both and the main stream does not wait."""
     self._prepare_backward(plan, first_idx)
     steps = plan["steps"]
     for i in range(len(steps) - 1, first_idx - 1, -1):
@@ -703,11 +724,23 @@ class Net(object):
         gx = dx_in
       x = st["x"] if st["x"] is not None else x_in
       self._bwd_step(plan, st, x, gx, False)
+      if after_step is not None:
+        part = plan["bn_desc_steps"].get(i)
+        if part is not None:
+          ops.bn_partials_reduce_batched(part[0], part[1], part[2], plan["bn_ws"], self.store.grads)
+        if plan.get("side_pending"):
+          done = torch.cuda.Event()
+          done.record()
+          self.side.wait_event(done)
+          with torch.cuda.stream(self.side):
+            after_step(i)
+        else:
+          after_step(i)
     if plan.get("side_pending"):
       torch.cuda.current_stream().wait_stream(self.side)      # join: gradients complete below here
       plan["side_pending"] = False
       plan["dc_events"] = [None, None]
-    if plan["bn_num"]:
+    if plan["bn_num"] and after_step is None:
       ops.bn_partials_reduce_batched(plan["bn_desc"], plan["bn_num"], plan["bn_chunks"],
                                      plan["bn_ws"], self.store.grads)
 
@@ -1318,8 +1351,10 @@ class FrcnnEngine(object):
                crop_ready=crop_ready)
     return bufs["features"], ctx
 
-  def backward(self, dfeatures, lddf, dfoff, ctx, after_second_stage=None):
-    """dfeatures: [B*N][lddf] buffer holding d(loss)/d(features) at columns [dfoff, dfoff+D)."""
+  def backward(self, dfeatures, lddf, dfoff, ctx, after_second_stage=None, after_block=None):
+    """dfeatures: [B*N][lddf] buffer holding d(loss)/d(features) at columns [dfoff, dfoff+D).
+    after_block(i): Net.backward's `after_step` for the second stage (per-block gradient
+    exchange, data_parallel.BlockReducer)."""
     bufs, b, n = ctx["bufs"], ctx["b"], ctx["n"]
     plan2 = bufs["plan2"]
     gnet = self.second.out_grad(plan2, 0)
@@ -1340,7 +1375,7 @@ class FrcnnEngine(object):
         bufs["dpooled"] = Ref(torch.empty_like(bufs["pooled"].t), bufs["pooled"].ld, 0,
                               bufs["pooled"].c)
       dpooled = bufs["dpooled"]
-    self.second.backward(plan2, bufs["pooled"], 0, dpooled)
+    self.second.backward(plan2, bufs["pooled"], 0, dpooled, after_step=after_block)
     if after_second_stage is not None:
       after_second_stage()
     if need_first:

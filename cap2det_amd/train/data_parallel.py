@@ -82,3 +82,55 @@ class OverlappedReducer(object):
         self._work.wait()
         self._work = None
     return 1.0 / self.world
+
+
+class BlockReducer(object):
+  """Per-block reduction of the flat gradient bucket under the backward pass.
+
+  The bucket is laid out in network order, [Mixed_4e | Mixed_5a | Mixed_5b | Mixed_5c | heads], and
+  the backward pass finishes it from the END: heads, Mixed_5c, 5b, 5a, and Mixed_4e last.  `cuts`
+  are the ascending offsets of those ranges inside `flat` (cuts[0] = 0, cuts[-1] = flat.numel());
+  `start(i)` launches the asynchronous all-reduce of range i as soon as the caller has enqueued the
+  last kernel that writes it — from inside whatever stream is current, so that the collective
+  (RCCL runs it on its own stream) is ordered behind that stream's work and nobody else waits —
+  and `finish()` reduces the ranges that were never started (the Mixed_4e prefix) and waits for
+  all of them.  At 3.4 ms per bf16 step the one 24 MB suffix of OverlappedReducer no longer hides
+  under the ≈0.6 ms of ROI-crop / Mixed_4e backward behind it; three ranges of 5-10 MB each start
+  0.5-2 ms earlier (≈0.1 ms per range at the per-link xGMI rate of an 8-GPU ring).
+  With one rank every call is a no-op (unless C2D_FORCE_ALLREDUCE=1: `collectives_on`)."""
+
+  def __init__(self, flat, cuts, group=None):
+    cuts = [int(c) for c in cuts]
+    if cuts[0] != 0 or cuts[-1] != flat.numel() or any(a >= b for a, b in zip(cuts, cuts[1:])):
+      raise ValueError("cuts must rise from 0 to the bucket size: %r" % (cuts,))
+    self.flat, self.cuts, self.group = flat, cuts, group
+    self._works = {}
+    _, self.world = world_info()
+    self.on = collectives_on()
+
+  def num_ranges(self):
+    return len(self.cuts) - 1
+
+  def start(self, i):
+    if self.on and i not in self._works:
+      self._works[i] = dist.all_reduce(self.flat[self.cuts[i]:self.cuts[i + 1]],
+                                       op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+  def finish(self):
+    if self.on:
+      # what is left, as few collectives as possible: runs of adjacent unstarted ranges
+      i, n = 0, self.num_ranges()
+      while i < n:
+        if i in self._works:
+          i += 1
+          continue
+        j = i
+        while j + 1 < n and (j + 1) not in self._works:
+          j += 1
+        dist.all_reduce(self.flat[self.cuts[i]:self.cuts[j + 1]], op=dist.ReduceOp.SUM,
+                        group=self.group)
+        i = j + 1
+      for w in self._works.values():
+        w.wait()
+      self._works = {}
+    return 1.0 / self.world

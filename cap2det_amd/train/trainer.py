@@ -172,6 +172,17 @@ class Trainer(object):
               if n.startswith("second_stage_feature_extraction")]
     lo = self.bucket[0]
     self._tail_split = (min(second) - lo) if second and min(second) > lo else 0
+    # per-block ranges of the bucket (data_parallel.BlockReducer): one cut where the variables of
+    # each second-stage block begin; the last block's range runs to the end (the heads)
+    net2 = self.model.engine.second
+    starts = {}
+    for i, names in enumerate(net2.order):
+      offs = [store.offset[v][0] for n in names for v in net2.layers[n].var_names()]
+      if offs and lo <= min(offs) < self.bucket[1]:
+        starts[i] = min(offs) - lo
+    cuts = sorted(set([0] + list(starts.values()) + [self.bucket[1] - lo]))
+    self._block_cuts = cuts
+    self._block_range = {i: cuts.index(o) for i, o in starts.items()}
     # hipGraph replay of the (static) step: removes the ~6 us host gap after each of the ~240
     # launches.  Inputs are staged into fixed device buffers; the dropout seed lives in HBM.
     self.use_graph = bool(use_graph)
@@ -242,7 +253,8 @@ class Trainer(object):
       lr = exponential_decay(lr, self.global_step, d.decay_steps, d.decay_rate, d.staircase)
     return lr
 
-  def _forward_backward(self, examples, after_second_stage=None, prefetch=None, **kwargs):
+  def _forward_backward(self, examples, after_second_stage=None, prefetch=None, after_block=None,
+                        **kwargs):
     model, store = self.model, self.model.store
     lo, hi = self.bucket
     # everything the step's accumulating kernels add into, cleared by ONE launch: the gradient
@@ -273,7 +285,7 @@ class Trainer(object):
         model.engine.prefetch_first_stage(prefetch[F.image], prefetch[F.proposals].shape[1], True)
       losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
       losses['regularization_loss'] = model.regularization_loss(step_zeroed=True)
-      model.backward(after_second_stage)
+      model.backward(after_second_stage, after_block)
     finally:
       # "zeroed by the step's one launch" holds for THIS backward pass only: if the forward pass or
       # the losses raise, a later direct model.backward() must zero its gradient map itself
@@ -349,8 +361,16 @@ class Trainer(object):
     kwargs["prefetch"] = prefetch
     store = self.model.store
     lo, hi = self.bucket
-    reducer = data_parallel.OverlappedReducer(store.grads[lo:hi], self._tail_split)
-    predictions, losses = self._forward_backward(examples, reducer.start_tail, **kwargs)
+    if os.environ.get("C2D_DP_BUCKETS", "blocks") == "blocks" and len(self._block_cuts) > 2:
+      # one asynchronous all-reduce per second-stage block, launched as the backward pass leaves
+      # the block (heads ride with the last block), the Mixed_4e prefix at the end
+      reducer = data_parallel.BlockReducer(store.grads[lo:hi], self._block_cuts)
+      ranges = self._block_range
+      hook = (lambda i: reducer.start(ranges[i]) if i in ranges else None) if reducer.on else None
+      predictions, losses = self._forward_backward(examples, None, after_block=hook, **kwargs)
+    else:
+      reducer = data_parallel.OverlappedReducer(store.grads[lo:hi], self._tail_split)
+      predictions, losses = self._forward_backward(examples, reducer.start_tail, **kwargs)
     scale = reducer.finish()
     self._apply_gradients(scale, self.learning_rate())
     self.global_step += 1

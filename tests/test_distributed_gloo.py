@@ -116,3 +116,48 @@ def test_overlapped_two_bucket_reducer(tmp_path):
   r = data_parallel.OverlappedReducer(t, 3)
   r.start_tail()
   assert r.finish() == 1.0 and t.tolist() == list(range(8))
+
+
+def _block_worker(rank, world, port, out_path):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    flat = torch.arange(1000, dtype=torch.float64) * (rank + 1)
+    red = data_parallel.BlockReducer(flat, [0, 137, 400, 650, 1000])
+    assert red.num_ranges() == 4
+    # the backward pass leaves the blocks from the end: ranges 3, 2, 1 are started as they become
+    # final, range 0 (Mixed_4e) is still being written and is reduced by finish()
+    red.start(3)
+    flat[400:650] += 0.25                  # block 2's last kernels
+    red.start(2)
+    red.start(2)                           # (a second start of a range is ignored)
+    red.start(1)
+    flat[:137] += 0.5
+    scale = red.finish()
+    if rank == 0:
+      np.save(out_path, flat.numpy() * scale)
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_block_reducer(tmp_path):
+  """data_parallel.BlockReducer: per-block asynchronous all-reduces in backward order, the
+  unstarted prefix in finish() — the reduced bucket is the mean over the ranks of what each
+  range held when it was handed over."""
+  out_path = str(tmp_path / "blocks.npy")
+  mp.spawn(_block_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+  got = np.load(out_path)
+  want = np.arange(1000, dtype=np.float64) * 1.5
+  want[400:650] += 0.25
+  want[:137] += 0.5
+  np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+  t = torch.arange(8, dtype=torch.float32)                  # single process: no-ops
+  r = data_parallel.BlockReducer(t, [0, 3, 8])
+  r.start(1)
+  assert r.finish() == 1.0 and t.tolist() == list(range(8))
+  with pytest.raises(ValueError):
+    data_parallel.BlockReducer(t, [0, 9])
+  # finish() merges adjacent unstarted ranges into one collective (checked by construction: the
+  # single-process path issues none)

@@ -35,7 +35,7 @@ def test_forced_allreduce_at_world_size_one_reproduces_the_plain_step():
   assert rep["backend"] == "nccl" and rep["world_size"] == 1
   assert rep["ranks_counted_by_all_reduce"] == 1
   modes = {c["mode"]: c for c in rep["checks"]}
-  assert modes["eager"]["collectives_with"] == 6 and modes["graph"]["collectives_with"] == 3
+  assert modes["eager"]["collectives_with"] == 12 and modes["graph"]["collectives_with"] == 3
   assert all(c["first_forward_bitwise_equal"] for c in rep["checks"])
 
 
