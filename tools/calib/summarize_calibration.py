@@ -53,7 +53,10 @@ def main():
   with open(plain_path) as f:
     plain = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
   fetch, write, mfma = per_kernel(fetch_dir), per_kernel(write_dir), per_kernel(mfma_dir)
-  tcc = per_kernel(tcc_dir) if tcc_dir and os.path.isdir(tcc_dir) else {}
+  try:
+    tcc = per_kernel(tcc_dir) if tcc_dir and os.path.isdir(tcc_dir) else {}
+  except SystemExit:
+    tcc = {}                     # (optional pass: counter names differ between rocprofv3 builds)
   dur = {}
   if stats_dir:
     for path in glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True):

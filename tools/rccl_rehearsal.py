@@ -95,10 +95,12 @@ def main():
     got = run(True, use_graph)
     name = "graph" if use_graph else "eager"
     chk = {"mode": name, "collectives_without": ref["collectives"], "collectives_with": got["collectives"]}
-    # without the switch a one-rank group issues nothing; with it: two per eager step (the second
-    # stage + heads suffix under the ROI-crop / Mixed_4e backward, then the Mixed_4e prefix), one
-    # per graph step (between the two replays)
-    good = ref["collectives"] == 0 and got["collectives"] == (3 if use_graph else 6)
+    # without the switch a one-rank group issues nothing; with it: four per eager step (one per
+    # second-stage block as the backward pass leaves it — Mixed_5c with the heads, 5b, 5a: issued
+    # from the filter-gradient stream, data_parallel.BlockReducer — then the Mixed_4e prefix; two
+    # with C2D_DP_BUCKETS=two), one per graph step (between the two replays)
+    per_step = 2 if os.environ.get("C2D_DP_BUCKETS") == "two" else 4
+    good = ref["collectives"] == 0 and got["collectives"] == (3 if use_graph else 3 * per_step)
     if not use_graph:
       good = good and got["streams"]["side"] and got["streams"]["lookahead"]
     fwd_equal = all(torch.equal(a, b) for a, b in zip(ref["scores0"], got["scores0"]))

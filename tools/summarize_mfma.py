@@ -17,7 +17,13 @@ fall into the SAME padding (100 of 144 (pixel, tap) pairs are real on a 4x4 map)
 `roofline.achieved` counts the algorithmic FLOPs of the convolution (all nine taps), so
 `mfma_busy` can sit BELOW `roofline.frac` — the difference is matrix-pipe time that was never
 spent.  On the other side it is not diluted by the clock: the chip holds ~2.1 GHz under this load,
-the nominal peaks assume 2.4."""
+the nominal peaks assume 2.4.
+
+Calibrated in round 4 (tools/calib/, profiles/r04_counter_calibration.json): pure
+v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16 loops on every SIMD (1 and 4 waves per SIMD) read
+0.992-0.995, the same loops on two of a CU's four SIMDs 0.489-0.497, and the counter itself equals
+64 / 32 cycles x the MFMAs issued to 1e-4 — the reading IS the busy fraction (no factor; the 0.5 %
+are the launch's ramp in GRBM_GUI_ACTIVE).  `per_kernel` lists every template instance."""
 import collections
 import re
 import csv
@@ -45,12 +51,18 @@ def main():
     raise SystemExit("no counter_collection.csv under " + pmc_dir)
   agg = collections.defaultdict(lambda: collections.defaultdict(float))
   launches = collections.defaultdict(set)
+  kagg = collections.defaultdict(lambda: collections.defaultdict(float))
+  klaunches = collections.defaultdict(set)
   for path in files:
     with open(path) as f:
       for row in csv.DictReader(f):
         fam = family(row["Kernel_Name"])
         if not fam:
           continue
+        km = re.search(r"(\w+_kernel(?:<[^>]*>)?)", row["Kernel_Name"])
+        if km:
+          kagg[km.group(1)][row["Counter_Name"]] += float(row["Counter_Value"])
+          klaunches[km.group(1)].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
         fams_of_row = [fam]
         if fam == "igemm":     # the big-tile kernels apart from the single-image first-stage ones
           fams_of_row.append("igemm_small_only" if "igemm_small" in row["Kernel_Name"]
@@ -69,9 +81,17 @@ def main():
         "GRBM_GUI_ACTIVE": gui,
         "mfma_busy": (busy / (gui / 8.0 * 256 * 4)) if gui else None,
     }
+  per_kernel = {}
+  for k, c in sorted(kagg.items()):
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+    per_kernel[k] = {"launches": len(klaunches[k]),
+                     "mfma_busy": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 1024)) if gui else None,
+                     "gui_share_of_family_time": None}
   with open(out_path, "w") as f:
     json.dump({"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4)",
-               "families": fams}, f, indent=1)
+               "calibration": "profiles/r04_counter_calibration.json: reads 0.992-0.995 at a true 1.0, "
+                              "0.489-0.497 at a true 0.5 (no factor applied)",
+               "families": fams, "per_kernel": per_kernel}, f, indent=1)
   for fam, v in fams.items():
     print("%-22s launches %5d  mfma_busy %s" % (fam, v["launches"], v["mfma_busy"]))
 

@@ -8,8 +8,14 @@ FETCH_DIR / WRITE_DIR are the output directories of two SEPARATE passes
 and the same with WRITE_SIZE: the two counters do not fit one pass on gfx950).  Units and
 corrections follow MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950 FETCH_SIZE
 tallies 128-B requests at 64 B, so it is DOUBLED; WRITE_SIZE is exact for 16-B/lane stores and
-float atomics.  Steps are counted by the launches of `midn_fwd_kernel` (exactly one per training
-step)."""
+float atomics.  The factors are CALIBRATED per access shape by tools/calib/ (round 4,
+profiles/r04_counter_calibration.json: kernels that read / write 1 GiB once): FETCH_SIZE reads
+exactly 1/2 for global loads of 4, 8 and 16 B per lane in contiguous runs of 64 B ... 1 KiB and
+for `buffer_load ... lds` of 4 / 16 B per lane (TCC_EA0_RDREQ counts one request per 128 B, the
+FETCH_SIZE expression prices it at 64 B); the one exception measured is LDS-DMA of 64-byte runs
+(x1.84: 9 % of its requests are re-fetches).  WRITE_SIZE reads 1.000 for 4-, 8-, 16-B stores and
+float atomics.  `FETCH_FACTORS` below maps kernel families to their access shape's factor.
+Steps are counted by the launches of `midn_fwd_kernel` (exactly one per training step)."""
 import collections
 import csv
 import glob
@@ -33,6 +39,15 @@ FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
     ("pool3x3", "pool3x3_"),
     ("adagrad", "adagrad_kernel"),
 ]
+
+
+# FETCH_SIZE correction per kernel family (access shape -> profiles/r04_counter_calibration.json).
+# Everything the step launches reads in one of the calibrated x2.000 shapes; the bf16 ring kernels
+# stage 64-byte rows (32-deep stages) in some launches and 128-byte rows in others: 2.0 for the
+# 128-byte launches, 1.84 for the 64-byte ones — the family average is taken as 1.92 and the spread
+# (+-4 %) is the stated uncertainty of that family's traffic.
+FETCH_FACTORS = {"igemm_bf16": 1.92}
+DEFAULT_FETCH_FACTOR = 2.0
 
 
 def family_of(name):
@@ -84,7 +99,8 @@ def main():
     fk, fl = fetch.get(fam, [0.0, 0])
     wk, wl = write.get(fam, [0.0, 0])
     launches = fl / float(fsteps) if fsteps else 0.0
-    rd = 2.0 * fk * 1024.0 / max(fsteps, 1)          # gfx950: FETCH_SIZE reads 1/2 (doubled)
+    ff = FETCH_FACTORS.get(fam, DEFAULT_FETCH_FACTOR)   # gfx950: FETCH_SIZE reads 1/2 (calibrated)
+    rd = ff * fk * 1024.0 / max(fsteps, 1)
     wr = wk * 1024.0 / max(wsteps, 1)
     fams[fam] = {
         "launches_per_step": launches,
@@ -92,14 +108,17 @@ def main():
         "hbm_write_bytes_per_step": wr,
         "hbm_bytes_per_step": rd + wr,
         "hbm_bytes_per_launch": (rd + wr) / launches if launches else None,
+        "fetch_factor": ff,
         "raw_FETCH_SIZE_KiB_per_step": fk / max(fsteps, 1),
         "raw_WRITE_SIZE_KiB_per_step": wk / max(wsteps, 1),
     }
   doc = {
       "source": {"fetch_pass": fetch_dir, "write_pass": write_dir,
                  "steps_in_fetch_pass": fsteps, "steps_in_write_pass": wsteps},
-      "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md §HBM); "
-                     "WRITE_SIZE as read",
+      "corrections": "KiB -> bytes (x1024); FETCH_SIZE x fetch_factor (2.0 on gfx950 for every "
+                     "calibrated access shape, 1.92 for the bf16 ring kernels' mix of 64- and "
+                     "128-byte LDS-DMA rows: profiles/r04_counter_calibration.json); WRITE_SIZE as "
+                     "read (calibrated 1.000)",
       "families": fams,
   }
   with open(out_path, "w") as f:
