@@ -1,0 +1,126 @@
+"""Multi-step evidence for the reduced-precision modes (the bf16 first stage changed the
+numerical operating point of configs[2] / [4] and only single-step bounds were committed).
+
+Trains the SAME model (seed, initial variables) on the SAME stream of synthetic batches (a pool of
+POOL images cycled, so the detector can fit them and the loss falls), with the SAME dropout seeds,
+in three storage modes:
+
+  fp32            : everything fp32 (the reference's arithmetic, configs[1] / [3])
+  bf16_fp32first  : second stage bf16, single-image first stage fp32 (rounds 2-3a; C2D_FIRST_STAGE_FP32=1)
+  bf16            : both towers bf16 behind the fp32 stem (round 3b default of compute_dtype="bf16")
+
+and reports the loss curves (every loss term, mean over windows of WINDOW steps) and how far the
+bf16 curves stray from the fp32 one.  The reference has no reduced-precision mode
+(/root/reference/models/utils.py:108-188 runs in fp32), so there is nothing to be identical to:
+what this shows is that optimisation follows the same trajectory within the step-to-step noise.
+
+  python tools/loss_curve.py OUT.json [--steps 400] [--hw 500] [--proposals 2000] [--dm 1.0]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+MODES = [("fp32", "fp32", None), ("bf16_fp32first", "bf16", "1"), ("bf16", "bf16", "0")]
+
+
+def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, device="cuda:0",
+               modes=MODES, seed=3):
+  import numpy as np
+  import torch
+  from cap2det_amd import synthetic
+  from cap2det_amd.train.trainer import Trainer
+
+  pipeline = synthetic.load_pipeline()
+  out = {"config": dict(steps=steps, image_hw=[hw, hw], proposals=proposals, depth_multiplier=dm,
+                        pool=pool, window=window, pipeline="voc07_groundtruth_hotpath",
+                        learning_rate=pipeline.train_config.learning_rate),
+         "curves": {}}
+  batches, init = None, None
+  for name, dtype, first_fp32 in modes:
+    if first_fp32 is None:
+      os.environ.pop("C2D_FIRST_STAGE_FP32", None)
+    else:
+      os.environ["C2D_FIRST_STAGE_FP32"] = first_fp32
+    trainer = Trainer(pipeline, device=device, depth_multiplier=dm, compute_dtype=dtype, seed=seed)
+    model = trainer.model
+    if init is None:
+      init = model.state_dict()
+      classes = model.label_extractor.classes
+      rng = np.random.default_rng(seed)
+      batches = []
+      for _ in range(pool):
+        ex = synthetic.make_examples(rng, 1, hw, hw, proposals, [proposals], classes)
+        # a structured image per pool entry (uniform noise looks the same to the network in every
+        # image: nothing to fit) — smooth per-channel patterns with random frequencies + noise
+        yy, xx = np.meshgrid(np.linspace(0, 1, hw), np.linspace(0, 1, hw), indexing="ij")
+        img = np.stack([np.sin(rng.uniform(3, 25) * yy + rng.uniform(0, 6)) *
+                        np.cos(rng.uniform(3, 25) * xx + rng.uniform(0, 6)) for _ in range(3)], -1)
+        ex["image"] = np.clip(127.5 + 100.0 * img + 20.0 * rng.standard_normal((hw, hw, 3)), 0,
+                              255).astype(np.float32)[None]
+        d = dict(ex)
+        for k in ("image", "proposals", "number_of_proposals"):
+          d[k] = torch.from_numpy(ex[k]).to(device).contiguous()
+        batches.append(d)
+    else:
+      model.load_state_dict(init)
+    log = []
+    for i in range(steps):
+      losses = trainer.train_step(batches[i % pool], dropout_seed=1000 + i)
+      log.append(losses)          # (device scalars: no host sync inside the loop)
+    torch.cuda.synchronize()
+    keys = sorted(log[0].keys())
+    series = {k: np.array([float(l[k]) for l in log]) for k in keys}
+    nwin = steps // window
+    out["curves"][name] = {
+        "first_stage": str(model.engine.first.dtype).replace("torch.", ""),
+        "second_stage": str(model.engine.second.dtype).replace("torch.", ""),
+        "windows": {k: [float(v[w * window:(w + 1) * window].mean()) for w in range(nwin)]
+                    for k, v in series.items()},
+        "first_step": {k: float(v[0]) for k, v in series.items()},
+        "all_finite": bool(all(np.isfinite(v).all() for v in series.values())),
+    }
+    del trainer, model
+    torch.cuda.empty_cache()
+  os.environ.pop("C2D_FIRST_STAGE_FP32", None)
+  ref = out["curves"][modes[0][0]]["windows"]
+  out["deviation_from_fp32"] = {}
+  for name, _, _ in modes[1:]:
+    cur = out["curves"][name]["windows"]
+    dev = {}
+    for k in ref:
+      a, b = np.array(ref[k]), np.array(cur[k])
+      dev[k] = float((np.abs(a - b) / np.maximum(np.abs(a), 1e-6)).max())
+    out["deviation_from_fp32"][name] = {"max_relative_window_deviation": dev,
+                                        "total_loss_first_window": [ref["total_loss"][0], cur["total_loss"][0]],
+                                        "total_loss_last_window": [ref["total_loss"][-1], cur["total_loss"][-1]]}
+  t = np.array(ref["total_loss"])
+  out["fp32_total_loss_fell_by"] = float(1.0 - t[-1] / t[0])
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("out")
+  ap.add_argument("--steps", type=int, default=400)
+  ap.add_argument("--hw", type=int, default=500)
+  ap.add_argument("--proposals", type=int, default=2000)
+  ap.add_argument("--dm", type=float, default=1.0)
+  ap.add_argument("--pool", type=int, default=8)
+  ap.add_argument("--window", type=int, default=25)
+  args = ap.parse_args()
+  doc = run_curves(args.steps, args.hw, args.proposals, args.dm, args.pool, args.window)
+  with open(args.out, "w") as f:
+    json.dump(doc, f, indent=1, sort_keys=True)
+  print(json.dumps({"fp32_total_loss_fell_by": doc["fp32_total_loss_fell_by"],
+                    "deviation_from_fp32": {k: v["max_relative_window_deviation"]["total_loss"]
+                                            for k, v in doc["deviation_from_fp32"].items()},
+                    "last_window_total": {k: v["windows"]["total_loss"][-1] for k, v in doc["curves"].items()}}))
+
+
+if __name__ == "__main__":
+  main()
