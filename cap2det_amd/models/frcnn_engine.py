@@ -1246,6 +1246,30 @@ class FrcnnEngine(object):
     # to another tensor, so "same data_ptr and version" really means "same pixels")
     bufs["prefetched"] = (image, image._version, done)
 
+  external_prefix = False    # see forward(): set by Trainer._graph_step around its capture
+
+  def prefix_output(self, bufs):
+    """(last prefix step, its output tensor) of this shape, or (None, None) without a prefix."""
+    upto = self._prefix_len(bufs)
+    if upto <= 0:
+      return None, None
+    last = bufs["plan1"]["steps"][upto - 1]
+    return last, last["y"].t
+
+  def run_prefix_into(self, bufs, image, out):
+    """The frozen first-stage prefix of `image` with its OUTPUT redirected to `out` (a tensor shaped
+    like the prefix output); the internal buffers of the prefix are the shape's own.  Runs on the
+    current stream (the hipGraph look-ahead branch, and its eager priming)."""
+    last, cur = self.prefix_output(bufs)
+    refs = self._output_refs(last)
+    for r in refs:
+      r.t = out
+    try:
+      self._run_prefix(bufs, image, self._prefix_len(bufs))
+    finally:
+      for r in refs:
+        r.t = cur
+
   def step_zero_list(self, image_shape, num_proposals):
     """Gradient maps the coming backward pass of this input shape accumulates into (the ROI-crop
     backward's destination), for the trainer's one-launch zeroing at the start of a step; a
@@ -1275,7 +1299,11 @@ class FrcnnEngine(object):
     bufs = self._buffers(b, h, w, n, is_training)
     upto = self._prefix_len(bufs)
     pre = bufs.pop("prefetched", None)
-    if (pre is not None and upto > 0 and pre[0].data_ptr() == image.data_ptr() and
+    if self.external_prefix and upto > 0:
+      # hipGraph capture with look-ahead (Trainer._graph_step): the prefix output buffer already
+      # holds this image's prefix (copied there from the look-ahead branch's buffer)
+      assert pre is None
+    elif (pre is not None and upto > 0 and pre[0].data_ptr() == image.data_ptr() and
         pre[0].shape == image.shape and pre[0]._version == pre[1] == image._version):
       # the look-ahead of the previous step computed this image's prefix: swap its buffer in
       last = bufs["plan1"]["steps"][upto - 1]

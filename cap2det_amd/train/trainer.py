@@ -357,7 +357,7 @@ class Trainer(object):
       kwargs["dropout_seed"] = dropout_key(self.seed, self.global_step, self.rank, self.world_size)
     if (self.use_graph and "dropout_mask" not in kwargs and
         not self.model.engine.dropout_on_feature_map):
-      return self._graph_step(examples, **kwargs)
+      return self._graph_step(examples, prefetch=prefetch, **kwargs)
     kwargs["prefetch"] = prefetch
     store = self.model.store
     lo, hi = self.bucket
@@ -399,30 +399,47 @@ class Trainer(object):
       cur = nxt
     return losses
 
-  def _graph_step(self, examples, dropout_seed=None, **kwargs):
+  def _graph_step(self, examples, dropout_seed=None, prefetch=None, **kwargs):
+    """hipGraph replay of the step WITH the eager schedule's streams (round 4): inside the capture
+    the filter gradients fork onto the side stream exactly as in the eager step (event record /
+    wait are capturable, the graph gets parallel branches), and the look-ahead — the frozen
+    first-stage prefix of the NEXT image — is a third branch of the same graph: it reads a static
+    `next image` buffer and writes the alternate prefix buffer, which the following replay copies
+    (2.4 MB) into place before its own Mixed_4e reads it.  `prefetch` must therefore be the batch
+    the caller passes as `examples` next (as in the eager look-ahead); if it was not, the prefix of
+    the current image is recomputed eagerly in front of the replay.  C2D_GRAPH_STREAMS=0 captures
+    everything on one stream (the round-3 form)."""
     from cap2det_amd.core.standard_fields import InputDataFields as F
     model, store = self.model, self.model.store
+    eng = model.engine
     lo, hi = self.bucket
     lr = self.learning_rate()
     labels = model.label_extractor.extract_labels(examples)      # host lookup + small kernel
-    model.engine.second.side = None        # one stream inside the captured graph
-    model.engine.prefetch_stream = None
+    streams = os.environ.get("C2D_GRAPH_STREAMS", "1") != "0" and eng.second.side is not None
+    if not streams:
+      eng.second.side = None        # one stream inside the captured graph
+      eng.prefetch_stream = None
     if self._lr_dev is None:
       self._lr_dev = torch.zeros(1, device=self.device)
     # the learning rate lives in device memory (like the dropout seed): a continuous
     # exponential_decay changes it every step without a re-capture
     self._lr_dev.fill_(lr)
     lr_dev = self._lr_dev
-    key = (tuple(examples[F.image].shape), tuple(examples[F.proposals].shape))
+    image = examples[F.image]
+    key = (tuple(image.shape), tuple(examples[F.proposals].shape))
     if self._graphs is None or self._graphs["key"] != key:
       # eager warm-up on this shape (allocates every buffer), then capture
-      st = {F.image: examples[F.image].clone(), F.proposals: examples[F.proposals].clone(),
+      st = {F.image: image.clone(), F.proposals: examples[F.proposals].clone(),
             F.num_proposals: examples[F.num_proposals].clone(), "labels": labels.clone(),
-            "seed": torch.zeros(1, dtype=torch.int64, device=self.device)}
+            "seed": torch.zeros(1, dtype=torch.int64, device=self.device),
+            "next_image": image.clone()}
       ex = {F.image: st[F.image], F.proposals: st[F.proposals],
             F.num_proposals: st[F.num_proposals]}
       # (every optimiser slot: rmsprop keeps momentum / mean-gradient slots beside slot 0)
       state = (store.values.clone(), [sl.clone() for sl in store.slots])
+      eng.invalidate_prefetch()
+      side_keep, pre_keep = eng.second.side, eng.prefetch_stream
+      eng.prefetch_stream = None          # (the eager look-ahead machinery stays out of the graph)
       self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
       self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
       torch.cuda.synchronize()
@@ -430,29 +447,63 @@ class Trainer(object):
       for sl, saved in zip(store.slots, state[1]):
         sl.copy_(saved)
       self.model.refresh(only_trainable=True)
-      side = torch.cuda.Stream()
-      side.wait_stream(torch.cuda.current_stream())
+      bufs = eng._buffers(image.shape[0], image.shape[1], image.shape[2],
+                          examples[F.proposals].shape[1], True)
+      last, p_cur = eng.prefix_output(bufs)
+      lookahead = streams and last is not None
+      p_next = torch.empty_like(p_cur) if lookahead else None
+      branch = torch.cuda.Stream() if lookahead else None
+      cap = torch.cuda.Stream()
+      cap.wait_stream(torch.cuda.current_stream())
       g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-      with torch.cuda.stream(side):
-        with torch.cuda.graph(g_fb, stream=side):
-          predictions, losses = self._forward_backward(ex, labels=st["labels"],
-                                                       dropout_seed=st["seed"])
-        with torch.cuda.graph(g_opt, stream=side):
+      with torch.cuda.stream(cap):
+        with torch.cuda.graph(g_fb, stream=cap):
+          if lookahead:
+            p_cur.copy_(p_next)                   # the previous replay's look-ahead result
+            fork = torch.cuda.Event()
+            fork.record()
+            branch.wait_event(fork)
+            with torch.cuda.stream(branch):
+              eng.run_prefix_into(bufs, st["next_image"], p_next)
+              joined = torch.cuda.Event()
+              joined.record()
+            eng.external_prefix = True
+          try:
+            predictions, losses = self._forward_backward(ex, labels=st["labels"],
+                                                         dropout_seed=st["seed"])
+          finally:
+            eng.external_prefix = False
+          if lookahead:
+            torch.cuda.current_stream().wait_event(joined)
+        with torch.cuda.graph(g_opt, stream=cap):
           self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
           total = self.model.total_loss()
-      torch.cuda.current_stream().wait_stream(side)
+      torch.cuda.current_stream().wait_stream(cap)
+      eng.prefetch_stream = pre_keep
       losses['total_loss'] = total
-      self._graphs = dict(key=key, fb=g_fb, opt=g_opt, predictions=predictions, losses=losses)
+      self._graphs = dict(key=key, fb=g_fb, opt=g_opt, predictions=predictions, losses=losses,
+                          lookahead=lookahead, bufs=bufs, p_next=p_next, primed=None)
       self._static = st
-    st = self._static
-    st[F.image].copy_(examples[F.image], non_blocking=True)
+    st, gr = self._static, self._graphs
+    st[F.image].copy_(image, non_blocking=True)
     st[F.proposals].copy_(examples[F.proposals], non_blocking=True)
     st[F.num_proposals].copy_(examples[F.num_proposals], non_blocking=True)
     st["labels"].copy_(labels, non_blocking=True)
     st["seed"].fill_(int(dropout_seed) if dropout_seed is not None else self.global_step)
-    self._graphs["fb"].replay()
+    if gr["lookahead"]:
+      if gr["primed"] != (image.data_ptr(), image._version):
+        # the look-ahead of the previous replay was not for this image (first step, or a caller
+        # that does not announce its batches): compute this image's prefix now
+        eng.run_prefix_into(gr["bufs"], st[F.image], gr["p_next"])
+      nxt = prefetch[F.image] if prefetch is not None else None
+      if nxt is not None and tuple(nxt.shape) == tuple(st["next_image"].shape):
+        st["next_image"].copy_(nxt, non_blocking=True)
+        gr["primed"] = (nxt.data_ptr(), nxt._version)
+      else:
+        gr["primed"] = None
+    gr["fb"].replay()
     data_parallel.allreduce_bucket(store.grads[lo:hi])
-    self._graphs["opt"].replay()
+    gr["opt"].replay()
     self.global_step += 1
-    self.predictions = self._graphs["predictions"]
-    return self._graphs["losses"]
+    self.predictions = gr["predictions"]
+    return gr["losses"]

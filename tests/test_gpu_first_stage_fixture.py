@@ -10,8 +10,9 @@ for the reference's 1000x1333 training shape) — must reproduce them:
   fp32 : samples within 2e-5 of the map's largest magnitude, channel norms within 2e-5 relative;
   bf16 first stage (`compute_dtype="bf16"`: every map behind the fp32 stem stored in bf16, fp32
   accumulation; twelve layers, one rounding of 2^-9 relative each): samples within 1.5e-2 of the
-  largest magnitude, channel norms within 1.5e-2 of the layer's largest channel norm (a channel
-  the ReLU leaves nearly dead has no relative accuracy of its own; observed values are printed).
+  largest magnitude, channel norms within 8e-3 of the layer's largest channel norm (a channel
+  the ReLU leaves nearly dead has no relative accuracy of its own); observed at Mixed_4e: samples
+  5e-3 / 6e-3, norms 3.5e-3 / 3.8e-3 at 500x500 / 1000x1333 (printed by the test).
 
 At 500x500 the forward instances of the `igemm_small*` family dispatched here must be the ones of
 the newest committed benchmark profiles (fp32: c1, bf16: c2)."""
@@ -30,7 +31,7 @@ from tests.golden import gen_first_stage_fixture as gen
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOL = {"fp32": dict(sample=2e-5, norm=2e-5), "bf16": dict(sample=1.5e-2, norm=1.5e-2)}
+TOL = {"fp32": dict(sample=2e-5, norm=2e-5), "bf16": dict(sample=1.5e-2, norm=8e-3)}
 
 
 def _profile_first_stage_forward_instances(cfg):
@@ -102,4 +103,6 @@ def test_first_stage_matches_the_float64_fixture(monkeypatch, hw, dtype):
     assert worst["Mixed_4e"][0] > 1e-5           # (it really ran in reduced precision)
   if hw == (500, 500):
     want = _profile_first_stage_forward_instances("c1" if dtype == "fp32" else "c2")
+    # (fp32 `igemm_small*<0, 4>` instances of the bf16 profile are the heads GEMM, not first stage)
+    want = {w for w in want if w.endswith(", 4>" if dtype == "fp32" else ", 2>")}
     assert want and want <= seen, (sorted(want), sorted(seen))

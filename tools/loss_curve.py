@@ -14,7 +14,7 @@ bf16 curves stray from the fp32 one.  The reference has no reduced-precision mod
 (/root/reference/models/utils.py:108-188 runs in fp32), so there is nothing to be identical to:
 what this shows is that optimisation follows the same trajectory within the step-to-step noise.
 
-  python tools/loss_curve.py OUT.json [--steps 400] [--hw 500] [--proposals 2000] [--dm 1.0]
+  python tools/loss_curve.py OUT.json [--steps 400] [--hw 500] [--proposals 2000] [--dm 1.0] [--lr 0.5]
 """
 import argparse
 import json
@@ -29,13 +29,18 @@ MODES = [("fp32", "fp32", None), ("bf16_fp32first", "bf16", "1"), ("bf16", "bf16
 
 
 def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, device="cuda:0",
-               modes=MODES, seed=3):
+               modes=MODES, seed=3, lr=None):
   import numpy as np
   import torch
   from cap2det_amd import synthetic
   from cap2det_amd.train.trainer import Trainer
 
   pipeline = synthetic.load_pipeline()
+  if lr is not None:
+    # the shipped 0.01 (configs/voc07_groundtruth.pbtxt:74) moves a freshly initialised detector
+    # by less than the fourth digit of its loss in a few hundred steps; a short demonstration run
+    # needs a rate at which the pool is visibly fitted
+    pipeline.train_config.learning_rate = lr
   out = {"config": dict(steps=steps, image_hw=[hw, hw], proposals=proposals, depth_multiplier=dm,
                         pool=pool, window=window, pipeline="voc07_groundtruth_hotpath",
                         learning_rate=pipeline.train_config.learning_rate),
@@ -49,7 +54,25 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
     trainer = Trainer(pipeline, device=device, depth_multiplier=dm, compute_dtype=dtype, seed=seed)
     model = trainer.model
     if init is None:
+      # He-normal convolution weights (the trainer's default initialiser is TF-slim's small
+      # truncated normal: activations shrink layer by layer, the features of a fresh detector are
+      # ~0 and nothing can be learned in a few hundred steps — real runs start from the ImageNet
+      # checkpoint, /root/reference/configs/voc07_groundtruth.pbtxt:47); BatchNorm statistics
+      # randomised around the identity so that the ReLUs see both signs
       init = model.state_dict()
+      irng = np.random.default_rng(seed + 100)
+      for k, v in init.items():
+        if k.endswith("/weights") and v.ndim == 4:
+          init[k] = (irng.standard_normal(v.shape) * np.sqrt(2.0 / (v.shape[0] * v.shape[1] * v.shape[2]))).astype(np.float32)
+        elif k.endswith("depthwise_weights"):
+          init[k] = (irng.standard_normal(v.shape) * np.sqrt(2.0 / (v.shape[0] * v.shape[1]))).astype(np.float32)
+        elif k.endswith("pointwise_weights"):
+          init[k] = (irng.standard_normal(v.shape) * np.sqrt(2.0 / v.shape[2])).astype(np.float32)
+        elif k.endswith("moving_mean") or k.endswith("/beta"):
+          init[k] = (0.1 * irng.standard_normal(v.shape)).astype(np.float32)
+        elif k.endswith("moving_variance") or k.endswith("/gamma"):
+          init[k] = irng.uniform(0.8, 1.25, v.shape).astype(np.float32)
+      model.load_state_dict(init)
       classes = model.label_extractor.classes
       rng = np.random.default_rng(seed)
       batches = []
@@ -112,8 +135,9 @@ def main():
   ap.add_argument("--dm", type=float, default=1.0)
   ap.add_argument("--pool", type=int, default=8)
   ap.add_argument("--window", type=int, default=25)
+  ap.add_argument("--lr", type=float, default=None)
   args = ap.parse_args()
-  doc = run_curves(args.steps, args.hw, args.proposals, args.dm, args.pool, args.window)
+  doc = run_curves(args.steps, args.hw, args.proposals, args.dm, args.pool, args.window, lr=args.lr)
   with open(args.out, "w") as f:
     json.dump(doc, f, indent=1, sort_keys=True)
   print(json.dumps({"fp32_total_loss_fell_by": doc["fp32_total_loss_fell_by"],
