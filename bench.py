@@ -507,6 +507,7 @@ def main(argv=None):
       timer.enabled = True
       trainer.use_graph = False
       side, second.side = second.side, None
+      alt, second.alt = second.alt, None
       trainer.model.engine.invalidate_prefetch()          # this step computes its own first stage
     nxt = batch if (not instrument and i + 1 < args.steps and
                     not (i + 2 == args.steps and not args.no_kernel_timing)) else None
@@ -515,6 +516,7 @@ def main(argv=None):
       timer.enabled = False
       trainer.use_graph = args.graph
       second.side = side
+      second.alt = alt
     marks[i + 1].record()
   sync()
   elapsed = time.perf_counter() - t0

@@ -188,7 +188,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        if ((m0 + (wm * MT + i) * 32 < a.M) && (n0 + (wn * NT + j) * 32 < a.N))
+        if (tile_has_rows<PM>(m0 + (wm * MT + i) * 32, a.M, a.g) && (n0 + (wn * NT + j) * 32 < a.N))
           tile_bits |= 1u << (i * NT + j);
     tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
 
@@ -219,7 +219,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
         const int hw = a.g.rh * a.g.rw;
 #pragma unroll
         for (int tb = 0; tb < BM / 32; ++tb) {
-          const unsigned t = (unsigned)(m0 >> 5) + tb;
+          const unsigned t = (unsigned)(m0 + tb * 32) >> a.g.pm;
           const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
           const unsigned px = t - grp * (unsigned)hw;
           const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);
@@ -1946,8 +1946,15 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   if (!row_major_only && a.nseg == 1 && a.g.kh * a.g.kw > 1 && hw <= 64 && a.g.nimg >= 64 &&
       a.N % 4 == 0 && a.g.sub == 1) {
     if (g_collect) return C2D_ERR_UNSUPPORTED;
-    a.g.pm = 1;
-    a.M = c2d_ceil_div(a.g.nimg, 32) * 32 * hw;
+    // image groups of 128 (= the rows of every pixel-major block tile: all of a block's MFMA tiles
+    // are then ONE pixel, see decompose<true>) unless rounding the image count up to 128 would add
+    // more than 10 % of empty rows; C2D_TUNE=1 C2D_PM_GROUP=32 keeps round 3's groups of 32
+    static const int pm_force = (tune && getenv("C2D_PM_GROUP")) ? atoi(getenv("C2D_PM_GROUP")) : 0;
+    const int n128 = c2d_ceil_div(a.g.nimg, 128) * 128;
+    // (the stream-K form — a workspace was passed — keeps groups of 32: its cost model,
+    // make_sk_plan, walks the pixels of a block's four tiles)
+    a.g.pm = (ws.ptr || pm_force == 32 || (pm_force != 128 && n128 * 10 > a.g.nimg * 11)) ? 5 : 7;
+    a.M = c2d_ceil_div(a.g.nimg, 1 << a.g.pm) * (1 << a.g.pm) * hw;
     // 128x64 tiles (4 waves per SIMD) measured best or within 3 % of best on every 3x3 layer of
     // the second stage (tools/sweep_igemm.py); 128x128 only when forced by the tuning hook.
     if (force == 4 && a.es == 2) {      // 256x128 block, 128x64 per wave (bf16 only)

@@ -126,7 +126,7 @@ void igemm_ring_kernel(IgemmArgs a) {
   unsigned row_bits = 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
-    if (m0 + (wm * MT + i) * 32 < a.M) row_bits |= 1u << i;
+    if (tile_has_rows<PM>(m0 + (wm * MT + i) * 32, a.M, a.g)) row_bits |= 1u << i;
   row_bits = __builtin_amdgcn_readfirstlane(row_bits);
 
   // Tap table, one tap per lane (every wave holds all of it): what changes from tap to tap —
@@ -150,7 +150,7 @@ void igemm_ring_kernel(IgemmArgs a) {
       const int hw = a.g.rh * a.g.rw;
 #pragma unroll
       for (int tb = 0; tb < BM / 32; ++tb) {
-        const unsigned t = (unsigned)(m0 >> 5) + tb;
+        const unsigned t = (unsigned)(m0 + tb * 32) >> a.g.pm;
         const unsigned grp = (unsigned)(((unsigned long long)t * a.g.magic_hw) >> 40);
         const unsigned px = t - grp * (unsigned)hw;
         const int y = (int)(((unsigned long long)px * a.g.magic_w) >> 40);

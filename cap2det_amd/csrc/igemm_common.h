@@ -27,7 +27,8 @@ struct ConvGeom {
                    // input pixel, each of which sees only the taps of matching parity
   int ky0, kx0, kstep, nky, nkx;  // tap subset: ky = ky0 + kstep*t, t < nky (same for kx)
   int nimg;        // images (ROIs) in the batch
-  int pm;          // 1: PIXEL-MAJOR row order (small maps, see decompose<true>)
+  int pm;          // PIXEL-MAJOR row order (small maps, see decompose<true>): 0 = off, else log2 of
+                   // the image-group size (5: groups of 32 images, 7: groups of 128)
 };
 
 // Row m of the iteration space -> (image, y, x).  Exact for m * d < 2^40 (always here).
@@ -37,18 +38,24 @@ struct RowPos {
 };
 
 // PM (pixel-major, used for the 3x3 convolutions over the tiny per-ROI maps): rows are ordered
-// (group of 32 images, pixel, image in group), m = ((grp * rh*rw) + pixel) * 32 + r, so every
-// aligned 32-row MFMA tile holds ONE pixel position of 32 images.  Whether a tap falls into the
-// SAME padding is then uniform over the tile and its MFMAs are skipped instead of multiplying
-// zeros (4x4 map: 100 of 144 (pixel, tap) pairs are real; 7x7: 361 of 441).
+// (group of G images, pixel, image in group), m = ((grp * rh*rw) + pixel) * G + r, G = 2^g.pm, so
+// every aligned 32-row MFMA tile holds ONE pixel position of 32 images.  Whether a tap falls into
+// the SAME padding is then uniform over the tile and its MFMAs are skipped instead of multiplying
+// zeros (4x4 map: 100 of 144 (pixel, tap) pairs are real; 7x7: 361 of 441).  Round 4: G = 128 = the
+// block's rows wherever the image count allows, so ALL of a block's tiles are one pixel: a tap is
+// then real or padding for the whole block, padding taps are never visited and no slab is staged
+// for a tap only some of the tiles use (with G = 32 a block of four pixels visited 7.5 taps on
+// average on a 4x4 map for the 6.25 its MFMAs needed: the matrix pipe of the pixel-major launches
+// was busy 0.61 of the time against 0.64-0.79 for the row-major ones, profiles/r04 per-kernel).
 template <bool PM = false>
 __device__ __forceinline__ RowPos decompose(int m, int M, const ConvGeom& g) {
   RowPos p;
   if (PM) {
-    const unsigned t = (unsigned)m >> 5, r = (unsigned)m & 31u;
+    const unsigned sh = (unsigned)g.pm;
+    const unsigned t = (unsigned)m >> sh, r = (unsigned)m & ((1u << sh) - 1u);
     const unsigned grp = (unsigned)(((unsigned long long)t * g.magic_hw) >> 40);
     const unsigned px = t - grp * (unsigned)(g.rh * g.rw);
-    p.img = (int)(grp * 32u + r);
+    p.img = (int)((grp << sh) + r);
     p.valid = m < M && p.img < g.nimg;
     p.y = (int)(((unsigned long long)px * g.magic_w) >> 40);
     p.x = (int)px - p.y * g.rw;
@@ -61,6 +68,18 @@ __device__ __forceinline__ RowPos decompose(int m, int M, const ConvGeom& g) {
   p.y = (int)(((unsigned long long)r * g.magic_w) >> 40);
   p.x = (int)r - p.y * g.rw;
   return p;
+}
+
+// Does the aligned 32-row MFMA tile that starts at row m hold any real row?  (PM: the images of
+// the last group beyond nimg are padding — with groups of 128 that can be whole tiles.)
+template <bool PM>
+__device__ __forceinline__ bool tile_has_rows(int m, int M, const ConvGeom& g) {
+  if (m >= M) return false;
+  if (!PM) return true;
+  const unsigned sh = (unsigned)g.pm;
+  const unsigned t = (unsigned)m >> sh;
+  const unsigned grp = (unsigned)(((unsigned long long)t * g.magic_hw) >> 40);
+  return (int)((grp << sh) + ((unsigned)m & ((1u << sh) - 1u))) < g.nimg;
 }
 
 // Source row (in the A operand's row space) for iteration row `p` and tap (ky,kx); -1 if none.

@@ -9,10 +9,16 @@ in three storage modes:
   bf16_fp32first  : second stage bf16, single-image first stage fp32 (rounds 2-3a; C2D_FIRST_STAGE_FP32=1)
   bf16            : both towers bf16 behind the fp32 stem (round 3b default of compute_dtype="bf16")
 
-and reports the loss curves (every loss term, mean over windows of WINDOW steps) and how far the
-bf16 curves stray from the fp32 one.  The reference has no reduced-precision mode
-(/root/reference/models/utils.py:108-188 runs in fp32), so there is nothing to be identical to:
-what this shows is that optimisation follows the same trajectory within the step-to-step noise.
+and reports the loss curves (every loss term, mean over windows of WINDOW steps), how far the
+bf16 curves stray from the fp32 one, and the PARAMETER TRAJECTORY: with w0 the common initial
+trainable variables, the distance the fp32 run moved them, ||w_fp32 - w0||, against the distance
+between the runs, ||w_mode - w_fp32||, and the cosine of the two displacements.  The reference has
+no reduced-precision mode (/root/reference/models/utils.py:108-188 runs in fp32), so there is
+nothing to be identical to: what this shows is that optimisation follows the same trajectory.
+(With a fresh detector the loss starts AT the label prior — sigmoid cross-entropy of 2 positives
+in 20 classes, 0.26-0.29 — and stays there for the first few hundred steps at the shipped learning
+rate: the loss windows say that the three modes see the same losses, the parameter trajectory says
+that they take the same steps.)
 
   python tools/loss_curve.py OUT.json [--steps 400] [--hw 500] [--proposals 2000] [--dm 1.0] [--lr 0.5]
 """
@@ -92,10 +98,20 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
     else:
       model.load_state_dict(init)
     log = []
+    blo, bhi = trainer.bucket
+    w0 = model.store.values[blo:bhi].double().clone()
     for i in range(steps):
       losses = trainer.train_step(batches[i % pool], dropout_seed=1000 + i)
       log.append(losses)          # (device scalars: no host sync inside the loop)
     torch.cuda.synchronize()
+    disp = model.store.values[blo:bhi].double() - w0
+    if name == modes[0][0]:
+      ref_disp = disp
+    traj = {"distance_moved": float(disp.norm()),
+            "distance_from_fp32_run": float((disp - ref_disp).norm()),
+            "relative_deviation": float((disp - ref_disp).norm() / ref_disp.norm()),
+            "cosine_with_fp32_displacement": float((disp * ref_disp).sum() / (disp.norm() * ref_disp.norm())),
+            "initial_norm": float(w0.norm())}
     keys = sorted(log[0].keys())
     series = {k: np.array([float(l[k]) for l in log]) for k in keys}
     nwin = steps // window
@@ -106,6 +122,7 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
                     for k, v in series.items()},
         "first_step": {k: float(v[0]) for k, v in series.items()},
         "all_finite": bool(all(np.isfinite(v).all() for v in series.values())),
+        "trajectory": traj,
     }
     del trainer, model
     torch.cuda.empty_cache()
@@ -143,7 +160,8 @@ def main():
   print(json.dumps({"fp32_total_loss_fell_by": doc["fp32_total_loss_fell_by"],
                     "deviation_from_fp32": {k: v["max_relative_window_deviation"]["total_loss"]
                                             for k, v in doc["deviation_from_fp32"].items()},
-                    "last_window_total": {k: v["windows"]["total_loss"][-1] for k, v in doc["curves"].items()}}))
+                    "last_window_total": {k: v["windows"]["total_loss"][-1] for k, v in doc["curves"].items()},
+                    "trajectory": {k: v["trajectory"] for k, v in doc["curves"].items()}}))
 
 
 if __name__ == "__main__":
