@@ -238,13 +238,14 @@ class KernelTimer(object):
     return out
 
 
-def cpu_baseline(pipeline, classes, num_proposals, budget_s=40.0):
+def cpu_baseline(pipeline, classes, num_proposals, budget_s=45.0, max_timed=5):
   """MEASURES full training steps of the CPU restatement of the reference semantics (the TF
   reference cannot run here): oracle/torch_step.train_step — `extract_frcnn_feature` and its
   gradient on torch-CPU (oneDNN convolutions + autograd, fp32, all host threads: what
   TensorFlow-CPU's Eigen/MKL-DNN kernels and tf.gradients do for the reference), heads / MIDN /
-  OICR / Adagrad in the numpy oracle — SURVEY.md §8d, BASELINE.md §4.  1 warm-up + up to 3 timed
-  steps at the benchmark's own size (one 500x500 image, `num_proposals` proposals); stops early
+  OICR / Adagrad in the numpy oracle — SURVEY.md §8d, BASELINE.md §4.  1 warm-up + up to
+  `max_timed` timed steps (5 at N = 2000, 10 at configs[0]'s N = 300: SURVEY §8d's 10 timed steps
+  where the bounded sample allows) at the benchmark's own size (one 500x500 image, `num_proposals` proposals); stops early
   once `budget_s` of timed work is spent (at least one timed step always runs).  Median."""
   import numpy as np
   import torch
@@ -266,7 +267,7 @@ def cpu_baseline(pipeline, classes, num_proposals, budget_s=40.0):
                    oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
   mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   times, warm = [], None
-  for i in range(4):
+  for i in range(1 + max_timed):
     t0 = time.perf_counter()
     with np.errstate(over="ignore"):
       torch_step.train_step(P, acc, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
@@ -684,7 +685,7 @@ def main(argv=None):
     if not args.no_cpu_baseline and world == 1 and not secondary:
       result["cpu_baseline"] = cpu_baseline(pipeline, classes, NUM_PROPOSALS)
       # configs[0] (N = 300, the reference's own CPU-runnable case): the same CPU step, SURVEY §8d
-      result["cpu_baseline_c0"] = cpu_baseline(pipeline, classes, 300, budget_s=15.0)
+      result["cpu_baseline_c0"] = cpu_baseline(pipeline, classes, 300, budget_s=20.0, max_timed=10)
     if world > 1:
       result["backend"] = ("gloo, all ranks on cuda:0 (C2D_BENCH_SAME_DEVICE: code-path validation, "
                            "the value is not a scaling point)" if same_device else "nccl (RCCL)")

@@ -913,3 +913,45 @@ def test_graph_step_equals_eager_step_rmsprop_slots():
   well = np.abs(ge) > 1e-3 * np.abs(ge).max()
   assert well.sum() > 1000
   assert np.abs(ve - vg)[well].max() <= 2e-2 * 0.001 * 3.2, np.abs(ve - vg)[well].max()
+
+
+@pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
+def test_branch_streams_are_neutral(compute_dtype):
+  """Round 4: the short branches of a second-stage Inception block run on a branch stream beside
+  the long one (Net._fwd_step / _bwd_step, C2D_BRANCH_STREAMS) with their own dC scratch set.  The
+  schedule must not change a number: the forward pass is bitwise equal to the one-stream order,
+  gradients and the update equal it to the order of the filter gradients' fp32 atomics (64 ROIs:
+  the per-ROI plan with fused block-entry GEMMs; three steps so that a missing cross-stream wait
+  has a chance to show)."""
+  from cap2det_amd.train.trainer import Trainer
+  pipeline = util_model.load_pipeline()
+  rng = np.random.default_rng(29)
+  out, ex = [], None
+  for branch in (True, False):
+    trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, compute_dtype=compute_dtype)
+    model = trainer.model
+    if branch:
+      assert model.engine.second.alt is not None, "branch streams are the default"
+    else:
+      model.engine.second.alt = None
+    classes = model.label_extractor.classes
+    P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
+    model.load_state_dict(P32)
+    if ex is None:
+      ex = _to_dev(util_model.make_examples(rng, 2, 40, 56, 32, [32, 20], classes))
+    steps = []
+    for s in range(3):
+      model.load_state_dict(P32)
+      losses = trainer.train_step(ex, dropout_seed=50 + s)
+      torch.cuda.synchronize()
+      lo, hi = trainer.bucket
+      steps.append(({k: float(v) for k, v in losses.items()},
+                    trainer.predictions["oicr_proposal_scores_at_3"].detach().clone(),
+                    model.store.grads[lo:hi].double().cpu().numpy().copy()))
+    out.append(steps)
+  for (la, sa, ga), (lb, sb, gb) in zip(*out):
+    assert torch.equal(sa, sb)                               # forward: bitwise
+    for k in la:
+      assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k])), k
+    tol = 5e-5 if compute_dtype == "fp32" else 5e-3
+    assert np.abs(ga - gb).max() <= tol * np.abs(ga).max()

@@ -100,9 +100,14 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
     log = []
     blo, bhi = trainer.bucket
     w0 = model.store.values[blo:bhi].double().clone()
+    keys = None
     for i in range(steps):
       losses = trainer.train_step(batches[i % pool], dropout_seed=1000 + i)
-      log.append(losses)          # (device scalars: no host sync inside the loop)
+      if keys is None:
+        keys = sorted(losses.keys())
+      # (the step returns views of the model's loss buffer, rewritten every step: keep a copy —
+      #  one small device kernel, no host synchronisation inside the loop)
+      log.append(torch.stack([losses[k].reshape(()) for k in keys]))
     torch.cuda.synchronize()
     disp = model.store.values[blo:bhi].double() - w0
     if name == modes[0][0]:
@@ -112,8 +117,8 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
             "relative_deviation": float((disp - ref_disp).norm() / ref_disp.norm()),
             "cosine_with_fp32_displacement": float((disp * ref_disp).sum() / (disp.norm() * ref_disp.norm())),
             "initial_norm": float(w0.norm())}
-    keys = sorted(log[0].keys())
-    series = {k: np.array([float(l[k]) for l in log]) for k in keys}
+    table = torch.stack(log).double().cpu().numpy()
+    series = {k: table[:, j] for j, k in enumerate(keys)}
     nwin = steps // window
     out["curves"][name] = {
         "first_stage": str(model.engine.first.dtype).replace("torch.", ""),
