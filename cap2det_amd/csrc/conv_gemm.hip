@@ -131,8 +131,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     s0 = rem - nt * sk.cost[r];
     mt = per * sk.period + r;
   } else {
-    mt = lb / a.n_tiles;
-    nt = lb - mt * a.n_tiles;
+    block_tile(a.g, a.n_tiles, blockIdx.x, gridDim.x, &mt, &nt);
   }
 
   const int ntaps = a.g.nky * a.g.nkx;
@@ -1713,7 +1712,7 @@ int fill_geom(ConvGeom* g, int ih, int iw, int kh, int kw, int stride, int mode)
   g->rw = mode == 0 ? g->ow : iw;
   g->sub = 1; g->y0 = 0; g->x0 = 0;
   g->ky0 = 0; g->kx0 = 0; g->kstep = 1; g->nky = kh; g->nkx = kw;
-  g->nimg = 0; g->pm = 0;
+  g->nimg = 0; g->pm = 0; g->lpt_ngx = 0;
   set_magic(g);
   return C2D_OK;
 }
@@ -1955,6 +1954,28 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     // make_sk_plan, walks the pixels of a block's four tiles)
     a.g.pm = (ws.ptr || pm_force == 32 || (pm_force != 128 && n128 * 10 > a.g.nimg * 11)) ? 5 : 7;
     a.M = c2d_ceil_div(a.g.nimg, 1 << a.g.pm) * (1 << a.g.pm) * hw;
+    // heavy pixels first (ConvGeom::lpt_ngx): every non-tuning pixel-major tile has 128 rows = one
+    // pixel of one image group; the image groups must split evenly over the 8 XCDs
+    static const bool lpt_off = tune && getenv("C2D_PM_LPT") && getenv("C2D_PM_LPT")[0] == '0';
+    const int ngrp = c2d_ceil_div(a.g.nimg, 128);
+    a.g.lpt_ngx = 0;
+    if (a.g.pm == 7 && ngrp % 8 == 0 && !lpt_off && force != 4 && force != 5 && !ws.ptr) {
+      int cnt[64];
+      for (int px = 0; px < hw; ++px) {
+        const int y = px / a.g.rw, x = px % a.g.rw;
+        cnt[px] = 0;
+        for (int ty = 0; ty < a.g.nky; ++ty)
+          for (int tx = 0; tx < a.g.nkx; ++tx) {
+            const int ky = a.g.ky0 + a.g.kstep * ty, kx = a.g.kx0 + a.g.kstep * tx;
+            cnt[px] += (a.g.mode == 0 ? tap_ok<0>(a.g, y, x, ky, kx) : tap_ok<1>(a.g, y, x, ky, kx)) ? 1 : 0;
+          }
+      }
+      int n = 0;
+      for (int c = a.g.nky * a.g.nkx; c >= 0; --c)          // stable, by falling tap count
+        for (int px = 0; px < hw; ++px)
+          if (cnt[px] == c) a.g.px_order[n++] = (unsigned char)px;
+      a.g.lpt_ngx = ngrp / 8;
+    }
     // 128x64 tiles (4 waves per SIMD) measured best or within 3 % of best on every 3x3 layer of
     // the second stage (tools/sweep_igemm.py); 128x128 only when forced by the tuning hook.
     if (force == 4 && a.es == 2) {      // 256x128 block, 128x64 per wave (bf16 only)

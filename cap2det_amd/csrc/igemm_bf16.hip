@@ -101,8 +101,8 @@ void igemm_ring_kernel(IgemmArgs a) {
   // does this wave hold a piece of the (partial) last pass of the weight rows?
   const bool b_last = !B_TAIL || wave * (1024 / RB) + (B_LOADS - 1) * ROWS_PER_PASS < BN;
 
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = lb / a.n_tiles, nt = lb - mt * a.n_tiles;
+  int mt, nt;
+  block_tile(a.g, a.n_tiles, blockIdx.x, gridDim.x, &mt, &nt);
   const int m0 = mt * BM, n0 = nt * BN;
   const int ntaps = a.g.nky * a.g.nkx;
   const int kslabs = (a.K + BKT - 1) / BKT;

@@ -27,6 +27,13 @@ struct ConvGeom {
                    // input pixel, each of which sees only the taps of matching parity
   int ky0, kx0, kstep, nky, nkx;  // tap subset: ky = ky0 + kstep*t, t < nky (same for kx)
   int nimg;        // images (ROIs) in the batch
+  // Pixel-major launches whose blocks are one pixel each (pm = 7, 128-row blocks): the blocks of
+  // an interior pixel visit nine taps, those of a corner four.  lpt_ngx > 0: block ids are dealt
+  // HEAVY PIXELS FIRST inside every XCD (longest-processing-time-first: the dispatcher hands blocks
+  // to free slots in id order, so the long blocks start first and the short ones fill the tail);
+  // lpt_ngx = image groups per XCD, px_order = the pixels by falling tap count (pm_tile_order).
+  int lpt_ngx;
+  unsigned char px_order[64];
   int pm;          // PIXEL-MAJOR row order (small maps, see decompose<true>): 0 = off, else log2 of
                    // the image-group size (5: groups of 32 images, 7: groups of 128)
 };
@@ -216,6 +223,25 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
   const int q = total >> 3, r = total & 7;
   const int xcd = id & 7, local = id >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// Block id -> (m-tile, n-tile).  Default: xcd_remap (tile order, n-tiles of an m-tile adjacent).
+// Heavy-first pixel-major launches (ConvGeom::lpt_ngx): XCD x owns the image groups
+// [x * ngx, (x + 1) * ngx); inside it the blocks run pixel-class-major (all groups' blocks of the
+// heaviest pixel first), the n-tiles of an m-tile still adjacent.
+__device__ __forceinline__ void block_tile(const ConvGeom& g, int n_tiles, int id, int total, int* mt,
+                                           int* nt) {
+  if (g.lpt_ngx > 0) {
+    const int xcd = id & 7, local = id >> 3;
+    const int t = local / n_tiles;
+    *nt = local - t * n_tiles;
+    const int j = t / g.lpt_ngx, gl = t - j * g.lpt_ngx;
+    *mt = (xcd * g.lpt_ngx + gl) * (g.rh * g.rw) + (int)g.px_order[j];
+    return;
+  }
+  const int lb = xcd_remap(id, total);
+  *mt = lb / n_tiles;
+  *nt = lb - *mt * n_tiles;
 }
 
 // Stream-K plan (host-computed, passed by value).  The iteration space of a launch is the

@@ -954,8 +954,24 @@ class Net(object):
         for j in range(len(bsteps) - 1, 0, -1):
           self._bwd_step(plan, bsteps[j], bsteps[j]["x"], bsteps[j - 1]["gy"], False)
 
+      fused = [b for b in firsts if gx is not None and b["kind"] == "conv" and
+               b["layer"].k == 1 and b["layer"].stride == 1 and "dc_entry" in b]
+      if len(fused) < 2:
+        fused = []
+      early = None       # a pooling FIRST op whose gradient goes out on the branch stream (below)
       if self.alt is not None and plan["scr_b"] is not None and st["n"] >= 64:
         mains, others = self._split_branches(st, None)
+        # The block-input gradient is the sum over the branches' first ops.  A pooling branch's share
+        # (Mixed_5a: 226 MB of max-pool gradient, Mixed_5c: 131 MB) only needs the block's output
+        # gradient: it is written on the branch stream, under the convolution tails of the other
+        # branches, as the FIRST writer of the block-input gradient; the entry GEMM accumulates.
+        pools = [bi for bi, b in enumerate(firsts) if b["kind"] == "pool" and not b.get("relu")]
+        rest_firsts = [b for b in firsts if not any(b is f for f in fused)]
+        if (gx is not None and len(pools) == 1 and len(rest_firsts) == 1 and fused and
+            all(bi != pools[0] for bi, _ in mains)):
+          early = pools[0]
+          if all(bi != early for bi, _ in others):
+            others = others + [(early, [])]     # (a branch that is ONLY the pool: no tail)
         if others:
           fork = torch.cuda.Event()
           fork.record()
@@ -965,6 +981,8 @@ class Net(object):
             try:
               for bi, _ in others:
                 tail(bi)
+                if bi == early:
+                  self._bwd_step(plan, firsts[bi], x, gx, False)
             finally:
               plan["on_alt"] = False
             joined = torch.cuda.Event()
@@ -976,16 +994,14 @@ class Net(object):
       else:
         for bi in range(len(st["branches"])):
           tail(bi)
-      fused = [b for b in firsts if gx is not None and b["kind"] == "conv" and
-               b["layer"].k == 1 and b["layer"].stride == 1 and "dc_entry" in b]
-      written = False
+      written = early is not None
       owner = st.get("fuse_out")
       if owner is not None and gx is not None and len(fused) >= 2:
         # block boundary fusion (see _prepare_backward): the other first ops (the pooling branch)
         # write the block-input gradient first, the multi-segment GEMM accumulates onto it and —
         # last writer — applies the BN/ReLU backward of the producers of the block input
-        for b in firsts:
-          if not any(b is f for f in fused):
+        for bi, b in enumerate(firsts):
+          if not any(b is f for f in fused) and bi != early:
             self._bwd_step(plan, b, x, gx, written)
             written = True
         deferred = []
@@ -1013,12 +1029,10 @@ class Net(object):
         ops.conv1x1_dgrad_multi(
             [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],
             [b["layer"].w_for(self.dtype) for b in fused],
-            [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off, rows, st["cin"], False)
+            [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off, rows, st["cin"], written)
         written = True
-      else:
-        fused = []
-      for b in firsts:
-        if any(b is f for f in fused):
+      for bi, b in enumerate(firsts):
+        if any(b is f for f in fused) or bi == early:
           continue
         self._bwd_step(plan, b, x, gx, written)
         if gx is not None:
