@@ -509,6 +509,8 @@ def main(argv=None):
       trainer.use_graph = False
       side, second.side = second.side, None
       alt, second.alt = second.alt, None
+      first_net = trainer.model.engine.first
+      alt1, first_net.alt = first_net.alt, None
       trainer.model.engine.invalidate_prefetch()          # this step computes its own first stage
     nxt = batch if (not instrument and i + 1 < args.steps and
                     not (i + 2 == args.steps and not args.no_kernel_timing)) else None
@@ -518,7 +520,9 @@ def main(argv=None):
       trainer.use_graph = args.graph
       second.side = side
       second.alt = alt
+      first_net.alt = alt1
     marks[i + 1].record()
+  host_enqueue = time.perf_counter() - t0       # the host is done queueing; the GPU may still run
   sync()
   elapsed = time.perf_counter() - t0
   # (the last step carries the per-kernel event pairs and is left out of the spread)
@@ -551,6 +555,9 @@ def main(argv=None):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
+        # time the host needed to QUEUE the timed steps (no synchronisation inside): well below
+        # ms_per_step = the GPU is the bottleneck, equal to it = the step is launch-bound
+        "host_enqueue_ms_per_step": 1000.0 * host_enqueue / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

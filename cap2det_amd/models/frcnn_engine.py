@@ -307,7 +307,9 @@ class Net(object):
     self._plans = {}
 
   side = None   # torch.cuda.Stream for the filter gradients, set by FrcnnEngine (eager mode only)
-  alt = None    # torch.cuda.Stream for the short branches of an Inception block (C2D_BRANCH_STREAMS=1)
+  alt = None    # torch.cuda.Stream for the short branches of an Inception block (C2D_BRANCH_STREAMS)
+  alt_min_n = 64    # ... of blocks over at least this many maps (the single-image first stage: 1 —
+                    # its backward pass is a chain of 10-30 us launches, three branches side by side)
 
   def _split_branches(self, st, skip_first):
     """(branch on the current stream, [branches for the branch stream]): the branch with the most
@@ -949,17 +951,26 @@ class Net(object):
       # the sum once, the remaining first ops (pools) accumulate into it afterwards.
       firsts = [bsteps[0] for bsteps in st["branches"]]
 
-      def tail(rest_owner):
-        bsteps = st["branches"][rest_owner]
-        for j in range(len(bsteps) - 1, 0, -1):
-          self._bwd_step(plan, bsteps[j], bsteps[j]["x"], bsteps[j - 1]["gy"], False)
-
       fused = [b for b in firsts if gx is not None and b["kind"] == "conv" and
                b["layer"].k == 1 and b["layer"].stride == 1 and "dc_entry" in b]
       if len(fused) < 2:
         fused = []
+      entry_wg = {}          # branch index -> deferred filter gradient of its fused entry convolution
+
+      def tail(rest_owner):
+        """Everything of a branch behind its first op, then — a fused entry convolution — the
+        BN/ReLU backward of the first op itself (its dC feeds the block's entry GEMM and the
+        grouped entry filter gradient): on whichever stream runs the branch."""
+        bsteps = st["branches"][rest_owner]
+        for j in range(len(bsteps) - 1, 0, -1):
+          self._bwd_step(plan, bsteps[j], bsteps[j]["x"], bsteps[j - 1]["gy"], False)
+        b0 = bsteps[0]
+        if any(b0 is f for f in fused):
+          got = []
+          self._conv_bwd(plan, b0, x, None, False, dc=b0["dc_entry"], defer=got)
+          entry_wg[rest_owner] = got
       early = None       # a pooling FIRST op whose gradient goes out on the branch stream (below)
-      if self.alt is not None and plan["scr_b"] is not None and st["n"] >= 64:
+      if self.alt is not None and plan["scr_b"] is not None and st["n"] >= self.alt_min_n:
         mains, others = self._split_branches(st, None)
         # The block-input gradient is the sum over the branches' first ops.  A pooling branch's share
         # (Mixed_5a: 226 MB of max-pool gradient, Mixed_5c: 131 MB) only needs the block's output
@@ -972,6 +983,14 @@ class Net(object):
           early = pools[0]
           if all(bi != early for bi, _ in others):
             others = others + [(early, [])]     # (a branch that is ONLY the pool: no tail)
+        # (branches that are ONLY a fused entry convolution: their BN/ReLU backward, see tail())
+        seen = set(bi for bi, _ in mains + others)
+        lone = [(bi, []) for bi, b in enumerate(firsts)
+                if bi not in seen and any(b is f for f in fused)]
+        if others or (mains and lone):
+          others = others + lone
+        else:
+          mains = mains + lone
         if others:
           fork = torch.cuda.Event()
           fork.record()
@@ -1004,9 +1023,7 @@ class Net(object):
           if not any(b is f for f in fused) and bi != early:
             self._bwd_step(plan, b, x, gx, written)
             written = True
-        deferred = []
-        for b in fused:
-          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"], defer=deferred)
+        deferred = [d for bi in sorted(entry_wg) for d in entry_wg[bi]]
         self._entry_wgrads(plan, x, deferred)
         rows = st["n"] * st["ih"] * st["iw"]
         ws0 = owner["ws_off"]
@@ -1020,9 +1037,7 @@ class Net(object):
             plan["bn_ws"][ws0:ws0 + owner["nb"] * 2 * owner["ctot"]], rows, st["cin"], written)
         return
       if len(fused) >= 2:
-        deferred = []
-        for b in fused:
-          self._conv_bwd(plan, b, x, None, False, dc=b["dc_entry"], defer=deferred)
+        deferred = [d for bi in sorted(entry_wg) for d in entry_wg[bi]]
         self._entry_wgrads(plan, x, deferred)
         rows = st["n"] * st["ih"] * st["iw"]
         segs = [self._entry_dc(b) for b in fused]
@@ -1109,6 +1124,9 @@ class FrcnnEngine(object):
       # (Net._fwd_step / _bwd_step): measured fp32 11.40 -> 11.27 ms, bf16 3.37 -> 3.26 ms per step
       if os.environ.get("C2D_BRANCH_STREAMS", "1") != "0":
         self.second.alt = torch.cuda.Stream(device=store.device)
+        if os.environ.get("C2D_BRANCH_STREAMS_FIRST", "1") != "0":
+          self.first.alt = self.second.alt
+          self.first.alt_min_n = 1
     self._shape_cache = {}
     self.first_trainable_idx = None
     self.last_crop_bwd = None      # which ROI-crop backward the last backward() ran (bench / tests)

@@ -438,12 +438,13 @@ class Trainer(object):
       # (every optimiser slot: rmsprop keeps momentum / mean-gradient slots beside slot 0)
       state = (store.values.clone(), [sl.clone() for sl in store.slots])
       eng.invalidate_prefetch()
-      pre_keep, alt_keep = eng.prefetch_stream, eng.second.alt
+      pre_keep, alt_keep, alt1_keep = eng.prefetch_stream, eng.second.alt, eng.first.alt
       eng.prefetch_stream = None          # (the eager look-ahead machinery stays out of the graph)
       # (the branch stream too: ending a capture that forked five streams crashes inside
       #  hipStreamEndCapture on ROCm 7.2 — and replay gains nothing from the branches, profiles/
       #  r04_graph_concurrency.json)
       eng.second.alt = None
+      eng.first.alt = None
       self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
       self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
       torch.cuda.synchronize()
@@ -485,6 +486,7 @@ class Trainer(object):
       torch.cuda.current_stream().wait_stream(cap)
       eng.prefetch_stream = pre_keep
       eng.second.alt = alt_keep
+      eng.first.alt = alt1_keep
       losses['total_loss'] = total
       self._graphs = dict(key=key, fb=g_fb, opt=g_opt, predictions=predictions, losses=losses,
                           lookahead=lookahead, bufs=bufs, p_next=p_next, primed=None)

@@ -934,6 +934,7 @@ def test_branch_streams_are_neutral(compute_dtype):
       assert model.engine.second.alt is not None, "branch streams are the default"
     else:
       model.engine.second.alt = None
+      model.engine.first.alt = None
     classes = model.label_extractor.classes
     P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
     model.load_state_dict(P32)

@@ -70,6 +70,16 @@ def main():
         for fq in fams_of_row:
           agg[fq][row["Counter_Name"]] += float(row["Counter_Value"])
           launches[fq].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+  # kernel durations INSIDE this PMC pass (its own --kernel-trace), when the trace is still there:
+  # the implied clock GRBM_GUI_ACTIVE / 8 / duration says whether the pass ran the kernels at the
+  # speed of the unprofiled run (MI355X_MICROARCH.md: profiled passes clock 3-6 % lower)
+  kdur = collections.defaultdict(float)
+  for path in glob.glob(os.path.join(pmc_dir, "**", "*kernel_trace.csv"), recursive=True):
+    with open(path) as f:
+      for row in csv.DictReader(f):
+        km = re.search(r"(\w+_kernel(?:<[^>]*>)?)", row["Kernel_Name"])
+        if km:
+          kdur[km.group(1)] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
   fams = {}
   for fam, c in sorted(agg.items()):
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
@@ -86,7 +96,8 @@ def main():
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
     per_kernel[k] = {"launches": len(klaunches[k]),
                      "mfma_busy": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 1024)) if gui else None,
-                     "gui_share_of_family_time": None}
+                     "avg_us_in_this_pass": (kdur[k] / 1e3 / len(klaunches[k])) if k in kdur else None,
+                     "implied_clock_GHz": (gui / 8.0 / kdur[k]) if k in kdur and kdur[k] else None}
   with open(out_path, "w") as f:
     json.dump({"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4)",
                "calibration": "profiles/r04_counter_calibration.json: reads 0.992-0.995 at a true 1.0, "
