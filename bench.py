@@ -542,8 +542,9 @@ def main(argv=None):
 
   if rank == 0:
     images = world * args.steps * images_per_gpu
-    crop_kernel = ("roi_crop_pool2_fwd_stream_kernel (crop_and_resize 14x14 fused with 2x2 max-pool, "
-                   "source columns streamed through registers)")
+    crop_kernel = ("roi_crop_pool2_fwd_rowwalk_kernel (crop_and_resize 14x14 fused with 2x2 max-pool: a "
+                   "lane owns a pooled column of a channel quad and walks the crop rows, one horizontal "
+                   "lerp per distinct source row)")
     result = {
         "metric": ("images/sec (500x500, 2000 proposals), full WSOD training step" if not secondary else
                    "SECONDARY operating point (not the BASELINE metric): images/sec (%dx%d, %d "
@@ -687,8 +688,8 @@ def main(argv=None):
             "avg_launch_ms": rc["ms"] / rc["launches"],
             "algorithmic_bytes_per_launch": rc["work"] / rc["launches"],
             # (the metric prices it against HBM; the counters say what actually limits it)
-            "limiter": "vector ALU (busy 87 % of the launch before round 3's instruction diet, "
-                       "profiles/r03_crop_counters.json, DESIGN.md section 3): not HBM-bound"}
+            "limiter": "vector ALU and the L1 / address path (64 B/clk/CU: 1.4 GB of tap fetches per "
+                       "launch), not HBM: profiles/r03_crop_counters*.json, DESIGN.md section 3"}
     if not args.no_cpu_baseline and world == 1 and not secondary:
       result["cpu_baseline"] = cpu_baseline(pipeline, classes, NUM_PROPOSALS)
       # configs[0] (N = 300, the reference's own CPU-runnable case): the same CPU step, SURVEY §8d

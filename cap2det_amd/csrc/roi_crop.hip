@@ -253,6 +253,108 @@ __device__ __forceinline__ void crop_pool2_stream_body(
   }
 }
 
+// Row-walking form of the same fused crop + 2x2/stride-2 max-pool (round 4).  TensorFlow
+// interpolates horizontally first: top = tl + (tr - tl) * lx on source row y.lo, bottom likewise on
+// y.hi, then out = top + (bottom - top) * ly.  The horizontally interpolated source row is the same
+// number for every crop row that samples it, and consecutive crop rows of a box share source rows
+// (boxes narrower than 14 feature pixels sample every row 2-8 times).  Here a lane owns ONE pooled
+// column (two crop columns) of a channel quad and walks the 14 crop rows top to bottom keeping the
+// two horizontally interpolated source rows of both columns in registers: one vertical lerp per
+// crop pixel plus one horizontal lerp per DISTINCT source row — 1.8 lerps per crop pixel on the
+// benchmark's boxes against 3 in the column-streaming form, the same operands in the same
+// operation order (bit-identical output).  Which source rows are new depends on the box only, so
+// the row bookkeeping is scalar.  (Round 3 tried four columns per lane: 132-146 VGPRs, three
+// waves per SIMD, slower; two columns need ~80.)
+template <typename TO>
+__device__ __forceinline__ void crop_pool2_rowwalk_body(
+    const float4* __restrict__ img, const SampleAxis* ys, const SampleAxis* xs,
+    TO* __restrict__ out, uchar4* __restrict__ argmax, size_t obase, int hf, int wf, int d4n,
+    int pout, int part, int splits) {
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int total = pout * d4n;
+  const unsigned long long ub = (unsigned long long)img;
+  const unsigned ub_lo = __builtin_amdgcn_readfirstlane((unsigned)ub);
+  const unsigned ub_hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(((unsigned long long)ub_hi << 32) | ub_lo), (short)0,
+      __builtin_amdgcn_readfirstlane(hf * wf * d4n * 16), 0x00020000);
+  auto ld = [&](unsigned voff, int soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
+  };
+  const int row_bytes = wf * d4n * 16;
+  for (int idx = part * blockDim.x + threadIdx.x; idx < total; idx += splits * blockDim.x) {
+    const int d4 = idx % d4n;
+    const int px = idx / d4n;
+    const SampleAxis x0 = xs[2 * px], x1 = xs[2 * px + 1];
+    const bool ok0 = x0.lo >= 0, ok1 = x1.lo >= 0;
+    // byte offsets of the four column taps inside a source row (a column out of range is zeroed
+    // below: its loads only need a valid address)
+    const unsigned cl0 = (unsigned)(max(x0.lo, 0) * d4n + d4) * 16u;
+    const unsigned ch0 = (unsigned)(max(x0.hi, 0) * d4n + d4) * 16u;
+    const unsigned cl1 = (unsigned)(max(x1.lo, 0) * d4n + d4) * 16u;
+    const unsigned ch1 = (unsigned)(max(x1.hi, 0) * d4n + d4) * 16u;
+    // (The four column taps of the lane's two crop columns overlap on narrow boxes — 2 or 3 distinct
+    //  ones; skipping the duplicate loads behind wave-uniform tests measured SLOWER, 93-97 us against
+    //  79-82: two more registers cost the sixth wave per SIMD, forced back it spills.)
+    float4 hl0 = zero, hl1 = zero, hh0 = zero, hh1 = zero;   // interpolated rows rowl / rowh
+    int rowl = -1, rowh = -1;                                // (scalar: uniform over the workgroup)
+    TO* op = out + (obase + (size_t)px * d4n + d4) * 4;
+    uchar4* ap = argmax ? argmax + obase + (size_t)px * d4n + d4 : nullptr;
+    for (int py = 0; py < pout; ++py) {
+      float4 v[2][2];
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const SampleAxis sy = ys[2 * py + dy];
+        const int lo = __builtin_amdgcn_readfirstlane(sy.lo);
+        const int hi = __builtin_amdgcn_readfirstlane(sy.hi);
+        if (lo < 0) { v[dy][0] = zero; v[dy][1] = zero; continue; }
+        const bool move_lo = lo != rowl && lo == rowh;          // the walk advanced by one row
+        const bool load_lo = lo != rowl && lo != rowh;
+        const bool load_hi = hi != lo && hi != rowh;
+        // (every load of the step first, then the lerps)
+        float4 a0, b0, a1, b1, c0, d0, c1, d1;
+        if (load_lo) {
+          const int so = lo * row_bytes;
+          a0 = ld(cl0, so); b0 = ld(ch0, so); a1 = ld(cl1, so); b1 = ld(ch1, so);
+        }
+        if (load_hi) {
+          const int so = hi * row_bytes;
+          c0 = ld(cl0, so); d0 = ld(ch0, so); c1 = ld(cl1, so); d1 = ld(ch1, so);
+        }
+        if (move_lo) { hl0 = mov4(hh0); hl1 = mov4(hh1); }
+        if (load_lo) { hl0 = lerp4(a0, b0, x0.lerp); hl1 = lerp4(a1, b1, x1.lerp); }
+        rowl = lo;
+        if (load_hi) { hh0 = lerp4(c0, d0, x0.lerp); hh1 = lerp4(c1, d1, x1.lerp); }
+        else if (hi == lo && rowh != hi) { hh0 = mov4(hl0); hh1 = mov4(hl1); }   // integer coordinate
+        rowh = hi;
+        v[dy][0] = lerp4(hl0, hh0, sy.lerp);
+        v[dy][1] = lerp4(hl1, hh1, sy.lerp);
+        if (!ok0) v[dy][0] = zero;
+        if (!ok1) v[dy][1] = zero;
+      }
+      // k = 0, 1, 2, 3 in order; strict '>' keeps the FIRST maximum (TF MaxPoolGrad tie rule)
+      const float4 c0_ = v[0][0], v0 = v[0][1], c2 = v[1][0], v1 = v[1][1];
+      float4 best = c0_;
+      uchar4 arg = make_uchar4(0, 0, 0, 0);
+      if (v0.x > best.x) { best.x = v0.x; arg.x = 1; }
+      if (v0.y > best.y) { best.y = v0.y; arg.y = 1; }
+      if (v0.z > best.z) { best.z = v0.z; arg.z = 1; }
+      if (v0.w > best.w) { best.w = v0.w; arg.w = 1; }
+      if (c2.x > best.x) { best.x = c2.x; arg.x = 2; }
+      if (c2.y > best.y) { best.y = c2.y; arg.y = 2; }
+      if (c2.z > best.z) { best.z = c2.z; arg.z = 2; }
+      if (c2.w > best.w) { best.w = c2.w; arg.w = 2; }
+      if (v1.x > best.x) { best.x = v1.x; arg.x = 3; }
+      if (v1.y > best.y) { best.y = v1.y; arg.y = 3; }
+      if (v1.z > best.z) { best.z = v1.z; arg.z = 3; }
+      if (v1.w > best.w) { best.w = v1.w; arg.w = 3; }
+      c2d_st4(op, best);
+      op += (size_t)pout * d4n * 4;
+      if (ap) { *ap = arg; ap += (size_t)pout * d4n; }
+    }
+  }
+}
+
 __device__ __forceinline__ void scatter1(float* __restrict__ dimg, int wf, int depth, int d,
                                          const SampleAxis& sy, const SampleAxis& sx, float g) {
   if (sy.lo < 0 || sx.lo < 0 || g == 0.0f) return;
@@ -608,6 +710,21 @@ __global__ __launch_bounds__(256) void roi_crop_pool2_fwd_stream_kernel(
                              (size_t)roi * pout * pout * d4n, hf, wf, d4n, pout, part, splits);
 }
 
+template <typename TO>
+__global__ __launch_bounds__(256) void roi_crop_pool2_fwd_rowwalk_kernel(
+    const float4* __restrict__ feat, const float* __restrict__ boxes,
+    const int32_t* __restrict__ box_ind, TO* __restrict__ out,
+    uchar4* __restrict__ argmax, int batch, int hf, int wf, int d4n, int crop, int pout,
+    int splits) {
+  __shared__ SampleAxis ys[kMaxCrop], xs[kMaxCrop];
+  const int roi = blockIdx.x / splits, part = blockIdx.x - roi * splits;
+  const int b = box_ind[roi];
+  if (b < 0 || b >= batch) return;
+  load_axes(ys, xs, boxes, roi, hf, wf, crop);
+  crop_pool2_rowwalk_body<TO>(feat + (size_t)b * hf * wf * d4n, ys, xs, out, argmax,
+                              (size_t)roi * pout * pout * d4n, hf, wf, d4n, pout, part, splits);
+}
+
 // (A prefetching variant — three-slot register ring over the sorted list of needed columns, the
 // next column's loads in flight while the current one is interpolated — measured 151 us against
 // 108 us: 104 VGPRs cost two of the six waves per SIMD and the slot selects add VALU work.)
@@ -625,8 +742,8 @@ static int crop_stream_splits() {
 static int crop_stream_form(int crop, int pool_k, int pool_s, int pout, int hf, int wf,
                             int depth) {
   static const char* e = getenv("C2D_TUNE") ? getenv("C2D_CROP_STREAM") : nullptr;
-  const int want = e ? atoi(e) : 1;
-  // the stream kernel addresses ONE image's map through a raw buffer descriptor with 32-bit byte
+  const int want = e ? atoi(e) : 2;       // 2: row-walking form (round 4), 1: column-streaming form
+  // the stream kernels address ONE image's map through a raw buffer descriptor with 32-bit byte
   // offsets: maps of 2 GiB and more take the generic kernel (64-bit pointer arithmetic)
   if ((long long)hf * wf * depth * 4 >= (1ll << 31)) return 0;
   return (pool_k == 2 && pool_s == 2 && crop == 2 * pout) ? want : 0;
@@ -657,7 +774,12 @@ extern "C" int c2d_roi_crop_pool_fwd(const float* feat, const float* boxes,
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
   const int form = crop_stream_form(crop, pool_k, pool_s, pout, hf, wf, depth);
-  if (form == 1)
+  if (form == 2)
+    hipLaunchKernelGGL(roi_crop_pool2_fwd_rowwalk_kernel<float>,
+                       dim3(num_boxes * crop_stream_splits()), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout, crop_stream_splits());
+  else if (form == 1)
     hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<float>,
                        dim3(num_boxes * crop_stream_splits()), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)feat, boxes, box_ind, out,
@@ -680,7 +802,12 @@ extern "C" int c2d_roi_crop_pool_fwd_bf16(const float* feat, const float* boxes,
   if (num_boxes == 0) return C2D_OK;
   const int pout = (crop - pool_k) / pool_s + 1;
   const int form = crop_stream_form(crop, pool_k, pool_s, pout, hf, wf, depth);
-  if (form == 1)
+  if (form == 2)
+    hipLaunchKernelGGL(roi_crop_pool2_fwd_rowwalk_kernel<c2d_bf16>,
+                       dim3(num_boxes * crop_stream_splits()), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,
+                       (uchar4*)argmax, batch, hf, wf, depth / 4, crop, pout, crop_stream_splits());
+  else if (form == 1)
     hipLaunchKernelGGL(roi_crop_pool2_fwd_stream_kernel<c2d_bf16>,
                        dim3(num_boxes * crop_stream_splits()), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)feat, boxes, box_ind, (c2d_bf16*)out,

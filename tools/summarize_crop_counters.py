@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-KERNELS = {"roi_crop_pool2_fwd_stream_kernel": "fwd_stream", "roi_bwd_strip_kernel": "bwd_strip",
+KERNELS = {"roi_crop_pool2_fwd_stream_kernel": "fwd_stream", "roi_crop_pool2_fwd_rowwalk_kernel": "fwd_rowwalk", "roi_bwd_strip_kernel": "bwd_strip",
            "roi_bin_rows_kernel": "bwd_bin_rows", "roi_bwd_sum_parts_kernel": "bwd_sum_parts",
            "roi_crop_pool_bwd_lds_kernel": "bwd_atomic_lds"}
 

@@ -32,6 +32,7 @@ FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
     ("wgrad", "wgrad3x3_kernel"),
     ("roi_crop_pool_fwd", "roi_crop_pool_fwd_kernel"),
     ("roi_crop_pool_fwd", "roi_crop_pool2_fwd_stream_kernel"),
+    ("roi_crop_pool_fwd", "roi_crop_pool2_fwd_rowwalk_kernel"),
     ("roi_crop_pool_bwd", "roi_bwd_"),
     ("roi_crop_pool_bwd", "roi_bin_rows_kernel"),
     ("roi_crop_pool_bwd", "roi_axes_kernel"),
