@@ -275,6 +275,35 @@ class Ref(object):
 # network executor
 # ----------------------------------------------------------------------------------------
 
+def _bf16_padded_width(n):
+  """Output columns the bf16 ring GEMM computes for n real ones (the tile rule of run_igemm,
+  csrc/conv_gemm.hip): full-width / 64-column tiles up to 384 columns (193..256: one 256-wide
+  tile), 256-wide tiles beyond unless more than 35 % of the last one would be padding."""
+  c64 = -(-n // 64) * 64
+  if n <= 384:
+    return 256 if 192 < n <= 256 else c64
+  c256 = -(-n // 256) * 256
+  return c256 if (c256 - n) * 20 <= 7 * n else c64
+
+
+def _bf16_entry_groups(couts):
+  """Partition of a block's 1x1 entry convolutions (by index) into one or two GEMM launches with
+  the fewest padded output columns: Mixed_5b's 352 + 192 + 160 + 128 = 832 columns are 1024 as one
+  launch of 256-wide tiles (a fifth of its MFMAs and weight stages on padding) and 512 + 320 as
+  {352, 160} + {192, 128}.  Two launches only when they save a tenth of the columns."""
+  n = len(couts)
+  best, best_cost = [list(range(n))], _bf16_padded_width(sum(couts))
+  limit = 0.9 * best_cost
+  for mask in range(1, 1 << (n - 1)):          # (index n - 1 always in the second group)
+    a = [i for i in range(n) if (mask >> i) & 1]
+    b = [i for i in range(n) if not (mask >> i) & 1]
+    cost = _bf16_padded_width(sum(couts[i] for i in a)) + _bf16_padded_width(sum(couts[i] for i in b))
+    if cost < best_cost and cost <= limit:
+      best, best_cost = [a, b], cost
+  return best
+
+
+
 class Net(object):
   """A stack of conv / pool / Inception-block ops with a static plan per input shape."""
 
@@ -490,9 +519,16 @@ class Net(object):
           if key not in cache:
             keep = [(b["layer"].wt_for(self.dtype), b["layer"].scale, b["layer"].shift, b["y"].t,
                      b["y"].ld, b["y"].off, b["layer"].cout, b.get("relu", True)) for _, b in entry]
-            cache[key] = (ops.conv_outs(keep), keep)
-          ops.conv1x1_fwd_multi(x.t, x.ld, x.off, cache[key][0], st["n"] * st["ih"] * st["iw"],
-                                st["cin"])
+            groups = ([list(range(len(entry)))]
+                      if self.dtype == torch.float32 or os.environ.get("C2D_BF16_ENTRY_SPLIT", "1") == "0"
+                      else _bf16_entry_groups([b["layer"].cout for _, b in entry]))
+            cache[key] = ([(ops.conv_outs([keep[i] for i in g]) if len(g) > 1 else None, g)
+                           for g in groups], keep)
+          for outs, g in cache[key][0]:
+            if outs is not None:
+              ops.conv1x1_fwd_multi(x.t, x.ld, x.off, outs, st["n"] * st["ih"] * st["iw"], st["cin"])
+            else:
+              self._fwd_step(entry[g[0]][1], x)
           fused = tuple(bi for bi, _ in entry)
       if self.alt is not None and st["n"] >= 64:
         # the long branch on this stream, the others on the branch stream beside it: a 3x3
@@ -1041,10 +1077,25 @@ class Net(object):
         self._entry_wgrads(plan, x, deferred)
         rows = st["n"] * st["ih"] * st["iw"]
         segs = [self._entry_dc(b) for b in fused]
-        ops.conv1x1_dgrad_multi(
-            [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],
-            [b["layer"].w_for(self.dtype) for b in fused],
-            [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off, rows, st["cin"], written)
+        cin = st["cin"]
+        cuts = [0, cin]
+        if self.dtype != torch.float32 and os.environ.get("C2D_BF16_ENTRY_SPLIT", "1") != "0":
+          # the same tile fit for the block-input gradient (its columns = the block's input
+          # channels): Mixed_5a's 576 columns are 768 as one launch, 384 + 192 as two column ranges
+          # (the weights of a 1x1 convolution are [cin][cout]: a column range is a row range)
+          whole = _bf16_padded_width(cin)
+          best = None
+          for c in range(64, cin, 64):
+            cost = _bf16_padded_width(c) + _bf16_padded_width(cin - c)
+            if cost <= 0.9 * whole and (best is None or (cost, -min(c, cin - c)) < best[0]):
+              best = ((cost, -min(c, cin - c)), c)       # fewest columns, then the evenest cut
+          if best is not None:
+            cuts = [0, best[1], cin]
+        for c0, c1 in zip(cuts, cuts[1:]):
+          ops.conv1x1_dgrad_multi(
+              [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],
+              [b["layer"].w_for(self.dtype)[:, :, c0:c1, :] for b in fused],
+              [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off + c0, rows, c1 - c0, written)
         written = True
       for bi, b in enumerate(firsts):
         if any(b is f for f in fused) or bi == early:
