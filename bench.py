@@ -571,7 +571,10 @@ def main(argv=None):
                                   "" if args.dtype == spec["dtype"] else " [precision overridden]",
                                   len(classes), type(trainer.model.label_extractor).__name__,
                                   images_per_gpu, image_hw[0], image_hw[1], num_proposals,
-                                  "fp32" if args.dtype == "fp32" else "bf16 storage / fp32 accumulate",
+                                  "fp32" if args.dtype == "fp32" else
+                                  "bf16 storage / fp32 accumulate in both towers behind the fp32 stem (no "
+                                  "reduced-precision reference exists: a changed numerical operating point, "
+                                  "bounded over 400 steps in profiles/r04_loss_curve.json)",
                                   ("+gloo all-reduce (ranks share cuda:0)" if same_device else "+RCCL all-reduce") if grouped else ""),
                    "baseline_config": args.config, "pipeline": spec["pipeline"] + ".pbtxt",
                    "images_per_gpu": images_per_gpu, "image_hw": list(image_hw),

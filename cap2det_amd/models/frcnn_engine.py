@@ -290,7 +290,10 @@ def _bf16_entry_groups(couts):
   """Partition of a block's 1x1 entry convolutions (by index) into one or two GEMM launches with
   the fewest padded output columns: Mixed_5b's 352 + 192 + 160 + 128 = 832 columns are 1024 as one
   launch of 256-wide tiles (a fifth of its MFMAs and weight stages on padding) and 512 + 320 as
-  {352, 160} + {192, 128}.  Two launches only when they save a tenth of the columns."""
+  {352, 160} + {192, 128}.  Two launches only when they save a tenth of the columns.
+  Opt-in (C2D_BF16_ENTRY_SPLIT=1): measured 3.129-3.133 ms per bf16 step against 3.118-3.128 with one
+  launch each (ring kernels 1.33 against 1.30 ms per step) — a second launch's ramp, epilogue and
+  extra pass over the input cost more than the padded columns, whose MFMAs ran in an idle pipe."""
   n = len(couts)
   best, best_cost = [list(range(n))], _bf16_padded_width(sum(couts))
   limit = 0.9 * best_cost
@@ -520,7 +523,7 @@ class Net(object):
             keep = [(b["layer"].wt_for(self.dtype), b["layer"].scale, b["layer"].shift, b["y"].t,
                      b["y"].ld, b["y"].off, b["layer"].cout, b.get("relu", True)) for _, b in entry]
             groups = ([list(range(len(entry)))]
-                      if self.dtype == torch.float32 or os.environ.get("C2D_BF16_ENTRY_SPLIT", "1") == "0"
+                      if self.dtype == torch.float32 or os.environ.get("C2D_BF16_ENTRY_SPLIT", "0") != "1"
                       else _bf16_entry_groups([b["layer"].cout for _, b in entry]))
             cache[key] = ([(ops.conv_outs([keep[i] for i in g]) if len(g) > 1 else None, g)
                            for g in groups], keep)
@@ -1079,7 +1082,7 @@ class Net(object):
         segs = [self._entry_dc(b) for b in fused]
         cin = st["cin"]
         cuts = [0, cin]
-        if self.dtype != torch.float32 and os.environ.get("C2D_BF16_ENTRY_SPLIT", "1") != "0":
+        if self.dtype != torch.float32 and os.environ.get("C2D_BF16_ENTRY_SPLIT", "0") == "1":
           # the same tile fit for the block-input gradient (its columns = the block's input
           # channels): Mixed_5a's 576 columns are 768 as one launch, 384 + 192 as two column ranges
           # (the weights of a 1x1 convolution are [cin][cout]: a column range is a row range)
