@@ -469,3 +469,29 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
     assert any(g[1:5] == tile for g in inst), (tile, sorted(bf16))
   for ring in (("64", "2"), ("32", "3")):
     assert any(g[6:8] == ring for g in inst), (ring, sorted(bf16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("n,hw,s", [(1024, 4, 1), (2000, 4, 1), (1024, 7, 1), (1024, 7, 2)])
+def test_pixel_major_heavy_first_order(ops, n, hw, s, dtype):
+  """Round 4: pixel-major blocks are ONE pixel of a 128-image group (ConvGeom::pm = 7) and, when
+  the image groups split evenly over the 8 XCDs (1024 and 2000 -> 2048 images: 8 / 16 groups),
+  their ids are dealt heavy pixels first (ConvGeom::lpt_ngx, block_tile()).  The oracle tests above
+  pick 256 images where they can (2 groups: tile order); here the heavy-first mapping itself meets
+  the float64 oracle — 4x4 and 7x7 maps, 2000 images (48 padding images in the last group: whole
+  MFMA tiles without rows), forward and input gradient, and the stride-2 input gradient (not
+  pixel-major: the row-major fallback of the same entry point)."""
+  cin, cout = 32, 64
+  lay = _Layer(ops, n, hw, cin, cout, 3, s, 31 + n + hw, dtype)
+  low = dtype == torch.bfloat16
+  x64, w64, dc64 = lay.x.astype(np.float64), lay.w.astype(np.float64), lay.dc.astype(np.float64)
+  got = lay.run(ops, "fwd")
+  inst = ops.last_dispatch()
+  _scale_close(_n(got), ref_ops.conv2d(x64, w64, s), 1.1 * 2.0 ** -8 if low else 2e-5,
+               "fwd n=%d hw=%d %s" % (n, hw, inst))
+  if s == 1:
+    assert any(", true," in i for i in inst), inst            # (the pixel-major instance)
+  got = lay.run(ops, "dgrad")
+  want, _ = ref_ops.conv2d_backward(x64, w64, dc64, s, need_dx=True)
+  _scale_close(_n(got), want, 1.1 * 2.0 ** -8 if low else 2e-5,
+               "dgrad n=%d hw=%d %s" % (n, hw, ops.last_dispatch()))
