@@ -6,6 +6,9 @@ pooling run on torch-CPU in float64 (oracle/torch_step.py, pinned against the ha
 step by tests/test_oracle_vs_torch.py), heads / MIDN / OICR / Adagrad in the numpy oracle.
 
 Run in the build container:  python tests/golden/gen_step_fixture.py
+(`C2D_FIXTURE_FULL=1 python tests/golden/gen_step_fixture.py` makes step_dm1_full.npz: the
+BENCHMARK'S OWN configuration — one 500x500 image, 2000 proposals, depth 1.0 — in float64: ~20 GB
+of host memory and several minutes on 8 cores.)
 The fixtures hold EXPECTED OUTPUTS only (scores, losses, gradient norms and sampled gradient /
 updated-variable entries); tests/test_gpu_step_fixture.py regenerates the seeded inputs and
 checks their checksums against the ones stored here."""
@@ -22,15 +25,20 @@ HW, DM, SAMPLES, HEAD_STD = 160, 1.0, 48, 0.01    # (head std: the reference's t
 SEEDS = {256: 6, 1100: 6}          # model seed per fixture (main() rejects seeds with near-tie arg-maxes)
 
 
-def inputs(n, classes):
+FULL = dict(n=2000, hw=500)      # the benchmark's own configuration (step_dm1_full.npz)
+
+
+def inputs(n, classes, hw=None):
   """The seeded inputs of a fixture (shared with the GPU test)."""
   from tests import util_model
-  rng = np.random.default_rng(1000 + n)
+  hw = HW if hw is None else hw
+  rng = np.random.default_rng(1000 + n + (0 if hw == HW else hw))
   real = n - n // 8
-  ex = util_model.make_examples(rng, 1, HW, HW, n, [real], classes)
+  ex = util_model.make_examples(rng, 1, hw, hw, n, [real], classes)
   # (the OICR arg-max over the proposals is a discrete choice: main() checks that none of them is a
   # near tie, so that fp32 and float64 select the same boxes)
-  P32, d = util_model.oracle_state(SEEDS[n], len(classes), 3, DM, head_std=HEAD_STD)
+  P32, d = util_model.oracle_state(SEEDS.get((n, hw), SEEDS.get(n, 6)), len(classes), 3, DM,
+                                   head_std=HEAD_STD)
   mask = (rng.uniform(size=(n, d)) < 0.5).astype(np.uint8)
   return ex, P32, mask, real
 
@@ -58,8 +66,9 @@ def main():
   mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
                    oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
-  for n in (256, 1100):
-    ex, P32, mask, real = inputs(n, classes)
+  full = os.environ.get("C2D_FIXTURE_FULL") == "1"
+  for n in ((FULL["n"],) if full else (256, 1100)):
+    ex, P32, mask, real = inputs(n, classes, FULL["hw"] if full else None)
     P = {k: v.astype(np.float64) for k, v in P32.items()}
     acc = {k: np.full(v.shape, 0.1) for k, v in P.items()}
     labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
@@ -102,7 +111,8 @@ def main():
         for k in names])
     arrays["updated_samples"] = np.stack([
         np.resize(P[k].reshape(-1)[sample_indices(k, P[k].size)], SAMPLES) for k in names])
-    path = os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n)
+    path = os.path.join(ROOT, "tests", "golden",
+                        "step_dm1_full.npz" if full else "step_dm1_n%d.npz" % n)
     np.savez_compressed(path, **arrays)
     print(path, os.path.getsize(path), "bytes; total_loss", out["total_loss"], "vars", len(names))
 

@@ -55,7 +55,16 @@ def profile_instances(csv_name=None):
 BF16_TOL = dict(score_rel=8e-2, logits=3e-2, loss=2e-2, grad=1e-1, norm=5e-2)
 
 
-@pytest.mark.parametrize("n", [256, 1100])
+def _fixture(n):
+  """(fixture arrays, proposals, image size) of fixture `n` (256, 1100, or "full": the benchmark's own
+  configuration, 2000 proposals on a 500x500 image)."""
+  if n == "full":
+    return (np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_full.npz")), gen.FULL["n"],
+            gen.FULL["hw"])
+  return np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n)), n, None
+
+
+@pytest.mark.parametrize("n", [256, 1100, "full"])
 def test_train_step_bf16_replays_the_float64_fixture(n):
   """The same fixtures through compute_dtype="bf16" (BASELINE configs[2] / [4] storage mode: first
   stage, ROI crop output and second stage in bf16, fp32 accumulation) on the benchmark's launch
@@ -64,13 +73,13 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
   probabilities; the OICR softmax scores 1.0 % / 1.1 %), logits 0.8 % / 0.5 %, losses <= 0.2 % /
   0.3 %, gradient samples 1.7 % / 2.2 % of the tensor's scale, gradient norms 0.6 %."""
   from cap2det_amd.train.trainer import Trainer
-  fix = np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n))
+  fix, n, hw = _fixture(n)
   pipeline = util_model.load_pipeline()
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM, compute_dtype="bf16")
   model = trainer.model
   assert model.engine.first.dtype == torch.bfloat16 and model.engine.second.dtype == torch.bfloat16
   classes = model.label_extractor.classes
-  ex, P32, mask, real = gen.inputs(n, classes)
+  ex, P32, mask, real = gen.inputs(n, classes, hw)
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   model.load_state_dict(P32)
   dev = dict(ex)
@@ -120,16 +129,19 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
   assert worst_g > 1e-5      # (it really ran in reduced precision)
 
 
-@pytest.mark.parametrize("n", [256, 1100])
+@pytest.mark.parametrize("n", [256, 1100, "full"])
 def test_train_step_replays_the_float64_fixture(monkeypatch, n):
+  """("full", round 4: the BENCHMARK'S OWN configuration — one 500x500 image, 2000 proposals, depth 1.0
+  — as one oracle-compared chain: first stage at 250^2 ... 32^2, the ROI crop of 2000 boxes on the
+  real 32x32x576 map, Mixed_5a-c on 98,000 / 32,000 rows, heads, losses, backward, Adagrad.)"""
   from cap2det_amd import hip_ops
   from cap2det_amd.train.trainer import Trainer
-  fix = np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n))
+  fix, n, hw = _fixture(n)
   pipeline = util_model.load_pipeline()
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM)
   model = trainer.model
   classes = model.label_extractor.classes
-  ex, P32, mask, real = gen.inputs(n, classes)
+  ex, P32, mask, real = gen.inputs(n, classes, hw)
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   assert real == int(fix["real"])
   model.load_state_dict(P32)
@@ -147,7 +159,7 @@ def test_train_step_replays_the_float64_fixture(monkeypatch, n):
     dev[k] = torch.from_numpy(ex[k]).to(DEV).contiguous()
   losses = trainer.train_step(dev, dropout_mask=torch.from_numpy(mask).to(DEV))
   torch.cuda.synchronize()
-  _dispatched[n] = seen
+  _dispatched[(n, hw)] = seen
   pred = trainer.predictions
   for i in range(4):
     got = pred["oicr_proposal_scores_at_%d" % i].detach().cpu().numpy().astype(np.float64)
