@@ -8,7 +8,9 @@ step by tests/test_oracle_vs_torch.py), heads / MIDN / OICR / Adagrad in the num
 Run in the build container:  python tests/golden/gen_step_fixture.py
 (`C2D_FIXTURE_FULL=1 python tests/golden/gen_step_fixture.py` makes step_dm1_full.npz: the
 BENCHMARK'S OWN configuration — one 500x500 image, 2000 proposals, depth 1.0 — in float64: ~20 GB
-of host memory and several minutes on 8 cores.)
+of host memory and under a minute on 8 cores; `C2D_FIXTURE_FULL=c2`: step_dm1_full_c2.npz, the same
+size under BASELINE configs[2] — coco17_extend_match, 80 classes, the labels extracted from a
+caption by the oracle's ExtendMatch extractor.)
 The fixtures hold EXPECTED OUTPUTS only (scores, losses, gradient norms and sampled gradient /
 updated-variable entries); tests/test_gpu_step_fixture.py regenerates the seeded inputs and
 checks their checksums against the ones stored here."""
@@ -28,13 +30,20 @@ SEEDS = {256: 6, 1100: 6}          # model seed per fixture (main() rejects seed
 FULL = dict(n=2000, hw=500)      # the benchmark's own configuration (step_dm1_full.npz)
 
 
-def inputs(n, classes, hw=None):
-  """The seeded inputs of a fixture (shared with the GPU test)."""
+def inputs(n, classes, hw=None, captions=False):
+  """The seeded inputs of a fixture (shared with the GPU test).  captions: a synthetic caption over
+  the shipped COCO open vocabulary rides along (`concat_caption_string`: BASELINE configs[2], the
+  labels come from the caption through the ExtendMatch extractor)."""
   from tests import util_model
   hw = HW if hw is None else hw
-  rng = np.random.default_rng(1000 + n + (0 if hw == HW else hw))
+  rng = np.random.default_rng(1000 + n + (0 if hw == HW else hw) + (7 if captions else 0))
   real = n - n // 8
   ex = util_model.make_examples(rng, 1, hw, hw, n, [real], classes)
+  if captions:
+    from cap2det_amd import synthetic
+    vocab = synthetic.read_lines(os.path.join(synthetic.DATA, "coco_open_vocab.txt"))
+    ex["concat_caption_string"] = synthetic.synthetic_captions(rng, 1, vocab, tokens=60,
+                                                               must_contain=["dog", "bicycle"])
   # (the OICR arg-max over the proposals is a discrete choice: main() checks that none of them is a
   # near tie, so that fp32 and float64 select the same boxes)
   P32, d = util_model.oracle_state(SEEDS.get((n, hw), SEEDS.get(n, 6)), len(classes), 3, DM,
@@ -66,12 +75,23 @@ def main():
   mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
                    oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
-  full = os.environ.get("C2D_FIXTURE_FULL") == "1"
+  full = os.environ.get("C2D_FIXTURE_FULL", "") in ("1", "c2")
+  c2 = os.environ.get("C2D_FIXTURE_FULL") == "c2"
+  if c2:
+    # BASELINE configs[2]: coco17_extend_match — 80 classes, labels from the caption (same loss
+    # weights, multipliers, learning rate and regulariser as voc07_groundtruth)
+    pipeline = synthetic.baseline_pipeline("c2")
+    name2id, classes = ref_labels.read_synonym_file(os.path.join(synthetic.DATA, "coco_label_synonyms.txt"))
+    mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   for n in ((FULL["n"],) if full else (256, 1100)):
-    ex, P32, mask, real = inputs(n, classes, FULL["hw"] if full else None)
+    ex, P32, mask, real = inputs(n, classes, FULL["hw"] if full else None, captions=c2)
     P = {k: v.astype(np.float64) for k, v in P32.items()}
     acc = {k: np.full(v.shape, 0.1) for k, v in P.items()}
-    labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
+    if c2:
+      labels = ref_labels.extend_match_extract(ex["concat_caption_string"], name2id, len(classes)).astype(np.float64)
+      assert labels.sum() >= 2
+    else:
+      labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
     ex64 = dict(image=ex["image"].astype(np.float64), number_of_proposals=ex["number_of_proposals"],
                 proposals=ex["proposals"].astype(np.float64))
     with np.errstate(over="ignore"):
@@ -95,10 +115,13 @@ def main():
     assert min(margins) > 1e-3, "pick another seed: an OICR arg-max is a near tie"
     arrays = {"checksum": checksum(ex, P32, mask), "real": np.int64(real),
               "min_argmax_margin": np.float64(min(margins))}
+    # (full-size fixtures keep the score tensors in float32: 1e-7 of their value, three orders
+    #  below the 1e-4 they are compared at, half the file)
+    keep = (lambda a: a.astype(np.float32)) if full else (lambda a: a)
     for i in range(4):
-      arrays["scores_%d" % i] = out["predictions"]["oicr_proposal_scores_at_%d" % i]
+      arrays["scores_%d" % i] = keep(out["predictions"]["oicr_proposal_scores_at_%d" % i])
     arrays["midn_class_logits"] = out["predictions"]["midn_class_logits"]
-    arrays["midn_proba_r_given_c"] = out["predictions"]["midn_proba_r_given_c"]
+    arrays["midn_proba_r_given_c"] = keep(out["predictions"]["midn_proba_r_given_c"])
     for k, v in out["losses"].items():
       arrays["loss/" + k] = np.float64(v)
     arrays["total_loss"] = np.float64(out["total_loss"])
@@ -112,7 +135,8 @@ def main():
     arrays["updated_samples"] = np.stack([
         np.resize(P[k].reshape(-1)[sample_indices(k, P[k].size)], SAMPLES) for k in names])
     path = os.path.join(ROOT, "tests", "golden",
-                        "step_dm1_full.npz" if full else "step_dm1_n%d.npz" % n)
+                        "step_dm1_full_c2.npz" if c2 else "step_dm1_full.npz" if full
+                        else "step_dm1_n%d.npz" % n)
     np.savez_compressed(path, **arrays)
     print(path, os.path.getsize(path), "bytes; total_loss", out["total_loss"], "vars", len(names))
 

@@ -58,8 +58,8 @@ BF16_TOL = dict(score_rel=8e-2, logits=3e-2, loss=2e-2, grad=1e-1, norm=5e-2)
 def _fixture(n):
   """(fixture arrays, proposals, image size) of fixture `n` (256, 1100, or "full": the benchmark's own
   configuration, 2000 proposals on a 500x500 image)."""
-  if n == "full":
-    return (np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_full.npz")), gen.FULL["n"],
+  if n in ("full", "full_c2"):
+    return (np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_%s.npz" % n)), gen.FULL["n"],
             gen.FULL["hw"])
   return np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n)), n, None
 
@@ -129,19 +129,24 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
   assert worst_g > 1e-5      # (it really ran in reduced precision)
 
 
-@pytest.mark.parametrize("n", [256, 1100, "full"])
+@pytest.mark.parametrize("n", [256, 1100, "full", "full_c2"])
 def test_train_step_replays_the_float64_fixture(monkeypatch, n):
-  """("full", round 4: the BENCHMARK'S OWN configuration — one 500x500 image, 2000 proposals, depth 1.0
+  """("full_c2": the same size under BASELINE configs[2] — coco17_extend_match, 80 classes, a 416-column
+  heads GEMM, MIDN / OICR on 2000 x 80, the labels extracted from the caption INSIDE the step by the
+  ExtendMatch extractor; the fixture's labels came from the oracle's extractor.)
+  ("full", round 4: the BENCHMARK'S OWN configuration — one 500x500 image, 2000 proposals, depth 1.0
   — as one oracle-compared chain: first stage at 250^2 ... 32^2, the ROI crop of 2000 boxes on the
   real 32x32x576 map, Mixed_5a-c on 98,000 / 32,000 rows, heads, losses, backward, Adagrad.)"""
-  from cap2det_amd import hip_ops
+  from cap2det_amd import hip_ops, synthetic
   from cap2det_amd.train.trainer import Trainer
+  c2 = n == "full_c2"       # BASELINE configs[2]: coco17_extend_match, 80 classes, labels from the caption
   fix, n, hw = _fixture(n)
-  pipeline = util_model.load_pipeline()
+  pipeline = synthetic.baseline_pipeline("c2") if c2 else util_model.load_pipeline()
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM)
   model = trainer.model
   classes = model.label_extractor.classes
-  ex, P32, mask, real = gen.inputs(n, classes, hw)
+  assert len(classes) == (80 if c2 else 20)
+  ex, P32, mask, real = gen.inputs(n, list(classes), hw, captions=c2)
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   assert real == int(fix["real"])
   model.load_state_dict(P32)
@@ -159,7 +164,8 @@ def test_train_step_replays_the_float64_fixture(monkeypatch, n):
     dev[k] = torch.from_numpy(ex[k]).to(DEV).contiguous()
   losses = trainer.train_step(dev, dropout_mask=torch.from_numpy(mask).to(DEV))
   torch.cuda.synchronize()
-  _dispatched[(n, hw)] = seen
+  if not c2:
+    _dispatched[(n, hw)] = seen
   pred = trainer.predictions
   for i in range(4):
     got = pred["oicr_proposal_scores_at_%d" % i].detach().cpu().numpy().astype(np.float64)
