@@ -10,7 +10,8 @@ Run in the build container:  python tests/golden/gen_step_fixture.py
 BENCHMARK'S OWN configuration — one 500x500 image, 2000 proposals, depth 1.0 — in float64: ~20 GB
 of host memory and under a minute on 8 cores; `C2D_FIXTURE_FULL=c2`: step_dm1_full_c2.npz, the same
 size under BASELINE configs[2] — coco17_extend_match, 80 classes, the labels extracted from a
-caption by the oracle's ExtendMatch extractor.)
+caption by the oracle's ExtendMatch extractor; `C2D_FIXTURE_FULL=op`: step_dm1_op.npz, the reference's
+as-shipped training shape — two keep-aspect 1000x1333 images, 500 proposals each.)
 The fixtures hold EXPECTED OUTPUTS only (scores, losses, gradient norms and sampled gradient /
 updated-variable entries); tests/test_gpu_step_fixture.py regenerates the seeded inputs and
 checks their checksums against the ones stored here."""
@@ -24,21 +25,26 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 HW, DM, SAMPLES, HEAD_STD = 160, 1.0, 48, 0.01    # (head std: the reference's truncated-normal 0.01, configs/*.pbtxt:58-72)
-SEEDS = {256: 6, 1100: 6}          # model seed per fixture (main() rejects seeds with near-tie arg-maxes)
+SEEDS = {256: 6, 1100: 6, (500, (1000, 1333)): 8}          # model seed per fixture (main() rejects seeds with near-tie arg-maxes)
 
 
 FULL = dict(n=2000, hw=500)      # the benchmark's own configuration (step_dm1_full.npz)
 
 
-def inputs(n, classes, hw=None, captions=False):
+OP = dict(n=500, hw=(1000, 1333), batch=2)   # the reference's as-shipped training shape (step_dm1_op.npz)
+
+
+def inputs(n, classes, hw=None, captions=False, batch=1):
   """The seeded inputs of a fixture (shared with the GPU test).  captions: a synthetic caption over
   the shipped COCO open vocabulary rides along (`concat_caption_string`: BASELINE configs[2], the
   labels come from the caption through the ExtendMatch extractor)."""
   from tests import util_model
   hw = HW if hw is None else hw
-  rng = np.random.default_rng(1000 + n + (0 if hw == HW else hw) + (7 if captions else 0))
+  h, w = hw if isinstance(hw, tuple) else (hw, hw)
+  rng = np.random.default_rng(1000 + n + (0 if hw == HW else h + w if isinstance(hw, tuple) else hw) +
+                              (7 if captions else 0))
   real = n - n // 8
-  ex = util_model.make_examples(rng, 1, hw, hw, n, [real], classes)
+  ex = util_model.make_examples(rng, batch, h, w, n, [real] + [n] * (batch - 1), classes)
   if captions:
     from cap2det_amd import synthetic
     vocab = synthetic.read_lines(os.path.join(synthetic.DATA, "coco_open_vocab.txt"))
@@ -46,9 +52,9 @@ def inputs(n, classes, hw=None, captions=False):
                                                                must_contain=["dog", "bicycle"])
   # (the OICR arg-max over the proposals is a discrete choice: main() checks that none of them is a
   # near tie, so that fp32 and float64 select the same boxes)
-  P32, d = util_model.oracle_state(SEEDS.get((n, hw), SEEDS.get(n, 6)), len(classes), 3, DM,
-                                   head_std=HEAD_STD)
-  mask = (rng.uniform(size=(n, d)) < 0.5).astype(np.uint8)
+  seed = int(os.environ.get("C2D_FIXTURE_SEED", SEEDS.get((n, hw), SEEDS.get(n, 6))))   # (env: seed scans)
+  P32, d = util_model.oracle_state(seed, len(classes), 3, DM, head_std=HEAD_STD)
+  mask = (rng.uniform(size=(batch * n, d)) < 0.5).astype(np.uint8)
   return ex, P32, mask, real
 
 
@@ -75,16 +81,20 @@ def main():
   mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
                    oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
-  full = os.environ.get("C2D_FIXTURE_FULL", "") in ("1", "c2")
+  full = os.environ.get("C2D_FIXTURE_FULL", "") in ("1", "c2", "op")
   c2 = os.environ.get("C2D_FIXTURE_FULL") == "c2"
+  op = os.environ.get("C2D_FIXTURE_FULL") == "op"
   if c2:
     # BASELINE configs[2]: coco17_extend_match — 80 classes, labels from the caption (same loss
     # weights, multipliers, learning rate and regulariser as voc07_groundtruth)
     pipeline = synthetic.baseline_pipeline("c2")
     name2id, classes = ref_labels.read_synonym_file(os.path.join(synthetic.DATA, "coco_label_synonyms.txt"))
     mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
-  for n in ((FULL["n"],) if full else (256, 1100)):
-    ex, P32, mask, real = inputs(n, classes, FULL["hw"] if full else None, captions=c2)
+  for n in ((OP["n"],) if op else (FULL["n"],) if full else (256, 1100)):
+    if op:
+      ex, P32, mask, real = inputs(n, classes, OP["hw"], batch=OP["batch"])
+    else:
+      ex, P32, mask, real = inputs(n, classes, FULL["hw"] if full else None, captions=c2)
     P = {k: v.astype(np.float64) for k, v in P32.items()}
     acc = {k: np.full(v.shape, 0.1) for k, v in P.items()}
     if c2:
@@ -101,14 +111,16 @@ def main():
     # best vs second-best proposal score of each labelled class, relative to the best
     margins = []
     pr = out["predictions"]
-    s0 = pr["midn_proba_r_given_c"][0, :real]
-    for i in range(3):
-      for c in np.nonzero(labels[0] > 0)[0]:
-        col = np.sort(s0[:, c])[::-1]
-        margins.append((col[0] - col[1]) / max(abs(col[0]), 1e-30))
-      sc = pr["oicr_proposal_scores_at_%d" % (i + 1)][0, :real]
-      e = np.exp(sc - sc.max(1, keepdims=True))
-      s0 = (e / e.sum(1, keepdims=True))[:, 1:]
+    nums = ex["number_of_proposals"]
+    for b in range(len(nums)):
+      s0 = pr["midn_proba_r_given_c"][b, :nums[b]]
+      for i in range(3):
+        for c in np.nonzero(labels[b] > 0)[0]:
+          col = np.sort(s0[:, c])[::-1]
+          margins.append((col[0] - col[1]) / max(abs(col[0]), 1e-30))
+        sc = pr["oicr_proposal_scores_at_%d" % (i + 1)][b, :nums[b]]
+        e = np.exp(sc - sc.max(1, keepdims=True))
+        s0 = (e / e.sum(1, keepdims=True))[:, 1:]
     print("n", n, "min arg-max margin", min(margins))
     if os.environ.get("C2D_FIXTURE_SCAN"):
       continue
@@ -135,7 +147,7 @@ def main():
     arrays["updated_samples"] = np.stack([
         np.resize(P[k].reshape(-1)[sample_indices(k, P[k].size)], SAMPLES) for k in names])
     path = os.path.join(ROOT, "tests", "golden",
-                        "step_dm1_full_c2.npz" if c2 else "step_dm1_full.npz" if full
+                        "step_dm1_op.npz" if op else "step_dm1_full_c2.npz" if c2 else "step_dm1_full.npz" if full
                         else "step_dm1_n%d.npz" % n)
     np.savez_compressed(path, **arrays)
     print(path, os.path.getsize(path), "bytes; total_loss", out["total_loss"], "vars", len(names))

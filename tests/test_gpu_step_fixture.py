@@ -61,6 +61,8 @@ def _fixture(n):
   if n in ("full", "full_c2"):
     return (np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_%s.npz" % n)), gen.FULL["n"],
             gen.FULL["hw"])
+  if n == "op":
+    return np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_op.npz")), gen.OP["n"], gen.OP["hw"]
   return np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n)), n, None
 
 
@@ -129,24 +131,28 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
   assert worst_g > 1e-5      # (it really ran in reduced precision)
 
 
-@pytest.mark.parametrize("n", [256, 1100, "full", "full_c2"])
+@pytest.mark.parametrize("n", [256, 1100, "full", "full_c2", "op"])
 def test_train_step_replays_the_float64_fixture(monkeypatch, n):
   """("full_c2": the same size under BASELINE configs[2] — coco17_extend_match, 80 classes, a 416-column
   heads GEMM, MIDN / OICR on 2000 x 80, the labels extracted from the caption INSIDE the step by the
   ExtendMatch extractor; the fixture's labels came from the oracle's extractor.)
+  ("op": the reference's as-shipped training shape — a batch of TWO keep-aspect 1000x1333 images with 500
+  proposals each, configs/voc07_groundtruth.pbtxt:9-23 — first stage on 500x667 ... 63x84 maps, the
+  ROI-crop backward on its wide-map strips, batch-mean losses.)
   ("full", round 4: the BENCHMARK'S OWN configuration — one 500x500 image, 2000 proposals, depth 1.0
   — as one oracle-compared chain: first stage at 250^2 ... 32^2, the ROI crop of 2000 boxes on the
   real 32x32x576 map, Mixed_5a-c on 98,000 / 32,000 rows, heads, losses, backward, Adagrad.)"""
   from cap2det_amd import hip_ops, synthetic
   from cap2det_amd.train.trainer import Trainer
   c2 = n == "full_c2"       # BASELINE configs[2]: coco17_extend_match, 80 classes, labels from the caption
+  op = n == "op"            # the reference's as-shipped training shape: two 1000x1333 images, 500 proposals
   fix, n, hw = _fixture(n)
   pipeline = synthetic.baseline_pipeline("c2") if c2 else util_model.load_pipeline()
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM)
   model = trainer.model
   classes = model.label_extractor.classes
   assert len(classes) == (80 if c2 else 20)
-  ex, P32, mask, real = gen.inputs(n, list(classes), hw, captions=c2)
+  ex, P32, mask, real = gen.inputs(n, list(classes), hw, captions=c2, batch=gen.OP["batch"] if op else 1)
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   assert real == int(fix["real"])
   model.load_state_dict(P32)
@@ -164,8 +170,10 @@ def test_train_step_replays_the_float64_fixture(monkeypatch, n):
     dev[k] = torch.from_numpy(ex[k]).to(DEV).contiguous()
   losses = trainer.train_step(dev, dropout_mask=torch.from_numpy(mask).to(DEV))
   torch.cuda.synchronize()
-  if not c2:
+  if not c2 and not op:
     _dispatched[(n, hw)] = seen
+  if op:       # (63x84 feature maps: the wide-map strips of the atomic-free ROI-crop backward)
+    assert model.engine.last_crop_bwd.startswith("row-owner"), model.engine.last_crop_bwd
   pred = trainer.predictions
   for i in range(4):
     got = pred["oicr_proposal_scores_at_%d" % i].detach().cpu().numpy().astype(np.float64)
