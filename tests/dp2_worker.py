@@ -11,7 +11,10 @@ multi-GPU run except for the transport: RCCL itself is rehearsed by tests/test_g
 Started fresh by torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment), never
 exec'ed from a process that touched the GPU.
 
-  python tests/dp2_worker.py OUT_PREFIX fp32|bf16 eager|graph dp|single
+  python tests/dp2_worker.py OUT_PREFIX fp32|bf16 eager|graph dp|single [small|full]
+
+`full`: the benchmark's own shape per rank (depth 1.0, one 500x500 image with 2000 proposals per
+rank; the single-process reference steps on both images = 4000 ROIs).
 """
 import os
 import sys
@@ -25,7 +28,10 @@ STEPS = 2
 
 
 def main():
+  global DM, HW, N, NUMS
   out_prefix, dtype, launch, mode = sys.argv[1:5]
+  if len(sys.argv) > 5 and sys.argv[5] == "full":
+    DM, HW, N, NUMS = 1.0, (500, 500), 2000, [2000, 1741]
   import numpy as np
   import torch
   import torch.distributed as dist
@@ -50,7 +56,7 @@ def main():
   trainer = Trainer(pipeline, device=dev, depth_multiplier=DM, use_graph=graph, compute_dtype=dtype)
   model = trainer.model
   classes = model.label_extractor.classes
-  P32, d = util_model.oracle_state(11, len(classes), K, DM)
+  P32, d = util_model.oracle_state(11, len(classes), K, DM, head_std=0.01 if DM == 1.0 else 0.05)
   model.load_state_dict(P32)
   rng = np.random.default_rng(31)
   losses_log = []

@@ -35,18 +35,22 @@ def _run(cmd, env):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("dtype,launch", [("fp32", "eager"), ("fp32", "graph"), ("bf16", "eager"),
-                                          ("bf16", "graph")])
-def test_two_ranks_equal_the_batch_of_two_step(tmp_path, dtype, launch):
+@pytest.mark.parametrize("dtype,launch,size", [("fp32", "eager", "small"), ("fp32", "graph", "small"),
+                                               ("bf16", "eager", "small"), ("bf16", "graph", "small"),
+                                               ("fp32", "eager", "full"), ("bf16", "eager", "full")])
+def test_two_ranks_equal_the_batch_of_two_step(tmp_path, dtype, launch, size):
+  """size "full": each rank steps on the benchmark's own shape (depth 1.0, 500x500, 2000 proposals: the
+  per-block collectives issued from the filter-gradient stream under the real backward pass, the
+  one-pixel blocks / heavy-first order / branch streams of the full-size launch plan)."""
   prefix = str(tmp_path / "dp2")
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
   for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "C2D_FORCE_ALLREDUCE"):
     env.pop(k, None)
-  out = _run([sys.executable, WORKER, prefix, dtype, launch, "single"], env)
+  out = _run([sys.executable, WORKER, prefix, dtype, launch, "single", size], env)
   assert os.path.exists(prefix + "_single_r0.done"), out
   out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
               "--master-addr", "127.0.0.1", "--master-port", _free_port(), WORKER, prefix, dtype,
-              launch, "dp"], env)
+              launch, "dp", size], env)
   assert os.path.exists(prefix + "_dp_r0.done") and os.path.exists(prefix + "_dp_r1.done"), out
   single = np.load(prefix + "_single_r0.npz")
   r0, r1 = np.load(prefix + "_dp_r0.npz"), np.load(prefix + "_dp_r1.npz")
@@ -57,14 +61,18 @@ def test_two_ranks_equal_the_batch_of_two_step(tmp_path, dtype, launch):
   # ... which is the batch-of-2 step, up to the order of fp32 sums (per-rank sums + all-reduce
   # against one GEMM over both images' rows; split-K atomics): every tensor here is fp32 in both
   # storage modes, and no bf16 rounding sits between the per-image forward passes and the sums
+  # (bf16 at full size: the batch-of-2 process launches other tile plans than a one-image rank —
+  #  64,000 against 32,000 rows —, their fp32 sums differ in order and an activation that sits on a
+  #  bf16 rounding boundary can round the other way: 1e-3 of scale observed, 5e-3 allowed)
+  tol = 5e-3 if (dtype, size) == ("bf16", "full") else 5e-5
   g_dp, g_one = 0.5 * r0["grads"].astype(np.float64), single["grads"].astype(np.float64)
   assert np.abs(g_one).max() > 1e-4
-  assert np.abs(g_dp - g_one).max() <= 5e-5 * np.abs(g_one).max()
+  assert np.abs(g_dp - g_one).max() <= tol * np.abs(g_one).max()
   step_one = single["values"].astype(np.float64)
   step_dp = r0["values"].astype(np.float64)
-  assert np.abs(step_dp - step_one).max() <= 5e-5 * np.abs(step_one).max()
+  assert np.abs(step_dp - step_one).max() <= tol * np.abs(step_one).max()
   acc_one, acc_dp = single["accum"].astype(np.float64), r0["accum"].astype(np.float64)
-  assert np.abs(acc_dp - acc_one).max() <= 5e-5 * np.abs(acc_one).max()
+  assert np.abs(acc_dp - acc_one).max() <= tol * np.abs(acc_one).max()
   # losses: a rank reports the mean over ITS image; their mean is the batch mean (the
   # regularisation loss is the same number everywhere)
   names = list(single["loss_names"])
@@ -73,4 +81,4 @@ def test_two_ranks_equal_the_batch_of_two_step(tmp_path, dtype, launch):
     mean = 0.5 * (r0["losses"][i] + r1["losses"][i])
     if name == "total_loss":
       continue            # (sum of the others)
-    assert abs(mean - single["losses"][i]) <= 1e-5 * max(1.0, abs(single["losses"][i])), name
+    assert abs(mean - single["losses"][i]) <= (2e-3 if tol > 1e-4 else 1e-5) * max(1.0, abs(single["losses"][i])), name
