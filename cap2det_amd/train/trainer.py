@@ -445,48 +445,51 @@ class Trainer(object):
       #  r04_graph_concurrency.json)
       eng.second.alt = None
       eng.first.alt = None
-      self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
-      self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
-      torch.cuda.synchronize()
-      store.values.copy_(state[0])                                # undo the warm-up update
-      for sl, saved in zip(store.slots, state[1]):
-        sl.copy_(saved)
-      self.model.refresh(only_trainable=True)
-      bufs = eng._buffers(image.shape[0], image.shape[1], image.shape[2],
-                          examples[F.proposals].shape[1], True)
-      last, p_cur = eng.prefix_output(bufs)
-      lookahead = streams and last is not None
-      p_next = torch.empty_like(p_cur) if lookahead else None
-      branch = torch.cuda.Stream() if lookahead else None
-      cap = torch.cuda.Stream()
-      cap.wait_stream(torch.cuda.current_stream())
-      g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-      with torch.cuda.stream(cap):
-        with torch.cuda.graph(g_fb, stream=cap):
-          if lookahead:
-            p_cur.copy_(p_next)                   # the previous replay's look-ahead result
-            fork = torch.cuda.Event()
-            fork.record()
-            branch.wait_event(fork)
-            with torch.cuda.stream(branch):
-              eng.run_prefix_into(bufs, st["next_image"], p_next)
-              joined = torch.cuda.Event()
-              joined.record()
-            eng.external_prefix = True
-          try:
-            predictions, losses = self._forward_backward(ex, labels=st["labels"],
-                                                         dropout_seed=st["seed"])
-          finally:
-            eng.external_prefix = False
-          if lookahead:
-            torch.cuda.current_stream().wait_event(joined)
-        with torch.cuda.graph(g_opt, stream=cap):
-          self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
-          total = self.model.total_loss()
-      torch.cuda.current_stream().wait_stream(cap)
-      eng.prefetch_stream = pre_keep
-      eng.second.alt = alt_keep
-      eng.first.alt = alt1_keep
+      try:
+        self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
+        self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
+        torch.cuda.synchronize()
+        store.values.copy_(state[0])                                # undo the warm-up update
+        for sl, saved in zip(store.slots, state[1]):
+          sl.copy_(saved)
+        self.model.refresh(only_trainable=True)
+        bufs = eng._buffers(image.shape[0], image.shape[1], image.shape[2],
+                            examples[F.proposals].shape[1], True)
+        last, p_cur = eng.prefix_output(bufs)
+        lookahead = streams and last is not None
+        p_next = torch.empty_like(p_cur) if lookahead else None
+        branch = torch.cuda.Stream() if lookahead else None
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(cap):
+          with torch.cuda.graph(g_fb, stream=cap):
+            if lookahead:
+              p_cur.copy_(p_next)                   # the previous replay's look-ahead result
+              fork = torch.cuda.Event()
+              fork.record()
+              branch.wait_event(fork)
+              with torch.cuda.stream(branch):
+                eng.run_prefix_into(bufs, st["next_image"], p_next)
+                joined = torch.cuda.Event()
+                joined.record()
+              eng.external_prefix = True
+            try:
+              predictions, losses = self._forward_backward(ex, labels=st["labels"],
+                                                           dropout_seed=st["seed"])
+            finally:
+              eng.external_prefix = False
+            if lookahead:
+              torch.cuda.current_stream().wait_event(joined)
+          with torch.cuda.graph(g_opt, stream=cap):
+            self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
+            total = self.model.total_loss()
+        torch.cuda.current_stream().wait_stream(cap)
+      finally:
+        # (also when the warm-up or the capture raises: the eager path must find its streams again)
+        eng.prefetch_stream = pre_keep
+        eng.second.alt = alt_keep
+        eng.first.alt = alt1_keep
       losses['total_loss'] = total
       self._graphs = dict(key=key, fb=g_fb, opt=g_opt, predictions=predictions, losses=losses,
                           lookahead=lookahead, bufs=bufs, p_next=p_next, primed=None)
