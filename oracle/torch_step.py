@@ -106,6 +106,35 @@ def crop_and_resize(feat, boxes, box_ind, crop):
   return out.permute(0, 3, 1, 2)          # [R, D, crop, crop], channels_last memory
 
 
+def predict_scores(P, examples, options, oicr_iterations):
+  """Forward pass only (evaluation mode: no dropout), for fixtures at sizes the numpy oracle does not
+  finish in seconds: `extract_frcnn_feature` on torch-CPU in P's arithmetic type, heads / MIDN in
+  the numpy oracle.  Returns {oicr_proposal_scores_at_i, midn_proba_r_given_c, midn_class_logits}
+  exactly as oracle.ref_model.build_prediction does (models/cap2det_model.py:152-216)."""
+  dt = next(iter(P.values())).dtype.type
+  T = {k: torch.from_numpy(v) for k, v in P.items()}
+  x = _nchw(examples["image"].astype(dt)) * (2.0 / 255.0) - 1.0
+  x = x.contiguous(memory_format=torch.channels_last)
+  proposals = examples["proposals"]
+  batch, n, _ = proposals.shape
+  with torch.no_grad():
+    for op in ref_model.FIRST_STAGE:
+      x = _op(op, x, T, ref_model.FIRST_SCOPE)
+    box_ind = np.repeat(np.arange(batch, dtype=np.int64), n)
+    net = F.max_pool2d(crop_and_resize(x, proposals.reshape(-1, 4), box_ind, options.initial_crop_size),
+                       options.maxpool_kernel_size, options.maxpool_stride)
+    for op in ref_model.SECOND_STAGE:
+      net = _op(op, net, T, ref_model.SECOND_SCOPE)
+    f_np = net.mean(dim=(2, 3)).reshape(batch, n, -1).numpy()
+  class_logits, scores, proba, _ = ref_model.build_midn_network(examples["number_of_proposals"], f_np, P)
+  out = {"midn_class_logits": class_logits, "midn_proba_r_given_c": proba,
+         "oicr_proposal_scores_at_0": scores}
+  for i in range(oicr_iterations):
+    out["oicr_proposal_scores_at_%d" % (i + 1)] = (
+        f_np @ P["oicr/iter%d/weights" % (i + 1)] + P["oicr/iter%d/biases" % (i + 1)])
+  return out
+
+
 def train_step(P, accum, examples, labels, options, loss_opts, multipliers, learning_rate,
                l2_weight, dropout_mask=None):
   """Same contract as oracle.ref_model.train_step (P / accum updated in place).  The arithmetic
