@@ -342,6 +342,29 @@ def test_torch_cpu_step_in_float64_equals_numpy_oracle_step():
     assert P2[k].dtype == np.float64 and np.abs(P1[k] - P2[k]).max() <= 1e-10, k
 
 
+def test_torch_cpu_predict_scores_equals_numpy_oracle_prediction():
+  """oracle/torch_step.predict_scores — what tests/golden/gen_inference_fixture.py runs per evaluation
+  resolution — against the numpy oracle's float64 `build_prediction` in evaluation mode (no
+  dropout): same scores to float64 round-off, two images of different proposal counts."""
+  from oracle import torch_step
+  from cap2det_amd import synthetic
+  from tests import util_model
+  classes = synthetic.read_lines(synthetic.DATA + "/voc_label.txt")
+  dm, n = 0.5, 6
+  rng = np.random.default_rng(9)
+  P32, d = util_model.oracle_state(2, len(classes), 3, dm)
+  ex = synthetic.make_examples(rng, 2, 56, 72, n, [6, 4], classes)
+  ex64 = dict(image=ex["image"].astype(np.float64), number_of_proposals=ex["number_of_proposals"],
+              proposals=ex["proposals"].astype(np.float64))
+  P = {k: v.astype(np.float64) for k, v in P32.items()}
+  opts = ref_model.FrcnnOptions(depth_multiplier=dm)
+  want = ref_model.build_prediction(ex64, P, opts, 3, is_training=False)[0]
+  got = torch_step.predict_scores(P, ex64, opts, 3)
+  for key in ["oicr_proposal_scores_at_%d" % i for i in range(4)] + ["midn_class_logits",
+                                                                      "midn_proba_r_given_c"]:
+    np.testing.assert_allclose(got[key], want[key], rtol=1e-9, atol=1e-12, err_msg=key)
+
+
 def test_torch_backends_of_ref_ops_match_numpy():
   rng = np.random.default_rng(1)
   try:
