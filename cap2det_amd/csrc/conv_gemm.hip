@@ -1996,7 +1996,14 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   }
   // Tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 tiles.
   const long long big_blocks = (long long)c2d_ceil_div(a.M, 128) * c2d_ceil_div(a.N, 128);
-  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && !a.fy && !a.mo_n) {
+  // (a deep 1x1 GEMM over a few thousand rows — the 416-column heads of the 80-class configs,
+  //  2000 x 416 x 1024: 0.85 GFLOP — is better off on 64x64 tiles through LDS than on the
+  //  one-tile-per-block kernel, whose fragments come straight from memory: forward 37.8 -> 29.2 us;
+  //  the 112-column heads of the 20-class configs stay: 12.7 against 27.7 us)
+  static const bool keep_small = tune && getenv("C2D_IGEMM_KEEP_SMALL") != nullptr;
+  const bool deep_1x1 = a.g.kh * a.g.kw == 1 && a.M >= 1024 &&
+                        (long long)a.M * a.N * a.K >= 600000000ll && !keep_small;
+  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && !a.fy && !a.mo_n && !deep_1x1) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);

@@ -13,7 +13,7 @@ def timeit(fn, iters=50):
   for _ in range(iters): fn()
   e.record(); torch.cuda.synchronize()
   return s.elapsed_time(e)/iters*1e3
-n,cin,cout=2000,1024,112
+n,cin,cout=2000,1024,int(os.environ.get('HEADS_COLS','112'))
 x=torch.randn(n,cin,device=dev); wt=torch.randn(1,cout,cin,device=dev)*0.03; w=wt.permute(0,2,1).contiguous()
 y=torch.empty(n,cout,device=dev); dy=torch.randn(n,cout,device=dev); dx=torch.empty(n,cin,device=dev); dw=torch.zeros(1,cin,cout,device=dev)
 print("fwd %.1f us"%timeit(lambda: ops.conv_fwd(x,cin,0,wt,None,None,y,cout,0,n,1,1,cin,cout,1,1,1,False)), ops.last_dispatch())
