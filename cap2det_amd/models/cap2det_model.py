@@ -492,11 +492,42 @@ class Model(ModelBase):
     d = self.engine.feature_dims
     g = self.store.grad
     x = ctx["features"]
-    ops.conv_wgrad(x, d, 0, bufs["dlogits"], self._npad, 0, g[HEADS_W], b * n, 1, 1, d, self._npad,
-                   1, 1, 1)
-    ops.col_sum(bufs["dlogits"], self._npad, 0, g[HEADS_B], b * n, self._npad)
+    def head_variable_gradients():
+      ops.conv_wgrad(x, d, 0, bufs["dlogits"], self._npad, 0, g[HEADS_W], b * n, 1, 1, d, self._npad,
+                     1, 1, 1)
+      ops.col_sum(bufs["dlogits"], self._npad, 0, g[HEADS_B], b * n, self._npad)
+
+    # the heads' filter / bias gradients only meet the rest of the step at the gradient exchange and
+    # the optimiser: like the second stage's filter gradients they go out on the filter-gradient
+    # stream, beside the input gradient that the backward pass is waiting for (the 416-column heads
+    # of the 80-class configs: 41 us off the main stream)
+    side = self.engine.second.side
+    heads_done = None
+    if side is not None:
+      fork = torch.cuda.Event()
+      fork.record()
+      side.wait_event(fork)
+      with torch.cuda.stream(side):
+        head_variable_gradients()
+        heads_done = torch.cuda.Event()
+        heads_done.record()
+    else:
+      head_variable_gradients()
     ops.conv_dgrad(bufs["dlogits"], self._npad, 0, self.store.var[HEADS_W], bufs["dfeatures"], d, 0,
                    b * n, 1, 1, d, self._npad, 1, 1, 1, False)
+    if heads_done is not None:
+      # whoever hands the heads' gradients on (the data-parallel reducers' hooks) does so behind them
+      user_after2, user_block = after_second_stage, after_block
+
+      def after_second_stage():
+        torch.cuda.current_stream().wait_event(heads_done)
+        if user_after2 is not None:
+          user_after2()
+
+      if user_block is not None:
+        def after_block(i):
+          torch.cuda.current_stream().wait_event(heads_done)
+          user_block(i)
     self.engine.backward(bufs["dfeatures"], d, 0, ctx["fctx"], after_second_stage, after_block)
 
   def build_evaluation(self, predictions, examples=None, **kwargs):
