@@ -9,6 +9,7 @@
 // Layout: feature map NHWC fp32, channels vectorised as float4 (16 B/lane, coalesced).
 // One workgroup per ROI; the 2*crop sampling descriptors of the ROI live in LDS.
 #include <stdlib.h>
+#include <type_traits>
 #include "c2d_common.h"
 
 namespace {
@@ -509,11 +510,11 @@ constexpr int kBinSegs = 16;  // cell-range segments per row list = list parts o
 // are moved apart with weight 0 on the second.  Computed once per cell and row instead of 576 times.
 struct RowEntry {
   int cell_off;      // (roi * p*p + py * p + px) * depth
-  float wy0, wy1;    // weight of row y if the argmax sample is the upper / lower one
+  float wy0, dwy;    // weight of row y if the argmax sample is the upper one; lower minus upper
   int off0;          // lo_bytes | hi_bytes << 16 of the left sample
   float lx0;
-  int off1;
-  float lx1;
+  int xoff;          // off0 ^ (the right sample's offsets): off = off0 ^ (xoff & -sx)
+  float dlx;         // right sample's lerp weight minus the left one's
   int pad;
 };
 constexpr int kListPad = 16;   // zero-weight entries behind every list: the strip kernel walks
@@ -567,11 +568,16 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
         const int py = c / pout, px = c - py * pout;
         e.cell_off = cell * depth;
         e.wy0 = row_weight(ys[roi * crop + py * ps], y);
-        e.wy1 = row_weight(ys[roi * crop + py * ps + 1], y);
-        hit = e.wy0 != 0.0f || e.wy1 != 0.0f;
+        const float wy1 = row_weight(ys[roi * crop + py * ps + 1], y);
+        e.dwy = wy1 - e.wy0;
+        hit = e.wy0 != 0.0f || wy1 != 0.0f;
         if (hit) {
+          int off1;
+          float lx1;
           column_taps(xs[roi * crop + px * ps], wf, chunk, &e.off0, &e.lx0);
-          column_taps(xs[roi * crop + px * ps + 1], wf, chunk, &e.off1, &e.lx1);
+          column_taps(xs[roi * crop + px * ps + 1], wf, chunk, &off1, &lx1);
+          e.xoff = e.off0 ^ off1;
+          e.dlx = lx1 - e.lx0;
         }
       }
     }
@@ -587,53 +593,160 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
   }
   if (threadIdx.x < kListPad) {          // zero-weight tail (cell 0 is always a valid address)
     RowEntry z;
-    z.cell_off = 0; z.wy0 = 0.0f; z.wy1 = 0.0f; z.lx0 = 0.0f; z.lx1 = 0.0f; z.pad = 0;
-    z.off0 = z.off1 = (wf * chunk * 4) | ((wf * chunk * 4) << 16);
+    z.cell_off = 0; z.wy0 = 0.0f; z.dwy = 0.0f; z.lx0 = 0.0f; z.dlx = 0.0f; z.pad = 0;
+    z.off0 = (wf * chunk * 4) | ((wf * chunk * 4) << 16);
+    z.xoff = 0;
     list[running + threadIdx.x] = z;
   }
   if (threadIdx.x == 0) counts[((size_t)b * hf + y) * kBinSegs + seg] = running;
 }
 
-constexpr int kRowParts = kBinSegs;   // one list segment per workgroup (and per partial map)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t strip_rsrc(const void* p, long long bytes) {
+  const unsigned long long ub = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), (short)0,
+                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+template <typename R> __device__ __forceinline__ R strip_load(__amdgpu_buffer_rsrc_t rs, int v, int s);
+template <> __device__ __forceinline__ unsigned strip_load<unsigned>(__amdgpu_buffer_rsrc_t rs, int v, int s) {
+  return __builtin_amdgcn_raw_buffer_load_b32(rs, v, s, 0);
+}
+template <> __device__ __forceinline__ unsigned short strip_load<unsigned short>(__amdgpu_buffer_rsrc_t rs, int v, int s) {
+  return __builtin_amdgcn_raw_buffer_load_b16(rs, v, s, 0);
+}
+__device__ __forceinline__ float strip_value(unsigned raw) { return __uint_as_float(raw); }
+__device__ __forceinline__ float strip_value(unsigned short raw) {      // bf16 -> fp32: exact
+  return __uint_as_float((unsigned)raw << 16);
+}
 
-// grid (hf, depth / CHUNK, batch * kRowParts), block = CHUNK threads (lane <-> channel c0 + tid).
-// Part q walks segment q of the row list and writes its partial row into parts[q] (plain
-// stores); roi_bwd_sum_parts_kernel then adds the parts in a fixed order.
-// U list entries per trip: their scalar entry loads, then their 2*U vector loads, are issued
+constexpr int kRowParts = kBinSegs;   // strip workgroups (per channel chunk) = rows * kRowParts
+constexpr int kTrip = 16;             // list entries per trip of the strip kernel (= kListPad)
+
+// The strip kernel's work plan (built once per box set, with the lists).  The lists of one row
+// differ in length by 6x between segments (a segment is a range of cells = of boxes) and rows at
+// the map's border are half as long as those in the middle, and the strip launch is ONE round of
+// workgroups: with a workgroup per (row, segment) the launch lasted as long as its longest list,
+// 1.6x the mean.  So the lists are cut into TRIPS of kTrip entries (a segment's last trip runs
+// into its zero-weight tail), all trips of all rows form one sequence in (row, segment) order, and
+// workgroup w takes trips [w T / W, (w + 1) T / W): equal work, at most one row change per
+// workgroup in practice.  Every (workgroup, row) pair owns one partial row ("slot", numbered in
+// sequence order, so a row's slots are consecutive and the sum below has a fixed order).
+struct StripPlan {
+  int trips;          // T
+  int slots;          // partial rows in use
+  int pad[2];
+};
+// layout behind the StripPlan header (ints): wslot[W] | rowslot[2 R] (begin, end) | trip[2 maxT]
+// (entry index of the trip's first entry, row)
+
+// One workgroup; R = batch * hf rows, W strip workgroups per channel chunk.
+__global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __restrict__ counts,
+                                                              int32_t* __restrict__ plan, int R,
+                                                              int W, int cap) {
+  extern __shared__ int rowtrip[];                  // [R + 1] first trip of every row | [2 R] slots
+  int* rs = rowtrip + R + 1;
+  StripPlan* head = reinterpret_cast<StripPlan*>(plan);
+  int32_t* wslot = plan + 4;
+  int32_t* rowslot = wslot + W;
+  int32_t* trip = rowslot + 2 * R;
+  for (int y = threadIdx.x; y < R; y += blockDim.x) {
+    int t = 0;
+    for (int sgm = 0; sgm < kBinSegs; ++sgm) t += (counts[y * kBinSegs + sgm] + kTrip - 1) / kTrip;
+    rowtrip[y + 1] = t;
+    rs[2 * y] = rs[2 * y + 1] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rowtrip[0] = 0;
+    for (int y = 0; y < R; ++y) rowtrip[y + 1] += rowtrip[y];
+  }
+  __syncthreads();
+  const int T = rowtrip[R];
+  for (int i = threadIdx.x; i < R * kBinSegs; i += blockDim.x) {
+    const int y = i / kBinSegs, sgm = i - y * kBinSegs;
+    int pos = rowtrip[y];
+    for (int q = 0; q < sgm; ++q) pos += (counts[y * kBinSegs + q] + kTrip - 1) / kTrip;
+    const int n = (counts[i] + kTrip - 1) / kTrip;
+    for (int j = 0; j < n; ++j) {
+      trip[2 * (pos + j)] = i * cap + j * kTrip;
+      trip[2 * (pos + j) + 1] = y;
+    }
+  }
+  if (threadIdx.x == 0) {
+    int slot = 0, y = 0;
+    for (int w = 0; w < W; ++w) {
+      const int tb = (int)((long long)w * T / W), te = (int)((long long)(w + 1) * T / W);
+      wslot[w] = slot;
+      if (te == tb) continue;
+      while (rowtrip[y + 1] <= tb) ++y;             // (skips empty rows)
+      for (int yy = y; yy < R && rowtrip[yy] < te; ++yy) {
+        if (rowtrip[yy + 1] == rowtrip[yy]) continue;
+        if (rs[2 * yy + 1] == 0) rs[2 * yy] = slot;   // the row's first (workgroup, row) pair
+        rs[2 * yy + 1] = ++slot;
+      }
+    }
+    head->trips = T;
+    head->slots = slot;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * R; i += blockDim.x) rowslot[i] = rs[i];
+}
+
+// 1-D grid of W * chunks workgroups (w fastest), block = CHUNK threads (lane <-> channel c0 + tid).
+// A lane owns its channel's column of the LDS strip outright — zeroing, accumulation and the
+// write-out of a partial row need no barrier.
+// U list entries per half-trip: their scalar entry loads, then their 2*U vector loads, are issued
 // together before the first read-modify-write.
 template <int CHUNK, typename TG>
 __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
     const TG* __restrict__ dout, const uint8_t* __restrict__ argmax,
-    const RowEntry* __restrict__ lists, const int32_t* __restrict__ counts,
-    float* __restrict__ parts, int batch, int hf, int wf, int depth, int pout, int cap) {
+    const RowEntry* __restrict__ list, const int32_t* __restrict__ plan,
+    float* __restrict__ parts, int R, int W, int wf, int depth,
+    long long total_cells_depth) {
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [wf + 1][CHUNK] (+1: spare column)
-  const int y = blockIdx.x, c0 = blockIdx.y * CHUNK;
-  const int b = blockIdx.z / kRowParts, part = blockIdx.z % kRowParts;
+  const int w = blockIdx.x % W;
+  const int c0 = blockIdx.x / W * CHUNK;
+  const int T = reinterpret_cast<const StripPlan*>(plan)->trips;
+  const int tb = (int)((long long)w * T / W), te = (int)((long long)(w + 1) * T / W);
+  if (tb == te) return;
+  const int32_t* __restrict__ trip = plan + 4 + W + 2 * R;
+  int slot = __builtin_amdgcn_readfirstlane(plan[4 + w]);
   const int tid = threadIdx.x;
-  for (int i = tid; i < (wf + 1) * CHUNK; i += CHUNK) acc[i] = 0.0f;
-  __syncthreads();
-  const size_t lrow = ((size_t)b * hf + y) * kBinSegs + part;
-  const RowEntry* __restrict__ list = lists + lrow * cap;
-  const int count = __builtin_amdgcn_readfirstlane(counts[lrow]);
+  for (int x = 0; x <= wf; ++x) acc[x * CHUNK + tid] = 0.0f;
   char* const mine = reinterpret_cast<char*>(acc + tid);
   const bool on = c0 + tid < depth;                 // (ragged last chunk: depth % CHUNK != 0)
   const int cc = on ? c0 + tid : c0;
-  const TG* gcol = dout + cc;
-  const uint8_t* kcol = argmax + cc;
+  // dpooled / arg-max through raw buffer descriptors: the lane's channel is the vector offset, the
+  // entry's cell the SCALAR offset — no per-load address arithmetic in the vector ALU.
+  const __amdgpu_buffer_rsrc_t gres = strip_rsrc(dout, total_cells_depth * (long long)sizeof(TG));
+  const __amdgpu_buffer_rsrc_t kres = strip_rsrc(argmax, total_cells_depth);
+  const int gv = cc * (int)sizeof(TG), kv = cc;
   // U list entries per trip, two register sets in ping-pong: the dpooled / arg-max values of trip
   // t+1 are in flight while trip t is accumulated into the lane's own channel column, in list
   // order (reproducible sum).  An entry's fields are wave-uniform (scalar loads); it is read
   // twice (addresses, then weights) rather than kept: two live sets do not fit the 102 SGPRs.
   // Straight-line code: zero-weight entries pad the list to whole trips, samples outside the map
   // land in the spare column, and a lane whose arg-max sample does not touch this row adds 0.
+  // The per-lane choices (which vertical / horizontal sample the arg-max names) are MASKS, not
+  // selects between two scalars (gfx9 reads one scalar per vector instruction: a select between
+  // two costs two moves): value & -bit picks the lane's term of  w = wy0 + sy * dwy  and
+  // lx = lx0 + sx * dlx, and the packed column offsets are off0 ^ (xoff & -sx).  16 vector
+  // instructions per entry instead of 22 (the kernel is issue-bound: DESIGN.md section 3).
   constexpr int U = 8;
-  TG g[U], gn[U];               // raw loaded values: nothing consumes them before their trip
+#ifndef C2D_STRIP_DBG
+#define C2D_STRIP_DBG 0     // ablation builds (-DC2D_STRIP_DBG=1: no vector loads, 2: no LDS updates)
+#endif
+  float dbg_acc = 0.0f;
+  using Raw = typename std::conditional<sizeof(TG) == 2, unsigned short, unsigned>::type;
+  Raw g[U], gn[U];              // raw loaded values: nothing consumes them before their trip
   unsigned k[U], kn[U];
 #define C2D_STRIP_FETCH(G, K, I0)                                                              \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
     const int o = list[(I0) + u].cell_off;                                                     \
-    (G)[u] = gcol[o];                                                                          \
-    (K)[u] = kcol[o];                                                                          \
+    if (C2D_STRIP_DBG & 1) { (G)[u] = (Raw)(o + u); (K)[u] = o + u; continue; }                \
+    (G)[u] = strip_load<Raw>(gres, gv, o * (int)sizeof(TG));                                   \
+    (K)[u] = __builtin_amdgcn_raw_buffer_load_b8(kres, kv, o, 0);                              \
   }
   /* (all scalar entry loads of the trip first: SMEM and LDS share one wait counter, and an  */
   /*  entry load in flight would turn every LDS wait below into a wait for it as well)       */
@@ -643,53 +756,77 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
     _Pragma("unroll") for (int u = 0; u < U; ++u) e[u] = list[(I0) + u];                       \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                            \
-      const bool sx = (K)[u] & 1u, sy = (K)[u] >> 1;                                           \
-      const int off = sx ? e[u].off1 : e[u].off0;                                              \
+      const int mx = __builtin_amdgcn_sbfe((int)(K)[u], 0, 1);      /* -sx */                  \
+      const int my = __builtin_amdgcn_sbfe((int)(K)[u], 1, 1);      /* -sy */                  \
+      const int off = e[u].off0 ^ (e[u].xoff & mx);                                            \
       float* const plo = reinterpret_cast<float*>(mine + (off & 0xffff));                      \
       float* const phi = reinterpret_cast<float*>(mine + ((unsigned)off >> 16));               \
-      const float alo = *plo, ahi = *phi;              /* (distinct columns by construction) */ \
-      const float v = (sy ? e[u].wy1 : e[u].wy0) * (float)(G)[u];                              \
-      const float whi = v * (sx ? e[u].lx1 : e[u].lx0);                                        \
+      float alo, ahi;                                                                          \
+      if (C2D_STRIP_DBG & 2) { alo = dbg_acc; ahi = __int_as_float(off); }                     \
+      else { alo = *plo; ahi = *phi; }                 /* (distinct columns by construction) */ \
+      const float gf = strip_value((G)[u]);                                                    \
+      const float v = __builtin_fmaf(__int_as_float(__float_as_int(gf) & my), e[u].dwy,        \
+                                     gf * e[u].wy0);                                           \
+      const float whi = __builtin_fmaf(__int_as_float(__float_as_int(v) & mx), e[u].dlx,       \
+                                       v * e[u].lx0);                                          \
       /* TF CropAndResizeGradImage: (1 - lx) * dtop to column lo, lx * dtop to column hi */    \
+      if (C2D_STRIP_DBG & 2) { dbg_acc = alo + (v - whi) + (ahi + whi); continue; }            \
       *plo = alo + (v - whi);                                                                  \
       *phi = ahi + whi;                                                                        \
     }                                                                                          \
   }
-  if (count > 0) {
-    C2D_STRIP_FETCH(g, k, 0);
-    for (int i0 = 0; i0 < count; i0 += 2 * U) {    // fixed order: the sum is reproducible
-      C2D_STRIP_FETCH(gn, kn, i0 + U);             // (reads into the zero-weight tail at most)
-      __builtin_amdgcn_sched_barrier(0);
-      C2D_STRIP_ADD(g, k, i0);
-      __builtin_amdgcn_sched_barrier(0);
-      C2D_STRIP_FETCH(g, k, min(i0 + 2 * U, count));
-      __builtin_amdgcn_sched_barrier(0);
-      C2D_STRIP_ADD(gn, kn, i0 + U);
+  int row = __builtin_amdgcn_readfirstlane(trip[2 * tb + 1]);
+  auto flush = [&](int r, int sl) {        // the lane's column of partial row `sl` (row r), then zeros
+    float* drow = parts + ((size_t)sl * wf) * depth + c0 + tid;
+    if (on)
+      for (int x = 0; x < wf; ++x) drow[(size_t)x * depth] = acc[x * CHUNK + tid];
+    (void)r;
+  };
+  int i0 = __builtin_amdgcn_readfirstlane(trip[2 * tb]);
+  C2D_STRIP_FETCH(g, k, i0);
+  for (int t = tb; t < te; ++t) {                  // fixed order: the sum is reproducible
+    const int r = __builtin_amdgcn_readfirstlane(trip[2 * t + 1]);
+    if (r != row) {
+      flush(row, slot);
+      for (int x = 0; x <= wf; ++x) acc[x * CHUNK + tid] = 0.0f;
+      ++slot;
+      row = r;
     }
+    const int tn = min(t + 1, te - 1);             // (the last trip re-reads itself: harmless)
+    const int inext = __builtin_amdgcn_readfirstlane(trip[2 * tn]);
+    C2D_STRIP_FETCH(gn, kn, i0 + U);               // (reads into the zero-weight tail at most)
+    __builtin_amdgcn_sched_barrier(0);
+    C2D_STRIP_ADD(g, k, i0);
+    __builtin_amdgcn_sched_barrier(0);
+    C2D_STRIP_FETCH(g, k, inext);
+    __builtin_amdgcn_sched_barrier(0);
+    C2D_STRIP_ADD(gn, kn, i0 + U);
+    i0 = inext;
   }
 #undef C2D_STRIP_ADD
 #undef C2D_STRIP_FETCH
-  __syncthreads();
-  float* drow = parts + ((((size_t)part * batch + b) * hf + y) * wf) * depth + c0 + tid;
-  if (on)
-    for (int x = 0; x < wf; ++x) drow[(size_t)x * depth] = acc[x * CHUNK + tid];
+  if (C2D_STRIP_DBG & 2) acc[tid] = dbg_acc;
+  flush(row, slot);
 }
 
-// dfeat += part[0] + part[1] + ... (fixed order), float4 per lane.
+// dfeat[row] += its partial rows, in slot order (fixed), float4 per lane.  grid (R, x-blocks).
 __global__ __launch_bounds__(256) void roi_bwd_sum_parts_kernel(const float4* __restrict__ parts,
-                                                                float4* __restrict__ dfeat,
-                                                                long long n4) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
-    float4 s = parts[i];
-#pragma unroll
-    for (int q = 1; q < kRowParts; ++q) {
-      const float4 v = parts[(size_t)q * n4 + i];
+                                                                const int32_t* __restrict__ plan,
+                                                                float4* __restrict__ dfeat, int W,
+                                                                int R, int row4) {
+  const int y = blockIdx.x;
+  const int32_t* rowslot = plan + 4 + W;
+  const int sb = rowslot[2 * y], se = rowslot[2 * y + 1];
+  if (sb == se) return;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < row4; i += gridDim.y * blockDim.x) {
+    float4 s = parts[(size_t)sb * row4 + i];
+    for (int q = sb + 1; q < se; ++q) {
+      const float4 v = parts[(size_t)q * row4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    float4 d = dfeat[i];
+    float4 d = dfeat[(size_t)y * row4 + i];
     d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
-    dfeat[i] = d;
+    dfeat[(size_t)y * row4 + i] = d;
   }
 }
 
@@ -868,10 +1005,13 @@ extern "C" long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, in
   const long long pout = (crop - pool_k) / pool_s + 1;
   const long long cells = (long long)num_boxes * pout * pout;
   const long long seg_cap = ((cells + kBinSegs - 1) / kBinSegs + 255) / 256 * 256 + kListPad;
+  const long long rows = (long long)batch * hf, wgs = rows * kRowParts;
+  const long long plan_ints = 4 + wgs + 2 * rows + 2 * rows * kBinSegs * (seg_cap / kTrip);
   return 2ll * num_boxes * crop * (long long)sizeof(AxisRec) + 256 +
-         (long long)batch * hf * kBinSegs * 4 + 256 +
-         (long long)batch * hf * kBinSegs * seg_cap * (long long)sizeof(RowEntry) + 256 +
-         (long long)kRowParts * batch * hf * wf * depth * 4;
+         rows * kBinSegs * 4 + 256 +
+         rows * kBinSegs * seg_cap * (long long)sizeof(RowEntry) + 256 +
+         plan_ints * 4 + 256 +
+         (wgs + rows) * wf * depth * 4;          // one partial row per (workgroup, row) pair
 }
 
 // Channel chunk of the strip kernel = its workgroup size: the largest of 256 / 192 / 128 that
@@ -908,8 +1048,10 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 16 == 0);
   C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0 && pool_s > 0);
   if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) ||
-      strip_chunk(depth, wf) == 0 || wf < 2 || (long long)num_boxes * ((crop - pool_k) / pool_s + 1) * ((crop - pool_k) / pool_s + 1) *
-                        depth >= (1ll << 31))
+      strip_chunk(depth, wf) == 0 || wf < 2 ||
+      // (the strip kernel addresses dpooled through a raw buffer descriptor: 32-bit byte offsets)
+      (long long)num_boxes * ((crop - pool_k) / pool_s + 1) * ((crop - pool_k) / pool_s + 1) * depth *
+              (long long)sizeof(TG) >= (1ll << 31))
     return C2D_ERR_UNSUPPORTED;
   if (num_boxes == 0) return C2D_OK;
   if (workspace_bytes <
@@ -926,30 +1068,37 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   off = (off + (size_t)batch * hf * kBinSegs * 4 + 255) / 256 * 256;
   RowEntry* lists = (RowEntry*)(w + off);
   off = (off + (size_t)batch * hf * kBinSegs * cap * sizeof(RowEntry) + 255) / 256 * 256;
+  const int R = batch * hf, W = R * kRowParts;
+  if ((long long)R * kBinSegs * cap >= (1ll << 31) || (3ll * R + 1) * 4 > 64 * 1024)
+    return C2D_ERR_UNSUPPORTED;
+  int32_t* plan = (int32_t*)(w + off);
+  off = (off + (4 + (size_t)W + 2 * (size_t)R + 2 * (size_t)R * kBinSegs * (cap / kTrip)) * 4 + 255) /
+        256 * 256;
   float* parts = (float*)(w + off);
   hipStream_t st = (hipStream_t)stream;
-  if (phase != 2)
-  hipLaunchKernelGGL(roi_axes_kernel, dim3(c2d_ceil_div((long long)num_boxes * crop, 256)),
-                     dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
   const int chunk = strip_chunk(depth, wf);
-  if (phase != 2)
-  hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
-                     box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout, crop,
-                     cap);
+  if (phase != 2) {
+    hipLaunchKernelGGL(roi_axes_kernel, dim3(c2d_ceil_div((long long)num_boxes * crop, 256)),
+                       dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
+    hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
+                       box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout, crop,
+                       cap);
+    hipLaunchKernelGGL(roi_plan_strips_kernel, dim3(1), dim3(256), (size_t)(3 * R + 1) * 4, st,
+                       counts, plan, R, W, cap);
+  }
   if (phase == 1) return c2d_launch_status();
 #define C2D_STRIP(CHV)                                                                          \
-  hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>),                                          \
-                     dim3(hf, (depth + CHV - 1) / CHV, batch * kRowParts),                      \
+  hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>), dim3(W * ((depth + CHV - 1) / CHV)),      \
                      dim3(CHV), (size_t)CHV * (wf + 1) * sizeof(float), st, dout, argmax, lists, \
-                     counts, parts, batch, hf, wf, depth, pout, cap)
+                     plan, parts, R, W, wf, depth, (long long)num_boxes * pout * pout * depth)
   if (chunk == 256) { C2D_STRIP(256); }
   else if (chunk == 192) { C2D_STRIP(192); }
   else if (chunk == 128) { C2D_STRIP(128); }
   else { C2D_STRIP(64); }
 #undef C2D_STRIP
-  const long long n4 = (long long)batch * hf * wf * depth / 4;
-  hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, st,
-                     (const float4*)parts, (float4*)dfeat, n4);
+  const int row4 = wf * depth / 4;
+  hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3(R, (row4 + 1023) / 1024), dim3(256), 0, st,
+                     (const float4*)parts, plan, (float4*)dfeat, W, R, row4);
   return c2d_launch_status();
 }
 
