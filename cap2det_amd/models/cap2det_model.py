@@ -519,9 +519,9 @@ class Model(ModelBase):
       # whoever hands the heads' gradients on (the data-parallel reducers' hooks) does so behind them
       user_after2, user_block = after_second_stage, after_block
 
-      def after_second_stage():
-        torch.cuda.current_stream().wait_event(heads_done)
-        if user_after2 is not None:
+      if user_after2 is not None:
+        def after_second_stage():
+          torch.cuda.current_stream().wait_event(heads_done)
           user_after2()
 
       if user_block is not None:
@@ -529,6 +529,8 @@ class Model(ModelBase):
           torch.cuda.current_stream().wait_event(heads_done)
           user_block(i)
     self.engine.backward(bufs["dfeatures"], d, 0, ctx["fctx"], after_second_stage, after_block)
+    if heads_done is not None:
+      torch.cuda.current_stream().wait_event(heads_done)
 
   def build_evaluation(self, predictions, examples=None, **kwargs):
     """models/cap2det_model.py:332-343 returns {} in the reference."""

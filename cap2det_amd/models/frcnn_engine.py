@@ -80,6 +80,7 @@ GROUP_MAX_ROWS = 16384   # block inputs up to this many rows use grouped launche
 # block inputs from this many rows on take ONE grouped filter-gradient launch for their 1x1 entry
 # convolutions (c2d_conv1x1_wgrad_multi); below, the row splits of one output already fill the chip
 WGRAD_MULTI_MIN_ROWS = int(os.environ.get("C2D_WGRAD_MULTI_MIN_ROWS", "8192"))
+DC_SLOTS = max(2, int(os.environ.get("C2D_DC_SLOTS", "2")))   # dC scratch buffers per stream (see _prepare_backward)
 
 
 def _out_hw(h, w, stride):
@@ -591,11 +592,15 @@ class Net(object):
     # dC scratch.  Filter gradients on a side stream (see _conv_bwd): a second scratch so that the
     # next layer's BN/ReLU backward does not overwrite a dC the side stream is still reading.  A
     # second SET for the branches of an Inception block that run on the branch stream (self.alt).
+    # DC_SLOTS of them per set, taken in turn: the stream that runs the input gradients waits for the
+    # side stream only when it comes back to a slot, so it may run DC_SLOTS - 1 filter gradients
+    # ahead and reach the ROI-crop backward while the side stream still works.
     def scratch_set():
+      extra = DC_SLOTS - 1 if self.side is not None else 0
       return dict(dc=torch.empty(plan["scratch_elems"], device=dev, dtype=self.dtype),
-                  dc_alt=(torch.empty(plan["scratch_elems"], device=dev, dtype=self.dtype)
-                          if self.side is not None else None),
-                  events=[None, None], slot=0)
+                  dc_alt=([torch.empty(plan["scratch_elems"], device=dev, dtype=self.dtype)
+                           for _ in range(extra)] if extra else None),
+                  events=[None] * (extra + 1), slot=0)
     plan["scr"] = scratch_set()
     plan["scr_b"] = scratch_set() if self.alt is not None else None
     plan["on_alt"] = False
@@ -786,8 +791,19 @@ class Net(object):
     self._prepare_backward(plan, first_idx)
     return plan["steps"][-1]["gy"]
 
-  def backward(self, plan, x_in, first_idx=0, dx_in=None, after_step=None):
-    """Backpropagates plan['steps'][-1]['gy'] down to steps[first_idx]; gradients of the
+  def join(self, plan):
+    """The calling stream waits for the filter gradients still running on the side stream."""
+    if plan.get("side_pending"):
+      torch.cuda.current_stream().wait_stream(self.side)      # join: gradients complete below here
+      plan["side_pending"] = False
+      plan["scr"]["events"] = [None] * len(plan["scr"]["events"])
+      if plan["scr_b"] is not None:
+        plan["scr_b"]["events"] = [None] * len(plan["scr_b"]["events"])
+
+  def backward(self, plan, x_in, first_idx=0, dx_in=None, after_step=None, join=True):
+    """join=False: the caller calls join(plan) itself, later (FrcnnEngine.backward: behind the
+    ROI-crop backward and the first stage's backward pass, which do not need these gradients).
+    Backpropagates plan['steps'][-1]['gy'] down to steps[first_idx]; gradients of the
     variables are ACCUMULATED into the store's flat gradient buffer (zeroed once per step by
     the trainer).  dx_in: Ref receiving d(loss)/d(net input) (overwritten) or None.
     after_step(i): called when every kernel that writes the gradients of top-level step i's
@@ -817,12 +833,8 @@ class Net(object):
             after_step(i)
         else:
           after_step(i)
-    if plan.get("side_pending"):
-      torch.cuda.current_stream().wait_stream(self.side)      # join: gradients complete below here
-      plan["side_pending"] = False
-      plan["scr"]["events"] = [None, None]
-      if plan["scr_b"] is not None:
-        plan["scr_b"]["events"] = [None, None]
+    if join:
+      self.join(plan)
     if plan["bn_num"] and after_step is None:
       ops.bn_partials_reduce_batched(plan["bn_desc"], plan["bn_num"], plan["bn_chunks"],
                                      plan["bn_ws"], self.store.grads)
@@ -858,8 +870,8 @@ class Net(object):
       buf = scr["dc"]
       if side is not None:
         slot = scr["slot"]
-        scr["slot"] ^= 1
-        buf = scr["dc"] if slot == 0 else scr["dc_alt"]
+        scr["slot"] = (slot + 1) % len(scr["events"])
+        buf = scr["dc"] if slot == 0 else scr["dc_alt"][slot - 1]
         if scr["events"][slot] is not None:       # the side stream's last reader of this scratch
           torch.cuda.current_stream().wait_event(scr["events"][slot])
           scr["events"][slot] = None
@@ -1560,7 +1572,12 @@ class FrcnnEngine(object):
         bufs["dpooled"] = Ref(torch.empty_like(bufs["pooled"].t), bufs["pooled"].ld, 0,
                               bufs["pooled"].c)
       dpooled = bufs["dpooled"]
-    self.second.backward(plan2, bufs["pooled"], 0, dpooled, after_step=after_block)
+    # The second stage's filter gradients (side stream) are joined at the END of this function when
+    # nobody asks for them earlier: the ROI-crop backward and Mixed_4e's backward pass — 0.3 ms in
+    # which the chip is half empty — then run beside the filter gradients the side stream still owes.
+    lazy = (after_second_stage is None and need_first and self.second.side is not None and
+            os.environ.get("C2D_LAZY_JOIN", "1") != "0")
+    self.second.backward(plan2, bufs["pooled"], 0, dpooled, after_step=after_block, join=not lazy)
     if after_second_stage is not None:
       after_second_stage()
     if need_first:
@@ -1607,3 +1624,5 @@ class FrcnnEngine(object):
       if g32 is not gfeat.t:
         ops.cast_bf16(g32, gfeat.t)
       self.first.backward(plan1, bufs["stem_in"], self.first_trainable_idx, None)
+    if lazy:
+      self.second.join(plan2)
