@@ -96,6 +96,11 @@ def _match_labels(class_texts, table, num_classes, device):
 class LabelExtractor(abc.ABC):
   """Label extractor (models/label_extractor.py:71-93)."""
 
+  # Extractors whose device work is worth a stream of its own beside the detector's forward pass
+  # (the embedding / text-classifier forms: 0.2-0.3 ms of launches); the string-matching forms are
+  # one 3-us kernel, for which the two cross-stream events cost more than they hide.
+  overlaps_forward = False
+
   def __init__(self, options, device="cuda:0"):
     self._options = options
     self._classes = None
@@ -167,6 +172,8 @@ class ExtendMatchExtractor(LabelExtractor):
 class _OpenVocabularyExtractor(LabelExtractor):
   """Shared loading of label file + open vocabulary + GloVe table
   (models/label_extractor.py:217-230,338-351)."""
+
+  overlaps_forward = True
 
   def __init__(self, options, device="cuda:0"):
     super(_OpenVocabularyExtractor, self).__init__(options, device)

@@ -268,7 +268,9 @@ class Trainer(object):
     # instead of between its forward pass and its losses (0.2-0.3 ms per step for the text-
     # classifier extractors); build_loss waits for the event.
     stream = getattr(model.engine, "prefetch_stream", None)
-    if kwargs.get("labels") is None and stream is not None and os.environ.get("C2D_LABELS_SIDE_STREAM", "1") != "0":
+    want = os.environ.get("C2D_LABELS_SIDE_STREAM")     # "1" / "0" force either form
+    if (kwargs.get("labels") is None and stream is not None and
+        (want == "1" or (want != "0" and getattr(model.label_extractor, "overlaps_forward", False)))):
       main = torch.cuda.current_stream()
       fork = torch.cuda.Event(); fork.record()
       stream.wait_event(fork)
