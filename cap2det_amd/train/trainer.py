@@ -348,6 +348,20 @@ class Trainer(object):
         ops.optimizer_step(kind, v[off:end], g[off:end], slots, lr, p, flags, l1, l2, m, scale,
                            cols, 0 if cols is None else cols.numel(), lr_dev)
 
+  @staticmethod
+  def _dp_buckets():
+    """C2D_DP_BUCKETS=blocks|two; default: one exchange per second-stage block over RCCL (device-
+    side collectives queued behind the filter gradients), the two-bucket form over gloo, whose
+    collectives are staged through the host (the same-device rehearsal of bench.py --gpus N on a
+    one-GPU box: 46 ms against 200-990 ms per step with four host-staged collectives)."""
+    want = os.environ.get("C2D_DP_BUCKETS")
+    if want in ("blocks", "two"):
+      return want
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+      return "two"
+    return "blocks"
+
   def train_step(self, examples, prefetch=None, **kwargs):
     """One synchronous step; returns {loss name: 0-d device tensor} (+ 'total_loss',
     'regularization_loss').  No host synchronisation happens inside.  `prefetch`: the NEXT
@@ -363,7 +377,7 @@ class Trainer(object):
     kwargs["prefetch"] = prefetch
     store = self.model.store
     lo, hi = self.bucket
-    if os.environ.get("C2D_DP_BUCKETS", "blocks") == "blocks" and len(self._block_cuts) > 2:
+    if self._dp_buckets() == "blocks" and len(self._block_cuts) > 2:
       # one asynchronous all-reduce per second-stage block, launched as the backward pass leaves
       # the block (heads ride with the last block), the Mixed_4e prefix at the end
       reducer = data_parallel.BlockReducer(store.grads[lo:hi], self._block_cuts)

@@ -35,15 +35,20 @@ def _run(cmd, env):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("dtype,launch,size", [("fp32", "eager", "small"), ("fp32", "graph", "small"),
-                                               ("bf16", "eager", "small"), ("bf16", "graph", "small"),
-                                               ("fp32", "eager", "full"), ("bf16", "eager", "full")])
-def test_two_ranks_equal_the_batch_of_two_step(tmp_path, dtype, launch, size):
+@pytest.mark.parametrize("dtype,launch,size,buckets", [
+    ("fp32", "eager", "small", "blocks"), ("fp32", "graph", "small", "blocks"),
+    ("bf16", "eager", "small", "blocks"), ("bf16", "graph", "small", "blocks"),
+    ("fp32", "eager", "full", "blocks"), ("bf16", "eager", "full", "blocks"),
+    ("fp32", "eager", "small", "two")])
+def test_two_ranks_equal_the_batch_of_two_step(tmp_path, dtype, launch, size, buckets):
   """size "full": each rank steps on the benchmark's own shape (depth 1.0, 500x500, 2000 proposals: the
   per-block collectives issued from the filter-gradient stream under the real backward pass, the
-  one-pixel blocks / heavy-first order / branch streams of the full-size launch plan)."""
+  one-pixel blocks / heavy-first order / branch streams of the full-size launch plan).
+  buckets: C2D_DP_BUCKETS — "blocks" is the RCCL default (per-block exchange; forced here, over
+  gloo), "two" the two-bucket form that a gloo group takes by default (Trainer._dp_buckets)."""
   prefix = str(tmp_path / "dp2")
-  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+             C2D_DP_BUCKETS=buckets)
   for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "C2D_FORCE_ALLREDUCE"):
     env.pop(k, None)
   out = _run([sys.executable, WORKER, prefix, dtype, launch, "single", size], env)
