@@ -641,11 +641,27 @@ struct StripPlan {
 // (entry index of the trip's first entry, row)
 
 // One workgroup; R = batch * hf rows, W strip workgroups per channel chunk.
+// Slots in closed form: the (workgroup, row) pairs are the intervals the CUT POINTS — the first
+// trip of every non-empty workgroup and of every non-empty row — divide the trip sequence into, so
+// the pair that starts at trip p has slot |{cut points < p}| = starts(p) + rows(p) - both(p):
+// workgroup starts below p (workgroup w starts at floor(w T / W); all W are non-empty when
+// T >= W, else exactly one starts at every trip), non-empty rows that begin below p, and the
+// points that are both.  Every thread evaluates that for its workgroups / rows; the only serial
+// part is a prefix scan over the R rows.
+__device__ __forceinline__ int strip_starts_below(int p, int T, int W) {   // workgroup starts < p
+  if (p <= 0) return 0;
+  if (T < W) return min(p, T);
+  const long long c = ((long long)p * W + T - 1) / T;                       // ceil(p W / T)
+  return (int)(c < W ? c : W);
+}
+
 __global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __restrict__ counts,
                                                               int32_t* __restrict__ plan, int R,
                                                               int W, int cap) {
-  extern __shared__ int rowtrip[];                  // [R + 1] first trip of every row | [2 R] slots
-  int* rs = rowtrip + R + 1;
+  extern __shared__ int rowtrip[];        // [R + 1] first trip of every row | nzb | both | flag
+  int* nzb = rowtrip + R + 1;             // [R + 1] non-empty rows in front of row y
+  int* both = nzb + R + 1;                // [R + 1] of those: rows whose first trip is a workgroup's too
+  int* flag = both + R + 1;               // [R]     row y begins where a workgroup begins
   StripPlan* head = reinterpret_cast<StripPlan*>(plan);
   int32_t* wslot = plan + 4;
   int32_t* rowslot = wslot + W;
@@ -654,7 +670,6 @@ __global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __r
     int t = 0;
     for (int sgm = 0; sgm < kBinSegs; ++sgm) t += (counts[y * kBinSegs + sgm] + kTrip - 1) / kTrip;
     rowtrip[y + 1] = t;
-    rs[2 * y] = rs[2 * y + 1] = 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -663,6 +678,33 @@ __global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __r
   }
   __syncthreads();
   const int T = rowtrip[R];
+  for (int y = threadIdx.x; y < R; y += blockDim.x) {
+    const int c = rowtrip[y];
+    int f = 0;
+    if (rowtrip[y + 1] > c) {
+      if (T < W) {
+        f = 1;
+      } else {
+        const long long w0 = ((long long)c * W + T - 1) / T;        // first workgroup at or behind c
+        f = w0 < W && (int)(w0 * T / W) == c;
+      }
+    }
+    flag[y] = f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0, m = 0;
+    for (int y = 0; y < R; ++y) {
+      nzb[y] = n;
+      both[y] = m;
+      if (rowtrip[y + 1] > rowtrip[y]) { ++n; m += flag[y]; }
+    }
+    nzb[R] = n;
+    both[R] = m;
+    head->trips = T;
+    head->slots = strip_starts_below(T, T, W) + n - m;
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < R * kBinSegs; i += blockDim.x) {
     const int y = i / kBinSegs, sgm = i - y * kBinSegs;
     int pos = rowtrip[y];
@@ -673,24 +715,31 @@ __global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __r
       trip[2 * (pos + j) + 1] = y;
     }
   }
-  if (threadIdx.x == 0) {
-    int slot = 0, y = 0;
-    for (int w = 0; w < W; ++w) {
-      const int tb = (int)((long long)w * T / W), te = (int)((long long)(w + 1) * T / W);
-      wslot[w] = slot;
-      if (te == tb) continue;
-      while (rowtrip[y + 1] <= tb) ++y;             // (skips empty rows)
-      for (int yy = y; yy < R && rowtrip[yy] < te; ++yy) {
-        if (rowtrip[yy + 1] == rowtrip[yy]) continue;
-        if (rs[2 * yy + 1] == 0) rs[2 * yy] = slot;   // the row's first (workgroup, row) pair
-        rs[2 * yy + 1] = ++slot;
+  for (int w = threadIdx.x; w < W; w += blockDim.x) {
+    const int tb = (int)((long long)w * T / W), te = (int)((long long)(w + 1) * T / W);
+    int slot = 0;
+    if (te > tb) {
+      int lo = 0, hi = R - 1;                         // the row that holds trip tb
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowtrip[mid] <= tb) lo = mid; else hi = mid - 1;
       }
+      // (rows of no trips share their first trip with the row behind them: take the last)
+      const int y = lo;
+      const int inside = rowtrip[y] < tb ? 1 : 0;
+      slot = (T < W ? tb : w) + nzb[y] + inside - (both[y] + (inside ? flag[y] : 0));
     }
-    head->trips = T;
-    head->slots = slot;
+    wslot[w] = slot;
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * R; i += blockDim.x) rowslot[i] = rs[i];
+  for (int y = threadIdx.x; y < R; y += blockDim.x) {
+    int sb = 0, se = 0;
+    if (rowtrip[y + 1] > rowtrip[y]) {
+      sb = strip_starts_below(rowtrip[y], T, W) + nzb[y] - both[y];
+      se = sb + 1 + strip_starts_below(rowtrip[y + 1], T, W) - strip_starts_below(rowtrip[y] + 1, T, W);
+    }
+    rowslot[2 * y] = sb;
+    rowslot[2 * y + 1] = se;
+  }
 }
 
 // 1-D grid of W * chunks workgroups (w fastest), block = CHUNK threads (lane <-> channel c0 + tid).
@@ -809,25 +858,34 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
   flush(row, slot);
 }
 
-// dfeat[row] += its partial rows, in slot order (fixed), float4 per lane.  grid (R, x-blocks).
+// dfeat[row] += its partial rows, in slot order (fixed), one float4 per lane.  grid (x-blocks, R).
 __global__ __launch_bounds__(256) void roi_bwd_sum_parts_kernel(const float4* __restrict__ parts,
                                                                 const int32_t* __restrict__ plan,
                                                                 float4* __restrict__ dfeat, int W,
                                                                 int R, int row4) {
-  const int y = blockIdx.x;
+  const int y = blockIdx.y;
   const int32_t* rowslot = plan + 4 + W;
   const int sb = rowslot[2 * y], se = rowslot[2 * y + 1];
-  if (sb == se) return;
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < row4; i += gridDim.y * blockDim.x) {
-    float4 s = parts[(size_t)sb * row4 + i];
-    for (int q = sb + 1; q < se; ++q) {
-      const float4 v = parts[(size_t)q * row4 + i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    float4 d = dfeat[(size_t)y * row4 + i];
-    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
-    dfeat[(size_t)y * row4 + i] = d;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sb == se || i >= row4) return;
+  const float4* p = parts + (size_t)sb * row4 + i;
+  float4 s = p[0];
+  int q = sb + 1;
+  for (; q + 4 <= se; q += 4) {            // four loads in flight, summed in slot order
+    const float4 v0 = parts[(size_t)q * row4 + i], v1 = parts[(size_t)(q + 1) * row4 + i];
+    const float4 v2 = parts[(size_t)(q + 2) * row4 + i], v3 = parts[(size_t)(q + 3) * row4 + i];
+    s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+    s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+    s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+    s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
   }
+  for (; q < se; ++q) {
+    const float4 v = parts[(size_t)q * row4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4 d = dfeat[(size_t)y * row4 + i];
+  d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+  dfeat[(size_t)y * row4 + i] = d;
 }
 
 template <typename TO>
@@ -1069,7 +1127,7 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   RowEntry* lists = (RowEntry*)(w + off);
   off = (off + (size_t)batch * hf * kBinSegs * cap * sizeof(RowEntry) + 255) / 256 * 256;
   const int R = batch * hf, W = R * kRowParts;
-  if ((long long)R * kBinSegs * cap >= (1ll << 31) || (3ll * R + 1) * 4 > 64 * 1024)
+  if ((long long)R * kBinSegs * cap >= (1ll << 31) || (4ll * R + 3) * 4 > 64 * 1024)
     return C2D_ERR_UNSUPPORTED;
   int32_t* plan = (int32_t*)(w + off);
   off = (off + (4 + (size_t)W + 2 * (size_t)R + 2 * (size_t)R * kBinSegs * (cap / kTrip)) * 4 + 255) /
@@ -1083,7 +1141,7 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
     hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
                        box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout, crop,
                        cap);
-    hipLaunchKernelGGL(roi_plan_strips_kernel, dim3(1), dim3(256), (size_t)(3 * R + 1) * 4, st,
+    hipLaunchKernelGGL(roi_plan_strips_kernel, dim3(1), dim3(256), (size_t)(4 * R + 3) * 4, st,
                        counts, plan, R, W, cap);
   }
   if (phase == 1) return c2d_launch_status();
@@ -1097,7 +1155,7 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   else { C2D_STRIP(64); }
 #undef C2D_STRIP
   const int row4 = wf * depth / 4;
-  hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3(R, (row4 + 1023) / 1024), dim3(256), 0, st,
+  hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3((row4 + 255) / 256, R), dim3(256), 0, st,
                      (const float4*)parts, plan, (float4*)dfeat, W, R, row4);
   return c2d_launch_status();
 }
