@@ -366,16 +366,26 @@ void igemm_ring_kernel(IgemmArgs a) {
       }
     } else {
       frag_t bf[NT][KS];
+      if (!STEADY && (a.dbg & 16)) {          // (ablation: no B fragment reads)
+  #pragma unroll
+        for (int st = 0; st < KS; ++st)
+  #pragma unroll
+          for (int j = 0; j < NT; ++j)
+            bf[j][st] = __builtin_bit_cast(frag_t, f32x4{(float)it, (float)st, (float)j, 1.0f});
+      } else {
   #pragma unroll
       for (int st = 0; st < KS; ++st)
   #pragma unroll
         for (int j = 0; j < NT; ++j)
           bf[j][st] = *reinterpret_cast<const frag_t*>(
               bufb + brow_b[j] + (((ES == 2 ? 2 * st + lh : lh * KS + st) ^ bsw[j]) << 4));
+      }
       if (more) {
+        if (STEADY || !(a.dbg & 2)) {
   #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i)
-          if (i + 1 < B_LOADS || b_last) { C2D_PIECE_B(slot_in, i) }
+          for (int i = 0; i < B_LOADS; ++i)
+            if (i + 1 < B_LOADS || b_last) { C2D_PIECE_B(slot_in, i) }
+        }
   #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
         C2D_NOTE_TV(slot_in)
