@@ -98,6 +98,48 @@ def test_roi_crop_pool_bwd_workspace_form_is_exact_and_deterministic(ops):
 
 
 
+@pytest.mark.parametrize("kind,hf,wf,d,n", [("one", 32, 32, 64, 1), ("few", 32, 32, 64, 3),
+                                            ("band", 20, 17, 48, 40), ("one_image", 16, 16, 32, 50),
+                                            ("padded", 12, 12, 32, 9)])
+def test_roi_crop_pool_bwd_equal_shares_plan_edge_cases(ops, kind, hf, wf, d, n):
+  """The strip plan (roi_plan_strips_kernel: equal shares of ONE trip sequence over all row lists,
+  slots in closed form) on box sets that leave rows without a list entry, fewer trips than
+  workgroups, one image of the batch untouched, or nothing but zero-padded boxes
+  (readers/cap2det_reader.py:237,252: every tap of a padded box is pixel (0, 0))."""
+  rng = np.random.default_rng(len(kind) * 100 + n)
+  feat = np.maximum(rng.standard_normal((2, hf, wf, d)), 0).astype(np.float32)
+  if kind == "band":          # every box inside rows 5..8 of the map: most rows have no entry
+    y0 = rng.uniform(5.0, 6.5, n) / (hf - 1)
+    y1 = rng.uniform(6.5, 8.0, n) / (hf - 1)
+    x0 = rng.uniform(0.0, 0.5, n)
+    x1 = rng.uniform(0.5, 1.0, n)
+    boxes = np.stack([y0, x0, y1, x1], 1).astype(np.float32)
+  elif kind == "padded":
+    boxes = np.zeros((n, 4), np.float32)
+  else:
+    c = rng.uniform(0.2, 0.8, (n, 2))
+    sz = rng.uniform(0.05, 0.4, (n, 2))
+    boxes = np.concatenate([c - sz / 2, c + sz / 2], 1).astype(np.float32)
+  ind = (np.ones(n) if kind == "one_image" else rng.integers(0, 2, n)).astype(np.int32)
+  crop = ref_ops.crop_and_resize(feat, boxes, ind, 14)
+  pooled, arg = ref_ops.max_pool(crop, 2, 2, "VALID")
+  dout = rng.standard_normal(pooled.shape).astype(np.float32)
+  dcrop = ref_ops.max_pool_backward(crop.shape, arg, dout, 2, 2, "VALID")
+  want = ref_ops.crop_and_resize_grad_image(dcrop.astype(np.float64), boxes, ind, feat.shape)
+  ws = torch.empty(ops.roi_crop_pool_bwd_workspace_bytes(2, hf, wf, d, n, 14, 2, 2), dtype=torch.uint8,
+                   device=DEV)
+  outs = []
+  for _ in range(2):
+    dfeat = torch.full(feat.shape, -0.5, device=DEV)
+    ops.roi_crop_pool_bwd_ws(_t(dout), _t(arg), _t(boxes), _t(ind), dfeat, 14, 2, 2, ws)
+    outs.append(_n(dfeat))
+  scale = max(np.abs(want).max(), 1.0)
+  assert np.abs(outs[0] + 0.5 - want).max() <= 1e-5 * scale
+  np.testing.assert_array_equal(outs[0], outs[1])
+  if kind == "one_image":
+    np.testing.assert_array_equal(outs[0][0], np.full(feat.shape[1:], -0.5, np.float32))
+
+
 @pytest.mark.parametrize("hf,wf,d,n,chunk", [(63, 84, 192, 300, 192),    # 1000x1333 image: 192-channel strips
                                              (75, 100, 576, 100, 64),    # 1200x1600: 64-channel strips, 9 chunks
                                              (75, 100, 80, 90, 64),      # ragged last chunk
