@@ -620,6 +620,10 @@ __device__ __forceinline__ float strip_value(unsigned short raw) {      // bf16 
   return __uint_as_float((unsigned)raw << 16);
 }
 
+#ifndef C2D_STRIP_DBG
+#define C2D_STRIP_DBG 0     // ablation builds of the strip kernel (-DC2D_STRIP_DBG=1: no vector loads, 2: no LDS updates)
+#endif
+
 constexpr int kRowParts = kBinSegs;   // strip workgroups (per channel chunk) = rows * kRowParts
 constexpr int kTrip = 16;             // list entries per trip of the strip kernel (= kListPad)
 
@@ -783,10 +787,7 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
   // lx = lx0 + sx * dlx, and the packed column offsets are off0 ^ (xoff & -sx).  16 vector
   // instructions per entry instead of 22 (the kernel is issue-bound: DESIGN.md section 3).
   constexpr int U = 8;
-#ifndef C2D_STRIP_DBG
-#define C2D_STRIP_DBG 0     // ablation builds (-DC2D_STRIP_DBG=1: no vector loads, 2: no LDS updates)
-#endif
-  float dbg_acc = 0.0f;
+  float dbg_acc = 0.0f;         // (ablation builds only)
   using Raw = typename std::conditional<sizeof(TG) == 2, unsigned short, unsigned>::type;
   Raw g[U], gn[U];              // raw loaded values: nothing consumes them before their trip
   unsigned k[U], kn[U];
@@ -825,18 +826,17 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
     }                                                                                          \
   }
   int row = __builtin_amdgcn_readfirstlane(trip[2 * tb + 1]);
-  auto flush = [&](int r, int sl) {        // the lane's column of partial row `sl` (row r), then zeros
+  auto flush = [&](int sl) {               // the lane's column of partial row `sl`
     float* drow = parts + ((size_t)sl * wf) * depth + c0 + tid;
     if (on)
       for (int x = 0; x < wf; ++x) drow[(size_t)x * depth] = acc[x * CHUNK + tid];
-    (void)r;
   };
   int i0 = __builtin_amdgcn_readfirstlane(trip[2 * tb]);
   C2D_STRIP_FETCH(g, k, i0);
   for (int t = tb; t < te; ++t) {                  // fixed order: the sum is reproducible
     const int r = __builtin_amdgcn_readfirstlane(trip[2 * t + 1]);
     if (r != row) {
-      flush(row, slot);
+      flush(slot);
       for (int x = 0; x <= wf; ++x) acc[x * CHUNK + tid] = 0.0f;
       ++slot;
       row = r;
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
 #undef C2D_STRIP_ADD
 #undef C2D_STRIP_FETCH
   if (C2D_STRIP_DBG & 2) acc[tid] = dbg_acc;
-  flush(row, slot);
+  flush(slot);
 }
 
 // dfeat[row] += its partial rows, in slot order (fixed), one float4 per lane.  grid (x-blocks, R).
