@@ -305,6 +305,10 @@ def parse_args(argv=None):
                        "caption -> label branch inside the timed step")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-kernel-timing", action="store_true")
+  ap.add_argument("--host-inputs", action="store_true",
+                  help="secondary measurement (DESIGN.md section 7): every step's image / proposals / counts "
+                       "start in pinned HOST memory and are uploaded inside the timed region (the "
+                       "headline keeps its inputs resident in HBM)")
   ap.add_argument("--per-call", action="store_true",
                   help="also print one line per timed conv / ROI-crop call (stderr)")
   ap.add_argument("--graph", action="store_true", help="hipGraph replay of the step on one stream (measured, profiles/r03_bench_c{1,2}_graph.json: "
@@ -499,6 +503,25 @@ def main(argv=None):
   marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   t0 = time.perf_counter()
   marks[0].record()
+  host = None
+  if args.host_inputs:
+    tensor_keys = [k for k, v in batch.items() if isinstance(v, torch.Tensor)]
+    host = {k: batch[k].cpu().pin_memory() for k in tensor_keys}
+
+    copy_stream = torch.cuda.Stream(device=device)
+
+    def upload():
+      # on a stream of its own (the copy engine works beside the kernels of the step in flight);
+      # the compute stream waits for it — by the time it gets there the copy is long done
+      fresh = dict(batch)
+      with torch.cuda.stream(copy_stream):
+        for k in tensor_keys:
+          fresh[k] = host[k].to(device, non_blocking=True)
+      torch.cuda.current_stream().wait_stream(copy_stream)
+      for k in tensor_keys:
+        fresh[k].record_stream(torch.cuda.current_stream())
+      return fresh
+    cur_batch = upload()
   for i in range(args.steps):
     instrument = (not args.no_kernel_timing) and i == args.steps - 1
     if instrument:
@@ -514,7 +537,15 @@ def main(argv=None):
       trainer.model.engine.invalidate_prefetch()          # this step computes its own first stage
     nxt = batch if (not instrument and i + 1 < args.steps and
                     not (i + 2 == args.steps and not args.no_kernel_timing)) else None
-    losses = trainer.train_step(batch, dropout_seed=args.warmup + i, prefetch=nxt)
+    if host is not None:
+      # the next step's inputs cross PCIe while this step is being queued (an input pipeline's
+      # double buffer); the look-ahead takes the freshly uploaded image
+      nxt_up = upload() if i + 1 < args.steps else None
+      losses = trainer.train_step(cur_batch, dropout_seed=args.warmup + i,
+                                  prefetch=nxt_up if nxt is not None else None)
+      cur_batch = nxt_up
+    else:
+      losses = trainer.train_step(batch, dropout_seed=args.warmup + i, prefetch=nxt)
     if instrument:
       timer.enabled = False
       trainer.use_graph = args.graph
@@ -563,7 +594,8 @@ def main(argv=None):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.dtype == "fp32" else "bf16 storage (convolution towers behind the stem: first stage, ROI crop output, second stage), f32 accumulate",
-        "data": "synthetic",
+        "data": "synthetic" + (" (inputs uploaded from pinned host memory inside every timed step)"
+                               if args.host_inputs else ""),
         "config": {"workload": "%s%s: Inception-V2, %d classes, label extractor %s inside the step, "
                                "OICR x3, Mixed_4e + second stage + heads trainable, %d image(s) %dx%dx3 "
                                "per GPU, %d proposals, %s, Adagrad; fwd+loss+bwd+optimizer%s"
