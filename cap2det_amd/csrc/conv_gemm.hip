@@ -2003,7 +2003,13 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
   static const bool keep_small = tune && getenv("C2D_IGEMM_KEEP_SMALL") != nullptr;
   const bool deep_1x1 = a.g.kh * a.g.kw == 1 && a.M >= 1024 &&
                         (long long)a.M * a.N * a.K >= 600000000ll && !keep_small;
-  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= 16384 && !a.fy && !a.mo_n && !deep_1x1) {
+  // (up to 8192 rows: the 10,584-row maps of two 1000-px images — Mixed_4a-e at the reference's
+  //  as-shipped operating point — are better off on the 64x64 LDS tiles: 3.54 -> 3.17 ms per bf16
+  //  step of two images, 9.04 -> 8.78 fp32; the benchmark's 500x500 image keeps its 1024- and
+  //  3969-row layers here and moves Conv2d_2b/2c, 15,625 rows: 3.05 -> 3.02 / 10.83 -> 10.84 ms.
+  //  C2D_TUNE=1 C2D_IGEMM_SMALL_MAX_M=<rows>)
+  static const int small_max_m = (tune && getenv("C2D_IGEMM_SMALL_MAX_M")) ? atoi(getenv("C2D_IGEMM_SMALL_MAX_M")) : 8192;
+  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= small_max_m && !a.fy && !a.mo_n && !deep_1x1) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);

@@ -1126,7 +1126,16 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   off = (off + (size_t)batch * hf * kBinSegs * 4 + 255) / 256 * 256;
   RowEntry* lists = (RowEntry*)(w + off);
   off = (off + (size_t)batch * hf * kBinSegs * cap * sizeof(RowEntry) + 255) / 256 * 256;
-  const int R = batch * hf, W = R * kRowParts;
+  // strip workgroups per channel chunk: at most the batch * hf * kRowParts the workspace is sized
+  // for, and no more than give every workgroup ~16 trips of the expected ~3 list entries per
+  // cell (a workgroup zeroes and writes out a whole partial row of wf x chunk floats whatever its
+  // share: on the 63 x 84 maps of two 1000-px images with 500 boxes each, 2016 workgroups of 4
+  // trips wrote 414 MB of partial rows: ~570 of 14 take the bf16 step of that shape from 3.74
+  // to 3.54 ms, the fp32 step from 9.5 to 9.0)
+  const int R = batch * hf;
+  const long long trips_est = (long long)num_boxes * pout * pout * 3 / kTrip;
+  int W = (int)(trips_est / 16 < 256 ? 256 : (trips_est / 16 + 7) / 8 * 8);
+  if (W > R * kRowParts) W = R * kRowParts;
   if ((long long)R * kBinSegs * cap >= (1ll << 31) || (4ll * R + 3) * 4 > 64 * 1024)
     return C2D_ERR_UNSUPPORTED;
   int32_t* plan = (int32_t*)(w + off);
