@@ -528,14 +528,24 @@ __device__ __forceinline__ float row_weight(const AxisRec& r, int y) {
   return w;
 }
 
-__device__ __forceinline__ void column_taps(const AxisRec& a, int wf, int chunk, int* off,
-                                            float* lx) {
+// Column taps of one horizontal sample for the strip of columns [c0, c0 + wr): LDS byte offsets
+// (column - c0) * chunk * 4, taps outside the range (and samples outside the map) at the strip's
+// spare column wr.
+__device__ __forceinline__ void column_taps(const AxisRec& a, int wf, int chunk, int c0, int wr,
+                                            int* off, float* lx) {
   int lo = a.lo, hi = a.hi;
   *lx = a.lerp;
-  if (lo < 0) { lo = hi = wf; *lx = 0.0f; }                  // outside: the spare column
+  if (lo < 0) { lo = hi = -1; *lx = 0.0f; }                  // outside the map: the spare column
   else if (hi == lo) { hi = lo + 1 < wf ? lo + 1 : lo - 1; *lx = 0.0f; }
-  if (hi < 0) hi = wf;                                       // (wf == 1)
+  lo = (lo >= c0 && lo < c0 + wr) ? lo - c0 : wr;
+  hi = (hi >= c0 && hi < c0 + wr) ? hi - c0 : wr;
   *off = (lo * chunk * 4) | ((hi * chunk * 4) << 16);
+}
+
+// does either tap of the sample fall into the columns [c0, c0 + wr)?
+__device__ __forceinline__ bool taps_in_range(const AxisRec& a, int c0, int wr) {
+  if (a.lo < 0) return false;
+  return (a.lo >= c0 && a.lo < c0 + wr) || (a.hi >= c0 && a.hi < c0 + wr);
 }
 
 // grid (hf, kBinSegs, batch): stable compaction of the cells of one segment whose 2x2 pooling
@@ -544,15 +554,18 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
     const AxisRec* __restrict__ ys, const AxisRec* __restrict__ xs,
     const int32_t* __restrict__ box_ind, RowEntry* __restrict__ lists,
     int32_t* __restrict__ counts, int num_boxes, int hf, int wf, int depth, int chunk, int ps,
-    int pout, int crop, int cap) {
+    int pout, int crop, int cap, int nr, int wr) {
   __shared__ int wave_cnt[4];
   __shared__ int running;
-  const int y = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
+  // blockIdx.x = y * nr + r: "strip row" (feature row y, column range r = [r wr, r wr + wr))
+  const int y = blockIdx.x / nr, c0 = (blockIdx.x - y * nr) * wr;
+  const int seg = blockIdx.y, b = blockIdx.z;
   const int p2 = pout * pout;
   const int total = num_boxes * p2;
   const int per = ((total + kBinSegs - 1) / kBinSegs + 255) / 256 * 256;
   const int beg = seg * per, end = min(total, beg + per);
-  RowEntry* list = lists + (((size_t)b * hf + y) * kBinSegs + seg) * cap;
+  const size_t lrow = ((size_t)b * hf * nr + blockIdx.x) * kBinSegs + seg;
+  RowEntry* list = lists + lrow * cap;
   if (threadIdx.x == 0) running = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -570,12 +583,14 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
         e.wy0 = row_weight(ys[roi * crop + py * ps], y);
         const float wy1 = row_weight(ys[roi * crop + py * ps + 1], y);
         e.dwy = wy1 - e.wy0;
-        hit = e.wy0 != 0.0f || wy1 != 0.0f;
+        const AxisRec x0 = xs[roi * crop + px * ps], x1 = xs[roi * crop + px * ps + 1];
+        hit = (e.wy0 != 0.0f || wy1 != 0.0f) &&
+              (nr == 1 || taps_in_range(x0, c0, wr) || taps_in_range(x1, c0, wr));
         if (hit) {
           int off1;
           float lx1;
-          column_taps(xs[roi * crop + px * ps], wf, chunk, &e.off0, &e.lx0);
-          column_taps(xs[roi * crop + px * ps + 1], wf, chunk, &off1, &lx1);
+          column_taps(x0, wf, chunk, c0, wr, &e.off0, &e.lx0);
+          column_taps(x1, wf, chunk, c0, wr, &off1, &lx1);
           e.xoff = e.off0 ^ off1;
           e.dlx = lx1 - e.lx0;
         }
@@ -594,11 +609,11 @@ __global__ __launch_bounds__(256) void roi_bin_rows_kernel(
   if (threadIdx.x < kListPad) {          // zero-weight tail (cell 0 is always a valid address)
     RowEntry z;
     z.cell_off = 0; z.wy0 = 0.0f; z.dwy = 0.0f; z.lx0 = 0.0f; z.dlx = 0.0f; z.pad = 0;
-    z.off0 = (wf * chunk * 4) | ((wf * chunk * 4) << 16);
+    z.off0 = (wr * chunk * 4) | ((wr * chunk * 4) << 16);
     z.xoff = 0;
     list[running + threadIdx.x] = z;
   }
-  if (threadIdx.x == 0) counts[((size_t)b * hf + y) * kBinSegs + seg] = running;
+  if (threadIdx.x == 0) counts[lrow] = running;
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t strip_rsrc(const void* p, long long bytes) {
@@ -858,18 +873,22 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
   flush(slot);
 }
 
-// dfeat[row] += its partial rows, in slot order (fixed), one float4 per lane.  grid (x-blocks, R).
+// dfeat[strip row] += its partial rows, in slot order (fixed), one float4 per lane.
+// grid (x-blocks, R): strip row v = (feature row v / nr, columns [(v % nr) wr, ... + wr)).
 __global__ __launch_bounds__(256) void roi_bwd_sum_parts_kernel(const float4* __restrict__ parts,
                                                                 const int32_t* __restrict__ plan,
                                                                 float4* __restrict__ dfeat, int W,
-                                                                int R, int row4) {
-  const int y = blockIdx.y;
+                                                                int R, int nr, int wr, int wf,
+                                                                int depth4) {
+  const int v = blockIdx.y;
   const int32_t* rowslot = plan + 4 + W;
-  const int sb = rowslot[2 * y], se = rowslot[2 * y + 1];
+  const int sb = rowslot[2 * v], se = rowslot[2 * v + 1];
+  const int y = v / nr, c0 = (v - y * nr) * wr;
+  const int row4 = wr * depth4;                               // float4 per partial row
+  const int live4 = min(wr, wf - c0) * depth4;                // (the last range may be narrower)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (sb == se || i >= row4) return;
-  const float4* p = parts + (size_t)sb * row4 + i;
-  float4 s = p[0];
+  if (sb == se || i >= live4) return;
+  float4 s = parts[(size_t)sb * row4 + i];
   int q = sb + 1;
   for (; q + 4 <= se; q += 4) {            // four loads in flight, summed in slot order
     const float4 v0 = parts[(size_t)q * row4 + i], v1 = parts[(size_t)(q + 1) * row4 + i];
@@ -880,12 +899,13 @@ __global__ __launch_bounds__(256) void roi_bwd_sum_parts_kernel(const float4* __
     s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
   }
   for (; q < se; ++q) {
-    const float4 v = parts[(size_t)q * row4 + i];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const float4 u = parts[(size_t)q * row4 + i];
+    s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
   }
-  float4 d = dfeat[(size_t)y * row4 + i];
+  float4* out = dfeat + ((size_t)y * wf + c0) * depth4 + i;
+  float4 d = *out;
   d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
-  dfeat[(size_t)y * row4 + i] = d;
+  *out = d;
 }
 
 template <typename TO>
@@ -1054,6 +1074,25 @@ extern "C" int c2d_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax,
   return c2d_launch_status();
 }
 
+// A feature row wider than 32 columns is walked as nr STRIP ROWS of wr <= 32 columns each (round 4):
+// the LDS strip of a workgroup is (wr + 1) x chunk floats, and how many of them fit a CU is how many
+// waves hide the walk's scalar-load and LDS round trips — 33 columns x 192 channels are 6
+// workgroups (18 waves) per CU on the benchmark's 32-column map, 85 columns were 2 (6 waves) on the
+// 84-column maps of 1000-px images.  A cell is listed in every range one of its taps falls into (its
+// other taps go to that strip's spare column): a few % more list entries.  Measured (tools/
+// bench_crop_bwd.py, accumulation + part sum, fp32 / bf16 gradients, us): 84 x 84 map, 1000 boxes:
+// whole rows 210 / 206, strips of 42: 129 / 124, 28: 114 / 112, 20: 121 / 119, 14: 127 / 127;
+// 63 x 63: 151 / 145 -> 96 / 94 (32 columns); 48 x 48, 2000 boxes: 224 / 202 -> 179 / 156 (24); the
+// 32 x 32 map LOSES with two strips of 16 (144 / 131 -> 165 / 141) and keeps whole rows.
+// C2D_TUNE=1 C2D_ROI_STRIP_COLS=<columns> (0: whole rows).
+static void strip_ranges(int wf, int* nr, int* wr) {
+  static const int target = (getenv("C2D_TUNE") && getenv("C2D_ROI_STRIP_COLS"))
+                                ? atoi(getenv("C2D_ROI_STRIP_COLS")) : 32;
+  const int t = target > 0 ? target : wf;
+  *nr = (wf + t - 1) / t;
+  *wr = (wf + *nr - 1) / *nr;
+}
+
 extern "C" long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, int wf, int depth,
                                                            int num_boxes, int crop, int pool_k,
                                                            int pool_s) {
@@ -1063,21 +1102,21 @@ extern "C" long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, in
   const long long pout = (crop - pool_k) / pool_s + 1;
   const long long cells = (long long)num_boxes * pout * pout;
   const long long seg_cap = ((cells + kBinSegs - 1) / kBinSegs + 255) / 256 * 256 + kListPad;
-  const long long rows = (long long)batch * hf, wgs = rows * kRowParts;
+  int nr, wr;
+  strip_ranges(wf, &nr, &wr);
+  const long long rows = (long long)batch * hf * nr, wgs = rows * kRowParts;
   const long long plan_ints = 4 + wgs + 2 * rows + 2 * rows * kBinSegs * (seg_cap / kTrip);
   return 2ll * num_boxes * crop * (long long)sizeof(AxisRec) + 256 +
          rows * kBinSegs * 4 + 256 +
          rows * kBinSegs * seg_cap * (long long)sizeof(RowEntry) + 256 +
          plan_ints * 4 + 256 +
-         (wgs + rows) * wf * depth * 4;          // one partial row per (workgroup, row) pair
+         (wgs + rows) * wr * depth * 4;          // one partial row per (workgroup, strip row) pair
 }
 
 // Channel chunk of the strip kernel = its workgroup size: the largest of 256 / 192 / 128 that
-// divides the depth, else 64 with a ragged last chunk (576 -> 192: 768-byte segments per cell,
-// 25 KiB of LDS, six workgroups per CU) — and small enough that the byte offset of the strip's
-// spare column wf still fits the 16-bit halves of RowEntry::off0/off1: maps wider than 64 / 85
-// columns (the reference's 1000-px training images: up to ~100 x 75 feature pixels, readers/
-// cap2det_reader.py:143-172) fall back to narrower chunks, down to 64 channels at wf <= 255.
+// divides the depth, else 64 with a ragged last chunk (576 -> 192: 768-byte segments per cell) —
+// and small enough that the byte offset of the strip's spare column still fits the 16-bit halves
+// of RowEntry::off0 (strips are at most 32 columns wide since round 4: always).
 // 0: no chunk fits (the caller falls back to the atomic kernel).
 static int strip_chunk(int depth, int wf) {
   for (int c : {256, 192, 128})
@@ -1090,7 +1129,9 @@ extern "C" int c2d_roi_crop_pool_bwd_ws_supported(int wf, int depth, int crop, i
   if (wf < 2 || depth <= 0 || depth % 16 != 0 || pool_k != 2 || pool_s <= 0 || crop <= 0 ||
       crop > kMaxCrop || (crop - pool_k) / pool_s + 1 > 16)
     return 0;
-  return strip_chunk(depth, wf);
+  int nr, wr;
+  strip_ranges(wf, &nr, &wr);
+  return wf <= 255 ? strip_chunk(depth, wr) : 0;
 }
 
 template <typename TG>
@@ -1105,8 +1146,11 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   C2D_CHECK_ARG(boxes && box_ind && workspace && (phase == 1 || (dout && argmax && dfeat)));
   C2D_CHECK_ARG(batch > 0 && hf > 0 && wf > 0 && depth > 0 && depth % 16 == 0);
   C2D_CHECK_ARG(crop > 0 && crop <= kMaxCrop && num_boxes >= 0 && pool_s > 0);
+  int nr, wr;
+  strip_ranges(wf, &nr, &wr);
+  const int chunk = strip_chunk(depth, wr);
   if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) ||
-      strip_chunk(depth, wf) == 0 || wf < 2 ||
+      chunk == 0 || wf < 2 || wf > 255 ||
       // (the strip kernel addresses dpooled through a raw buffer descriptor: 32-bit byte offsets)
       (long long)num_boxes * ((crop - pool_k) / pool_s + 1) * ((crop - pool_k) / pool_s + 1) * depth *
               (long long)sizeof(TG) >= (1ll << 31))
@@ -1118,54 +1162,60 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
     return C2D_ERR_WORKSPACE;
   const int pout = (crop - pool_k) / pool_s + 1;
   const int cap = ((num_boxes * pout * pout + kBinSegs - 1) / kBinSegs + 255) / 256 * 256 + kListPad;
+  const int R = batch * hf * nr;              // strip rows: (image, feature row, column range)
+  if ((long long)R * kBinSegs * cap >= (1ll << 31) || (4ll * R + 3) * 4 > 64 * 1024)
+    return C2D_ERR_UNSUPPORTED;
   char* w = (char*)workspace;
   AxisRec* ys = (AxisRec*)w;
   AxisRec* xs = ys + (size_t)num_boxes * crop;
   size_t off = ((2 * (size_t)num_boxes * crop * sizeof(AxisRec)) + 255) / 256 * 256;
   int32_t* counts = (int32_t*)(w + off);
-  off = (off + (size_t)batch * hf * kBinSegs * 4 + 255) / 256 * 256;
+  off = (off + (size_t)R * kBinSegs * 4 + 255) / 256 * 256;
   RowEntry* lists = (RowEntry*)(w + off);
-  off = (off + (size_t)batch * hf * kBinSegs * cap * sizeof(RowEntry) + 255) / 256 * 256;
-  // strip workgroups per channel chunk: at most the batch * hf * kRowParts the workspace is sized
-  // for, and no more than give every workgroup ~16 trips of the expected ~3 list entries per
-  // cell (a workgroup zeroes and writes out a whole partial row of wf x chunk floats whatever its
-  // share: on the 63 x 84 maps of two 1000-px images with 500 boxes each, 2016 workgroups of 4
-  // trips wrote 414 MB of partial rows: ~570 of 14 take the bf16 step of that shape from 3.74
-  // to 3.54 ms, the fp32 step from 9.5 to 9.0)
-  const int R = batch * hf;
+  off = (off + (size_t)R * kBinSegs * cap * sizeof(RowEntry) + 255) / 256 * 256;
+  // Strip workgroups per channel chunk.  A workgroup zeroes and writes out a whole partial row of
+  // wr x chunk floats whatever its share, so: no more than give every workgroup ~16 trips of the
+  // expected ~3 list entries per cell (on the 63 x 84 maps of two 1000-px images with 500 boxes
+  // each, 2016 workgroups of 4 trips wrote 414 MB of partial rows); ONE round of resident
+  // workgroups when that is within reach (equal shares: a second round of a few would double the
+  // launch), whole rounds otherwise; at most the R * kRowParts the workspace is sized for.
+  const int nchunks = (depth + chunk - 1) / chunk;
+  const size_t lds = (size_t)chunk * (wr + 1) * sizeof(float);
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 30 * 64 / chunk) per_cu = 30 * 64 / chunk;      // (wave slots: 42 VGPRs)
+  if (per_cu < 1) per_cu = 1;
+  const int round1 = 256 * per_cu / nchunks > 8 ? 256 * per_cu / nchunks / 8 * 8 : 8;
   const long long trips_est = (long long)num_boxes * pout * pout * 3 / kTrip;
   int W = (int)(trips_est / 16 < 256 ? 256 : (trips_est / 16 + 7) / 8 * 8);
+  if (W > round1) W = W <= 3 * round1 / 2 ? round1 : (W + round1 - 1) / round1 * round1;
   if (W > R * kRowParts) W = R * kRowParts;
-  if ((long long)R * kBinSegs * cap >= (1ll << 31) || (4ll * R + 3) * 4 > 64 * 1024)
-    return C2D_ERR_UNSUPPORTED;
   int32_t* plan = (int32_t*)(w + off);
   off = (off + (4 + (size_t)W + 2 * (size_t)R + 2 * (size_t)R * kBinSegs * (cap / kTrip)) * 4 + 255) /
         256 * 256;
   float* parts = (float*)(w + off);
   hipStream_t st = (hipStream_t)stream;
-  const int chunk = strip_chunk(depth, wf);
   if (phase != 2) {
     hipLaunchKernelGGL(roi_axes_kernel, dim3(c2d_ceil_div((long long)num_boxes * crop, 256)),
                        dim3(256), 0, st, boxes, ys, xs, num_boxes, hf, wf, crop);
-    hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf, kBinSegs, batch), dim3(256), 0, st, ys, xs,
-                       box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout, crop,
-                       cap);
+    hipLaunchKernelGGL(roi_bin_rows_kernel, dim3(hf * nr, kBinSegs, batch), dim3(256), 0, st, ys,
+                       xs, box_ind, lists, counts, num_boxes, hf, wf, depth, chunk, pool_s, pout,
+                       crop, cap, nr, wr);
     hipLaunchKernelGGL(roi_plan_strips_kernel, dim3(1), dim3(256), (size_t)(4 * R + 3) * 4, st,
                        counts, plan, R, W, cap);
   }
   if (phase == 1) return c2d_launch_status();
 #define C2D_STRIP(CHV)                                                                          \
-  hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>), dim3(W * ((depth + CHV - 1) / CHV)),      \
-                     dim3(CHV), (size_t)CHV * (wf + 1) * sizeof(float), st, dout, argmax, lists, \
-                     plan, parts, R, W, wf, depth, (long long)num_boxes * pout * pout * depth)
+  hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>), dim3(W * nchunks), dim3(CHV), lds, st,    \
+                     dout, argmax, lists, plan, parts, R, W, wr, depth,                         \
+                     (long long)num_boxes * pout * pout * depth)
   if (chunk == 256) { C2D_STRIP(256); }
   else if (chunk == 192) { C2D_STRIP(192); }
   else if (chunk == 128) { C2D_STRIP(128); }
   else { C2D_STRIP(64); }
 #undef C2D_STRIP
-  const int row4 = wf * depth / 4;
+  const int row4 = wr * depth / 4;
   hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3((row4 + 255) / 256, R), dim3(256), 0, st,
-                     (const float4*)parts, plan, (float4*)dfeat, W, R, row4);
+                     (const float4*)parts, plan, (float4*)dfeat, W, R, nr, wr, wf, depth / 4);
   return c2d_launch_status();
 }
 

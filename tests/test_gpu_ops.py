@@ -140,15 +140,16 @@ def test_roi_crop_pool_bwd_equal_shares_plan_edge_cases(ops, kind, hf, wf, d, n)
     np.testing.assert_array_equal(outs[0][0], np.full(feat.shape[1:], -0.5, np.float32))
 
 
-@pytest.mark.parametrize("hf,wf,d,n,chunk", [(63, 84, 192, 300, 192),    # 1000x1333 image: 192-channel strips
-                                             (75, 100, 576, 100, 64),    # 1200x1600: 64-channel strips, 9 chunks
+@pytest.mark.parametrize("hf,wf,d,n,chunk", [(63, 84, 192, 300, 192),    # 1000x1333 image: three column ranges of 28
+                                             (75, 100, 576, 100, 192),   # 1200x1600: four ranges of 25, three chunks
                                              (75, 100, 80, 90, 64),      # ragged last chunk
                                              (9, 255, 64, 60, 64),       # widest supported map
                                              (32, 32, 576, 120, 192)])   # the benchmark's map
 def test_roi_crop_pool_bwd_workspace_form_on_wide_maps(ops, hf, wf, d, n, chunk):
   """The reference trains on keep-aspect 1000-px images x {1.2, .8, .6, .4} (configs/
   voc07_groundtruth.pbtxt:9-23, readers/cap2det_reader.py:143-172): feature maps up to ~100
-  columns wide.  The atomic-free row-owner backward covers them with narrower channel strips."""
+  columns wide.  The atomic-free row-owner backward walks a feature row as strips of at most 32
+  columns (round 4; before: whole rows with narrower channel chunks)."""
   from cap2det_amd import synthetic
   assert ops.roi_crop_pool_bwd_ws_supported(wf, d, 14, 2, 2) == chunk
   assert ops.roi_crop_pool_bwd_ws_supported(256, d, 14, 2, 2) == 0

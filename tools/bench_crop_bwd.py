@@ -52,7 +52,8 @@ for dt in (torch.float32, torch.bfloat16):
 
 # list-length balance: counts[hf][kBinSegs] sits behind the two axis tables in the workspace
 off = (2 * N * 14 * 16 + 255) // 256 * 256
-counts = ws[off:off + hf * 16 * 4].view(torch.int32).view(hf, 16).cpu()
-print("entries per (row, segment): mean %.0f max %d min %d; per row: %s" % (
+nr = -(-wf // int(os.environ.get("C2D_ROI_STRIP_COLS", "32") or wf))     # column ranges per row
+counts = ws[off:off + hf * nr * 16 * 4].view(torch.int32).view(hf * nr, 16).cpu()
+print("entries per (strip row, segment): mean %.0f max %d min %d; per row: %s" % (
     counts.float().mean().item(), counts.max().item(), counts.min().item(), counts.sum(1).tolist()))
 print("entries per cell: %.2f" % (counts.sum().item() / (N * 49.0)))
