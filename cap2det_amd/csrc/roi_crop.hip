@@ -674,10 +674,33 @@ __device__ __forceinline__ int strip_starts_below(int p, int T, int W) {   // wo
   return (int)(c < W ? c : W);
 }
 
+// exclusive prefix of (a, b, c) over the 256 threads of the workgroup (wave shuffles + the four wave
+// totals through LDS); *ta / *tb / *tc: the totals
+__device__ __forceinline__ void plan_scan3(int& a, int& b, int& c, int* ta, int* tb, int* tc,
+                                           int* wsum /* [12] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ia = a, ib = b, ic = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64), uc = __shfl_up(ic, o, 64);
+    if (lane >= o) { ia += ua; ib += ub; ic += uc; }
+  }
+  __syncthreads();
+  if (lane == 63) { wsum[wave] = ia; wsum[4 + wave] = ib; wsum[8 + wave] = ic; }
+  __syncthreads();
+  int oa = 0, ob = 0, oc = 0;
+  for (int w = 0; w < wave; ++w) { oa += wsum[w]; ob += wsum[4 + w]; oc += wsum[8 + w]; }
+  *ta = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  *tb = wsum[4] + wsum[5] + wsum[6] + wsum[7];
+  *tc = wsum[8] + wsum[9] + wsum[10] + wsum[11];
+  a = oa + ia - a; b = ob + ib - b; c = oc + ic - c;
+}
+
 __global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __restrict__ counts,
                                                               int32_t* __restrict__ plan, int R,
                                                               int W, int cap) {
   extern __shared__ int rowtrip[];        // [R + 1] first trip of every row | nzb | both | flag
+  __shared__ int wsum[12];
   int* nzb = rowtrip + R + 1;             // [R + 1] non-empty rows in front of row y
   int* both = nzb + R + 1;                // [R + 1] of those: rows whose first trip is a workgroup's too
   int* flag = both + R + 1;               // [R]     row y begins where a workgroup begins
@@ -685,19 +708,26 @@ __global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __r
   int32_t* wslot = plan + 4;
   int32_t* rowslot = wslot + W;
   int32_t* trip = rowslot + 2 * R;
-  for (int y = threadIdx.x; y < R; y += blockDim.x) {
+  // every thread owns a run of consecutive rows: its sums, a scan over the threads, its prefixes
+  const int per = (R + 255) / 256;
+  const int y0 = min(R, (int)threadIdx.x * per), y1 = min(R, y0 + per);
+  int mine = 0, z0 = 0, z1 = 0, tot, t1, t2;
+  for (int y = y0; y < y1; ++y) {
     int t = 0;
     for (int sgm = 0; sgm < kBinSegs; ++sgm) t += (counts[y * kBinSegs + sgm] + kTrip - 1) / kTrip;
-    rowtrip[y + 1] = t;
+    flag[y] = t;                          // (the row's trips, until its flag is known)
+    mine += t;
+  }
+  plan_scan3(mine, z0, z1, &tot, &t1, &t2, wsum);
+  const int T = tot;
+  if (threadIdx.x == 0) rowtrip[R] = T;
+  for (int y = y0; y < y1; ++y) {
+    rowtrip[y] = mine;
+    mine += flag[y];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    rowtrip[0] = 0;
-    for (int y = 0; y < R; ++y) rowtrip[y + 1] += rowtrip[y];
-  }
-  __syncthreads();
-  const int T = rowtrip[R];
-  for (int y = threadIdx.x; y < R; y += blockDim.x) {
+  int n = 0, m = 0, z2 = 0;
+  for (int y = y0; y < y1; ++y) {
     const int c = rowtrip[y];
     int f = 0;
     if (rowtrip[y + 1] > c) {
@@ -707,21 +737,27 @@ __global__ __launch_bounds__(256) void roi_plan_strips_kernel(const int32_t* __r
         const long long w0 = ((long long)c * W + T - 1) / T;        // first workgroup at or behind c
         f = w0 < W && (int)(w0 * T / W) == c;
       }
+      ++n;
+      m += f;
     }
     flag[y] = f;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int n = 0, m = 0;
-    for (int y = 0; y < R; ++y) {
-      nzb[y] = n;
-      both[y] = m;
-      if (rowtrip[y + 1] > rowtrip[y]) { ++n; m += flag[y]; }
+  const int n_mine = n, m_mine = m;
+  plan_scan3(n, m, z2, &t1, &t2, &tot, wsum);
+  {
+    int nn = n, mm = m;
+    for (int y = y0; y < y1; ++y) {
+      nzb[y] = nn;
+      both[y] = mm;
+      if (rowtrip[y + 1] > rowtrip[y]) { ++nn; mm += flag[y]; }
     }
-    nzb[R] = n;
-    both[R] = m;
+    (void)n_mine; (void)m_mine;
+  }
+  if (threadIdx.x == 0) {
+    nzb[R] = t1;
+    both[R] = t2;
     head->trips = T;
-    head->slots = strip_starts_below(T, T, W) + n - m;
+    head->slots = strip_starts_below(T, T, W) + t1 - t2;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < R * kBinSegs; i += blockDim.x) {
