@@ -518,7 +518,9 @@ int c2d_clip_gradient_norms(float* grads, const float* values, const C2dClipDesc
 
 /* Atomic-free, bitwise-reproducible form of c2d_roi_crop_pool_bwd (same semantics: adds into
  * dfeat).  Needs a caller-owned device workspace of at least
- * c2d_roi_crop_pool_bwd_workspace_bytes(...) bytes (sampling tables + per-row cell lists);
+ * c2d_roi_crop_pool_bwd_workspace_bytes(...) bytes (sampling tables, per-row cell lists, the
+ * strip kernel's work plan and its partial rows; feature rows wider than 32 columns are walked
+ * as strips of at most 32 columns, each with lists of its own);
  * returns C2D_ERR_WORKSPACE if it is too small, C2D_ERR_UNSUPPORTED unless
  * c2d_roi_crop_pool_bwd_ws_supported(...) != 0: pool_k == 2, the pooled map at most 16x16,
  * depth % 16 == 0 and 2 <= wf <= 255 (use c2d_roi_crop_pool_bwd then).  Maps of the reference's
