@@ -467,16 +467,21 @@ __global__ __launch_bounds__(512) void roi_crop_pool_bwd_lds_kernel(
 // ---------------------------------------------------------------------------------------------
 // Atomic-free, bitwise-reproducible backward ("row owner" form).
 //   1. roi_axes_kernel      : the 2*crop sampling descriptors of every box -> workspace tables.
-//   2. roi_bin_rows_kernel  : for every feature-map row y, the ORDERED list of pooled cells
-//                             (roi, py, px) that can touch row y (a stable compaction, so the
-//                             summation order below is fixed).
-//   3. roi_bwd_strip_kernel : one workgroup per (row y, channel chunk, list part) walks its list.
-//                             ONE LANE OWNS ONE CHANNEL of the row strip [wf][chunk] in LDS for the
-//                             whole walk, so its read-modify-writes race with nobody (no atomics,
+//   2. roi_bin_rows_kernel  : for every STRIP ROW (feature row y x a range of at most 32 columns),
+//                             the ORDERED list of pooled cells (roi, py, px) that can touch it (a
+//                             stable compaction per cell-range segment, so the summation order
+//                             below is fixed).
+//   3. roi_plan_strips_kernel : cuts all lists into trips of 16 entries, strings them into ONE
+//                             sequence and hands every strip workgroup an equal share of it.
+//   4. roi_bwd_strip_kernel : a workgroup (share w, channel chunk) walks its trips.
+//                             ONE LANE OWNS ONE CHANNEL of the row strip [wr + 1][chunk] in LDS for
+//                             the whole walk, so its read-modify-writes race with nobody (no atomics,
 //                             no private copies); a list entry's operands are wave-uniform (scalar
 //                             loads) and the dpooled / arg-max reads of an entry are contiguous
-//                             chunk-wide segments of the cell's channel row.
-//   4. roi_bwd_sum_parts_kernel : adds the parts in a fixed order into the gradient map.
+//                             chunk-wide segments of the cell's channel row; a partial row per
+//                             (workgroup, strip row) pair.
+//   5. roi_bwd_sum_parts_kernel : adds a strip row's partial rows in a fixed order into the
+//                             gradient map.
 // LDS float atomics retire ~1.4 lane-adds per clock per CU and global float atomics are at the
 // chip-wide atomic rate already; this form has neither.
 // (Round 1 walked the lists with 16 lane groups x 16 channels and 16 private strips per
@@ -639,7 +644,7 @@ __device__ __forceinline__ float strip_value(unsigned short raw) {      // bf16 
 #define C2D_STRIP_DBG 0     // ablation builds of the strip kernel (-DC2D_STRIP_DBG=1: no vector loads, 2: no LDS updates)
 #endif
 
-constexpr int kRowParts = kBinSegs;   // strip workgroups (per channel chunk) = rows * kRowParts
+constexpr int kRowParts = kBinSegs;   // strip workgroups per channel chunk: at most strip rows * kRowParts
 constexpr int kTrip = 16;             // list entries per trip of the strip kernel (= kListPad)
 
 // The strip kernel's work plan (built once per box set, with the lists).  The lists of one row
