@@ -634,13 +634,22 @@ def main(argv=None):
     low_cfg = "c2" if args.dtype == "bf16" else "c1"
     import glob
     for pattern, into in (("r*_traffic_%s.json" % low_cfg, traffic), ("r*_mfma_%s.json" % low_cfg, mfma)):
-      try:
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))[-1]   # latest round
-        with open(newest) as f:
-          into.update(json.load(f)["families"])
-        result.setdefault("pmc_summaries", []).append(os.path.basename(newest))
-      except Exception:
-        pass
+      # newest round first; a file that does not parse is REPORTED and the next older one is tried
+      # (round 4 committed four truncated summaries and the line silently lost its traffic fields)
+      for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+          with open(cand) as f:
+            fams = json.load(f)["families"]
+          if not fams:
+            raise ValueError("no kernel families in the summary")
+          into.update(fams)
+          result.setdefault("pmc_summaries", []).append(os.path.basename(cand))
+          break
+        except Exception as e:   # noqa: BLE001 -- reported in the line, never swallowed
+          result.setdefault("pmc_summaries_error", []).append(
+              "%s: %s: %s" % (os.path.basename(cand), type(e).__name__, e))
+      else:
+        result.setdefault("pmc_summaries_error", []).append("no profiles/%s parses" % pattern)
     if not args.no_kernel_timing and args.per_call:
       for (family, work, s, e, _nb), (name, ints) in zip(timer.records, timer.shapes):
         ms = s.elapsed_time(e)

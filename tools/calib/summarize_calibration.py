@@ -14,6 +14,8 @@ import json
 import os
 import re
 import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from _atomic import write_json  # noqa: E402
 
 
 def rows(directory):
@@ -105,8 +107,7 @@ def main():
     if base in tcc:
       rec["tcc"] = tcc[base][-1]
     doc["memory"][name] = rec
-  with open(out_path, "w") as fo:
-    json.dump(doc, fo, indent=1, sort_keys=True)
+  write_json(out_path, doc, indent=1, sort_keys=True)
   for name, r in doc["mfma"].items():
     print("%-28s reading %.4f  true %.2f  counter/expected cycles %.4f" %
           (name, r["mfma_busy_reading"] or 0, r["true_busy"], r["counter_over_expected_cycles"] or 0))

@@ -26,6 +26,8 @@ import argparse
 import json
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _atomic import write_json  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -160,8 +162,7 @@ def main():
   ap.add_argument("--lr", type=float, default=None)
   args = ap.parse_args()
   doc = run_curves(args.steps, args.hw, args.proposals, args.dm, args.pool, args.window, lr=args.lr)
-  with open(args.out, "w") as f:
-    json.dump(doc, f, indent=1, sort_keys=True)
+  write_json(args.out, doc, indent=1, sort_keys=True)
   print(json.dumps({"fp32_total_loss_fell_by": doc["fp32_total_loss_fell_by"],
                     "deviation_from_fp32": {k: v["max_relative_window_deviation"]["total_loss"]
                                             for k, v in doc["deviation_from_fp32"].items()},

@@ -9,6 +9,8 @@ import glob
 import json
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _atomic import write_json  # noqa: E402
 
 KERNELS = {"roi_crop_pool2_fwd_stream_kernel": "fwd_stream", "roi_crop_pool2_fwd_rowwalk_kernel": "fwd_rowwalk", "roi_bwd_strip_kernel": "bwd_strip",
            "roi_bin_rows_kernel": "bwd_bin_rows", "roi_bwd_sum_parts_kernel": "bwd_sum_parts",
@@ -57,9 +59,8 @@ def main():
         if c in e:
           e[c + "_per_wave_cycle"] = e[c] / e["SQ_WAVE_CYCLES"]
     summary[k] = e
-  with open(out, "w") as f:
-    json.dump({"source": "tools/crop_counters.sh (rocprofv3 --pmc, separate passes)", "kernels": summary},
-              f, indent=1, sort_keys=True)
+  write_json(out, {"source": "tools/crop_counters.sh (rocprofv3 --pmc, separate passes)", "kernels": summary},
+             indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,8 @@ import glob
 import json
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _atomic import write_json  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarize_pmc import family_of  # noqa: E402
@@ -98,11 +100,11 @@ def main():
                      "mfma_busy": (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 1024)) if gui else None,
                      "avg_us_in_this_pass": (kdur[k] / 1e3 / len(klaunches[k])) if k in kdur else None,
                      "implied_clock_GHz": (gui / 8.0 / kdur[k]) if k in kdur and kdur[k] else None}
-  with open(out_path, "w") as f:
-    json.dump({"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4)",
-               "calibration": "profiles/r04_counter_calibration.json: reads 0.992-0.995 at a true 1.0, "
-                              "0.489-0.497 at a true 0.5 (no factor applied)",
-               "families": fams, "per_kernel": per_kernel}, f, indent=1)
+  write_json(out_path,
+             {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 * 4)",
+              "calibration": "profiles/r04_counter_calibration.json: reads 0.992-0.995 at a true 1.0, "
+                             "0.489-0.497 at a true 0.5 (no factor applied)",
+              "families": fams, "per_kernel": per_kernel}, indent=1)
   for fam, v in fams.items():
     print("%-22s launches %5d  mfma_busy %s" % (fam, v["launches"], v["mfma_busy"]))
 

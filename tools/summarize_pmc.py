@@ -23,6 +23,8 @@ import json
 import os
 import re
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _atomic import write_json  # noqa: E402
 
 FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
     ("igemm", "igemm_nt_kernel"),
@@ -122,8 +124,7 @@ def main():
                      "read (calibrated 1.000)",
       "families": fams,
   }
-  with open(out_path, "w") as f:
-    json.dump(doc, f, indent=1, sort_keys=True)
+  write_json(out_path, doc, indent=1, sort_keys=True)
   for fam, v in fams.items():
     print("%-20s %6.1f launches/step  read %9.1f MB  write %9.1f MB per step"
           % (fam, v["launches_per_step"], v["hbm_read_bytes_per_step"] / 1e6,

@@ -13,6 +13,8 @@ import glob
 import json
 import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _atomic import write_json  # noqa: E402
 
 
 def analyse(directory):
@@ -62,8 +64,7 @@ def main():
     label, d = arg.split("=", 1)
     out[label] = analyse(d)
     print(label, json.dumps(out[label]))
-  with open(sys.argv[1], "w") as f:
-    json.dump(out, f, indent=1, sort_keys=True)
+  write_json(sys.argv[1], out, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
