@@ -320,6 +320,14 @@ def parse_args(argv=None):
                   help="SECONDARY operating point: images per GPU per step (reference: batch_size 2)")
   ap.add_argument("--proposals", type=int, default=None,
                   help="SECONDARY operating point: proposals per image (reference: max_num_proposals 500)")
+  ap.add_argument("--reader", action="store_true",
+                  help="SECONDARY measurement (SURVEY.md section 8 row f1): TFRecord shards of synthetic JPEGs + "
+                       "proposals written with the repo's own writer -> cap2det_reader (host decode on "
+                       "threads, GPU flip / resize / pad) -> Trainer.train; reports reader-fed images/s "
+                       "beside the resident-input value of the same process")
+  ap.add_argument("--reader-records", type=int, default=64, help="--reader: records per run (cycled)")
+  ap.add_argument("--reader-workers", type=int, default=10,
+                  help="--reader: map_num_parallel_calls (host decode threads; the shipped configs say 10)")
   ap.add_argument("--dtype", choices=["fp32", "bf16"], default=None,
                   help="override the config's precision: fp32 = exact fp32 everywhere; bf16 = the "
                        "convolution towers behind the stem (first stage, ROI crop output, second stage) "
@@ -413,6 +421,151 @@ def stub_main(args):
   return 0
 
 
+def write_reader_shards(out_dir, rng, classes, vocab, records, image_hw, num_proposals, shards=4):
+  """TFRecord shards in the layout of dataset-tools/create_pascal_tf_record.py:147-196 /
+  create_coco_tf_record.py:197-242 (the 15 features readers/cap2det_reader.py parses): a structured
+  synthetic JPEG (baseline, 4:2:0, quality 90: what PIL writes and the datasets hold), SelectiveSearch-
+  shaped proposals, two object texts and a tokenised caption that names one class."""
+  import io
+  import numpy as np
+  from PIL import Image
+  from cap2det_amd import synthetic
+  from cap2det_amd.readers import tfrecord as T
+  h, w = image_hw
+  y, x = np.mgrid[0:h, 0:w]
+  single = [c for c in classes if " " not in c]
+  per_shard = [[] for _ in range(shards)]
+  for r in range(records):
+    img = np.clip(np.stack([128 + 90 * np.sin(x / (9.0 + r % 7) + c) * np.cos(y / (5.0 + r % 5) - c)
+                            for c in range(3)], -1) + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format="JPEG", quality=90)
+    pb = synthetic.synthetic_boxes(rng, num_proposals)
+    ob = synthetic.synthetic_boxes(rng, 2)
+    picks = rng.choice(len(classes), 2, replace=False)
+    texts = [classes[i].encode() for i in picks]
+    cap = synthetic.synthetic_captions(rng, 1, vocab, tokens=60,
+                                       must_contain=[single[int(rng.integers(0, len(single)))]])[0]
+    cap = [t for t in cap if t]
+    f = {
+        "image/height": (T.INT64, [h]), "image/width": (T.INT64, [w]),
+        "image/source_id": (T.BYTES, [("%08d" % r).encode()]),
+        "image/encoded": (T.BYTES, [buf.getvalue()]), "image/format": (T.BYTES, [b"jpeg"]),
+        "image/object/bbox/ymin": (T.FLOAT, ob[:, 0].tolist()), "image/object/bbox/xmin": (T.FLOAT, ob[:, 1].tolist()),
+        "image/object/bbox/ymax": (T.FLOAT, ob[:, 2].tolist()), "image/object/bbox/xmax": (T.FLOAT, ob[:, 3].tolist()),
+        "image/object/class/text": (T.BYTES, texts), "image/object/class/label": (T.INT64, [int(i) for i in picks]),
+        "image/caption/string": (T.BYTES, [t.encode() for t in cap]),
+        "image/caption/offset": (T.INT64, [0]), "image/caption/length": (T.INT64, [len(cap)]),
+        "image/proposal/bbox/ymin": (T.FLOAT, pb[:, 0].tolist()), "image/proposal/bbox/xmin": (T.FLOAT, pb[:, 1].tolist()),
+        "image/proposal/bbox/ymax": (T.FLOAT, pb[:, 2].tolist()), "image/proposal/bbox/xmax": (T.FLOAT, pb[:, 3].tolist()),
+    }
+    per_shard[r % shards].append(T.encode_example(f))
+  paths = []
+  for i, recs in enumerate(per_shard):
+    paths.append(os.path.join(out_dir, "bench-%05d-of-%05d.record" % (i, shards)))
+    T.write_records(paths[-1], recs)
+  return paths, sum(len(r) for recs in per_shard for r in recs)
+
+
+def reader_main(args):
+  """`bench.py --reader`: the timed region is Trainer.train over cap2det_reader — record framing +
+  CRC, tf.Example parsing and JPEG decoding on host threads, uploads from pinned memory on the input
+  thread's copy stream, flip / resize / pad on the GPU, the look-ahead fed from the NEXT batch — at
+  the headline shape (or --image-hw / --batch / --proposals).  One JSON line, labelled SECONDARY:
+  reader-fed images/s, the resident-input images/s of the same process and their ratio."""
+  import shutil
+  import tempfile
+  import numpy as np
+  import torch
+  from cap2det_amd import synthetic
+  from cap2det_amd.protos import reader_pb2, text_format
+  from cap2det_amd.readers import cap2det_reader
+  from cap2det_amd.train.trainer import Trainer
+  device = "cuda:0"
+  torch.cuda.set_device(0)
+  spec = synthetic.BASELINE_CONFIGS[args.config]
+  if args.dtype is None:
+    args.dtype = spec["dtype"]
+  image_hw = tuple(args.image_hw) if args.image_hw else (IMAGE_HW, IMAGE_HW)
+  images_per_gpu = args.batch or 1
+  num_proposals = args.proposals or NUM_PROPOSALS
+  scratch = tempfile.mkdtemp(prefix="c2d_bench_reader_")
+  try:
+    pipeline = synthetic.baseline_pipeline(args.config, scratch)
+    trainer = Trainer(pipeline, device=device, seed=1234, compute_dtype=args.dtype,
+                      allow_missing_pretrained=True)
+    classes = trainer.model.label_extractor.classes
+    rng = np.random.default_rng(77)
+    t_w = time.perf_counter()
+    paths, nbytes = write_reader_shards(scratch, rng, classes, synthetic.caption_vocabulary(pipeline),
+                                        args.reader_records, image_hw, num_proposals)
+    t_w = time.perf_counter() - t_w
+    opt = reader_pb2.Reader()
+    text_format.Merge("""
+      cap2det_reader {
+        input_pattern: "%s/bench-*.record"
+        interleave_cycle_length: 2
+        is_training: true
+        shuffle_buffer_size: 16
+        map_num_parallel_calls: %d
+        prefetch_buffer_size: 500
+        batch_size: %d
+        max_num_proposals: %d
+        image_resizer { default_resizer {} }
+        preprocess_options { random_flip_left_right_prob: 0.5 }
+      }""" % (scratch, args.reader_workers, images_per_gpu, num_proposals), opt)
+    input_fn = cap2det_reader.get_input_fn(opt.cap2det_reader, device=device, seed=5)
+    total = args.warmup + args.steps
+    clock = {}
+
+    def log(step, losses):
+      if step == args.warmup:
+        torch.cuda.synchronize()
+        clock["t0"] = time.perf_counter()
+
+    # (a) reader-fed: ONE Trainer.train call; the clock starts behind the warm-up steps
+    losses = trainer.train(input_fn(), max_steps=total, log=log)
+    torch.cuda.synchronize()
+    fed = time.perf_counter() - clock["t0"]
+    fed_loss = float(losses["total_loss"].item())
+    # (b) the same process on resident inputs: one reader batch kept in HBM, stepped K times with
+    # the look-ahead on the same tensors (what the headline command measures)
+    batch = next(iter(input_fn()))
+    torch.cuda.synchronize()
+    for i in range(args.warmup):
+      trainer.train_step(batch, prefetch=batch if i + 1 < args.warmup else None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+      trainer.train_step(batch, prefetch=batch if i + 1 < args.steps else None)
+    torch.cuda.synchronize()
+    resident = time.perf_counter() - t0
+  finally:
+    shutil.rmtree(scratch, ignore_errors=True)
+  images = args.steps * images_per_gpu
+  result = {
+      "metric": "SECONDARY (input pipeline, SURVEY section 8 row f1; not the BASELINE metric): images/sec of "
+                "Trainer.train fed by cap2det_reader from TFRecord shards (%dx%d JPEG, %d proposals, "
+                "%d image(s) per step)" % (image_hw[0], image_hw[1], num_proposals, images_per_gpu),
+      "value": images / fed, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": 1000.0 * fed / args.steps, "higher_is_better": True, "scaling": "weak",
+      "vs_baseline": None,
+      "dtype": "f32" if args.dtype == "fp32" else "bf16 storage, f32 accumulate",
+      "data": "synthetic JPEG records (%d records, %.1f MB, written in %.1f s with cap2det_amd.readers."
+              "tfrecord.write_records), decoded inside the timed region" % (args.reader_records, nbytes / 1e6, t_w),
+      "config": {"workload": spec["title"] + " fed by the reader", "baseline_config": args.config,
+                 "images_per_gpu": images_per_gpu, "image_hw": list(image_hw), "proposals": num_proposals,
+                 "reader": "map_num_parallel_calls %d, shuffle 16, flip 0.5, default_resizer, "
+                           "input thread + copy stream, 2 batches ahead" % args.reader_workers},
+      "resident_inputs": {"value": images / resident, "ms_per_step": 1000.0 * resident / args.steps},
+      "reader_over_resident": resident / fed,
+      "final_total_loss": fed_loss,
+  }
+  print(json.dumps(result))
+  sys.stdout.flush()
+  return 0
+
+
 def main(argv=None):
   argv = sys.argv[1:] if argv is None else argv
   args = parse_args(argv)
@@ -420,6 +573,10 @@ def main(argv=None):
     sys.exit(launch_ranks(args, argv))
   if os.environ.get("C2D_BENCH_STUB") == "1":
     sys.exit(stub_main(args))
+  if args.reader:
+    if args.gpus != 1:
+      raise SystemExit("--reader is a single-GPU secondary measurement")
+    sys.exit(reader_main(args))
 
   import torch
   import torch.distributed as dist

@@ -1175,6 +1175,30 @@ extern "C" int c2d_roi_crop_pool_bwd_ws_supported(int wf, int depth, int crop, i
   return wf <= 255 ? strip_chunk(depth, wr) : 0;
 }
 
+// Everything c2d_roi_crop_pool_bwd_ws / _prepare / _run check before they touch the workspace, as
+// one query a caller can cache per shape (elem_size: 4 = fp32, 2 = bf16 pooled gradients):
+// returns the channel chunk (> 0) when the row-owner form covers the shape, 0 when it would return
+// C2D_ERR_UNSUPPORTED (the caller then runs c2d_roi_crop_pool_bwd).  Beyond the per-map rules of
+// c2d_roi_crop_pool_bwd_ws_supported: the pooled gradient must stay below 2 GiB (32-bit buffer
+// offsets: fp32 7x7x576 cells -> fewer than 19,022 boxes), the row lists below 2^31 entries, and
+// the plan kernel's row table inside 64 KiB of LDS (batch * hf * strips-per-row <= 4095).
+extern "C" int c2d_roi_crop_pool_bwd_ws_shape_supported(int batch, int hf, int wf, int depth,
+                                                        int num_boxes, int crop, int pool_k,
+                                                        int pool_s, int elem_size) {
+  const int chunk = c2d_roi_crop_pool_bwd_ws_supported(wf, depth, crop, pool_k, pool_s);
+  if (chunk <= 0 || batch <= 0 || hf <= 0 || num_boxes < 0 || (elem_size != 4 && elem_size != 2))
+    return 0;
+  const long long pout = (crop - pool_k) / pool_s + 1;
+  if (num_boxes >= (1 << 23) || (long long)num_boxes * pout * pout * depth * elem_size >= (1ll << 31))
+    return 0;
+  int nr, wr;
+  strip_ranges(wf, &nr, &wr);
+  const long long cap = ((num_boxes * pout * pout + kBinSegs - 1) / kBinSegs + 255) / 256 * 256 + kListPad;
+  const long long R = (long long)batch * hf * nr;
+  if (R * kBinSegs * cap >= (1ll << 31) || (4 * R + 3) * 4 > 64 * 1024) return 0;
+  return chunk;
+}
+
 template <typename TG>
 static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, const float* boxes,
                                      const int32_t* box_ind, float* dfeat, int batch, int hf, int wf,
@@ -1190,11 +1214,10 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   int nr, wr;
   strip_ranges(wf, &nr, &wr);
   const int chunk = strip_chunk(depth, wr);
-  if (pool_k != 2 || (crop - pool_k) / pool_s + 1 > 16 || num_boxes >= (1 << 23) ||
-      chunk == 0 || wf < 2 || wf > 255 ||
-      // (the strip kernel addresses dpooled through a raw buffer descriptor: 32-bit byte offsets)
-      (long long)num_boxes * ((crop - pool_k) / pool_s + 1) * ((crop - pool_k) / pool_s + 1) * depth *
-              (long long)sizeof(TG) >= (1ll << 31))
+  // (the strip kernel addresses dpooled through a raw buffer descriptor: 32-bit byte offsets; the
+  //  plan kernel keeps its row table in LDS — every limit lives in the shape query)
+  if (chunk == 0 || c2d_roi_crop_pool_bwd_ws_shape_supported(batch, hf, wf, depth, num_boxes, crop,
+                                                             pool_k, pool_s, (int)sizeof(TG)) <= 0)
     return C2D_ERR_UNSUPPORTED;
   if (num_boxes == 0) return C2D_OK;
   if (workspace_bytes <
@@ -1204,8 +1227,6 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
   const int pout = (crop - pool_k) / pool_s + 1;
   const int cap = ((num_boxes * pout * pout + kBinSegs - 1) / kBinSegs + 255) / 256 * 256 + kListPad;
   const int R = batch * hf * nr;              // strip rows: (image, feature row, column range)
-  if ((long long)R * kBinSegs * cap >= (1ll << 31) || (4ll * R + 3) * 4 > 64 * 1024)
-    return C2D_ERR_UNSUPPORTED;
   char* w = (char*)workspace;
   AxisRec* ys = (AxisRec*)w;
   AxisRec* xs = ys + (size_t)num_boxes * crop;

@@ -78,6 +78,14 @@ def roi_crop_pool_bwd_ws_supported(wf, depth, crop, pool_k, pool_s):
   return int(_lib.load().c2d_roi_crop_pool_bwd_ws_supported(wf, depth, crop, pool_k, pool_s))
 
 
+def roi_crop_pool_bwd_ws_shape_supported(batch, hf, wf, depth, num_boxes, crop, pool_k, pool_s,
+                                         elem_size):
+  """Channel chunk when the atomic-free backward covers the whole CALL (map width, pooled-gradient
+  bytes, list and row-table limits), 0 = it would return C2D_ERR_UNSUPPORTED."""
+  return int(_lib.load().c2d_roi_crop_pool_bwd_ws_shape_supported(batch, hf, wf, depth, num_boxes,
+                                                                  crop, pool_k, pool_s, elem_size))
+
+
 def roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes, crop, pool_k, pool_s):
   return int(_lib.load().c2d_roi_crop_pool_bwd_workspace_bytes(batch, hf, wf, depth, num_boxes,
                                                                crop, pool_k, pool_s))

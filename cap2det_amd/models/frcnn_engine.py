@@ -602,6 +602,10 @@ class Net(object):
                            for _ in range(extra)] if extra else None),
                   events=[None] * (extra + 1), slot=0)
     plan["scr"] = scratch_set()
+    # (the branch stream's set is made on demand: a plan first prepared while Net.alt was switched
+    # off — Trainer._graph_step's warm-up and capture — must not leave every LATER eager step of the
+    # shape without its branch streams)
+    plan["scratch_set"] = scratch_set
     plan["scr_b"] = scratch_set() if self.alt is not None else None
     plan["on_alt"] = False
     steps = plan["steps"]
@@ -1021,6 +1025,8 @@ class Net(object):
           self._conv_bwd(plan, b0, x, None, False, dc=b0["dc_entry"], defer=got)
           entry_wg[rest_owner] = got
       early = None       # a pooling FIRST op whose gradient goes out on the branch stream (below)
+      if self.alt is not None and plan["scr_b"] is None and st["n"] >= self.alt_min_n:
+        plan["scr_b"] = plan["scratch_set"]()
       if self.alt is not None and plan["scr_b"] is not None and st["n"] >= self.alt_min_n:
         mains, others = self._split_branches(st, None)
         # The block-input gradient is the sum over the branches' first ops.  A pooling branch's share
@@ -1321,7 +1327,7 @@ class FrcnnEngine(object):
     fh, fw = bufs["plan1"]["oh"], bufs["plan1"]["ow"]
     p = (self.crop - self.pool_k) // self.pool_s + 1
     d = self.first.cout
-    bufs.update(fh=fh, fw=fw, p=p,
+    bufs.update(fh=fh, fw=fw, p=p, b=b, n=n,
                 pooled=Ref(torch.empty(b * n * p * p, d, device=dev, dtype=self.act_dtype), d, 0, d),
                 pool_arg=torch.empty(b * n * p * p, d, dtype=torch.uint8, device=dev),
                 box_ind=torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(n)
@@ -1334,11 +1340,16 @@ class FrcnnEngine(object):
     return bufs
 
   def _crop_bwd_ws_ok(self, bufs, d):
-    """The atomic-free row-owner backward covers this shape (maps up to 255 columns wide: the
-    reference's 1000-px training images give up to ~100; c2d_roi_crop_pool_bwd_ws_supported)."""
+    """The atomic-free row-owner backward covers this CALL — map width (up to 255 columns: the
+    reference's 1000-px training images give up to ~100), pooled-gradient bytes, list and row-table
+    limits (c2d_roi_crop_pool_bwd_ws_shape_supported); decided once per shape, so a batch the strip
+    form cannot take (e.g. more than 21 images of 84-column maps, or >= 19,022 fp32 boxes) runs the
+    atomic kernel instead of raising C2D_ERR_UNSUPPORTED inside the step."""
     if "crop_ws_ok" not in bufs:
-      bufs["crop_ws_ok"] = ops.roi_crop_pool_bwd_ws_supported(bufs["fw"], d, self.crop, self.pool_k,
-                                                              self.pool_s) > 0
+      pooled = bufs["pooled"].t
+      bufs["crop_ws_ok"] = ops.roi_crop_pool_bwd_ws_shape_supported(
+          bufs["b"], bufs["fh"], bufs["fw"], d, bufs["b"] * bufs["n"], self.crop, self.pool_k,
+          self.pool_s, pooled.element_size()) > 0
     return bufs["crop_ws_ok"]
 
   def _crop_ws(self, bufs, b, n, d):

@@ -254,7 +254,7 @@ class Trainer(object):
     return lr
 
   def _forward_backward(self, examples, after_second_stage=None, prefetch=None, after_block=None,
-                        **kwargs):
+                        prefetch_ready=None, **kwargs):
     model, store = self.model, self.model.store
     lo, hi = self.bucket
     # everything the step's accumulating kernels add into, cleared by ONE launch: the gradient
@@ -284,6 +284,9 @@ class Trainer(object):
       if prefetch is not None:
         # look-ahead: the frozen first-stage layers of the NEXT batch's image run on a side stream
         # under this step's second stage (FrcnnEngine.prefetch_first_stage)
+        if prefetch_ready is not None and getattr(model.engine, "prefetch_stream", None) is not None:
+          # (the next batch came from an input thread's copy stream: only its READER waits for it)
+          model.engine.prefetch_stream.wait_event(prefetch_ready)
         model.engine.prefetch_first_stage(prefetch[F.image], prefetch[F.proposals].shape[1], True)
       losses = dict(model.build_loss(predictions, examples=examples, **kwargs))
       losses['regularization_loss'] = model.regularization_loss(step_zeroed=True)
@@ -362,19 +365,21 @@ class Trainer(object):
       return "two"
     return "blocks"
 
-  def train_step(self, examples, prefetch=None, **kwargs):
+  def train_step(self, examples, prefetch=None, prefetch_ready=None, **kwargs):
     """One synchronous step; returns {loss name: 0-d device tensor} (+ 'total_loss',
     'regularization_loss').  No host synchronisation happens inside.  `prefetch`: the NEXT
     step's examples, when the caller already has them (an input pipeline always does): their
-    frozen first-stage layers are computed under this step's kernels."""
+    frozen first-stage layers are computed under this step's kernels.  `prefetch_ready`: the event
+    behind the uploads of `prefetch` when they were queued on another stream (Trainer.train)."""
     if kwargs.get("dropout_seed") is None and kwargs.get("dropout_mask") is None:
       # slim.dropout draws a fresh mask every step on every worker (models/utils.py:171-174):
       # the counter-based generator is keyed on (trainer seed, global step, rank)
       kwargs["dropout_seed"] = dropout_key(self.seed, self.global_step, self.rank, self.world_size)
     if (self.use_graph and "dropout_mask" not in kwargs and
         not self.model.engine.dropout_on_feature_map):
-      return self._graph_step(examples, prefetch=prefetch, **kwargs)
+      return self._graph_step(examples, prefetch=prefetch, prefetch_ready=prefetch_ready, **kwargs)
     kwargs["prefetch"] = prefetch
+    kwargs["prefetch_ready"] = prefetch_ready
     store = self.model.store
     lo, hi = self.bucket
     if self._dp_buckets() == "blocks" and len(self._block_cuts) > 2:
@@ -395,47 +400,63 @@ class Trainer(object):
     return losses
 
   # -- hipGraph path ------------------------------------------------------------------
-  def train(self, batches, max_steps=None, save_dir=None, save_every=None, log=None):
+  def train(self, batches, max_steps=None, save_dir=None, save_every=None, log=None,
+            prefetch_depth=2):
     """train/trainer.py:210-235 (`tf.estimator.train_and_evaluate`'s training half): consumes an
     iterable of example dicts (e.g. `cap2det_reader.get_input_fn(...)()`) until it ends or
     `train_config.max_steps` / `max_steps` is reached, always holding ONE batch of look-ahead
-    for `train_step(prefetch=...)`; optional periodic checkpoints.  Returns the last losses."""
+    for `train_step(prefetch=...)`; optional periodic checkpoints.  Returns the last losses.
+    `prefetch_depth`: batches the input thread keeps ready (the reference's
+    `prefetch_buffer_size`, readers/cap2det_reader.py:266, counts batches too)."""
     limit = max_steps if max_steps is not None else (self.train_config.max_steps or None)
-    it = iter(batches)
-    copy_stream = (torch.cuda.Stream(device=self.device)
-                   if torch.device(self.device).type == "cuda" else None)
+    from cap2det_amd.readers.prefetch import DevicePrefetcher, adopt
+    on_gpu = torch.device(self.device).type == "cuda"
+    # The input function runs in a thread of its own under a copy stream (readers/prefetch.py): the
+    # uploads and reader kernels of batch k+1 are queued while step k-1 is still on the GPU and
+    # NEVER wait for the compute stream.  What waits is the reader of a batch: the compute stream
+    # for the batch it is about to step on (long finished by then), the look-ahead stream for the
+    # next one (`prefetch_ready`).  Round 4 made the copy stream wait for the compute stream and
+    # the compute stream for the copy stream around every pull: the upload then sat between two
+    # steps (ADVICE r4; tests/test_gpu_reader.py::test_train_overlaps_the_uploads).
+    src = DevicePrefetcher(batches, self.device, depth=prefetch_depth)
+    eng = self.model.engine
+    # Two Python threads now share the interpreter lock: this one queues ~250 launches per step,
+    # the input thread assembles batches.  Both hold the lock for microseconds at a time, but a
+    # thread that WANTS it only asks the holder to let go after the switch interval — 5 ms by
+    # default, longer than a whole bf16 step.  Measured on configs[2] (bench.py --reader, 3.18 ms per
+    # step on resident inputs): 3.97 ms at the default, 3.54 at 0.5 ms, 3.21 at 50 us.
+    import sys
+    switch_interval = sys.getswitchinterval()
+    sys.setswitchinterval(min(switch_interval, 5e-5))
 
     def pull():
-      """The reader's uploads (and its resize / flip kernels) go out on a stream of their own: on
-      the compute stream they sit between the step's kernels (0.3-0.7 ms per step measured with
-      bench.py --host-inputs), here they run beside the step in flight."""
-      if copy_stream is None:
-        return next(it, None)
-      main = torch.cuda.current_stream()
-      copy_stream.wait_stream(main)
-      with torch.cuda.stream(copy_stream):
-        batch = next(it, None)
-      main.wait_stream(copy_stream)
-      if batch is not None:
-        for v in batch.values():
-          if isinstance(v, torch.Tensor) and v.is_cuda:
-            v.record_stream(main)
+      batch = next(src, None)
+      if batch is not None and on_gpu:
+        adopt(batch, torch.cuda.current_stream(), getattr(eng, "prefetch_stream", None))
       return batch
 
-    cur = pull()
     losses = None
-    while cur is not None and (limit is None or self.global_step < limit):
-      nxt = pull()
-      last = limit is not None and self.global_step + 1 >= limit
-      losses = self.train_step(cur, prefetch=None if last else nxt)
-      if log is not None:
-        log(self.global_step, losses)
-      if save_dir and save_every and self.global_step % save_every == 0:
-        self.save_checkpoint(save_dir)
-      cur = nxt
+    try:
+      cur = pull()
+      while cur is not None and (limit is None or self.global_step < limit):
+        nxt = pull()
+        last = limit is not None and self.global_step + 1 >= limit
+        if on_gpu and cur.get("_ready") is not None:
+          torch.cuda.current_stream().wait_event(cur["_ready"])
+        ahead = None if (last or nxt is None) else nxt
+        losses = self.train_step(cur, prefetch=ahead,
+                                 prefetch_ready=None if ahead is None else ahead.get("_ready"))
+        if log is not None:
+          log(self.global_step, losses)
+        if save_dir and save_every and self.global_step % save_every == 0:
+          self.save_checkpoint(save_dir)
+        cur = nxt
+    finally:
+      sys.setswitchinterval(switch_interval)
+      src.close()
     return losses
 
-  def _graph_step(self, examples, dropout_seed=None, prefetch=None, **kwargs):
+  def _graph_step(self, examples, dropout_seed=None, prefetch=None, prefetch_ready=None, **kwargs):
     """hipGraph replay of the step WITH the eager schedule's streams (round 4): inside the capture
     the filter gradients fork onto the side stream exactly as in the eager step (event record /
     wait are capturable, the graph gets parallel branches), and the look-ahead — the frozen
@@ -537,14 +558,20 @@ class Trainer(object):
     st["labels"].copy_(labels, non_blocking=True)
     st["seed"].fill_(int(dropout_seed) if dropout_seed is not None else self.global_step)
     if gr["lookahead"]:
-      if gr["primed"] != (image.data_ptr(), image._version):
+      primed = gr["primed"]
+      if primed is None or primed[0] is not image or primed[1] != image._version:
         # the look-ahead of the previous replay was not for this image (first step, or a caller
         # that does not announce its batches): compute this image's prefix now
         eng.run_prefix_into(gr["bufs"], st[F.image], gr["p_next"])
       nxt = prefetch[F.image] if prefetch is not None else None
       if nxt is not None and tuple(nxt.shape) == tuple(st["next_image"].shape):
+        if prefetch_ready is not None:
+          torch.cuda.current_stream().wait_event(prefetch_ready)
         st["next_image"].copy_(nxt, non_blocking=True)
-        gr["primed"] = (nxt.data_ptr(), nxt._version)
+        # (the announced tensor is HELD: while it is referenced its memory cannot be handed to
+        # another tensor, so "same tensor, same version" below really means "same pixels" — a bare
+        # (data_ptr, version) pair matched a freshly allocated image at a recycled address)
+        gr["primed"] = (nxt, nxt._version)
       else:
         gr["primed"] = None
     gr["fb"].replay()

@@ -33,9 +33,9 @@ extern "C" {
 #define C2D_ERR_DATA (-5)        /* malformed input data (record framing, protobuf, JPEG stream) */
 
 /* ABI version, bumped whenever an entry point is added or a signature changes (round 1: 100 with
- * 28 entry points; round 4: 400).  c2d_version() returns the value the library was built with:
+ * 28 entry points; round 4: 400; round 5: 500).  c2d_version() returns the value the library was built with:
  * a host side compiled against another header must refuse to run (cap2det_amd/_lib.py does). */
-#define C2D_ABI_VERSION 400
+#define C2D_ABI_VERSION 500
 int c2d_version(void);
 /* Human readable message for a C2D_ERR_* code (static storage). */
 const char* c2d_error_string(int code);
@@ -528,6 +528,14 @@ int c2d_clip_gradient_norms(float* grads, const float* values, const C2dClipDesc
  * inside that range; the value returned is the channel chunk (= workgroup size) the strip kernel
  * will use for (wf, depth). */
 int c2d_roi_crop_pool_bwd_ws_supported(int wf, int depth, int crop, int pool_k, int pool_s);
+/* The same question for a whole call (round 5): every condition under which
+ * c2d_roi_crop_pool_bwd_ws / _prepare / _run return C2D_ERR_UNSUPPORTED, so that a caller decides
+ * ONCE per shape which backward it runs instead of meeting the error inside a training step.  On
+ * top of the per-map rules: pooled gradient < 2 GiB (elem_size 4 = fp32, 2 = bf16; fp32 7x7x576
+ * cells: fewer than 19,022 boxes), row lists < 2^31 entries, batch * hf * (strips per feature
+ * row) <= 4095.  Returns the channel chunk (> 0) or 0. */
+int c2d_roi_crop_pool_bwd_ws_shape_supported(int batch, int hf, int wf, int depth, int num_boxes,
+                                             int crop, int pool_k, int pool_s, int elem_size);
 long long c2d_roi_crop_pool_bwd_workspace_bytes(int batch, int hf, int wf, int depth,
                                                 int num_boxes, int crop, int pool_k, int pool_s);
 int c2d_roi_crop_pool_bwd_ws(const float* dout, const uint8_t* argmax, const float* boxes,

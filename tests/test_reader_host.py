@@ -209,3 +209,35 @@ def test_hash_bucket_is_stable_and_spread():
   assert counts.min() > 400 and counts.max() < 600          # ~500 each
   # shards are a partition
   assert sum(int((buckets == k).sum()) for k in range(8)) == len(ids)
+
+
+def test_device_prefetcher_on_cpu():
+  """readers/prefetch.py (the reference's dataset.prefetch, readers/cap2det_reader.py:266): order
+  kept, the producer's exception re-raised in the consumer, close() ends an endless source."""
+  import torch
+  from cap2det_amd.readers.prefetch import DevicePrefetcher
+
+  def gen(n, fail_at=None):
+    for i in range(n):
+      if i == fail_at:
+        raise RuntimeError("boom")
+      yield {"i": i, "t": torch.zeros(3)}
+
+  p = DevicePrefetcher(gen(7), "cpu", depth=2)
+  got = list(p)
+  assert [b["i"] for b in got] == list(range(7)) and all(b["_ready"] is None for b in got)
+  assert next(p, "end") == "end"
+  p.close()
+  p = DevicePrefetcher(gen(5, fail_at=2), "cpu")
+  seen = []
+  try:
+    for b in p:
+      seen.append(b["i"])
+    raise AssertionError("the producer's exception was swallowed")
+  except RuntimeError as e:
+    assert str(e) == "boom" and seen == [0, 1]
+  p.close()
+  p = DevicePrefetcher(gen(10 ** 9), "cpu", depth=2)
+  next(p)
+  p.close()
+  assert not p._thread.is_alive()
