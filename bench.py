@@ -238,15 +238,17 @@ class KernelTimer(object):
     return out
 
 
-def cpu_baseline(pipeline, classes, num_proposals, budget_s=45.0, max_timed=5):
+def cpu_baseline(pipeline, classes, num_proposals, budget_s=100.0, warmup=3, max_timed=10):
   """MEASURES full training steps of the CPU restatement of the reference semantics (the TF
   reference cannot run here): oracle/torch_step.train_step — `extract_frcnn_feature` and its
-  gradient on torch-CPU (oneDNN convolutions + autograd, fp32, all host threads: what
+  gradient on torch-CPU (oneDNN convolutions + autograd, fp32, host threads: what
   TensorFlow-CPU's Eigen/MKL-DNN kernels and tf.gradients do for the reference), heads / MIDN /
-  OICR / Adagrad in the numpy oracle — SURVEY.md §8d, BASELINE.md §4.  1 warm-up + up to
-  `max_timed` timed steps (5 at N = 2000, 10 at configs[0]'s N = 300: SURVEY §8d's 10 timed steps
-  where the bounded sample allows) at the benchmark's own size (one 500x500 image, `num_proposals` proposals); stops early
-  once `budget_s` of timed work is spent (at least one timed step always runs).  Median."""
+  OICR / Adagrad in the numpy oracle — SURVEY.md §8d, BASELINE.md §4's protocol: `warmup` (3)
+  warm-up + `max_timed` (10) timed full steps at the benchmark's own size (one 500x500 image,
+  `num_proposals` proposals), median / p10 / p90, the per-stage split and the CPU ROI-crop rate
+  under the same algorithmic-bytes definition.  Bounded: the warm-up shrinks to one step when a
+  step is slower than budget_s / 12, and the timed steps stop once `budget_s` of timed work is
+  spent (at least one always runs) — the counts actually used are reported."""
   import numpy as np
   import torch
   from oracle import ref_labels, ref_model, torch_step
@@ -260,37 +262,49 @@ def cpu_baseline(pipeline, classes, num_proposals, budget_s=45.0, max_timed=5):
   P, d = util_model.oracle_state(0, len(classes), 3, 1.0)
   acc = {k: np.full(v.shape, 0.1, np.float32) for k, v in P.items()}
   ex = synthetic.make_examples(rng, 1, IMAGE_HW, IMAGE_HW, num_proposals, [num_proposals], classes)
+  t_lab = time.perf_counter()
   labels = ref_labels.groundtruth_extract(ex["object_texts"], classes)
+  t_lab = time.perf_counter() - t_lab
   mask = (rng.uniform(size=(num_proposals, d)) < 0.5).astype(np.uint8)
   opts = ref_model.FrcnnOptions()
   loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
                    oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
   mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
-  times, warm = [], None
-  for i in range(1 + max_timed):
+
+  def one(timings=None):
     t0 = time.perf_counter()
     with np.errstate(over="ignore"):
-      torch_step.train_step(P, acc, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask)
-    dt = time.perf_counter() - t0
-    if i == 0:
-      warm = dt
-      if dt > budget_s:            # a slow host: the warm-up step is the sample
-        times.append(dt)
-        break
-    else:
-      times.append(dt)
-      if sum(times) + dt > budget_s:
-        break
-  times.sort()
-  med = times[len(times) // 2]
+      torch_step.train_step(P, acc, ex, labels, opts, loss_opts, mults, 0.01, 1e-6, mask, timings=timings)
+    return time.perf_counter() - t0
+
+  warm = [one()]
+  if warm[0] <= budget_s / 12.0:
+    warm += [one() for _ in range(warmup - 1)]
+  times, stages = [], {}
+  for _ in range(max_timed):
+    if times and sum(times) + times[-1] > budget_s:
+      break
+    times.append(one(stages))
+  order = sorted(times)
+  pick = lambda q: order[min(len(order) - 1, int(q * len(order)))]
+  med = order[len(order) // 2]
+  split = {k: v / len(times) for k, v in stages.items()}
+  split["label_branch(groundtruth match, once)"] = t_lab
+  crop_bytes = 4.0 * (num_proposals * 14 * 14 * 576 + 32 * 32 * 576 + num_proposals * 4)
+  crop_s = split.get("roi_crop_forward")
   return dict(value=1.0 / med, unit="images/s", cores=int(cores), kind="port",
-              step_s={"median": med, "min": times[0], "max": times[-1], "timed_steps": len(times),
-                      "warmup_step": warm},
+              step_s={"median": med, "p10": pick(0.1), "p90": pick(0.9), "min": order[0], "max": order[-1],
+                      "timed_steps": len(times), "warmup_steps": len(warm), "warmup_step": warm[0]},
+              stage_s_per_step=split,
+              roi_crop_cpu={"achieved": crop_bytes / crop_s / 1e9 if crop_s else None, "unit": "GB/s",
+                            "algorithmic_bytes": crop_bytes,
+                            "definition": "unfused crop_and_resize 14x14 (the CPU path materialises it): "
+                                          "N*14*14*576*4 written + map + boxes read, SURVEY 8d"},
               sample=("CPU restatement of the reference semantics (not TensorFlow): full fp32 train "
                       "step (fwd + losses + bwd + Adagrad) with the Inception-V2 towers, "
                       "crop_and_resize and pooling on torch-CPU (oneDNN + autograd, %d threads) and "
-                      "heads/MIDN/OICR/Adagrad in numpy; 1 image 500x500 with %d proposals; 1 warm-up "
-                      "+ %d timed full steps, median" % (cores, num_proposals, len(times))))
+                      "heads/MIDN/OICR/Adagrad in numpy; 1 image 500x500 with %d proposals; %d warm-up "
+                      "+ %d timed full steps, median" % (cores, num_proposals, len(warm), len(times))))
 
 
 def parse_args(argv=None):
@@ -335,6 +349,30 @@ def parse_args(argv=None):
   return ap.parse_args(argv)
 
 
+def pin_rank_to_cores(local_rank, local_world):
+  """One disjoint, contiguous share of the host cores per local rank (in-process
+  os.sched_setaffinity BEFORE torch starts its threads: every thread created later inherits it;
+  never an `env` / `taskset` hop in front of a rank, never a re-exec).  Eight ranks that each need
+  ~2.2 ms of host time per 3-ms bf16 step, plus RCCL's proxy threads, otherwise wander over the
+  same cores.  Returns what was chosen (reported in the JSON line), or None when there is nothing
+  to do (one rank, no sched_setaffinity, fewer cores than ranks)."""
+  if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+    return None
+  if os.environ.get("C2D_NO_AFFINITY") == "1":
+    return None
+  try:
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+      return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return {"cores_per_rank": per, "rank0_first_core": cores[0], "rank0_last_core": cores[per - 1],
+            "host_cores": len(cores), "this_rank": [mine[0], mine[-1]]}
+  except OSError:
+    return None
+
+
 def launch_ranks(args, argv):
   """`python bench.py --gpus N` as a plain command: this parent never touches the GPU (it does
   not even import torch: the devices are counted from the KFD topology in sysfs); it starts
@@ -375,11 +413,13 @@ def stub_main(args):
   max-over-ranks / JSON plumbing of this file with the training step replaced by the
   data-parallel exchange alone — the two-bucket OverlappedReducer over gloo on a CPU bucket of
   the real size — so that the multi-rank path is exercised where no GPU exists."""
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  affinity = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")),
+                               int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
   import torch
   import torch.distributed as dist
   from cap2det_amd.train import data_parallel
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  rank = int(os.environ.get("RANK", "0"))
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -387,14 +427,25 @@ def stub_main(args):
     raise SystemExit(3)                      # (launcher test: a failing rank fails the command)
   bucket = torch.zeros(7_100_000)
   split = 1_110_000
+  # the per-block cuts of the real bucket, [Mixed_4e | Mixed_5a | 5b | 5c + heads] (Trainer._block_cuts)
+  cuts = [0, 1_110_000, 2_030_000, 4_480_000, 7_100_000]
   def step(i):
     bucket.fill_(float(rank + 1 + i))
-    red = data_parallel.OverlappedReducer(bucket, split)
-    red.start_tail()
+    if i % 2 == 0:
+      red = data_parallel.OverlappedReducer(bucket, split)
+      red.start_tail()
+    else:
+      # per-block exchange as the backward pass issues it: last block first; every fourth step one
+      # block is never announced (finish() must pick it up with the Mixed_4e prefix)
+      red = data_parallel.BlockReducer(bucket, cuts)
+      for blk in (3, 2, 1):
+        if not (i % 4 == 3 and blk == 2):
+          red.start(blk)
     scale = red.finish()
     want = sum(r + 1 + i for r in range(world)) * scale
     got = bucket * scale
-    assert abs(float(got[0]) - want) < 1e-6 and abs(float(got[-1]) - want) < 1e-6, (float(got[0]), want)
+    for q in (0, cuts[1], cuts[2], cuts[3] - 1, -1):
+      assert abs(float(got[q]) - want) < 1e-6, (i, q, float(got[q]), want)
   for i in range(args.warmup):
     step(i)
   if world > 1:
@@ -415,7 +466,8 @@ def stub_main(args):
                       "n_gpus": args.gpus, "world_size": world, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                      "stub": True, "backend": "gloo"}))
+                      "stub": True, "backend": "gloo", "cpu_affinity": affinity,
+                      "exchanges": "two-bucket (even steps) and per-block (odd steps) over the real cuts"}))
   if world > 1:
     dist.destroy_process_group()
   return 0
@@ -528,9 +580,12 @@ def reader_main(args):
     torch.cuda.synchronize()
     fed = time.perf_counter() - clock["t0"]
     fed_loss = float(losses["total_loss"].item())
+    input_wait, enqueue = trainer.input_wait_s, trainer.enqueue_s
     # (b) the same process on resident inputs: one reader batch kept in HBM, stepped K times with
     # the look-ahead on the same tensors (what the headline command measures)
-    batch = next(iter(input_fn()))
+    it = iter(input_fn())
+    batch = next(it)
+    it.close()
     torch.cuda.synchronize()
     for i in range(args.warmup):
       trainer.train_step(batch, prefetch=batch if i + 1 < args.warmup else None)
@@ -558,6 +613,10 @@ def reader_main(args):
                  "reader": "map_num_parallel_calls %d, shuffle 16, flip 0.5, default_resizer, "
                            "input thread + copy stream, 2 batches ahead" % args.reader_workers},
       "resident_inputs": {"value": images / resident, "ms_per_step": 1000.0 * resident / args.steps},
+      # host time of the training thread per step, warm-up steps included: waiting for the input
+      # thread / queueing the step's launches
+      "host_ms_per_step": {"waiting_for_input": 1000.0 * input_wait / total,
+                           "queueing_the_step": 1000.0 * enqueue / total},
       "reader_over_resident": resident / fed,
       "final_total_loss": fed_loss,
   }
@@ -578,11 +637,12 @@ def main(argv=None):
       raise SystemExit("--reader is a single-GPU secondary measurement")
     sys.exit(reader_main(args))
 
-  import torch
-  import torch.distributed as dist
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  affinity = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+  import torch
+  import torch.distributed as dist
   if world != args.gpus:
     raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
   # C2D_BENCH_SAME_DEVICE=1 (validation of the multi-rank code path on a 1-GPU box only): every
@@ -772,6 +832,8 @@ def main(argv=None):
         "world_size": world,
         "final_total_loss": total_loss,
     }
+    if affinity:
+      result["cpu_affinity"] = affinity
     if grouped:
       result["process_group"] = {"backend": backend, "world_size": dist.get_world_size(),
                                  "ranks_counted_by_all_reduce": ranks_counted,
@@ -894,7 +956,7 @@ def main(argv=None):
     if not args.no_cpu_baseline and world == 1 and not secondary:
       result["cpu_baseline"] = cpu_baseline(pipeline, classes, NUM_PROPOSALS)
       # configs[0] (N = 300, the reference's own CPU-runnable case): the same CPU step, SURVEY §8d
-      result["cpu_baseline_c0"] = cpu_baseline(pipeline, classes, 300, budget_s=20.0, max_timed=10)
+      result["cpu_baseline_c0"] = cpu_baseline(pipeline, classes, 300, budget_s=30.0)
     if world > 1:
       result["backend"] = ("gloo, all ranks on cuda:0 (C2D_BENCH_SAME_DEVICE: code-path validation, "
                            "the value is not a scaling point)" if same_device else "nccl (RCCL)")

@@ -77,7 +77,13 @@ def resized_shape(options, height, width):
 
 
 def get_input_fn(options, device="cuda:0", seed=0):
-  """Returns a callable that yields batches (dicts keyed by InputDataFields names)."""
+  """Returns a callable that yields batches (dicts keyed by InputDataFields names).  A batch is made
+  in two halves — `_batch_host` (numpy / Python: padded_batch, box scaling, every random decision)
+  and `_batch_device` (uploads through the pinned staging ring + flip / resize / pad kernels on the
+  CURRENT stream) — so that a caller can run the whole generator on an input thread under a copy
+  stream (readers/prefetch.py).  (Round 5 also built the host half as a forked child process with a
+  shared-memory pixel ring: bitwise the same batches, but 0.56-0.66 of the resident-input rate
+  against 0.85-0.99 for the thread form, profiles/r05_experiments/README.md; not in the tree.)"""
   options = unwrap(options)
   if not isinstance(options, reader_pb2.Cap2DetReader):
     raise ValueError('options has to be an instance of Reader.')
@@ -202,8 +208,9 @@ def get_input_fn(options, device="cuda:0", seed=0):
     assert 0 <= numer < denom
     return tfrecord.to_hash_bucket(ex[InputDataFields.image_id], denom) == numer
 
-  def _batch(exs, rng):
-    """padded_batch + `_batch_resize_image_fn` + `_batch_scale_box_fn`."""
+  def _batch_host(exs, rng):
+    """padded_batch + `_batch_scale_box_fn` and every decision of `_batch_resize_image_fn`: the
+    host half of a batch (numpy / Python only; the decoded images ride along under '_u8')."""
     b = len(exs)
     n = options.max_num_proposals
     out = {}
@@ -239,11 +246,9 @@ def get_input_fn(options, device="cuda:0", seed=0):
     if options.decode_image:
       shapes = np.stack([e[InputDataFields.image_shape] for e in exs])
       ph, pw = int(shapes[:, 0].max()), int(shapes[:, 1].max())
-      canvas = torch.empty(b, ph, pw, _IMAGE_CHANNELS, device=device)
-      for i, e in enumerate(exs):
-        u8 = _upload(e["_image_u8"])
-        ops.image_resize_pad_u8(u8, e["_flip_left_right"], canvas[i], int(shapes[i, 0]),
-                                int(shapes[i, 1]))
+      out["_u8"] = [e["_image_u8"] for e in exs]
+      out["_canvas"] = (ph, pw, shapes.copy())          # canvas size + per-image resized shapes
+      out["_rescale"] = None
       out[InputDataFields.image_height] = np.array([e[InputDataFields.image_height] for e in exs], np.int32)
       out[InputDataFields.image_width] = np.array([e[InputDataFields.image_width] for e in exs], np.int32)
       if len(options.batch_resize_scale_value) > 0:
@@ -251,13 +256,10 @@ def get_input_fn(options, device="cuda:0", seed=0):
         scale = np.float32(options.batch_resize_scale_value[index])
         out["_batch_scale"] = float(scale)
         nh, nw = _rint(scale * np.float32(ph)), _rint(scale * np.float32(pw))
-        resized = torch.empty(b, nh, nw, _IMAGE_CHANNELS, device=device)
-        for i in range(b):
-          ops.resize_bilinear(canvas[i], nh, nw, out=resized[i])
-        canvas, ph, pw = resized, nh, nw
+        out["_rescale"] = (nh, nw)
+        ph, pw = nh, nw
         shapes = np.stack([[_rint(scale * np.float32(s[0])), _rint(scale * np.float32(s[1])), s[2]]
                            for s in shapes]).astype(np.int32)
-      out[InputDataFields.image] = canvas
       out[InputDataFields.image_shape] = shapes
       # `_batch_scale_box_fn`: box * img / pad in fp32, in this order
       img_h = shapes[:, 0].astype(np.float32)[:, None]
@@ -270,11 +272,33 @@ def get_input_fn(options, device="cuda:0", seed=0):
 
       ob, pr = scale_box(ob), scale_box(pr)
     out[InputDataFields.object_boxes] = ob
-    out[InputDataFields.proposals] = _upload(pr)
+    out[InputDataFields.proposals] = pr
+    return out
+
+  def _batch_device(out):
+    """The device half of a batch, on the CURRENT stream: uploads, flip + legacy-bilinear resize +
+    zero padding into the batch canvas, `_batch_resize_image_fn`'s rescale."""
+    images = out.pop("_u8", None)
+    if images is not None:
+      ph, pw, shapes = out.pop("_canvas")
+      rescale = out.pop("_rescale")
+      b = len(images)
+      canvas = torch.empty(b, ph, pw, _IMAGE_CHANNELS, device=device)
+      for i, img in enumerate(images):
+        ops.image_resize_pad_u8(_upload(img), out["_flip_left_right"][i], canvas[i], int(shapes[i, 0]),
+                                int(shapes[i, 1]))
+      if rescale is not None:
+        nh, nw = rescale
+        resized = torch.empty(b, nh, nw, _IMAGE_CHANNELS, device=device)
+        for i in range(b):
+          ops.resize_bilinear(canvas[i], nh, nw, out=resized[i])
+        canvas = resized
+      out[InputDataFields.image] = canvas
+    out[InputDataFields.proposals] = _upload(out[InputDataFields.proposals])
     out[InputDataFields.num_proposals] = _upload(out[InputDataFields.num_proposals])
     return out
 
-  def _input_fn():
+  def _host_batches():
     rng = np.random.default_rng(seed)
     workers = max(int(options.map_num_parallel_calls), 1)
     batch_size = int(options.batch_size)
@@ -288,14 +312,18 @@ def get_input_fn(options, device="cuda:0", seed=0):
         if _keep(ex):
           exs.append(ex)
         if len(exs) == batch_size:
-          yield _batch(exs, rng)
+          yield _batch_host(exs, rng)
           exs = []
       for fut in window:
         ex = fut.result()
         if _keep(ex):
           exs.append(ex)
         if len(exs) == batch_size:       # drop_remainder=True
-          yield _batch(exs, rng)
+          yield _batch_host(exs, rng)
           exs = []
+
+  def _input_fn():
+    for host in _host_batches():
+      yield _batch_device(host)
 
   return _input_fn

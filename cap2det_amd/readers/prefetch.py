@@ -85,6 +85,14 @@ class DevicePrefetcher(object):
     except queue.Empty:
       pass
     self._thread.join(timeout=5.0)
+    # (a generator source may own resources — the reader's input process and its shared memory:
+    #  end it here, once the thread that was running it has stopped)
+    closer = getattr(self._it, "close", None)
+    if closer is not None and not self._thread.is_alive():
+      try:
+        closer()
+      except Exception:   # noqa: BLE001
+        pass
 
 
 def adopt(batch, *streams):

@@ -427,10 +427,16 @@ class Trainer(object):
     # step on resident inputs): 3.97 ms at the default, 3.54 at 0.5 ms, 3.21 at 50 us.
     import sys
     switch_interval = sys.getswitchinterval()
-    sys.setswitchinterval(min(switch_interval, 5e-5))
+    sys.setswitchinterval(min(switch_interval, float(os.environ.get("C2D_SWITCH_INTERVAL", "5e-5"))))
+
+    import time
+    self.input_wait_s = 0.0        # host time this thread spent waiting for the input thread
+    self.enqueue_s = 0.0           # host time inside train_step (queueing the step's launches)
 
     def pull():
+      t0 = time.perf_counter()
       batch = next(src, None)
+      self.input_wait_s += time.perf_counter() - t0
       if batch is not None and on_gpu:
         adopt(batch, torch.cuda.current_stream(), getattr(eng, "prefetch_stream", None))
       return batch
@@ -444,8 +450,10 @@ class Trainer(object):
         if on_gpu and cur.get("_ready") is not None:
           torch.cuda.current_stream().wait_event(cur["_ready"])
         ahead = None if (last or nxt is None) else nxt
+        t0 = time.perf_counter()
         losses = self.train_step(cur, prefetch=ahead,
                                  prefetch_ready=None if ahead is None else ahead.get("_ready"))
+        self.enqueue_s += time.perf_counter() - t0
         if log is not None:
           log(self.global_step, losses)
         if save_dir and save_every and self.global_step % save_every == 0:

@@ -136,10 +136,20 @@ def predict_scores(P, examples, options, oicr_iterations):
 
 
 def train_step(P, accum, examples, labels, options, loss_opts, multipliers, learning_rate,
-               l2_weight, dropout_mask=None):
+               l2_weight, dropout_mask=None, timings=None):
   """Same contract as oracle.ref_model.train_step (P / accum updated in place).  The arithmetic
   type is P's: float32 for the timed CPU baseline, float64 for the committed mid-size fixtures
-  (tests/golden/gen_step_fixture.py)."""
+  (tests/golden/gen_step_fixture.py).  `timings`: a dict that receives the wall seconds of the
+  step's stages (BASELINE.md section 4's per-stage split; the backward pass of the towers is ONE
+  autograd call and is reported as one stage)."""
+  import time
+  marks = [time.perf_counter()]
+
+  def lap(name):
+    if timings is not None:
+      now = time.perf_counter()
+      timings[name] = timings.get(name, 0.0) + (now - marks[0])
+      marks[0] = now
   K = loss_opts["oicr_iterations"]
   dt = next(iter(P.values())).dtype.type
   tdt = torch.float64 if dt == np.float64 else torch.float32
@@ -165,11 +175,14 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
       x = _op(op, x, T, ref_model.FIRST_SCOPE)
   for op in spec1[split:]:
     x = _op(op, x, T, ref_model.FIRST_SCOPE)
+  lap("first_stage_forward")
   proposals = examples["proposals"]
   batch, n, _ = proposals.shape
   box_ind = np.repeat(np.arange(batch, dtype=np.int64), n)
   cropped = crop_and_resize(x, proposals.reshape(-1, 4), box_ind, options.initial_crop_size)
+  lap("roi_crop_forward")
   pooled = F.max_pool2d(cropped, options.maxpool_kernel_size, options.maxpool_stride)
+  lap("roi_maxpool_forward")
   net = pooled
   for op in ref_model.SECOND_STAGE:
     net = _op(op, net, T, ref_model.SECOND_SCOPE)
@@ -179,6 +192,7 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
         dropout_mask.astype(dt)).reshape(avg.shape)
   features = avg.reshape(batch, n, -1)
 
+  lap("second_stage_forward")
   f_np = features.detach().numpy()
   num_proposals = examples["number_of_proposals"]
   class_logits, scores, proba, midn_saved = ref_model.build_midn_network(num_proposals, f_np, P)
@@ -191,6 +205,7 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
   loss_dict, loss_grads = ref_model.build_loss(predictions, labels, loss_opts)
   dfeatures, grads = ref_model.heads_backward(
       loss_grads, dict(features=f_np, midn=midn_saved), P, K)
+  lap("heads_losses_and_their_gradients")
   names = list(leaves)
   gs = torch.autograd.grad(features, [leaves[k] for k in names],
                            torch.from_numpy(np.ascontiguousarray(dfeatures, dt)).to(tdt),
@@ -198,5 +213,8 @@ def train_step(P, accum, examples, labels, options, loss_opts, multipliers, lear
   for k, g in zip(names, gs):
     if g is not None:
       grads[k] = g.numpy()
-  return ref_model.finish_step(P, accum, grads, loss_dict, mult, dt, learning_rate,
-                               l2_weight, predictions=predictions)
+  lap("towers_backward(second stage, ROI crop, trainable first stage)")
+  out = ref_model.finish_step(P, accum, grads, loss_dict, mult, dt, learning_rate,
+                              l2_weight, predictions=predictions)
+  lap("regularisers_and_adagrad")
+  return out

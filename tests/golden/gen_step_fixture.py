@@ -12,6 +12,10 @@ of host memory and under a minute on 8 cores; `C2D_FIXTURE_FULL=c2`: step_dm1_fu
 size under BASELINE configs[2] — coco17_extend_match, 80 classes, the labels extracted from a
 caption by the oracle's ExtendMatch extractor; `C2D_FIXTURE_FULL=op`: step_dm1_op.npz, the reference's
 as-shipped training shape — two keep-aspect 1000x1333 images, 500 proposals each.)
+`C2D_FIXTURE_FULL=c3` / `c4`: step_dm1_full_c3.npz / _c4.npz, the same size under BASELINE configs[3] /
+[4] — coco17 / flickr30k_text_classifier_match — with a caption that contains NO class name, so that the
+TEXT-CLASSIFIER MLP (models/label_extractor.py:353-472), not the exact-match override (:469-472),
+decides the image-level labels: text_classifier_case() below.)
 The fixtures hold EXPECTED OUTPUTS only (scores, losses, gradient norms and sampled gradient /
 updated-variable entries); tests/test_gpu_step_fixture.py regenerates the seeded inputs and
 checks their checksums against the ones stored here."""
@@ -25,7 +29,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 HW, DM, SAMPLES, HEAD_STD = 160, 1.0, 48, 0.01    # (head std: the reference's truncated-normal 0.01, configs/*.pbtxt:58-72)
-SEEDS = {256: 6, 1100: 6, (500, (1000, 1333)): 8}          # model seed per fixture (main() rejects seeds with near-tie arg-maxes)
+SEEDS = {256: 6, 1100: 6, (500, (1000, 1333)): 8, (2000, 500, 4): 9}          # model seed per fixture (main() rejects seeds with near-tie arg-maxes)
 
 
 FULL = dict(n=2000, hw=500)      # the benchmark's own configuration (step_dm1_full.npz)
@@ -34,7 +38,7 @@ FULL = dict(n=2000, hw=500)      # the benchmark's own configuration (step_dm1_f
 OP = dict(n=500, hw=(1000, 1333), batch=2)   # the reference's as-shipped training shape (step_dm1_op.npz)
 
 
-def inputs(n, classes, hw=None, captions=False, batch=1):
+def inputs(n, classes, hw=None, captions=False, batch=1, salt=0):
   """The seeded inputs of a fixture (shared with the GPU test).  captions: a synthetic caption over
   the shipped COCO open vocabulary rides along (`concat_caption_string`: BASELINE configs[2], the
   labels come from the caption through the ExtendMatch extractor)."""
@@ -42,7 +46,7 @@ def inputs(n, classes, hw=None, captions=False, batch=1):
   hw = HW if hw is None else hw
   h, w = hw if isinstance(hw, tuple) else (hw, hw)
   rng = np.random.default_rng(1000 + n + (0 if hw == HW else h + w if isinstance(hw, tuple) else hw) +
-                              (7 if captions else 0))
+                              (7 if captions else 0) + 100 * salt)
   real = n - n // 8
   ex = util_model.make_examples(rng, batch, h, w, n, [real] + [n] * (batch - 1), classes)
   if captions:
@@ -52,10 +56,63 @@ def inputs(n, classes, hw=None, captions=False, batch=1):
                                                                must_contain=["dog", "bicycle"])
   # (the OICR arg-max over the proposals is a discrete choice: main() checks that none of them is a
   # near tie, so that fp32 and float64 select the same boxes)
-  seed = int(os.environ.get("C2D_FIXTURE_SEED", SEEDS.get((n, hw), SEEDS.get(n, 6))))   # (env: seed scans)
+  seed = int(os.environ.get("C2D_FIXTURE_SEED", SEEDS.get((n, hw, salt), SEEDS.get((n, hw), SEEDS.get(n, 6)))))   # (env: seed scans)
   P32, d = util_model.oracle_state(seed, len(classes), 3, DM, head_std=HEAD_STD)
   mask = (rng.uniform(size=(batch * n, d)) < 0.5).astype(np.uint8)
   return ex, P32, mask, real
+
+
+def text_classifier_case(config, out_dir, all_oov=False):
+  """Synthetic GloVe table + text-classifier weights for BASELINE configs[3] / [4] (the real
+  `data/*_300d.npy` and `zoo/` checkpoint are missing from the reference checkout) under which the
+  MLP decides the labels: a 60-token caption over the config's open vocabulary from which every
+  raw class name has been removed (the exact-match vector of models/label_extractor.py:465-472 is
+  all zero), layer-2 biases chosen so that THREE classes clear the 0.7 threshold with a logit
+  margin >= 1.1 and the other 77 stay below it by as much (a discrete decision fp32 and float64
+  must share).  all_oov: every token is out of vocabulary — `masked_maximum` then returns the axis
+  MINIMUM over all rows, padding included (core/utils.py:75-79): the hidden
+  vector of the OOV embedding row.  Writes the two files the pipeline names; returns the caption,
+  the OOV row, the file paths and the float64 oracle's labels."""
+  from cap2det_amd import synthetic
+  from oracle import ref_labels
+  spec = synthetic.BASELINE_CONFIGS[config]
+  vocab = synthetic.read_lines(os.path.join(synthetic.DATA, spec["vocab"]))
+  classes = synthetic.read_lines(os.path.join(synthetic.DATA, "coco_label.txt"))
+  rng = np.random.default_rng(4040 + len(vocab) + (1 if all_oov else 0))
+  emb = (0.4 * rng.standard_normal((len(vocab), 300))).astype(np.float32)
+  oov_row = (0.03 * (rng.uniform(size=(1, 300)) * 2 - 1)).astype(np.float32)
+  w1 = (rng.standard_normal((300, 400)) / np.sqrt(300)).astype(np.float32)
+  b1 = (0.1 * rng.standard_normal(400)).astype(np.float32)
+  w2 = (rng.standard_normal((400, len(classes))) / 6.0).astype(np.float32)
+  if all_oov:
+    caption = [["zzzoov%d" % i for i in range(40)] + [""] * 20]
+  else:
+    names = set(classes)
+    filler = [w for w in vocab[:500] if w not in names]
+    cap = synthetic.synthetic_captions(rng, 1, vocab, tokens=60)[0]
+    caption = [[filler[i % len(filler)] if t in names else t for i, t in enumerate(cap)]]
+  ids = ref_labels.tokens_to_ids(caption, vocab)
+  assert all_oov == bool((ids == len(vocab)).all())
+  full = np.concatenate([emb, oov_row]).astype(np.float64)
+  f64 = lambda a: a.astype(np.float64)
+  base = ref_labels.text_classifier_logits(ids, full, f64(w1), f64(b1), f64(w2), np.zeros(len(classes)))[0]
+  fire = np.sort(rng.choice(len(classes), 3, replace=False))
+  target = -2.0 - rng.uniform(0, 1, len(classes))
+  target[fire] = 2.0 + rng.uniform(0, 1, 3)
+  b2 = (target - base).astype(np.float32)
+  exact = ref_labels.match_labels(caption, classes)
+  labels = ref_labels.text_classifier_match_extract(ids, exact, full, f64(w1), f64(b1), f64(w2), f64(b2), 0.7)
+  assert exact.sum() == 0 and sorted(np.nonzero(labels[0])[0]) == list(fire), (exact.sum(), labels.sum())
+  os.makedirs(out_dir, exist_ok=True)
+  ef = os.path.join(out_dir, "open_vocab_300d_%s.npy" % config)
+  wf = os.path.join(out_dir, "text_classifier_%s.npz" % config)
+  np.save(ef, emb)
+  np.savez(wf, **{"text_classifier/layer1/weights": w1, "text_classifier/layer1/biases": b1,
+                  "text_classifier/layer2/weights": w2, "text_classifier/layer2/biases": b2})
+  pipeline = synthetic.load_pipeline(spec["pipeline"], open_vocabulary_word_embedding_file=ef,
+                                     text_classifier_checkpoint_file=wf)
+  return dict(caption=caption, oov_row=oov_row, embedding=emb, labels=labels, fire=fire,
+              pipeline=pipeline, classes=classes)
 
 
 def checksum(ex, P32, mask):
@@ -81,9 +138,17 @@ def main():
   mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   loss_opts = dict(midn_loss_weight=1.0, oicr_loss_weight=0.5, oicr_iterations=3,
                    oicr_iou_threshold=0.6, oicr_use_proba_r_given_c=True)
-  full = os.environ.get("C2D_FIXTURE_FULL", "") in ("1", "c2", "op")
+  full = os.environ.get("C2D_FIXTURE_FULL", "") in ("1", "c2", "c3", "c4", "op")
   c2 = os.environ.get("C2D_FIXTURE_FULL") == "c2"
   op = os.environ.get("C2D_FIXTURE_FULL") == "op"
+  tc = os.environ.get("C2D_FIXTURE_FULL") if os.environ.get("C2D_FIXTURE_FULL") in ("c3", "c4") else None
+  case = None
+  if tc:
+    # BASELINE configs[3] / [4]: the labels come from the text-classifier MLP (no class name in the caption)
+    import tempfile
+    case = text_classifier_case(tc, tempfile.mkdtemp(prefix="c2d_fixture_"))
+    pipeline, classes = case["pipeline"], case["classes"]
+    mults = [(g.scope, g.multiplier) for g in pipeline.train_config.gradient_multiplier]
   if c2:
     # BASELINE configs[2]: coco17_extend_match — 80 classes, labels from the caption (same loss
     # weights, multipliers, learning rate and regulariser as voc07_groundtruth)
@@ -94,12 +159,16 @@ def main():
     if op:
       ex, P32, mask, real = inputs(n, classes, OP["hw"], batch=OP["batch"])
     else:
-      ex, P32, mask, real = inputs(n, classes, FULL["hw"] if full else None, captions=c2)
+      ex, P32, mask, real = inputs(n, classes, FULL["hw"] if full else None, captions=c2,
+                                   salt=0 if not tc else 3 if tc == "c3" else 4)
     P = {k: v.astype(np.float64) for k, v in P32.items()}
     acc = {k: np.full(v.shape, 0.1) for k, v in P.items()}
     if c2:
       labels = ref_labels.extend_match_extract(ex["concat_caption_string"], name2id, len(classes)).astype(np.float64)
       assert labels.sum() >= 2
+    elif tc:
+      labels = case["labels"].astype(np.float64)
+      assert labels.sum() == 3
     else:
       labels = ref_labels.groundtruth_extract(ex["object_texts"], classes).astype(np.float64)
     ex64 = dict(image=ex["image"].astype(np.float64), number_of_proposals=ex["number_of_proposals"],
@@ -127,6 +196,8 @@ def main():
     assert min(margins) > 1e-3, "pick another seed: an OICR arg-max is a near tie"
     arrays = {"checksum": checksum(ex, P32, mask), "real": np.int64(real),
               "min_argmax_margin": np.float64(min(margins))}
+    if tc:
+      arrays["labels"] = labels
     # (full-size fixtures keep the score tensors in float32: 1e-7 of their value, three orders
     #  below the 1e-4 they are compared at, half the file)
     keep = (lambda a: a.astype(np.float32)) if full else (lambda a: a)
@@ -147,7 +218,8 @@ def main():
     arrays["updated_samples"] = np.stack([
         np.resize(P[k].reshape(-1)[sample_indices(k, P[k].size)], SAMPLES) for k in names])
     path = os.path.join(ROOT, "tests", "golden",
-                        "step_dm1_op.npz" if op else "step_dm1_full_c2.npz" if c2 else "step_dm1_full.npz" if full
+                        "step_dm1_op.npz" if op else "step_dm1_full_c2.npz" if c2 else
+                        "step_dm1_full_%s.npz" % tc if tc else "step_dm1_full.npz" if full
                         else "step_dm1_n%d.npz" % n)
     np.savez_compressed(path, **arrays)
     print(path, os.path.getsize(path), "bytes; total_loss", out["total_loss"], "vars", len(names))

@@ -29,6 +29,47 @@ def test_plain_command_launches_two_ranks():
   assert out["value"] > 0 and out["ms_per_step"] > 0
 
 
+def test_plain_command_launches_eight_ranks():
+  """SCALE readiness: the driver's 8-GPU command shape on this CPU box — eight ranks
+  through the launcher, both gradient exchanges over the REAL per-block cuts of the bucket (the
+  per-block reducer with uneven start() coverage on odd steps), one disjoint core set per rank chosen
+  in-process and reported in the line."""
+  r = _run({"C2D_BENCH_STUB": "1"}, "--gpus", "8", "--steps", "4", "--warmup", "1")
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["stub"] is True
+  aff = out["cpu_affinity"]
+  ncores = len(os.sched_getaffinity(0))
+  if ncores >= 8:
+    assert aff["cores_per_rank"] == ncores // 8 and aff["host_cores"] == ncores
+    assert aff["this_rank"][1] - aff["this_rank"][0] + 1 >= aff["cores_per_rank"]
+
+
+def test_rank_core_sets_are_disjoint(monkeypatch):
+  sys.path.insert(0, ROOT)
+  import bench
+  cores = sorted(os.sched_getaffinity(0))
+  try:
+    seen = []
+    for r in range(4):
+      os.sched_setaffinity(0, cores)
+      got = bench.pin_rank_to_cores(r, 4)
+      if len(cores) < 4:
+        assert got is None
+        continue
+      mine = sorted(os.sched_getaffinity(0))
+      assert len(mine) == len(cores) // 4 and got["this_rank"] == [mine[0], mine[-1]]
+      assert not set(mine) & set(seen)
+      seen += mine
+    os.sched_setaffinity(0, cores)
+    assert bench.pin_rank_to_cores(0, 1) is None                 # one rank keeps every core
+    assert sorted(os.sched_getaffinity(0)) == cores
+  finally:
+    os.sched_setaffinity(0, cores)
+
+
 def test_single_rank_stub_runs_in_process():
   r = _run({"C2D_BENCH_STUB": "1"}, "--steps", "2", "--warmup", "0")
   assert r.returncode == 0, r.stderr[-2000:]

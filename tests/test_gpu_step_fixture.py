@@ -58,7 +58,7 @@ BF16_TOL = dict(score_rel=8e-2, logits=3e-2, loss=2e-2, grad=1e-1, norm=5e-2)
 def _fixture(n):
   """(fixture arrays, proposals, image size) of fixture `n` (256, 1100, or "full": the benchmark's own
   configuration, 2000 proposals on a 500x500 image)."""
-  if n in ("full", "full_c2"):
+  if n in ("full", "full_c2", "full_c3", "full_c4"):
     return (np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_%s.npz" % n)), gen.FULL["n"],
             gen.FULL["hw"])
   if n == "op":
@@ -66,8 +66,36 @@ def _fixture(n):
   return np.load(os.path.join(ROOT, "tests", "golden", "step_dm1_n%d.npz" % n)), n, None
 
 
-@pytest.mark.parametrize("n", [256, 1100, "full"])
-def test_train_step_bf16_replays_the_float64_fixture(n):
+def _text_classifier_setup(tag, tmp_path, compute_dtype):
+  """Trainer + inputs of the "full_c3" / "full_c4" fixtures: BASELINE configs[3] / [4] with the
+  synthetic GloVe table / classifier of gen.text_classifier_case, whose caption names NO class, so
+  the text-classifier MLP decides the labels inside the step (models/label_extractor.py:442-472)."""
+  from cap2det_amd.train.trainer import Trainer
+  cfg = tag[-2:]
+  case = gen.text_classifier_case(cfg, str(tmp_path))
+  trainer = Trainer(case["pipeline"], device=DEV, depth_multiplier=gen.DM, compute_dtype=compute_dtype)
+  ext = trainer.model.label_extractor
+  assert type(ext).__name__ == "TextClassifierMatchExtractor" and list(ext.classes) == case["classes"]
+  ext.set_embedding(case["embedding"], oov_row=case["oov_row"])     # (un-seeded in the reference)
+  ex, P32, mask, real = gen.inputs(gen.FULL["n"], case["classes"], gen.FULL["hw"],
+                                   salt=3 if cfg == "c3" else 4)
+  ex["concat_caption_string"] = case["caption"]
+  return trainer, case, ex, P32, mask, real
+
+
+def _check_mlp_decided_the_labels(trainer, case, fix):
+  """The labels the step trained on are the float64 oracle's, came from the MLP (no exact match) and
+  are the three classes the fixture was built to fire."""
+  labels = trainer.model._ctx["labels"].detach().cpu().numpy()
+  np.testing.assert_array_equal(labels, fix["labels"])
+  np.testing.assert_array_equal(labels, case["labels"])
+  assert sorted(np.nonzero(labels[0])[0]) == list(case["fire"]) and labels.sum() == 3
+  from oracle import ref_labels
+  assert ref_labels.match_labels(case["caption"], case["classes"]).sum() == 0
+
+
+@pytest.mark.parametrize("n", [256, 1100, "full", "full_c4"])
+def test_train_step_bf16_replays_the_float64_fixture(n, tmp_path):
   """The same fixtures through compute_dtype="bf16" (BASELINE configs[2] / [4] storage mode: first
   stage, ROI crop output and second stage in bf16, fp32 accumulation) on the benchmark's launch
   plan.  There is no bf16 reference; the bounds (BF16_TOL) are what the roundings allow, the
@@ -75,13 +103,18 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
   probabilities; the OICR softmax scores 1.0 % / 1.1 %), logits 0.8 % / 0.5 %, losses <= 0.2 % /
   0.3 %, gradient samples 1.7 % / 2.2 % of the tensor's scale, gradient norms 0.6 %."""
   from cap2det_amd.train.trainer import Trainer
+  tc = n if n in ("full_c3", "full_c4") else None     # BASELINE configs[4]: the text classifier decides the labels
   fix, n, hw = _fixture(n)
-  pipeline = util_model.load_pipeline()
-  trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM, compute_dtype="bf16")
-  model = trainer.model
+  if tc:
+    trainer, case, ex, P32, mask, real = _text_classifier_setup(tc, tmp_path, "bf16")
+    model = trainer.model
+  else:
+    pipeline = util_model.load_pipeline()
+    trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM, compute_dtype="bf16")
+    model = trainer.model
+    classes = model.label_extractor.classes
+    ex, P32, mask, real = gen.inputs(n, classes, hw)
   assert model.engine.first.dtype == torch.bfloat16 and model.engine.second.dtype == torch.bfloat16
-  classes = model.label_extractor.classes
-  ex, P32, mask, real = gen.inputs(n, classes, hw)
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   model.load_state_dict(P32)
   dev = dict(ex)
@@ -89,6 +122,8 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
     dev[k] = torch.from_numpy(ex[k]).to(DEV).contiguous()
   losses = trainer.train_step(dev, dropout_mask=torch.from_numpy(mask).to(DEV))
   torch.cuda.synchronize()
+  if tc:
+    _check_mlp_decided_the_labels(trainer, case, fix)
   pred = trainer.predictions
   seen = {}
   for i in range(4):
@@ -122,7 +157,7 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
     if norm is not None and norm > 1e-12:
       worst_n = max(worst_n, abs(float(np.sqrt((g * g).sum())) - norm) / norm)
   seen["grad"], seen["norm"] = worst_g, worst_n
-  print("bf16 fixture replay n=%d:" % n, {k: float("%.3g" % v) for k, v in seen.items()})
+  print("bf16 fixture replay %s n=%d:" % (tc or "", n), {k: float("%.3g" % v) for k, v in seen.items()})
   for k, v in seen.items():
     if k.startswith("score_abs"):
       continue                # (reported only: the scale of the scores differs per refinement)
@@ -131,9 +166,13 @@ def test_train_step_bf16_replays_the_float64_fixture(n):
   assert worst_g > 1e-5      # (it really ran in reduced precision)
 
 
-@pytest.mark.parametrize("n", [256, 1100, "full", "full_c2", "op"])
-def test_train_step_replays_the_float64_fixture(monkeypatch, n):
-  """("full_c2": the same size under BASELINE configs[2] — coco17_extend_match, 80 classes, a 416-column
+@pytest.mark.parametrize("n", [256, 1100, "full", "full_c2", "full_c3", "op"])
+def test_train_step_replays_the_float64_fixture(monkeypatch, tmp_path, n):
+  """("full_c3", round 5: BASELINE configs[3] — coco17_text_classifier_match — at the benchmark's size
+  with a caption that names NO class: the GloVe gather + text-classifier MLP + 0.7 threshold decide the
+  labels inside the step, models/label_extractor.py:353-472; three classes fire.  Its bf16 twin
+  "full_c4" — flickr30k vocabulary — is replayed by the bf16 test above.)
+  ("full_c2": the same size under BASELINE configs[2] — coco17_extend_match, 80 classes, a 416-column
   heads GEMM, MIDN / OICR on 2000 x 80, the labels extracted from the caption INSIDE the step by the
   ExtendMatch extractor; the fixture's labels came from the oracle's extractor.)
   ("op": the reference's as-shipped training shape — a batch of TWO keep-aspect 1000x1333 images with 500
@@ -146,13 +185,19 @@ def test_train_step_replays_the_float64_fixture(monkeypatch, n):
   from cap2det_amd.train.trainer import Trainer
   c2 = n == "full_c2"       # BASELINE configs[2]: coco17_extend_match, 80 classes, labels from the caption
   op = n == "op"            # the reference's as-shipped training shape: two 1000x1333 images, 500 proposals
+  tc = n if n == "full_c3" else None
   fix, n, hw = _fixture(n)
-  pipeline = synthetic.baseline_pipeline("c2") if c2 else util_model.load_pipeline()
-  trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM)
-  model = trainer.model
-  classes = model.label_extractor.classes
-  assert len(classes) == (80 if c2 else 20)
-  ex, P32, mask, real = gen.inputs(n, list(classes), hw, captions=c2, batch=gen.OP["batch"] if op else 1)
+  if tc:
+    trainer, case, ex, P32, mask, real = _text_classifier_setup(tc, tmp_path, "fp32")
+    model = trainer.model
+    classes = model.label_extractor.classes
+  else:
+    pipeline = synthetic.baseline_pipeline("c2") if c2 else util_model.load_pipeline()
+    trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM)
+    model = trainer.model
+    classes = model.label_extractor.classes
+    ex, P32, mask, real = gen.inputs(n, list(classes), hw, captions=c2, batch=gen.OP["batch"] if op else 1)
+  assert len(classes) == (80 if (c2 or tc) else 20)
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   assert real == int(fix["real"])
   model.load_state_dict(P32)
@@ -170,7 +215,9 @@ def test_train_step_replays_the_float64_fixture(monkeypatch, n):
     dev[k] = torch.from_numpy(ex[k]).to(DEV).contiguous()
   losses = trainer.train_step(dev, dropout_mask=torch.from_numpy(mask).to(DEV))
   torch.cuda.synchronize()
-  if not c2 and not op:
+  if tc:
+    _check_mlp_decided_the_labels(trainer, case, fix)
+  if not c2 and not op and not tc:
     _dispatched[(n, hw)] = seen
   if op:       # (63x84 feature maps: the wide-map strips of the atomic-free ROI-crop backward)
     assert model.engine.last_crop_bwd.startswith("row-owner"), model.engine.last_crop_bwd
