@@ -121,6 +121,43 @@ def main():
     chk["ok"] = bool(good)
     ok = ok and good
     report["checks"].append(chk)
+  # The per-block exchange (the RCCL default: asynchronous all-reduces issued from INSIDE the
+  # filter-gradient stream, joined with Work.wait() on the main stream, the side stream itself
+  # joined at the end of engine.backward) against the two-bucket form, both forced at one rank.
+  # A collective that started before its block's last writer, or an optimiser that ran before a
+  # collective finished, loses a whole layer's contribution — an O(1) error; what two correct runs
+  # differ by is the order of the remaining fp32 atomics (heads / Mixed_4e filter gradients, loss
+  # scalars: ~1e-7 of the bucket's scale even with C2D_WGRAD_PARTIALS=1).  So: the two forms must
+  # agree to 1e-5 of scale on the reduced gradients and on the updated variables, and no worse
+  # than ten times what two runs of the SAME form differ by.
+  def grads_after_first_step(buckets):
+    os.environ["C2D_FORCE_ALLREDUCE"] = "1"
+    os.environ["C2D_WGRAD_PARTIALS"] = "1"
+    os.environ["C2D_DP_BUCKETS"] = buckets
+    try:
+      trainer = Trainer(pipeline, device=dev, seed=21)
+      before = calls["n"]
+      trainer.train_step(batches[0], dropout_seed=40, prefetch=batches[1])
+      torch.cuda.synchronize()
+      lo, hi = trainer.bucket
+      return trainer.model.store.grads[lo:hi].clone(), trainer.model.store.values[lo:hi].clone(), calls["n"] - before
+    finally:
+      for k in ("C2D_WGRAD_PARTIALS", "C2D_DP_BUCKETS", "C2D_FORCE_ALLREDUCE"):
+        os.environ.pop(k, None)
+  g_blocks, v_blocks, n_blocks = grads_after_first_step("blocks")
+  g_again, v_again, _ = grads_after_first_step("blocks")
+  g_two, v_two, n_two = grads_after_first_step("two")
+  def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / a.double().abs().max())
+  chk = {"mode": "blocks_vs_two", "collectives_blocks": n_blocks, "collectives_two": n_two,
+         "same_form_gradient_diff_of_scale": rel(g_blocks, g_again),
+         "gradient_diff_of_scale": rel(g_blocks, g_two),
+         "updated_variables_diff_of_scale": rel(v_blocks, v_two)}
+  bound = max(1e-5, 10.0 * chk["same_form_gradient_diff_of_scale"])
+  chk["ok"] = bool(chk["gradient_diff_of_scale"] <= bound and
+                   chk["updated_variables_diff_of_scale"] <= 1e-5 and n_blocks == 4 and n_two == 2)
+  ok = ok and chk["ok"]
+  report["checks"].append(chk)
   # what the process group itself counts
   ones = torch.ones(1, device=dev, dtype=torch.int32)
   real_all_reduce(ones)
