@@ -643,6 +643,9 @@ def main(argv=None):
   affinity = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
   import torch
   import torch.distributed as dist
+  if affinity:
+    # (torch sizes its intra-op pool by the host's core count: keep it inside this rank's share)
+    torch.set_num_threads(max(1, min(affinity["cores_per_rank"], 16)))
   if world != args.gpus:
     raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
   # C2D_BENCH_SAME_DEVICE=1 (validation of the multi-rank code path on a 1-GPU box only): every

@@ -10,7 +10,7 @@ set -x
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
-T=${PROFILE_TAG:-r02}
+T=${PROFILE_TAG:-r05}
 cd /tmp; export TMPDIR=/tmp
 for CFG in c1 c2; do
   B="python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline"
@@ -40,5 +40,6 @@ timeout 400 python bench.py > $O/${T}_summaries/${T}_bench_c1.json 2> $O/${T}_be
 for CFG in c2 c3 c4; do timeout 300 python bench.py --config $CFG --no-cpu-baseline > $O/${T}_summaries/${T}_bench_${CFG}.json 2> $O/${T}_bench_${CFG}.err; done
 C2D_WGRAD_SIDE_STREAM=0 timeout 300 python bench.py --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c1_serial.json 2> $O/${T}_bench_c1_serial.err
 C2D_WGRAD_SIDE_STREAM=0 timeout 300 python bench.py --config c2 --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c2_serial.json 2> $O/${T}_bench_c2_serial.err
-timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/${T}_summaries/${T}_bench_gpus2_same_device.json 2> $O/${T}_bench_gpus2.err
+# (gloo prints its connection banner to stdout: keep the JSON line only)
+timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2> $O/${T}_bench_gpus2.err | grep '^{' | tail -1 > $O/${T}_summaries/${T}_bench_gpus2_same_device.json
 ls -la $O/${T}_summaries; du -sh $O/${T}_*
