@@ -50,7 +50,10 @@ constexpr int ring_blocks_per_cu(int lds_bytes) {
 // v_mfma_f32_32x32x2_f32 (exact fp32; round 3: the same ring with 16- or 32-float stages, i.e. the
 // same 64- / 128-byte rows — the register-staged igemm_nt_kernel of conv_gemm.hip spends 11 % of
 // its launches on operand staging and needs a second barrier per slab).
-template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES>
+// FUSED: the instance whose epilogue carries the producer layer's BN/ReLU backward (IgemmArgs::fy;
+// input-gradient launches of bf16 networks).  Its own instantiation: the epilogue's column sums and
+// per-column facts must not cost the plain kernels a register.
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED = false>
 __global__ __launch_bounds__(WM * WN * 64,
                              ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 > 0
                                  ? ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 : 1)
@@ -460,103 +463,183 @@ void igemm_ring_kernel(IgemmArgs a) {
   // stores 16 B (8 bf16 / 4 fp32) of ONE output row, neighbouring lanes neighbouring columns.
   constexpr int SCOLS = NT * 32;
   constexpr int SSTR = SCOLS + 4;
-  constexpr int FHALVES = WM * WN * 32 * SSTR * 4 <= LDS_BYTES ? 1 : 2;
-  if (MODE == 1 && a.fy != nullptr) {
-    // Fused BN/ReLU backward of the producer layer (see IgemmArgs::fy; an option of bf16
-    // networks): it sums over the rows per column, so every lane keeps FOUR fixed columns and a
-    // pass covers 64 / (SCOLS / 4) rows.
-    // (wide wave tiles: the 32-row strip goes through the staging slice as two halves of 16 rows)
-    constexpr int HALVES = FHALVES;
+  if constexpr (FUSED) {
+    // Fused BN/ReLU backward of the producer layer (see IgemmArgs::fy; input-gradient launches):
+    // dc = dx * [y > 0] * scale, and per column the sums of dz = dx * [y > 0] and dz * (y - beta) /
+    // gamma over the block's rows.  Round 5: the same structure as the plain epilogue below — the
+    // output row of every tile row and the producer's per-column facts once per block in LDS tables,
+    // 16 bytes per lane and store — with ONE difference: a lane keeps a FIXED 16-byte column chunk
+    // (lane % CPRW) for the whole block, because it sums per column; a pass covers 64 / CPRW rows
+    // (tiles whose chunk count does not divide 64 leave the last lanes idle: 128x192 tiles use 60
+    // of 64).  Round 2's form (four columns per lane, a row decomposition with two divisions and the
+    // producer routing from kernarg in every pass, inside the plain kernel: its registers were the
+    // plain kernel's) made the fused launches of the bf16 step cost more than the separate
+    // bn_relu_bwd kernels they replaced (2.98 against 2.95 ms per step; this form 2.915 against
+    // 2.925, same box, alternating runs).  Fetching the producer's outputs of the whole block tile
+    // up front (one load latency per block instead of one per strip) was tried on top and lost to
+    // its 32 spilled registers (2.96 ms).
+    constexpr int CW = 16 / ES;                    // columns per lane and store
+    constexpr int CPRW = SCOLS / CW;               // chunks per strip row
+    constexpr int RPPF = 64 / CPRW;                // rows per pass
+    constexpr int TAB_BYTES = (BM + 3 * BN) * 4;
+    constexpr int HALVES = WM * WN * 32 * SSTR * 4 + TAB_BYTES <= LDS_BYTES ? 1 : 2;
     constexpr int HROWS = 32 / HALVES;
-    static_assert(WM * WN * HROWS * SSTR * 4 <= LDS_BYTES, "epilogue staging exceeds LDS");
+    constexpr int STAGE_BYTES = WM * WN * HROWS * SSTR * 4;
+    constexpr int NPASSF = (HROWS + RPPF - 1) / RPPF;
+    static_assert(STAGE_BYTES + TAB_BYTES <= LDS_BYTES, "epilogue staging exceeds LDS");
+    static_assert(NTHREADS * 2 * CW * 4 <= LDS_BYTES, "column-sum exchange exceeds LDS");
+    static_assert(CPRW <= 64 && RPPF >= 1, "strip row wider than a wave");
     float* stage = reinterpret_cast<float*>(smem) + wave * (HROWS * SSTR);
-    constexpr int C4 = SCOLS / 4;
-    constexpr int RPP = 64 / C4;
-    static_assert(HROWS % RPP == 0, "epilogue passes vs strip rows");
-    const int ec4 = lane % C4, er = lane / C4;
-    const bool lane_on = er < RPP;                // (C4 does not divide 64: the last lanes idle)
-    const int ncol = n0 + wn * SCOLS + ec4 * 4;
-    f32x4 esc = {1.f, 1.f, 1.f, 1.f}, esh = {0.f, 0.f, 0.f, 0.f};
-    const bool ncol_ok = ncol < a.N && lane_on;
-    if (ncol_ok && a.scale) esc = *reinterpret_cast<const f32x4*>(a.scale + ncol);
-    if (ncol_ok && a.shift) esh = *reinterpret_cast<const f32x4*>(a.shift + ncol);
-    // several convolutions in one GEMM: this lane's four columns belong to one of them
-    float* oC = a.C; int oldc = a.ldc, ocoff = a.c_off + ncol, orelu = a.relu;
-    if (MODE == 0 && a.mo_n && ncol_ok) {
-      const MoOut o = mo_output(a, ncol);
-      oC = o.C; oldc = o.ldc; ocoff = o.coff + (ncol - o.lo); orelu = o.relu;
-      esc = *reinterpret_cast<const f32x4*>(o.scale + (ncol - o.lo));
-      esh = *reinterpret_cast<const f32x4*>(o.shift + (ncol - o.lo));
+    int* const drow_tab = reinterpret_cast<int*>(smem + STAGE_BYTES);   // output row of tile row r, or -1
+    float* const tab_sc = reinterpret_cast<float*>(drow_tab + BM);      // producer's BN scale (NaN: the
+    float* const tab_be = tab_sc + BN;                                  // column passes unchanged), beta
+    float* const tab_ig = tab_be + BN;                                  // and 1 / gamma (0: no gamma)
+    for (int r = tid; r < BM; r += NTHREADS) {
+      const int m = m0 + r;
+      bool row_ok = m < a.M;
+      int drow = m;
+      if (PM || a.g.sub > 1) {
+        const RowPos p = decompose<PM>(m, a.M, a.g);
+        row_ok = p.valid;
+        drow = (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw + p.x * a.g.sub + a.g.x0;
+      }
+      drow_tab[r] = row_ok ? drow : -1;
     }
-    // fused BN/ReLU backward of the producer layer (see IgemmArgs::fy)
-    const bool fused = MODE == 1 && a.fy != nullptr;
-    f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fbe = fsc, fig = fsc, fsb = fsc, fsg = fsc;
-    bool fpass = false;      // columns of a pooling branch: plain gradient
-    if (fused && ncol_ok) fpass = fused_bn_params(a, ncol, fsc, fbe, fig);
-  #pragma unroll
+    for (int c = tid; c < BN; c += NTHREADS) {
+      const int ncol = n0 + c;
+      float sc = __builtin_nanf(""), be = 0.f, ig = 0.f;
+      if (ncol < a.N) {
+        int p = 0, lo = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (q + 1 < a.fnprod && ncol >= a.fseg_end[q]) { p = q + 1; lo = a.fseg_end[q]; }
+        if (!a.fident[p]) {
+          sc = a.fscale[p][ncol - lo];
+          if (a.fgamma[p]) {
+            be = a.fbeta[p][ncol - lo];
+            const float ga = a.fgamma[p][ncol - lo];
+            ig = ga != 0.f ? 1.f / ga : 0.f;
+          }
+        }
+      }
+      tab_sc[c] = sc; tab_be[c] = be; tab_ig[c] = ig;
+    }
+    __syncthreads();
+    const int chunk = lane % CPRW, rsub = lane / CPRW;
+    const bool lane_on = rsub < RPPF;
+    const int lcol = wn * SCOLS + chunk * CW;
+    const int ncol = n0 + lcol;
+    const bool col_ok = lane_on && ncol < a.N;
+    float csc[CW], cbe[CW], cig[CW], sb[CW], sg[CW];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) {
+      csc[e] = tab_sc[lcol + e]; cbe[e] = tab_be[lcol + e]; cig[e] = tab_ig[lcol + e];
+      sb[e] = 0.f; sg[e] = 0.f;
+    }
+    __syncthreads();       // (every lane has its column facts: the exchange below reuses the memory)
+    constexpr int GP = NPASSF < 4 ? NPASSF : 4;     // passes whose loads are in flight together
+#pragma unroll
     for (int i = 0; i < MT; ++i) {
-  #pragma unroll
+#pragma unroll
       for (int h = 0; h < HALVES; ++h) {
-  #pragma unroll
+#pragma unroll
         for (int j = 0; j < NT; ++j)
-  #pragma unroll
+#pragma unroll
           for (int rr = 0; rr < 16 / HALVES; ++rr) {
             const int r = h * (16 / HALVES) + rr;
-            // accumulator register r of lane (li, lh) is row (r & 3) + 8 * (r >> 2) + 4 * lh of the
-            // strip, i.e. row (rr & 3) + 8 * (rr >> 2) + 4 * lh of half h
             stage[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * SSTR + j * 32 + li] = acc[i][j][r];
           }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // the strip is in LDS
         __builtin_amdgcn_wave_barrier();
-  #pragma unroll
-        for (int pass = 0; pass < HROWS / RPP; ++pass) {
-          const int row = pass * RPP + (lane_on ? er : 0);
-          const int m = m0 + (wm * MT + i) * 32 + h * HROWS + row;
-          f32x4 v = *reinterpret_cast<const f32x4*>(&stage[row * SSTR + ec4 * 4]);
-          bool row_ok = m < a.M;
-          int drow = m;
-          if (PM || (MODE == 1 && a.g.sub > 1)) {
-            const RowPos p = decompose<PM>(m, a.M, a.g);
-            row_ok = p.valid;
-            drow = MODE == 0 ? (p.img * a.g.rh + p.y) * a.g.rw + p.x
-                             : (p.img * a.g.ih + p.y * a.g.sub + a.g.y0) * a.g.iw +
-                                   p.x * a.g.sub + a.g.x0;
-          }
-          if (row_ok && ncol_ok) {
-            v = v * esc + esh;
-            if (orelu) {
-              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+        for (int pg = 0; pg < NPASSF; pg += GP) {
+          f32x4 yraw[GP], oldv[GP];
+          int drow[GP];
+#pragma unroll
+          for (int q = 0; q < GP; ++q) {
+            const int row = (pg + q) * RPPF + rsub;
+            drow[q] = (pg + q < NPASSF && col_ok && row < HROWS)
+                          ? drow_tab[(wm * MT + i) * 32 + h * HROWS + row] : -1;
+            if (drow[q] >= 0) {
+              const char* ysrc = reinterpret_cast<const char*>(a.fy) +
+                                 ((size_t)drow[q] * a.fldy + a.fyoff + ncol) * ES;
+              yraw[q] = *reinterpret_cast<const f32x4*>(ysrc);
+              if (a.accumulate)
+                oldv[q] = *reinterpret_cast<const f32x4*>(
+                    reinterpret_cast<const char*>(a.C) + ((size_t)drow[q] * a.ldc + a.c_off + ncol) * ES);
             }
+          }
+#pragma unroll
+          for (int q = 0; q < GP; ++q) {
+            if (drow[q] < 0) continue;
+            const int row = (pg + q) * RPPF + rsub;
+            float v[CW], yv[CW];
+#pragma unroll
+            for (int e = 0; e < CW; e += 4)
+              *reinterpret_cast<f32x4*>(&v[e]) =
+                  *reinterpret_cast<const f32x4*>(&stage[row * SSTR + chunk * CW + e]);
             if constexpr (ES == 2) {
-              bf16x4* dst = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(oC) +
-                                                      (size_t)drow * oldc + ocoff);
+              const bf16x8 yb = __builtin_bit_cast(bf16x8, yraw[q]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) yv[e] = (float)yb[e];
               if (a.accumulate) {
-                const bf16x4 o = *dst;
-                v.x += (float)o[0]; v.y += (float)o[1]; v.z += (float)o[2]; v.w += (float)o[3];
+                const bf16x8 o = __builtin_bit_cast(bf16x8, oldv[q]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
               }
-              if (fused && !fpass)
-                v = fused_bn_item(v, load_act4<2>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
-                                  fig, fsb, fsg);
-              bf16x4 o;
-              o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-              *dst = o;
             } else {
-              f32x4* dst = reinterpret_cast<f32x4*>(oC + (size_t)drow * oldc + ocoff);
-              if (a.accumulate) v += *dst;
-              if (fused && !fpass)
-                v = fused_bn_item(v, load_act4<4>(a.fy, (size_t)drow * a.fldy + a.fyoff + ncol), fsc, fbe,
-                                  fig, fsb, fsg);
-              *dst = v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) yv[e] = yraw[q][e];
+              if (a.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += oldv[q][e];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < CW; ++e) {
+              if (csc[e] == csc[e]) {             // (NaN: a pooling branch's column, plain gradient)
+                const float dz = yv[e] > 0.f ? v[e] : 0.f;
+                sb[e] += dz;
+                sg[e] += dz * (yv[e] - cbe[e]) * cig[e];
+                v[e] = dz * csc[e];
+              }
+            }
+            char* dst = reinterpret_cast<char*>(a.C) + ((size_t)drow[q] * a.ldc + a.c_off + ncol) * ES;
+            if constexpr (ES == 2) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+              *reinterpret_cast<bf16x8*>(dst) = o;
+            } else {
+              *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
             }
           }
         }
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (fused)      // (block-uniform)
-      fused_bn_finish<WM, WN, SCOLS, RPP>(reinterpret_cast<float*>(smem), nullptr, a.fpart,
-                                          a.fpart_row0, a.N, fsb, fsg, tid, wave, ec4, er, lane_on,
-                                          n0, mt);
+    // column sums of the block: lane sums -> LDS -> fixed-order sums over the lanes (rows of a pass)
+    // and waves (row tiles) that share a column -> the block's row of the partials (no atomics)
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(smem);
+    if (lane_on) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e) {
+        red[(wave * 64 + lane) * 2 * CW + e] = sb[e];
+        red[(wave * 64 + lane) * 2 * CW + CW + e] = sg[e];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * BN; idx += NTHREADS) {
+      const int k = idx / BN, c = idx - k * BN;
+      const int wn_c = c / SCOLS, cl = c - wn_c * SCOLS;
+      const int ch = cl / CW, e = cl - ch * CW;
+      float t = 0.f;
+      for (int wm_ = 0; wm_ < WM; ++wm_)
+        for (int r = 0; r < RPPF; ++r)
+          t += red[((wm_ * WN + wn_c) * 64 + r * CPRW + ch) * 2 * CW + k * CW + e];
+      if (n0 + c < a.N) a.fpart[((size_t)(a.fpart_row0 + mt) * 2 + k) * a.N + n0 + c] = t;
+    }
   } else {
     // Round 3 (tools/trace_ring.py): the passes above cost 400 - 600 cycles each — per pass a
     // row decomposition (two divisions for pixel-major rows), the routing of a multi-output
@@ -755,6 +838,18 @@ int launch_one(IgemmArgs a, hipStream_t s) {
 #ifdef C2D_RING_TRACE
   a.trace = g_ring_trace;
 #endif
+  if constexpr (MODE == 1 && ES == 2) {
+    if (a.fy != nullptr) {      // the producer's BN/ReLU backward rides in the epilogue
+      dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, true>"
+                           : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true>",
+                        MODE, WM, WN, MT, NT, BKT, D, ES);
+      hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES, true>),
+                         dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
+      return c2d_launch_status();
+    }
+  } else if (a.fy != nullptr) {
+    return C2D_ERR_UNSUPPORTED;   // (fp32 networks fuse in igemm_nt_kernel, conv_gemm.hip)
+  }
   dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d>"
                        : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d>",
                     MODE, WM, WN, MT, NT, BKT, D, ES);
