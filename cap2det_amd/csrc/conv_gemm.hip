@@ -2411,8 +2411,7 @@ extern "C" int c2d_conv1x1_dgrad_multi_bn_relu(int nseg, const float* const* dcs
                           IgemmWs{nullptr, 0}, stream, 4, &fb);
 }
 
-extern "C" int c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks(int nseg, const int* couts, int rows,
-                                                              int cin) {
+static int dgrad_multi_bn_relu_blocks(int nseg, const int* couts, int rows, int cin, int es) {
   C2D_CHECK_ARG(nseg >= 1 && nseg <= 4 && couts);
   FusedBn fb = {};
   fb.nprod = 1; fb.seg_end[0] = cin; fb.ident[0] = 1; fb.query = true;
@@ -2421,8 +2420,35 @@ extern "C" int c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks(int nseg, const in
   int lds[4];
   for (int i = 0; i < nseg; ++i) lds[i] = couts[i];
   const int rc = dgrad_multi_impl(nseg, nullptr, lds, nullptr, nullptr, couts, nullptr, cin, 0, rows,
-                                  cin, 0, IgemmWs{nullptr, 0}, nullptr, 4, &fb);
+                                  cin, 0, IgemmWs{nullptr, 0}, nullptr, es, &fb);
   return rc == C2D_OK ? blocks : -1;
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks(int nseg, const int* couts, int rows,
+                                                              int cin) {
+  return dgrad_multi_bn_relu_blocks(nseg, couts, rows, cin, 4);
+}
+
+// bf16 storage (round 5): the ring kernel's fused epilogue instance behind the same interface
+extern "C" int c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks_bf16(int nseg, const int* couts,
+                                                                   int rows, int cin) {
+  return dgrad_multi_bn_relu_blocks(nseg, couts, rows, cin, 2);
+}
+
+extern "C" int c2d_conv1x1_dgrad_multi_bn_relu_bf16(int nseg, const void* const* dcs, const int* ldcs,
+                                                    const int* coffs, const void* const* ws,
+                                                    const int* couts, const void* y, int ldy,
+                                                    int yoff, int nprod, const C2dBnProducer* prods,
+                                                    void* dx, int lddx, int dxoff, float* partials,
+                                                    int rows, int cin, int accumulate, void* stream) {
+  FusedBn fb = {};
+  int rc = fused_from_producers(&fb, y, ldy, yoff, nprod, prods, partials);
+  if (rc) return rc;
+  C2D_CHECK_ARG(ldy % 8 == 0 && yoff % 8 == 0);
+  for (int p = 0; p < nprod; ++p) C2D_CHECK_ARG(prods[p].width % 8 == 0);
+  return dgrad_multi_impl(nseg, (const float* const*)dcs, ldcs, coffs, (const float* const*)ws, couts,
+                          (float*)dx, lddx, dxoff, rows, cin, accumulate, IgemmWs{nullptr, 0}, stream,
+                          2, &fb);
 }
 
 extern "C" int c2d_conv1x1_dgrad_multi(int nseg, const float* const* dcs, const int* ldcs,

@@ -359,9 +359,12 @@ class BnProducer(ctypes.Structure):
               ("width", ctypes.c_int), ("identity", ctypes.c_int)]
 
 
-def conv1x1_dgrad_multi_bn_relu_blocks(couts, rows, cin):
+def conv1x1_dgrad_multi_bn_relu_blocks(couts, rows, cin, dtype=torch.float32):
   arr = (ctypes.c_int * len(couts))(*couts)
-  return int(_lib.load().c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks(len(couts), arr, rows, cin))
+  lib = _lib.load()
+  fn = (lib.c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks_bf16 if dtype == torch.bfloat16
+        else lib.c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks)
+  return int(fn(len(couts), arr, rows, cin))
 
 
 def bn_producers(prods):
@@ -379,13 +382,16 @@ def bn_producers(prods):
 def conv1x1_dgrad_multi_bn_relu(dcs, ldcs, coffs, ws, couts, y, ldy, yoff, prods, dx, lddx, dxoff,
                                 partials, rows, cin, accumulate):
   """c2d_conv1x1_dgrad_multi as the last writer of a block-input gradient, fused with the
-  BN/ReLU backward of the producers of the block input (fp32).  prods: bn_producers(...)."""
+  BN/ReLU backward of the producers of the block input (fp32 or bf16 storage; the partial sums
+  are fp32).  prods: bn_producers(...)."""
   n = len(dcs)
-  assert dcs[0].dtype == torch.float32
+  low = dcs[0].dtype == torch.bfloat16
+  assert all(t.dtype == dcs[0].dtype for t in list(dcs) + list(ws) + [y, dx]) and partials.dtype == torch.float32
   pa = (ctypes.c_void_p * n)(*[_p(t) for t in dcs])
   pw = (ctypes.c_void_p * n)(*[_p(t) for t in ws])
   il = (ctypes.c_int * n)(*ldcs); io = (ctypes.c_int * n)(*coffs); ic = (ctypes.c_int * n)(*couts)
-  _lib.call("c2d_conv1x1_dgrad_multi_bn_relu", n, pa, il, io, pw, ic, _p(y), ldy, yoff, len(prods),
+  _lib.call("c2d_conv1x1_dgrad_multi_bn_relu_bf16" if low else "c2d_conv1x1_dgrad_multi_bn_relu",
+            n, pa, il, io, pw, ic, _p(y), ldy, yoff, len(prods),
             prods, _p(dx), lddx, dxoff, _p(partials), rows, cin, int(accumulate), _stream())
 
 

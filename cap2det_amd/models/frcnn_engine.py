@@ -645,11 +645,14 @@ class Net(object):
     # Consecutive convolutions of a branch over per-ROI maps: the consumer's input-gradient GEMM
     # applies the producer's BN/ReLU backward in its epilogue (c2d_conv_dgrad_bn_relu) — the
     # producer's bn_relu_bwd launch, the store of its dy and the re-read disappear.  Measured per
-    # step: fp32 12.33 -> 12.13 ms; bf16 4.13 -> 4.18 ms (its GEMMs are short and their epilogue
-    # is already a quarter of each launch), so bf16 networks keep the separate launches.
+    # step: fp32 12.33 -> 12.13 ms.  bf16 networks kept the separate launches through round 4 (4.13
+    # -> 4.18 ms, 2.95 -> 2.98: round 2's fused pass form inside the plain ring kernel cost more
+    # than the launches it removed); round 5 rebuilt the ring kernel's fused epilogue on LDS tables
+    # and 16-byte stores as an instance of its own (igemm_bf16.hip, FUSED): 2.925 -> 2.915 ms per
+    # step and 26 -> 12 bn_relu_bwd launches, so both storage modes fuse now.
     # C2D_FUSE_BN_BWD=0|1 forces either form.
     fuse = os.environ.get("C2D_FUSE_BN_BWD")
-    if (fuse == "1") if fuse in ("0", "1") else (self.dtype == torch.float32):
+    if fuse != "0":
       for i in range(first_idx, len(steps)):
         if steps[i]["kind"] != "block":
           continue
@@ -667,21 +670,21 @@ class Net(object):
               prod["fused_blocks"] = nb
               if "dc_entry" in prod:        # (entry convolution of the fused multi-segment dgrad)
                 prod["dc_entry"] = prod["gy"].t
-      # The same at a block boundary (fp32): the summed input gradient of a block whose input is
+      # The same at a block boundary: the summed input gradient of a block whose input is
       # the concat buffer of the block in front is written last by the multi-segment GEMM of its
       # 1x1 entry convolutions (c2d_conv1x1_dgrad_multi_bn_relu) — it applies the BN/ReLU backward
       # of the LAST op of every branch of the block in front, per column range.
       for i in range(first_idx + 1, len(steps)):
         cur, prev = steps[i], steps[i - 1]
-        if not (cur["kind"] == "block" and prev["kind"] == "block" and cur["n"] >= 64 and
-                self.dtype == torch.float32):
+        if not (cur["kind"] == "block" and prev["kind"] == "block" and cur["n"] >= 64):
           continue
         entry = [b[0] for b in cur["branches"] if "dc_entry" in b[0]]
         lasts = [b[-1] for b in prev["branches"]]
         if len(entry) < 2 or not all(p["kind"] == "pool" or p["layer"].trainable for p in lasts):
           continue
         rows = cur["n"] * cur["ih"] * cur["iw"]
-        nb = ops.conv1x1_dgrad_multi_bn_relu_blocks([b["layer"].cout for b in entry], rows, cur["cin"])
+        nb = ops.conv1x1_dgrad_multi_bn_relu_blocks([b["layer"].cout for b in entry], rows, cur["cin"],
+                                                    self.dtype)
         if nb <= 0:
           continue
         owner = dict(nb=nb, ctot=cur["cin"], keep=[])

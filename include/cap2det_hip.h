@@ -325,6 +325,16 @@ int c2d_conv1x1_dgrad_multi_bn_relu(int nseg, const float* const* dcs, const int
                                     const C2dBnProducer* prods, float* dx, int lddx, int dxoff,
                                     float* partials, int rows, int cin, int accumulate,
                                     void* stream);
+/* The same for bf16 storage (round 5; dcs / ws / y / dx bf16, partials fp32; every width, leading
+ * dimension and offset a multiple of 8): the DMA-ring kernel's fused epilogue instance. */
+int c2d_conv1x1_dgrad_multi_bn_relu_partial_blocks_bf16(int nseg, const int* couts, int rows,
+                                                        int cin);
+int c2d_conv1x1_dgrad_multi_bn_relu_bf16(int nseg, const void* const* dcs, const int* ldcs,
+                                         const int* coffs, const void* const* ws, const int* couts,
+                                         const void* y, int ldy, int yoff, int nprod,
+                                         const C2dBnProducer* prods, void* dx, int lddx, int dxoff,
+                                         float* partials, int rows, int cin, int accumulate,
+                                         void* stream);
 int c2d_conv_dgrad_bn_relu(const float* dc, int ldc, int coff, const float* w, const float* y,
                            int ldy, int yoff, const float* scale, const float* beta,
                            const float* gamma, float* dc_out, float* partials, int n, int ih,

@@ -372,16 +372,21 @@ def test_conv_dgrad_bn_relu(ops, case, with_gamma):
     (3333, 256, (96, 64, 32), (96, 32, 128)),          # the middle one a pooling branch
     (5000, 1024, (352, 192, 160), (352, 320, 224, 128)),   # Mixed_5b -> Mixed_5c widths
 ])
-def test_conv1x1_dgrad_multi_bn_relu(ops, rows, cin, couts, widths, accumulate):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_conv1x1_dgrad_multi_bn_relu(ops, rows, cin, couts, widths, accumulate, dtype):
   """Summed 1x1 input gradient of a block as the last writer of the block-input gradient, with
   the BN/ReLU backward of the producers of the block input per column range; the second of three
-  producers is a pooling branch (plain gradient, zero sums)."""
+  producers is a pooling branch (plain gradient, zero sums).  bf16 storage (round 5: the DMA-ring
+  kernel's fused epilogue instance): operands rounded to bf16 first, dc within one bf16 rounding of
+  the float64 result on those operands, the fp32 column sums to 1e-3 of their scale."""
   rng = np.random.default_rng(31)
   assert sum(widths) == cin
-  dcs = [rng.standard_normal((rows, c)).astype(np.float32) for c in couts]
-  wsn = [(rng.standard_normal((cin, c)) / np.sqrt(c)).astype(np.float32) for c in couts]
-  y = np.maximum(rng.standard_normal((rows, cin)), 0).astype(np.float32)
-  base = rng.standard_normal((rows, cin)).astype(np.float32)
+  low = dtype == torch.bfloat16
+  rnd = (lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()) if low else (lambda a: a)
+  dcs = [rnd(rng.standard_normal((rows, c)).astype(np.float32)) for c in couts]
+  wsn = [rnd((rng.standard_normal((cin, c)) / np.sqrt(c)).astype(np.float32)) for c in couts]
+  y = rnd(np.maximum(rng.standard_normal((rows, cin)), 0).astype(np.float32))
+  base = rnd(rng.standard_normal((rows, cin)).astype(np.float32))
   dx = sum(d.astype(np.float64) @ w.astype(np.float64).T for d, w in zip(dcs, wsn))
   if accumulate:
     dx = dx + base
@@ -405,20 +410,25 @@ def test_conv1x1_dgrad_multi_bn_relu(ops, rows, cin, couts, widths, accumulate):
       keep.append(t)
       prods.append(t + (width,))
     off += width
-  nb = ops.conv1x1_dgrad_multi_bn_relu_blocks(list(couts), rows, cin)
+  nb = ops.conv1x1_dgrad_multi_bn_relu_blocks(list(couts), rows, cin, dtype)
   assert nb >= 1
-  out = _t(base).clone() if accumulate else torch.full((rows, cin), 5.0, device=DEV)
+  out = (_t(base).clone() if accumulate else torch.full((rows, cin), 5.0, device=DEV)).to(dtype)
   part = torch.full((nb, 2, cin), 7.0, device=DEV)
-  wts = [_t(w) for w in wsn]                       # [cin][cout], as c2d_conv1x1_dgrad_multi
-  ops.conv1x1_dgrad_multi_bn_relu([_t(d) for d in dcs], list(couts), [0] * len(couts), wts,
-                                  list(couts), _t(y), cin, 0, ops.bn_producers(prods), out, cin, 0,
-                                  part, rows, cin, accumulate)
+  wts = [_t(w).to(dtype) for w in wsn]             # [cin][cout], as c2d_conv1x1_dgrad_multi
+  ops.conv1x1_dgrad_multi_bn_relu([_t(d).to(dtype) for d in dcs], list(couts), [0] * len(couts), wts,
+                                  list(couts), _t(y).to(dtype), cin, 0, ops.bn_producers(prods), out,
+                                  cin, 0, part, rows, cin, accumulate)
+  if low:
+    assert ops.last_dispatch()[0].endswith(", 2, true>"), ops.last_dispatch()    # the fused ring instance
   sc = np.abs(want).max()
-  np.testing.assert_allclose(_n(out), want, rtol=1e-4, atol=1e-5 * sc + 1e-6)
+  if low:
+    assert np.abs(_n(out.float()) - want).max() <= 1.1 * 2.0 ** -8 * sc
+  else:
+    np.testing.assert_allclose(_n(out), want, rtol=1e-4, atol=1e-5 * sc + 1e-6)
   sums = _n(part).astype(np.float64).sum(0)
   for k in range(2):
-    np.testing.assert_allclose(sums[k], want_sums[k], rtol=1e-4,
-                               atol=1e-4 * max(np.abs(want_sums[k]).max(), 1.0))
+    np.testing.assert_allclose(sums[k], want_sums[k], rtol=1e-3 if low else 1e-4,
+                               atol=(1e-3 if low else 1e-4) * max(np.abs(want_sums[k]).max(), 1.0))
 
 
 @pytest.mark.parametrize("mode,stride", [(0, 1), (0, 2), (1, 1)])

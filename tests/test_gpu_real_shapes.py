@@ -236,6 +236,128 @@ def test_block_entry_dgrad_multi(ops, block, dtype):
 
 
 
+# consumers whose input gradient carries the BN/ReLU backward of the convolution that produced their
+# input (Net._prepare_backward, form 1): (name, map side, cin = producer's cout, cout, kernel, stride)
+FUSED_INNER_LAYERS = [
+    ("5a/B0/3x3s2", 7, 128, 192, 3, 2), ("5a/B1/3x3", 7, 192, 256, 3, 1), ("5a/B1/3x3s2", 7, 256, 256, 3, 2),
+    ("5bc/B1/3x3", 4, 192, 320, 3, 1), ("5b/B2/3x3a", 4, 160, 224, 3, 1), ("5bc/B2/3x3b", 4, 224, 224, 3, 1),
+    ("5c/B2/3x3a", 4, 192, 224, 3, 1),
+]
+
+
+@pytest.mark.parametrize("layer", FUSED_INNER_LAYERS, ids=[l[0] for l in FUSED_INNER_LAYERS])
+def test_second_stage_fused_dgrad_bf16(ops, layer):
+  """Round 5: bf16 networks fuse the producer's BN/ReLU backward into the consumer's input-gradient
+  GEMM (igemm_ring_kernel<..., FUSED = true>).  Every fused layer of Mixed_5a-c at the instance the
+  benchmark-size call dispatches: dc within one bf16 rounding of the float64 oracle on the same
+  bf16 operands, the fp32 column sums to 1e-3 of their scale."""
+  name, hw, cin, cout, k, s = layer
+  oh = -(-hw // s)
+
+  def run(n, check):
+    rng = np.random.default_rng(17 + n)
+    w = _bf16_round((rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32))
+    dc = _bf16_round(rng.standard_normal((n, oh, oh, cout)).astype(np.float32))
+    y = _bf16_round(np.maximum(rng.standard_normal((n, hw, hw, cin)), 0).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(cin)).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    nb = ops.conv_dgrad_bn_relu_blocks(torch.bfloat16, n, hw, hw, cin, cout, k, k, s)
+    out = torch.full((n * hw * hw, cin), 9.0, device=DEV, dtype=torch.bfloat16)
+    part = torch.full((nb, 2, cin), 7.0, device=DEV)
+    bf = lambda a: _t(a).to(torch.bfloat16)
+    ops.conv_dgrad_bn_relu(bf(dc).view(-1, cout), cout, 0, bf(w).view(k * k, cin, cout), bf(y).view(-1, cin),
+                           cin, 0, _t(scale), _t(beta), _t(gamma), out, part, n, hw, hw, cin, cout, k, k, s)
+    inst = ops.last_dispatch()
+    if check:
+      dx, _ = ref_ops.conv2d_backward(np.zeros((n, hw, hw, cin)), w.astype(np.float64), dc.astype(np.float64), s)
+      dz = dx * (y > 0)
+      _scale_close(_n(out).reshape(n, hw, hw, cin), dz * scale, 1.1 * 2.0 ** -8, "%s fused dc %s" % (name, inst))
+      sums = part.double().sum(0).cpu().numpy()
+      for got, want in ((sums[0], dz.reshape(-1, cin).sum(0)),
+                        (sums[1], (dz * (y.astype(np.float64) - beta) / gamma).reshape(-1, cin).sum(0))):
+        assert np.abs(got - want).max() <= 1e-3 * max(np.abs(want).max(), 1.0), name
+    return inst
+
+  want_inst = run(N_BENCH, False)
+  assert all(i.endswith(", true>") for i in want_inst), want_inst
+  for n in (256, 704, N_BENCH):
+    if run(n, False) == want_inst:
+      assert run(n, True) == want_inst
+      break
+  else:
+    raise AssertionError((name, want_inst))
+  _seen.update(want_inst)
+
+
+@pytest.mark.parametrize("block", ["Mixed_5b", "Mixed_5c"])
+def test_block_entry_dgrad_multi_fused_bf16(ops, block):
+  """The block-boundary form in bf16 (round 5, c2d_conv1x1_dgrad_multi_bn_relu_bf16): the multi-segment
+  entry gradient of Mixed_5b / 5c as last writer of the block-input gradient, applying the BN/ReLU
+  backward of the last convolution of every branch of the block in front (Mixed_5a: 192 + 256
+  convolution columns + 576 max-pool columns; Mixed_5b: 352 + 320 + 224 + 128), accumulating onto the
+  pooling branch's share — at the benchmark's instance."""
+  hw, cin = 4, 1024
+  couts, widths, ident = {
+      "Mixed_5b": ([352, 192, 160, 128], [192, 256, 576], [False, False, True]),
+      "Mixed_5c": ([352, 192, 192], [352, 320, 224, 128], [False, False, False, False])}[block]
+
+  def run(n, check):
+    rng = np.random.default_rng(5 + n)
+    rows = n * hw * hw
+    dcs = [_bf16_round(rng.standard_normal((rows, c)).astype(np.float32)) for c in couts]
+    ws = [_bf16_round((rng.standard_normal((cin, c)) / np.sqrt(c * len(couts))).astype(np.float32)) for c in couts]
+    y = _bf16_round(np.maximum(rng.standard_normal((rows, cin)), 0).astype(np.float32))
+    base = _bf16_round(rng.standard_normal((rows, cin)).astype(np.float32))
+    prods, keep, off = [], [], 0
+    want = want_sums = None
+    if check:
+      dx = sum(d.astype(np.float64) @ w.astype(np.float64).T for d, w in zip(dcs, ws)) + base
+      want, want_sums = np.empty_like(dx), np.zeros((2, cin))
+    for width, idn in zip(widths, ident):
+      sl = slice(off, off + width)
+      if idn:
+        prods.append((None, None, None, width))
+        if check:
+          want[:, sl] = dx[:, sl]
+      else:
+        scale = rng.uniform(0.5, 1.5, width).astype(np.float32)
+        beta = (0.1 * rng.standard_normal(width)).astype(np.float32)
+        gamma = rng.uniform(0.5, 1.5, width).astype(np.float32)
+        t = (_t(scale), _t(beta), _t(gamma))
+        keep.append(t)
+        prods.append(t + (width,))
+        if check:
+          dz = dx[:, sl] * (y[:, sl] > 0)
+          want[:, sl] = dz * scale
+          want_sums[0, sl] = dz.sum(0)
+          want_sums[1, sl] = (dz * (y[:, sl].astype(np.float64) - beta) / gamma).sum(0)
+      off += width
+    nb = ops.conv1x1_dgrad_multi_bn_relu_blocks(couts, rows, cin, torch.bfloat16)
+    bf = lambda a: _t(a).to(torch.bfloat16)
+    out = bf(base).clone()
+    part = torch.full((nb, 2, cin), 7.0, device=DEV)
+    ops.conv1x1_dgrad_multi_bn_relu([bf(d) for d in dcs], couts, [0] * len(couts), [bf(w) for w in ws], couts,
+                                    bf(y), cin, 0, ops.bn_producers(prods), out, cin, 0, part, rows, cin, True)
+    inst = ops.last_dispatch()
+    if check:
+      _scale_close(_n(out), want, 1.1 * 2.0 ** -8, "%s fused entry dgrad %s" % (block, inst))
+      sums = part.double().sum(0).cpu().numpy()
+      for k_ in range(2):
+        assert np.abs(sums[k_] - want_sums[k_]).max() <= 1e-3 * max(np.abs(want_sums[k_]).max(), 1.0)
+    return inst
+
+  want_inst = run(N_BENCH, False)
+  assert all(i.endswith(", true>") for i in want_inst), want_inst
+  for n in (256, 704, N_BENCH):
+    if run(n, False) == want_inst:
+      assert run(n, True) == want_inst
+      break
+  else:
+    raise AssertionError((block, want_inst))
+  _seen.update(want_inst)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("block", ["Mixed_5a", "Mixed_5b", "Mixed_5c"])
 def test_block_entry_wgrad_multi(ops, block, dtype):
@@ -459,7 +581,7 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   # layers), row-major and pixel-major, forward and input gradient, both ring forms:
   # igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES = 2>
   import re
-  inst = [re.match(r"igemm_ring_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d+), (\d), 2>", k)
+  inst = [re.match(r"igemm_ring_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d+), (\d), 2(?:, true)?>", k)
           for k in _seen]
   inst = [m.groups() for m in inst if m]
   for mode in ("0", "1"):
