@@ -58,6 +58,7 @@ class KernelTimer(object):
     self.torch = torch
     self.records = []   # (family, work, start_event, end_event, algorithmic HBM bytes)
     self.shapes = []    # (entry point, integer arguments) per record, for --per-call
+    self.fused = {}     # family -> launches that also carry a BN/ReLU backward in their epilogue
     self.enabled = False
 
   def wrap(self, ops):
@@ -170,6 +171,8 @@ class KernelTimer(object):
         if fam == "igemm_nt_bf16" and small_rows(fn.__name__, args):
           fam = "igemm_small_bf16"
         t.records.append((fam, w, s, e, nbytes))
+        if fn.__name__ in ("conv_dgrad_bn_relu", "conv1x1_dgrad_multi_bn_relu"):
+          t.fused[fam] = t.fused.get(fam, 0) + 1
         t.shapes.append((fn.__name__, tuple(a for a in args if isinstance(a, (int, bool)))))
         return r
       return inner
@@ -896,6 +899,10 @@ def main(argv=None):
                 # the MFMAs actually issued — padding taps are skipped, `achieved` counts all taps
                 "mfma_busy": mfma.get(traffic_key, {}).get("mfma_busy"),
                 "calls_per_step": f["launches"], "avg_call_ms": f["ms"] / f["launches"],
+                # input-gradient launches whose epilogue also does the producer layer's BN/ReLU
+                # backward (mask, scale, per-column sums; the separate bn_relu_bwd launch is gone):
+                # their whole duration is in `family_ms_per_step`, only the GEMM's FLOPs in `achieved`
+                "calls_with_fused_bn_relu_backward": timer.fused.get(key, 0),
                 # per call the binding roofline is max(FLOPs / matrix peak, algorithmic bytes /
                 # 8 TB/s): `binding_frac` = sum of those ideal times / measured time; short-K bf16
                 # GEMMs (1x1 block-entry convolutions, ~100-300 FLOP/B) are HBM-bound calls

@@ -850,8 +850,9 @@ int launch_one(IgemmArgs a, hipStream_t s) {
   } else if (a.fy != nullptr) {
     return C2D_ERR_UNSUPPORTED;   // (fp32 networks fuse in igemm_nt_kernel, conv_gemm.hip)
   }
-  dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d>"
-                       : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d>",
+  // (spelled as rocprofv3 prints the instance: the FUSED flag included)
+  dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, false>"
+                       : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false>",
                     MODE, WM, WN, MT, NT, BKT, D, ES);
   hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES>),
                      dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);

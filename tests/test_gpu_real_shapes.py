@@ -579,9 +579,9 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   # the direct-to-LDS bf16 ring kernel in the block tiles the benchmark shapes dispatch (128x64,
   # 128x256, the full-width 128x192 / 128x320 / 128x384 of the 160..192-, 320- and 352-channel
   # layers), row-major and pixel-major, forward and input gradient, both ring forms:
-  # igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES = 2>
+  # igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES = 2, FUSED>
   import re
-  inst = [re.match(r"igemm_ring_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d+), (\d), 2(?:, true)?>", k)
+  inst = [re.match(r"igemm_ring_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d+), (\d), 2, (?:true|false)>", k)
           for k in _seen]
   inst = [m.groups() for m in inst if m]
   for mode in ("0", "1"):

@@ -12,7 +12,7 @@ O=$R/gpurun_out
 mkdir -p $O
 T=${PROFILE_TAG:-r05}
 cd /tmp; export TMPDIR=/tmp
-for CFG in c1 c2; do
+for CFG in ${PROFILE_CFGS:-c1 c2}; do
   B="python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_${CFG}_stats -o s -- $B > $O/${T}_${CFG}_stats.log 2>&1
   export C2D_WGRAD_SIDE_STREAM=0
@@ -24,7 +24,7 @@ for CFG in c1 c2; do
 done
 cd $R
 mkdir -p $O/${T}_summaries
-for CFG in c1 c2; do
+for CFG in ${PROFILE_CFGS:-c1 c2}; do
   python3 tools/summarize_pmc.py $O/${T}_summaries/${T}_traffic_${CFG}.json $O/${T}_${CFG}_fetch $O/${T}_${CFG}_write
   python3 tools/summarize_mfma.py $O/${T}_summaries/${T}_mfma_${CFG}.json $O/${T}_${CFG}_mfma
   for K in stats serial_stats; do

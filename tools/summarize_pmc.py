@@ -58,7 +58,7 @@ def family_of(name):
   # bf16 MFMA peak
   if "wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16_kernel" in name or "wgrad_reduce_kernel" in name:
     return "wgrad_bf16"
-  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring_kernel<[^>]*, 2>", name):
+  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring_kernel<[^>]*, 2(?:, (?:true|false))?>", name):
     return "igemm_bf16"
   if re.search(r"igemm_small(_group)?_kernel<\d, 2>", name):
     return "igemm_small_bf16"      # the bf16 step's single-image first stage
