@@ -1503,7 +1503,7 @@ constexpr int W3B_RSG = 256 + 64;   // 128 bf16 per dC row + pad
 // KG = K-groups (see wgrad_tn_bf16_kernel): KG x (4 * WI) waves on the same output tile, each
 // group on its own images with its own staging buffers, summed through LDS before the atomics.
 template <int WC, int IMGS, int WI, int KG>
-__global__ __launch_bounds__(256 * WI * KG, WI * KG == 1 ? 2 : 1) void wgrad3x3_bf16_kernel(Wgrad3Args a) {
+__device__ __forceinline__ void wgrad3x3_bf16_body(const Wgrad3Args& a, const int split, const int t) {
   constexpr int NT = 256 * WI;                // threads of one K-group
   constexpr int PW = WC + 2;
   constexpr int HW = WC * WC;
@@ -1524,9 +1524,6 @@ __global__ __launch_bounds__(256 * WI * KG, WI * KG == 1 ? 2 : 1) void wgrad3x3_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 2, wj = wave & 3;
   const int li = lane & 31, lh = lane >> 5;
-  const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
-  const int split = logical / a.tiles;
-  const int t = logical - split * a.tiles;
   const int jt = t % a.jtiles, it_ = t / a.jtiles;
   const int i0 = it_ * 32 * WI, j0 = jt * 128;
   // the split's rows in equal shares per K-group (host: rows_per_split is a multiple of KG * R);
@@ -1669,6 +1666,39 @@ __global__ __launch_bounds__(256 * WI * KG, WI * KG == 1 ? 2 : 1) void wgrad3x3_
       }
     }
   }
+}
+
+template <int WC, int IMGS, int WI, int KG>
+__global__ __launch_bounds__(256 * WI * KG, WI * KG == 1 ? 2 : 1) void wgrad3x3_bf16_kernel(Wgrad3Args a) {
+  const int logical = xcd_remap(blockIdx.x, a.tiles * a.splits);
+  const int split = logical / a.tiles;
+  wgrad3x3_bf16_body<WC, IMGS, WI, KG>(a, split, logical - split * a.tiles);
+}
+
+// The nine-tap filter gradients of SEVERAL 3x3 convolutions over the same per-ROI maps — the 3x3
+// layers of one Inception block — in ONE launch (round 5).  A nine-tap launch of 4x4 maps is
+// dominated by what does not scale with its rows: 252 workgroups x 147 KB of fp32 atomics (37 MB at
+// the chip's 1.3 TB/s) and the ramps, 45 of its 55 us (time = 45 us + 0.8 us per 128-row slab,
+// profiles/r05_experiments/README.md).  The problems of a group share the row splits, so the launch
+// has as many splits as ALL its tiles leave room for in one round of workgroups: a third of the
+// atomics and of the ramps of three launches.  Block -> (split, problem, tile); all tiles of a
+// split consecutive on one XCD.
+constexpr int WGRAD3_GROUP_MAX = 3;
+struct Wgrad3GroupArgs {
+  Wgrad3Args a[WGRAD3_GROUP_MAX];
+  int first[WGRAD3_GROUP_MAX + 1];   // first tile of problem p inside a split; [num] = tiles per split
+  int num, splits;
+};
+template <int WC, int IMGS>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_group_kernel(Wgrad3GroupArgs g) {
+  const int total = g.first[g.num];
+  const int logical = xcd_remap(blockIdx.x, total * g.splits);
+  const int split = logical / total;
+  int t = logical - split * total;
+  int p = 0;
+  for (int i = 1; i < g.num; ++i)
+    if (t >= g.first[i]) p = i;
+  wgrad3x3_bf16_body<WC, IMGS, 1, 1>(g.a[p], split, t - g.first[p]);
 }
 
 // dW[i] += sum over splits (in split order: reproducible) of the slabs written by the bf16
@@ -2865,6 +2895,56 @@ extern "C" int c2d_conv1x1_wgrad_multi_bf16(const void* x, int ldx, int xoff, in
 }
 
 // ---- split-K slabs instead of atomics (bf16 MFMA filter gradients) -----------------------------
+// Grouped nine-tap filter gradients (wgrad3x3_bf16_group_kernel): `num` 3x3 / stride-1 / SAME
+// convolutions over the same n maps of hw x hw (4 or 7), bf16 operands, fp32 atomics into dws[p].
+// C2D_ERR_UNSUPPORTED when a problem is not one the nine-tap kernel takes (the caller launches
+// them one by one).
+extern "C" int c2d_conv3x3_wgrad_multi_bf16(int num, const void* const* xs, const int* ldxs,
+                                            const int* xoffs, const void* const* dcs,
+                                            const int* ldcs, const int* coffs, float* const* dws,
+                                            const int* cins, const int* couts, int n, int hw,
+                                            void* stream) {
+  dispatch_reset();
+  C2D_CHECK_ARG(num >= 1 && num <= WGRAD3_GROUP_MAX && xs && ldxs && xoffs && dcs && ldcs && coffs &&
+                dws && cins && couts && n > 0);
+  if (!(hw == 4 || hw == 7) || n < 256 || !wgrad_bf16_mfma_enabled()) return C2D_ERR_UNSUPPORTED;
+  Wgrad3GroupArgs g = {};
+  g.num = num;
+  int total = 0;
+  const int M = n * hw * hw;
+  for (int p = 0; p < num; ++p) {
+    C2D_CHECK_ARG(xs[p] && dcs[p] && dws[p] && cins[p] > 0 && couts[p] > 0);
+    if (cins[p] % 32 || couts[p] % 32 || ldxs[p] % 8 || xoffs[p] % 8 || ldcs[p] % 8 || coffs[p] % 8 ||
+        wgrad3_bf16_igroups(cins[p]) != 1)
+      return C2D_ERR_UNSUPPORTED;
+    C2D_CHECK_ARG((long long)M * ldxs[p] * 2 < (long long)OOB_OFFSET &&
+                  (long long)M * ldcs[p] * 2 < (long long)OOB_OFFSET);
+    Wgrad3Args& b = g.a[p];
+    b.A = (const float*)xs[p]; b.lda = ldxs[p]; b.a_off = xoffs[p];
+    b.G = (const float*)dcs[p]; b.ldg = ldcs[p]; b.g_off = coffs[p]; b.dW = dws[p];
+    b.M = M; b.I = cins[p]; b.J = couts[p]; b.h = hw; b.w = hw;
+    b.itiles = c2d_ceil_div(cins[p], 32); b.jtiles = c2d_ceil_div(couts[p], 128);
+    b.tiles = b.itiles * b.jtiles;
+    b.part_stride = 0;
+    g.first[p] = total;
+    total += b.tiles;
+  }
+  g.first[num] = total;
+  const int slab = hw == 4 ? 8 * 16 : 2 * 49;            // whole images per slab
+  const int nslabs = c2d_ceil_div(M, slab);
+  int splits = wgrad_bf16_slots(hw == 4 ? 256 : 384) / total;   // one round of resident workgroups
+  if (splits < 1) splits = 1;
+  if (splits > nslabs / 4) splits = nslabs / 4 > 0 ? nslabs / 4 : 1;
+  const int rows_per_split = c2d_ceil_div(nslabs, splits) * slab;
+  g.splits = c2d_ceil_div(M, rows_per_split);
+  for (int p = 0; p < num; ++p) { g.a[p].rows_per_split = rows_per_split; g.a[p].splits = g.splits; }
+  const dim3 grid(total * g.splits);
+  dispatch_note("wgrad3x3_bf16_group_kernel<%d, %d>", hw, hw == 4 ? 8 : 2);
+  if (hw == 4) hipLaunchKernelGGL((wgrad3x3_bf16_group_kernel<4, 8>), grid, dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL((wgrad3x3_bf16_group_kernel<7, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+  return c2d_launch_status();
+}
+
 extern "C" int c2d_conv_wgrad_bf16_splits(int ldx, int xoff, int ldc, int coff, int n, int ih,
                                           int iw, int cin, int cout, int kh, int kw, int stride) {
   int splits = 0;

@@ -254,6 +254,25 @@ def conv1x1_wgrad_multi(x, ldx, xoff, dcs, ldcs, coffs, dws, couts, rows, cin):
             ptrs(*[_p(t) for t in dws]), ints(*couts), rows, cin, _stream())
 
 
+def conv3x3_wgrad_multi(probs, n, hw):
+  """Nine-tap filter gradients of several 3x3 / stride-1 convolutions over the same per-ROI maps in
+  ONE launch (bf16 operands).  probs: [(x, ldx, xoff, dc, ldc, coff, dw, cin, cout), ...] (<= 3).
+  Returns False when the library declines the group (C2D_ERR_UNSUPPORTED): launch them one by one."""
+  k = len(probs)
+  assert all(p[0].dtype == torch.bfloat16 and p[3].dtype == torch.bfloat16 and p[6].dtype == torch.float32
+             for p in probs)
+  xs = (ctypes.c_void_p * k)(*[_p(p[0]) for p in probs])
+  dcs = (ctypes.c_void_p * k)(*[_p(p[3]) for p in probs])
+  dws = (ctypes.c_void_p * k)(*[_p(p[6]) for p in probs])
+  ints = lambda i: (ctypes.c_int * k)(*[int(p[i]) for p in probs])
+  rc = _lib.load().c2d_conv3x3_wgrad_multi_bf16(k, xs, ints(1), ints(2), dcs, ints(4), ints(5), dws,
+                                                ints(7), ints(8), n, hw, _stream())
+  if rc == -2:         # C2D_ERR_UNSUPPORTED
+    return False
+  _lib.check(rc, "c2d_conv3x3_wgrad_multi_bf16")
+  return True
+
+
 def conv_wgrad(x, ldx, xoff, dc, ldc, coff, dw, n, ih, iw, cin, cout, kh, kw, stride):
   fn = "c2d_conv_wgrad_bf16" if x.dtype == torch.bfloat16 else "c2d_conv_wgrad"
   assert x.dtype == dc.dtype and dw.dtype == torch.float32

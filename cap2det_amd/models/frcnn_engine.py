@@ -80,6 +80,11 @@ GROUP_MAX_ROWS = 16384   # block inputs up to this many rows use grouped launche
 # block inputs from this many rows on take ONE grouped filter-gradient launch for their 1x1 entry
 # convolutions (c2d_conv1x1_wgrad_multi); below, the row splits of one output already fill the chip
 WGRAD_MULTI_MIN_ROWS = int(os.environ.get("C2D_WGRAD_MULTI_MIN_ROWS", "8192"))
+# bf16 networks, C2D_WGRAD3_GROUP=1: one grouped launch for the nine-tap filter gradients of a
+# block's 3x3 layers (Net._w3_flush; Mixed_5b's three layers 176 -> 116 us alone, a third of their
+# split-K atomics).  Measured NEUTRAL inside the step (2.909-2.917 against 2.910-2.927 ms, three
+# alternating runs): off by default, like every change that is faster alone and equal in the step.
+W3_GROUP = os.environ.get("C2D_WGRAD3_GROUP", "0") == "1"
 DC_SLOTS = max(2, int(os.environ.get("C2D_DC_SLOTS", "2")))   # dC scratch buffers per stream (see _prepare_backward)
 
 
@@ -873,6 +878,16 @@ class Net(object):
       # the consumer's fused input-gradient launch left this layer's dc in its gradient buffer
       # (an inner layer's own dense buffer, or its columns of a concat gradient)
       dc, dcld, dcoff = gy.t, gy.ld, gy.off
+    # bf16 networks: the nine-tap filter gradients of a block's 3x3 layers go out as ONE grouped
+    # launch at the end of the block (_w3_flush).  A deferred layer's dc must outlive the block: a
+    # layer whose dc would sit in the rotating scratch gets a buffer of its own.
+    group3 = (plan.get("w3_pending") is not None and L.trainable and L.k == 3 and L.stride == 1 and
+              st["ih"] == st["iw"] and st["ih"] in (4, 7) and st["n"] >= 256 and L.cin % 32 == 0 and
+              L.cout % 32 == 0 and st.get("wpart") is None and defer is None)
+    if dc is None and group3 and "fused_blocks" not in st:
+      if "dc_own" not in st:
+        st["dc_own"] = torch.empty(rows, L.cout, device=self.store.device, dtype=self.dtype)
+      dc = st["dc_own"]
     if dc is None:
       buf = scr["dc"]
       if side is not None:
@@ -918,6 +933,8 @@ class Net(object):
                       rows, L.cout)
     if tr and defer is not None and slot is None and st.get("wpart") is None:
       defer.append((st, dc, dcld, dcoff))
+    elif group3 and slot is None:
+      plan["w3_pending"].append((st, x, dc, dcld, dcoff))
     elif tr and side is not None:
       # dW only meets the rest of the step at the all-reduce / optimiser: it runs on a side stream
       # beside the input-gradient GEMM of the same layer, each filling the other's partial rounds
@@ -946,6 +963,36 @@ class Net(object):
     elif gx is not None:
       ops.conv_dgrad(dc, dcld, dcoff, L.w_for(self.dtype), gx.t, gx.ld, gx.off,
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
+
+  def _w3_flush(self, plan):
+    """The nine-tap filter gradients a block deferred (_conv_bwd, group3) as ONE launch on the
+    filter-gradient stream: c2d_conv3x3_wgrad_multi_bf16 shares the row splits between the layers,
+    so three layers cost a third of the split-K atomics and of the ramps of three launches
+    (Mixed_5b: 176 -> 116 us alone).  Called on the stream that has seen every deferred dc."""
+    pending, plan["w3_pending"] = plan.get("w3_pending"), None
+    if not pending:
+      return
+    side = self.side if plan["scr"]["dc_alt"] is not None else None
+
+    def launch():
+      st0 = pending[0][0]
+      if len(pending) >= 2 and ops.conv3x3_wgrad_multi(
+          [(x.t, x.ld, x.off, dc, dcld, dcoff, self.store.grad[st["layer"].name + "/weights"],
+            st["layer"].cin, st["layer"].cout) for st, x, dc, dcld, dcoff in pending],
+          st0["n"], st0["ih"]):
+        return
+      for st, x, dc, dcld, dcoff in pending:
+        self._wgrad(plan, st, x, dc, dcld, dcoff)
+
+    if side is not None:
+      ready = torch.cuda.Event()
+      ready.record()
+      side.wait_event(ready)
+      with torch.cuda.stream(side):
+        launch()
+      plan["side_pending"] = True
+    else:
+      launch()
 
   def _entry_wgrads(self, plan, x, deferred):
     """Filter gradients of a block's 1x1 entry convolutions, which all read the block input: ONE
@@ -1028,6 +1075,7 @@ class Net(object):
           self._conv_bwd(plan, b0, x, None, False, dc=b0["dc_entry"], defer=got)
           entry_wg[rest_owner] = got
       early = None       # a pooling FIRST op whose gradient goes out on the branch stream (below)
+      plan["w3_pending"] = [] if (self.dtype == torch.bfloat16 and W3_GROUP) else None
       if self.alt is not None and plan["scr_b"] is None and st["n"] >= self.alt_min_n:
         plan["scr_b"] = plan["scratch_set"]()
       if self.alt is not None and plan["scr_b"] is not None and st["n"] >= self.alt_min_n:
@@ -1073,6 +1121,7 @@ class Net(object):
       else:
         for bi in range(len(st["branches"])):
           tail(bi)
+      self._w3_flush(plan)
       written = early is not None
       owner = st.get("fuse_out")
       if owner is not None and gx is not None and len(fused) >= 2:

@@ -192,6 +192,17 @@ int c2d_conv1x1_wgrad_multi_bf16(const void* x, int ldx, int xoff, int nseg,
                                  float* const* dws, const int* couts, int rows, int cin,
                                  void* stream);
 
+/* The filter gradients of `num` (<= 3) 3x3 / stride-1 / SAME convolutions over the same n per-ROI
+ * maps of hw x hw (4 or 7) — the 3x3 layers of one Inception block — in ONE launch with shared row
+ * splits (round 5: a third of the split-K atomics and of the ramps of three launches).  bf16
+ * operands (channel counts multiples of 32; leading dimensions / offsets multiples of 8), fp32
+ * atomics into dws[p][9][cin_p][cout_p].  C2D_ERR_UNSUPPORTED when a problem is not one the
+ * nine-tap kernel takes: launch them with c2d_conv_wgrad_bf16 then. */
+int c2d_conv3x3_wgrad_multi_bf16(int num, const void* const* xs, const int* ldxs, const int* xoffs,
+                                 const void* const* dcs, const int* ldcs, const int* coffs,
+                                 float* const* dws, const int* cins, const int* couts, int n,
+                                 int hw, void* stream);
+
 /* dw[kh*kw][cin][cout] += Conv2DBackpropFilter(x, dc)  (fp32 atomics over row splits; the
  * caller zero-fills dw once per step). */
 int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, int coff,

@@ -418,3 +418,40 @@ def test_feature_map_dropout_branch_bf16_tracks_fp32():
   cos = float(g32 @ g16 / (np.linalg.norm(g32) * np.linalg.norm(g16)))
   assert cos >= 0.995, cos
   assert float(np.abs(g32 - g16).max()) > 0.0
+
+
+@pytest.mark.parametrize("n,hw,layers", [
+    (300, 4, [(64, 160), (96, 32), (32, 64)]),          # three 4x4 layers, ragged last slab
+    (2000, 4, [(192, 320), (160, 224), (224, 224)]),    # Mixed_5b at the benchmark's size
+    (257, 7, [(32, 192), (128, 96)]),                   # 7x7 maps, two layers
+])
+def test_conv3x3_wgrad_multi_bf16(n, hw, layers):
+  """c2d_conv3x3_wgrad_multi_bf16 (round 5): the nine-tap filter gradients of a block's 3x3 layers
+  in ONE launch with shared row splits — every output equal to the single-layer launch's up to the
+  order of the split-K atomics, and within 1e-4 of scale of the float64 oracle on the same bf16
+  operands (small case)."""
+  from cap2det_amd import hip_ops as ops
+  rng = np.random.default_rng(n + hw)
+  probs, singles, keep = [], [], []
+  for cin, cout in layers:
+    x, x64 = _bf(rng.standard_normal((n, hw, hw, cin)))
+    dc, dc64 = _bf(rng.standard_normal((n, hw, hw, cout)))
+    dw = torch.zeros(9, cin, cout, device=DEV)
+    dw1 = torch.zeros(9, cin, cout, device=DEV)
+    probs.append((x.view(-1, cin), cin, 0, dc.view(-1, cout), cout, 0, dw, cin, cout))
+    ops.conv_wgrad(x.view(-1, cin), cin, 0, dc.view(-1, cout), cout, 0, dw1, n, hw, hw, cin, cout, 3, 3, 1)
+    assert ops.last_dispatch()[0].startswith("wgrad3x3_bf16_kernel<%d" % hw)
+    singles.append(dw1)
+    keep.append((x64, dc64))
+  assert ops.conv3x3_wgrad_multi(probs, n, hw) is True
+  assert ops.last_dispatch() == ["wgrad3x3_bf16_group_kernel<%d, %d>" % (hw, 8 if hw == 4 else 2)]
+  for (cin, cout), p, dw1, (x64, dc64) in zip(layers, probs, singles, keep):
+    scale = float(dw1.abs().max())
+    assert float((p[6] - dw1).abs().max()) <= 2e-5 * scale, (cin, cout)
+    if n <= 300:
+      _, want = ref_ops.conv2d_backward(x64, np.zeros((3, 3, cin, cout)), dc64, 1, need_dx=False)
+      assert np.abs(p[6].cpu().numpy().reshape(3, 3, cin, cout) - want).max() <= 1e-4 * np.abs(want).max()
+  # a layer the nine-tap kernel does not take (cin not a multiple of 32): the group is declined
+  x = torch.zeros(n * hw * hw, 40, device=DEV, dtype=torch.bfloat16)
+  dc = torch.zeros(n * hw * hw, 64, device=DEV, dtype=torch.bfloat16)
+  assert ops.conv3x3_wgrad_multi([(x, 40, 0, dc, 64, 0, torch.zeros(9, 40, 64, device=DEV), 40, 64)], n, hw) is False
