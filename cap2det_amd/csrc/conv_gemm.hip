@@ -2606,13 +2606,18 @@ static bool wgrad_bf16_mfma_enabled() {
 }
 // C2D_WGRAD_BF16_SLOTS=<percent>: resident-workgroup budget of the bf16 filter-gradient launches
 // relative to the default (fewer workgroups = fewer split-K atomics, less latency hiding).
+// Round 5: 75 % of a resident round by default.  A filter-gradient workgroup on a CU (59 KB of LDS
+// for the nine-tap kernel) leaves room for ONE of the main stream's ring-GEMM workgroups instead
+// of two, and those GEMMs live on co-residency (section 3b of DESIGN.md); a quarter fewer
+// filter-gradient workgroups measured 2.922-2.926 against 2.945-3.002 ms per bf16 step over three
+// alternating runs (85 %: 2.948-2.959, 65 %: 2.934-2.949, 50 %: 2.99).
 static int wgrad_bf16_slots(int slots) {
   static const bool tune = getenv("C2D_TUNE") != nullptr;
   if (tune) {
     const char* e = getenv("C2D_WGRAD_BF16_SLOTS");
     if (e && atoi(e) > 0) return slots * atoi(e) / 100;
   }
-  return slots;
+  return slots * 3 / 4;
 }
 static int wgrad3_bf16_igroups(int cin) {
   static const bool tune = getenv("C2D_TUNE") != nullptr;
