@@ -20,7 +20,8 @@ in 20 classes, 0.26-0.29 — and stays there for the first few hundred steps at 
 rate: the loss windows say that the three modes see the same losses, the parameter trajectory says
 that they take the same steps.)
 
-  python tools/loss_curve.py OUT.json [--steps 400] [--hw 500] [--proposals 2000] [--dm 1.0] [--lr 0.5]
+  python tools/loss_curve.py OUT.json [--steps 400] [--hw 500] [--proposals 2000] [--dm 1.0] [--lr RATE]
+(default: the shipped learning rate, 0.01; at 0.5 a fresh detector diverges within the first window)
 """
 import argparse
 import json
