@@ -1071,12 +1071,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * ES,
                                                  ((long long)a.M * a.lda - a.a_off) * ES);
   const int aq4 = (tid & 7) * 4, ar0 = tid >> 3;        // x: LDS rows ar0 + 32u, float4 col aq4
-  unsigned goffs[G_LD], aoffs[A_LD];
-#pragma unroll
-  for (int u = 0; u < G_LD; ++u) {
-    const int k = gkr + u * 8;
-    goffs[u] = k < R ? (unsigned)(k * a.ldg + min(j0 + gc4, a.J - 4)) * (unsigned)ES : OOB_OFFSET;
-  }
+  // dC rows gkr + 8u: one per-lane offset, the 8-row steps ride in the scalar offset (a register
+  // per load would cost the two-image 7x7 form eleven spills); only the last load can hold rows
+  // >= R (they stay zero)
+  unsigned aoffs[A_LD];
+  const unsigned goff0 = (unsigned)(gkr * a.ldg + min(j0 + gc4, a.J - 4)) * (unsigned)ES;
+  const unsigned goff_last = gkr + (G_LD - 1) * 8 < R ? goff0 : OOB_OFFSET;
+  const int gstep = 8 * a.ldg * ES;
 #pragma unroll
   for (int u = 0; u < A_LD; ++u) {
     const int r = ar0 + u * 32;
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
   {                                                                                            \
     const int sg = (MB) * a.ldg * ES, sa = (MB) * a.lda * ES;                                  \
     _Pragma("unroll") for (int u = 0; u < G_LD; ++u)                                           \
-        rg[u] = buf_load_elems4<ES>(rsG, goffs[u], sg);                                        \
+        rg[u] = buf_load_elems4<ES>(rsG, u == G_LD - 1 ? goff_last : goff0, sg + u * gstep);   \
     _Pragma("unroll") for (int u = 0; u < A_LD; ++u)                                           \
         ra[u] = buf_load_elems4<ES>(rsA, aoffs[u], sa);                                        \
   }
@@ -2694,7 +2695,8 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     b.M = n * ih * iw; b.I = cin; b.J = cout; b.h = ih; b.w = iw;
     b.itiles = cin / 32; b.jtiles = c2d_ceil_div(cout, 128); b.tiles = b.itiles * b.jtiles;
     C2D_CHECK_ARG((long long)b.M * ldx * 4 < (long long)OOB_OFFSET && (long long)b.M * ldc * 4 < (long long)OOB_OFFSET);
-    const int slab = iw == 4 ? 32 : 49;                    // whole images per slab
+    static const int pair7 = (getenv("C2D_TUNE") && getenv("C2D_WGRAD3_PAIR7")) ? atoi(getenv("C2D_WGRAD3_PAIR7")) : 1;
+    const int slab = iw == 4 ? 32 : pair7 ? 98 : 49;       // whole images per slab
     const int nslabs = c2d_ceil_div(b.M, slab);
     // 2 blocks per CU in ONE round: rounding the split count UP put a handful of blocks into a
     // second round that cost half a round again (192->256 on 7x7: 516 blocks, 0.94 -> 0.64 ms)
@@ -2709,8 +2711,9 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     if (partial) b.dW = partial;
     const dim3 grid(b.tiles * b.splits);
     hipStream_t st = (hipStream_t)stream;
-    dispatch_note("wgrad3x3_kernel<%d, %d, %d>", iw, iw == 4 ? 2 : 1, ES);
+    dispatch_note("wgrad3x3_kernel<%d, %d, %d>", iw, iw == 4 || pair7 ? 2 : 1, ES);
     if (iw == 4) hipLaunchKernelGGL((wgrad3x3_kernel<4, 2, ES>), grid, dim3(256), 0, st, b);
+    else if (pair7) hipLaunchKernelGGL((wgrad3x3_kernel<7, 2, ES>), grid, dim3(256), 0, st, b);
     else hipLaunchKernelGGL((wgrad3x3_kernel<7, 1, ES>), grid, dim3(256), 0, st, b);
     return c2d_launch_status();
   }

@@ -204,6 +204,8 @@ CONV_CASES = [
     (700, 4, 4, 96, 224, 3, 1),   # enough tiles for stream-K shares that cut tiles (K = 9 x 3 slabs)
     (900, 7, 7, 64, 96, 1, 1),    # 1x1, row-major stream-K
     (261, 7, 7, 32, 160, 3, 2),   # stride-2 nine-tap filter gradient (n >= 256), odd image count
+    (257, 7, 7, 32, 96, 3, 1),    # nine-tap filter gradient on 7x7 maps, two-image slabs, odd image count
+    (259, 4, 4, 32, 64, 3, 1),    # ... on 4x4 maps, odd image count
 ]
 
 
