@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void sigmoid_ce_kernel(const float* __restrict
 
 // grid (C, B): picks the most confident proposal of class c (masked_argmax, first index on
 // ties, axis minimum taken over padded rows too) and stores its index and box.
-__global__ __launch_bounds__(256) void oicr_select_kernel(
+__device__ __forceinline__ void oicr_select_body(
     const float* __restrict__ s0, int ld, int off, const int32_t* __restrict__ num_proposals,
     const float* __restrict__ boxes, int32_t* __restrict__ idx_out, float* __restrict__ box_out,
     int N, int C) {
@@ -232,12 +232,36 @@ __global__ __launch_bounds__(256) void oicr_select_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void oicr_select_kernel(
+    const float* __restrict__ s0, int ld, int off, const int32_t* __restrict__ num_proposals,
+    const float* __restrict__ boxes, int32_t* __restrict__ idx_out, float* __restrict__ box_out,
+    int N, int C) {
+  oicr_select_body(s0, ld, off, num_proposals, boxes, idx_out, box_out, N, C);
+}
+
+// All K refinement stages in one launch (grid (C, B, K)): stage 0 searches s0, stage k > 0 the
+// class columns of softmax(scores of stage k - 1) in Q (rows of C + 1, background first), which
+// oicr_softmax_kernel has written; indices / boxes of stage k at idx_out + k B C / box_out + 4 k B C.
+__global__ __launch_bounds__(256) void oicr_select_multi_kernel(
+    const float* __restrict__ s0, int ld, int off, const float* __restrict__ Q,
+    const int32_t* __restrict__ num_proposals, const float* __restrict__ boxes,
+    int32_t* __restrict__ idx_out, float* __restrict__ box_out, int B, int N, int C) {
+  const int k = blockIdx.z;
+  const size_t bc = (size_t)B * C;
+  if (k > 0) {
+    s0 = Q + (size_t)(k - 1) * B * N * (C + 1);
+    ld = C + 1;
+    off = 1;
+  }
+  oicr_select_body(s0, ld, off, num_proposals, boxes, idx_out + k * bc, box_out + 4 * k * bc, N, C);
+}
+
 __device__ __forceinline__ float box_area(float y0, float x0, float y1, float x1) {
   return fmaxf(x1 - x0, 0.0f) * fmaxf(y1 - y0, 0.0f);
 }
 
 // One wave per proposal row; lanes stride over the C+1 columns.
-__global__ __launch_bounds__(256) void oicr_loss_kernel(
+__device__ __forceinline__ void oicr_loss_body(
     const float* __restrict__ S, int ld, int off, const float* __restrict__ top_boxes,
     const float* __restrict__ boxes, const float* __restrict__ labels,
     const int32_t* __restrict__ num_proposals, float iou_thr, float weight, int B, int N, int C,
@@ -309,6 +333,52 @@ __global__ __launch_bounds__(256) void oicr_loss_kernel(
   if (lane != 0) contrib = 0.f;
   const float tot = block_sum(contrib, red);
   if (threadIdx.x == 0 && loss && tot != 0.f) atomicAdd(loss, tot);
+}
+
+__global__ __launch_bounds__(256) void oicr_loss_kernel(
+    const float* __restrict__ S, int ld, int off, const float* __restrict__ top_boxes,
+    const float* __restrict__ boxes, const float* __restrict__ labels,
+    const int32_t* __restrict__ num_proposals, float iou_thr, float weight, int B, int N, int C,
+    float* __restrict__ loss, float* __restrict__ dS, int lddS, int doff,
+    float* __restrict__ Q) {
+  oicr_loss_body(S, ld, off, top_boxes, boxes, labels, num_proposals, iou_thr, weight, B, N, C,
+                 loss, dS, lddS, doff, Q);
+}
+
+// Stage k = blockIdx.y of K: score / gradient columns off + k (C + 1), its own top boxes, loss
+// scalar and softmax plane.
+__global__ __launch_bounds__(256) void oicr_loss_multi_kernel(
+    const float* __restrict__ S, int ld, int off, const float* __restrict__ top_boxes,
+    const float* __restrict__ boxes, const float* __restrict__ labels,
+    const int32_t* __restrict__ num_proposals, float iou_thr, float weight, int B, int N, int C,
+    float* __restrict__ loss, float* __restrict__ dS, int lddS, int doff,
+    float* __restrict__ Q) {
+  const int k = blockIdx.y;
+  oicr_loss_body(S, ld, off + k * (C + 1), top_boxes + (size_t)4 * k * B * C, boxes, labels,
+                 num_proposals, iou_thr, weight, B, N, C, loss + k, dS, lddS, doff + k * (C + 1),
+                 Q + (size_t)k * B * N * (C + 1));
+}
+
+// softmax of the score rows of stages 0 .. K - 2 (blockIdx.y), exactly as oicr_loss_body computes
+// and stores it (same lanes, same reductions: the same bits) — what the selection of the NEXT stage
+// searches, ahead of the loss kernels that used to produce it one stage at a time.
+__global__ __launch_bounds__(256) void oicr_softmax_kernel(const float* __restrict__ S, int ld,
+                                                           int off, int B, int N, int C,
+                                                           float* __restrict__ Q) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)B * N) return;
+  const int k = blockIdx.y;
+  const int C1 = C + 1;
+  const float* s = S + row * ld + off + k * C1;
+  float mx = -INFINITY;
+  for (int j = lane; j < C1; j += 64) mx = fmaxf(mx, s[j]);
+  mx = c2d_wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < C1; j += 64) se += expf(s[j] - mx);
+  se = c2d_wave_sum(se);
+  float* q = Q + ((size_t)k * B * N + row) * C1;
+  for (int j = lane; j < C1; j += 64) q[j] = expf(s[j] - mx) / se;
 }
 
 // labels[b][c] = 1 if any ids[b][t] == c (ids >= C are out-of-vocabulary)
@@ -753,6 +823,30 @@ extern "C" int c2d_oicr_loss_fwd_bwd(const float* scores, int ld, int off,
                      (hipStream_t)stream, scores, ld, off, top_boxes, boxes, labels,
                      num_proposals, iou_threshold, weight, batch, n, num_classes, loss, dscores,
                      lddl, doff, softmax_out);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_oicr_refine_fwd_bwd(const float* scores, int ld, int off, int stages,
+                                       const float* s0, int s0_ld, int s0_off,
+                                       const float* boxes, const float* labels,
+                                       const int32_t* num_proposals, float iou_threshold,
+                                       float weight, int batch, int n, int num_classes,
+                                       float* loss, float* dscores, int lddl, int doff,
+                                       float* softmax_out, int32_t* idx, float* top_boxes,
+                                       void* stream) {
+  C2D_CHECK_ARG(scores && s0 && boxes && labels && num_proposals && softmax_out && idx && top_boxes);
+  C2D_CHECK_ARG(batch > 0 && n > 0 && num_classes > 0 && stages > 0);
+  const long long rows = (long long)batch * n;
+  hipStream_t st = (hipStream_t)stream;
+  if (stages > 1)
+    hipLaunchKernelGGL(oicr_softmax_kernel, dim3(c2d_ceil_div(rows, 4), stages - 1), dim3(256), 0, st,
+                       scores, ld, off, batch, n, num_classes, softmax_out);
+  hipLaunchKernelGGL(oicr_select_multi_kernel, dim3(num_classes, batch, stages), dim3(256), 0, st,
+                     s0, s0_ld, s0_off, softmax_out, num_proposals, boxes, idx, top_boxes, batch, n,
+                     num_classes);
+  hipLaunchKernelGGL(oicr_loss_multi_kernel, dim3(c2d_ceil_div(rows, 4), stages), dim3(256), 0, st,
+                     scores, ld, off, top_boxes, boxes, labels, num_proposals, iou_threshold, weight,
+                     batch, n, num_classes, loss, dscores, lddl, doff, softmax_out);
   return c2d_launch_status();
 }
 

@@ -542,6 +542,18 @@ def oicr_loss_fwd_bwd(scores, ld, off, top_boxes, boxes, labels, num_proposals, 
             _p(dscores), lddl, doff, _p(softmax_out), _stream())
 
 
+def oicr_refine_fwd_bwd(scores, ld, off, stages, s0, s0_ld, s0_off, boxes, labels, num_proposals,
+                        iou_threshold, weight, batch, n, c, loss, dscores, lddl, doff, softmax_out,
+                        idx, top_boxes):
+  """All OICR stages in three launches (c2d_oicr_refine_fwd_bwd): `loss` [stages], `softmax_out`
+  [stages, batch * n, c + 1], `idx` [stages, batch, c], `top_boxes` [stages, batch, c, 4]."""
+  assert softmax_out.is_contiguous() and softmax_out.numel() == stages * batch * n * (c + 1)
+  assert idx.numel() == stages * batch * c and top_boxes.numel() == stages * batch * c * 4
+  _lib.call("c2d_oicr_refine_fwd_bwd", _p(scores), ld, off, stages, _p(s0), s0_ld, s0_off, _p(boxes),
+            _p(labels), _p(num_proposals), float(iou_threshold), float(weight), batch, n, c,
+            _p(loss), _p(dscores), lddl, doff, _p(softmax_out), _p(idx), _p(top_boxes), _stream())
+
+
 def labels_from_ids(ids, num_classes, labels):
   batch, t = ids.shape
   _lib.call("c2d_labels_from_ids", _p(ids) if t > 0 else None, batch, t, num_classes, _p(labels),

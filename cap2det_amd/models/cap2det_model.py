@@ -7,6 +7,7 @@ graph, `build_loss` also produces d(loss)/d(head logits) and `backward()` runs t
 gradient kernels into the flat gradient buffer consumed by `train/trainer.py`.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -313,9 +314,9 @@ class Model(ModelBase):
           class_logits=torch.empty(b, c, device=dev),
           dclass_logits=torch.empty(b, c, device=dev),
           scores0=torch.empty(b, n, c, device=dev),
-          softmax=[torch.empty(b * n, c + 1, device=dev) for _ in range(k)],
-          idx=torch.empty(b, c, dtype=torch.int32, device=dev),
-          top_boxes=torch.empty(b, c, 4, device=dev),
+          softmax=torch.empty(max(k, 1), b * n, c + 1, device=dev),      # [stage] planes
+          idx=torch.empty(max(k, 1), b, c, dtype=torch.int32, device=dev),
+          top_boxes=torch.empty(max(k, 1), b, c, 4, device=dev),
           dfeatures=torch.empty(b * n, self.engine.feature_dims, device=dev))
     return self._cache[key]
 
@@ -453,11 +454,21 @@ class Model(ModelBase):
     # s0 = concat(0, proba or scores): the class columns are searched directly (:306-312)
     s0 = bufs["proba"] if options.oicr_use_proba_r_given_c else bufs["scores0"]
     s0_ld, s0_off = c, 0
+    if k > 0 and os.environ.get("C2D_OICR_STAGEWISE") != "1":
+      # all stages in three launches: stage i + 1 selects on softmax(scores_i)[..., 1:] (:328),
+      # which depends on the forward pass only, not on the loss of stage i
+      ops.oicr_refine_fwd_bwd(bufs["logits"], self._npad, 2 * c, k, s0, s0_ld, s0_off, proposals,
+                              labels, num_proposals, options.oicr_iou_threshold,
+                              options.oicr_loss_weight, b, n, c, losses[1:1 + k], bufs["dlogits"],
+                              self._npad, 2 * c, bufs["softmax"], bufs["idx"], bufs["top_boxes"])
+      for i in range(k):
+        loss_dict['oicr_cross_entropy_loss_at_{}'.format(i + 1)] = losses[i + 1]
+      return loss_dict
     for i in range(k):
       off = 2 * c + i * (c + 1)
-      ops.oicr_select(s0, s0_ld, s0_off, num_proposals, proposals, bufs["idx"], bufs["top_boxes"],
-                      b, n, c)
-      ops.oicr_loss_fwd_bwd(bufs["logits"], self._npad, off, bufs["top_boxes"], proposals, labels,
+      ops.oicr_select(s0, s0_ld, s0_off, num_proposals, proposals, bufs["idx"][i],
+                      bufs["top_boxes"][i], b, n, c)
+      ops.oicr_loss_fwd_bwd(bufs["logits"], self._npad, off, bufs["top_boxes"][i], proposals, labels,
                             num_proposals, options.oicr_iou_threshold, options.oicr_loss_weight, b,
                             n, c, losses[i + 1:i + 2], bufs["dlogits"], self._npad, off,
                             bufs["softmax"][i])

@@ -422,6 +422,19 @@ int c2d_oicr_loss_fwd_bwd(const float* scores, int ld, int off, const float* top
                           const int32_t* num_proposals, float iou_threshold, float weight,
                           int batch, int n, int num_classes, float* loss, float* dscores,
                           int lddl, int doff, float* softmax_out, void* stream);
+/* All `stages` OICR refinement losses of a step (the loop of models/cap2det_model.py:306-330:
+ * select on s0, loss 1, select on softmax(scores 1)[..., 1:], loss 2, ...) in three launches
+ * instead of two per stage — the selection of stage k needs only the SCORES of stage k - 1, which
+ * the forward pass has left behind, not its loss.  Stage k reads / writes the C+1 columns at
+ * off + k (C+1) / doff + k (C+1), adds its loss to loss[k], and leaves softmax_out[k][batch*n][C+1],
+ * idx[k][batch][C], top_boxes[k][batch][C][4].  Bitwise the results of `stages` pairs of
+ * c2d_oicr_select / c2d_oicr_loss_fwd_bwd (the loss scalars up to the order of their atomics). */
+int c2d_oicr_refine_fwd_bwd(const float* scores, int ld, int off, int stages, const float* s0,
+                            int s0_ld, int s0_off, const float* boxes, const float* labels,
+                            const int32_t* num_proposals, float iou_threshold, float weight,
+                            int batch, int n, int num_classes, float* loss, float* dscores,
+                            int lddl, int doff, float* softmax_out, int32_t* idx,
+                            float* top_boxes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Caption -> label branch  (models/label_extractor.py)

@@ -709,6 +709,61 @@ def test_oicr_select_and_loss(ops, c):
   np.testing.assert_allclose(_n(q).reshape(b, n, c + 1), ref_ops.softmax(s1), rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("b,n,c,stages", [(2, 61, 5, 3), (1, 2000, 20, 3), (2, 300, 80, 2), (1, 77, 7, 1)])
+def test_oicr_refine_all_stages_at_once(ops, b, n, c, stages):
+  """c2d_oicr_refine_fwd_bwd (three launches for all stages) against the stage-by-stage calls it
+  replaces — indices, top boxes, softmax planes and score gradients BITWISE, the loss scalars to the
+  order of their atomics — and stage by stage against the oracle (models/cap2det_model.py:306-330:
+  stage k + 1 selects on softmax(scores of stage k)[..., 1:]).  Scores live in the column slices of
+  a wider head-logits buffer, as in the model."""
+  rng = np.random.default_rng(53 + n)
+  num = np.minimum(n, rng.integers(max(1, n // 2), n + 1, b)).astype(np.int32); num[0] = n
+  boxes = np.stack([_edge_boxes(rng, n) for _ in range(b)]).astype(np.float32)
+  ld, off = 2 * c + stages * (c + 1) + 3, 2 * c
+  logits = rng.standard_normal((b * n, ld)).astype(np.float32)
+  s0 = rng.uniform(0, 1, (b, n, c)).astype(np.float32)
+  s0[0, 1, 0] = s0[0, min(9, n - 1), 0] = 5.0        # tied maxima -> first index
+  labels = (rng.uniform(size=(b, c)) > 0.5).astype(np.float32); labels[0, 0] = 1
+  tl, ts0, tb, tlab, tnum = _t(logits), _t(s0), _t(boxes), _t(labels), _t(num)
+  # stage by stage
+  idx1 = torch.empty(stages, b, c, dtype=torch.int32, device=DEV)
+  top1 = torch.empty(stages, b, c, 4, device=DEV)
+  q1 = torch.empty(stages, b * n, c + 1, device=DEV)
+  loss1 = torch.zeros(stages, device=DEV); ds1 = torch.zeros(b * n, ld, device=DEV)
+  src, sld, soff = ts0, c, 0
+  for k in range(stages):
+    ops.oicr_select(src, sld, soff, tnum, tb, idx1[k], top1[k], b, n, c)
+    ops.oicr_loss_fwd_bwd(tl, ld, off + k * (c + 1), top1[k], tb, tlab, tnum, 0.5, 0.7, b, n, c,
+                          loss1[k:k + 1], ds1, ld, off + k * (c + 1), q1[k])
+    src, sld, soff = q1[k], c + 1, 1
+  # at once
+  idx2 = torch.full((stages, b, c), -1, dtype=torch.int32, device=DEV)
+  top2 = torch.full((stages, b, c, 4), -1.0, device=DEV)
+  q2 = torch.full((stages, b * n, c + 1), -1.0, device=DEV)
+  loss2 = torch.zeros(stages, device=DEV); ds2 = torch.zeros(b * n, ld, device=DEV)
+  ops.oicr_refine_fwd_bwd(tl, ld, off, stages, ts0, c, 0, tb, tlab, tnum, 0.5, 0.7, b, n, c, loss2, ds2,
+                          ld, off, q2, idx2, top2)
+  torch.cuda.synchronize()
+  assert torch.equal(idx1, idx2) and torch.equal(top1, top2)
+  assert torch.equal(q1, q2) and torch.equal(ds1, ds2)
+  np.testing.assert_allclose(_n(loss2), _n(loss1), rtol=2e-6)
+  assert float(ds2[:, :off].abs().max()) == 0 and float(ds2[:, off + stages * (c + 1):].abs().max()) == 0
+  # oracle, stage by stage
+  prev = np.concatenate([np.zeros((b, n, 1), np.float32), s0], axis=-1)
+  mask = ref_ops.sequence_mask(num, n)
+  for k in range(stages):
+    sk = logits.reshape(b, n, ld)[:, :, off + k * (c + 1):off + (k + 1) * (c + 1)]
+    want_idx = ref_ops.masked_argmax(prev[:, :, 1:], mask[..., None], dim=1)
+    np.testing.assert_array_equal(_n(idx2[k]), want_idx)
+    want_loss, want_ds, _ = ref_model.calc_oicr_loss(labels, num, boxes, prev, sk, 0.5)
+    np.testing.assert_allclose(_n(loss2)[k], 0.7 * want_loss, rtol=3e-5)
+    got = _n(ds2).reshape(b, n, ld)[:, :, off + k * (c + 1):off + (k + 1) * (c + 1)]
+    np.testing.assert_allclose(got, 0.7 * want_ds, rtol=1e-4, atol=1e-8)
+    prev = ref_ops.softmax(sk)
+    np.testing.assert_allclose(_n(q2[k]).reshape(b, n, c + 1), prev, rtol=1e-5, atol=1e-8)
+    prev = _n(q2[k]).reshape(b, n, c + 1)      # (the next selection sees the device's own bits)
+
+
 def test_labels_and_text_classifier(ops):
   rng = np.random.default_rng(41)
   b, t, v, e, h, c = 4, 9, 50, 300, 400, 7
