@@ -566,6 +566,19 @@ __global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __rest
 }
 
 // g' = mult * (g + l2 * w); acc += g'^2; w -= lr * g' / sqrt(acc)       (TF ApplyAdagrad)
+// One operation order for every kernel that applies the rule (the products of g' rounded
+// separately, the accumulator update one fma — what adagrad_kernel has always compiled to), so that
+// the one-launch forms are bitwise the per-segment launches.
+__device__ __forceinline__ void adagrad_update(float& wi, float& ai, float g, float lr, float l2,
+                                               float mult, float grad_scale) {
+#pragma clang fp contract(off)
+  const float t1 = g * grad_scale, t2 = l2 * wi;
+  const float gi = mult * (t1 + t2);
+  ai = __builtin_fmaf(gi, gi, ai);
+  const float u = lr * gi;
+  wi = wi - u / sqrtf(ai);
+}
+
 __global__ __launch_bounds__(256) void adagrad_kernel(float* __restrict__ w,
                                                       const float* __restrict__ g,
                                                       float* __restrict__ acc, long long n,
@@ -573,11 +586,37 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float* __restrict__ w,
                                                       float grad_scale) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    const float wi = w[i];
-    const float gi = mult * (g[i] * grad_scale + l2 * wi);
-    const float a = acc[i] + gi * gi;
-    acc[i] = a;
-    w[i] = wi - lr * gi / sqrtf(a);
+    float wi = w[i], ai = acc[i];
+    adagrad_update(wi, ai, g[i], lr, l2, mult, grad_scale);
+    acc[i] = ai;
+    w[i] = wi;
+  }
+}
+
+// The same update over up to eight segments of the flat buffers in ONE launch (grid.y = segment;
+// runs of variables that share multiplier and L2 weight: second stage / head weights / head
+// biases), optionally leaving the bf16 mirror of the updated values behind (bf16 networks read
+// their input-gradient operand from it: no separate cast pass over the store).
+struct AdagradSegs {
+  long long off[8], end[8];
+  float mult[8], l2[8];
+};
+__global__ __launch_bounds__(256) void adagrad_multi_kernel(float* __restrict__ w,
+                                                            const float* __restrict__ g,
+                                                            float* __restrict__ acc,
+                                                            AdagradSegs segs, float lr,
+                                                            float grad_scale,
+                                                            c2d_bf16* __restrict__ w16) {
+  const int sgi = blockIdx.y;
+  const long long end = segs.end[sgi];
+  const float mult = segs.mult[sgi], l2 = segs.l2[sgi];
+  for (long long i = segs.off[sgi] + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < end;
+       i += (long long)gridDim.x * blockDim.x) {
+    float wi = w[i], ai = acc[i];
+    adagrad_update(wi, ai, g[i], lr, l2, mult, grad_scale);
+    acc[i] = ai;
+    w[i] = wi;
+    if (w16) w16[i] = (c2d_bf16)wi;
   }
 }
 
@@ -709,7 +748,7 @@ struct FoldDesc { long long gamma, beta, mean, var, scale, shift; int c, begin; 
 
 __global__ __launch_bounds__(256) void transpose_taps_batched_kernel(
     const TransDesc* __restrict__ desc, int num, const float* __restrict__ src_base,
-    float* __restrict__ dst_base) {
+    float* __restrict__ dst_base, c2d_bf16* __restrict__ dst16_base) {
   __shared__ float tile[32][33];
   int lo = 0, hi = num - 1;          // last descriptor with tile_begin <= blockIdx.x
   while (lo < hi) {
@@ -732,7 +771,12 @@ __global__ __launch_bounds__(256) void transpose_taps_batched_kernel(
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const int j = j0 + k, i = i0 + tx;
-    if (i < d.rows && j < d.cols) dst[(size_t)j * d.rows + i] = tile[tx][k];
+    if (i < d.rows && j < d.cols) {
+      dst[(size_t)j * d.rows + i] = tile[tx][k];
+      if (dst16_base)      // the bf16 mirror of the derived operand (same element offsets)
+        dst16_base[d.dst_off + (size_t)tap * d.rows * d.cols + (size_t)j * d.rows + i] =
+            (c2d_bf16)tile[tx][k];
+    }
   }
 }
 
@@ -1201,6 +1245,31 @@ extern "C" int c2d_adagrad_step_ex(float* w, const float* g, float* acc, long lo
   return c2d_launch_status();
 }
 
+extern "C" int c2d_adagrad_step_multi(float* values, const float* grads, float* accum,
+                                      int num_segments, const long long* offsets,
+                                      const long long* ends, const float* mults,
+                                      const float* l2s, float lr, float grad_scale,
+                                      void* values_bf16, void* stream) {
+  C2D_CHECK_ARG(values && grads && accum && offsets && ends && mults && l2s);
+  C2D_CHECK_ARG(num_segments > 0 && num_segments <= 8);
+  AdagradSegs segs;
+  long long longest = 0;
+  for (int i = 0; i < 8; ++i) {
+    const bool on = i < num_segments;
+    C2D_CHECK_ARG(!on || (offsets[i] >= 0 && ends[i] >= offsets[i]));
+    segs.off[i] = on ? offsets[i] : 0;
+    segs.end[i] = on ? ends[i] : 0;
+    segs.mult[i] = on ? mults[i] : 0.f;
+    segs.l2[i] = on ? l2s[i] : 0.f;
+    if (on && ends[i] - offsets[i] > longest) longest = ends[i] - offsets[i];
+  }
+  if (longest == 0) return C2D_OK;
+  hipLaunchKernelGGL(adagrad_multi_kernel, dim3(grid_for(longest), num_segments), dim3(256), 0,
+                     (hipStream_t)stream, values, grads, accum, segs, lr, grad_scale,
+                     (c2d_bf16*)values_bf16);
+  return c2d_launch_status();
+}
+
 static_assert(sizeof(ClipDesc) == sizeof(C2dClipDesc), "C2dClipDesc layout");
 extern "C" int c2d_clip_gradient_norms(float* grads, const float* values,
                                        const C2dClipDesc* desc, int num, float grad_scale,
@@ -1251,7 +1320,18 @@ extern "C" int c2d_transpose_taps_batched(const void* desc, int num, int total_t
                                           void* stream) {
   C2D_CHECK_ARG(desc && src_base && dst_base && num > 0 && total_tiles > 0);
   hipLaunchKernelGGL(transpose_taps_batched_kernel, dim3(total_tiles), dim3(256), 0,
-                     (hipStream_t)stream, (const TransDesc*)desc, num, src_base, dst_base);
+                     (hipStream_t)stream, (const TransDesc*)desc, num, src_base, dst_base,
+                     (c2d_bf16*)nullptr);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_transpose_taps_batched_mirror(const void* desc, int num, int total_tiles,
+                                                 const float* src_base, float* dst_base,
+                                                 void* dst_bf16, void* stream) {
+  C2D_CHECK_ARG(desc && src_base && dst_base && dst_bf16 && num > 0 && total_tiles > 0);
+  hipLaunchKernelGGL(transpose_taps_batched_kernel, dim3(total_tiles), dim3(256), 0,
+                     (hipStream_t)stream, (const TransDesc*)desc, num, src_base, dst_base,
+                     (c2d_bf16*)dst_bf16);
   return c2d_launch_status();
 }
 

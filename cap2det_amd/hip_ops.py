@@ -289,6 +289,13 @@ def transpose_taps_batched(desc, num, total_tiles, src_base, dst_base):
             _stream())
 
 
+def transpose_taps_batched_mirror(desc, num, total_tiles, src_base, dst_base, dst_bf16):
+  """transpose_taps_batched that also writes the bf16 mirror of every transposed operand."""
+  assert dst_bf16.dtype == torch.bfloat16 and dst_bf16.numel() == dst_base.numel()
+  _lib.call("c2d_transpose_taps_batched_mirror", _p(desc), num, total_tiles, _p(src_base),
+            _p(dst_base), _p(dst_bf16), _stream())
+
+
 def bn_fold_batched(desc, num, total_channels, vars_base, stats_base, eps, out_base):
   _lib.call("c2d_bn_fold_batched", _p(desc), num, total_channels, _p(vars_base), _p(stats_base),
             float(eps), _p(out_base), _stream())
@@ -663,6 +670,22 @@ def text_pool_bwd(dhidden, pre, ids, hidden_units, vocab_size, keep_mask, keep_p
 def adagrad_step(w, g, acc, lr, l2, mult, grad_scale=1.0):
   _lib.call("c2d_adagrad_step", _p(w), _p(g), _p(acc), w.numel(), float(lr), float(l2),
             float(mult), float(grad_scale), _stream())
+
+
+def adagrad_step_multi(values, grads, accum, segments, lr, grad_scale=1.0, values_bf16=None):
+  """adagrad_step over `segments` = [(offset, end, mult, l2), ...] (<= 8) of the flat buffers in one
+  launch; values_bf16: the bf16 mirror of `values` to refresh along the way (or None)."""
+  n = len(segments)
+  assert 0 < n <= 8 and values.numel() == grads.numel() == accum.numel()
+  assert all(0 <= s[0] <= s[1] <= values.numel() for s in segments)
+  assert values_bf16 is None or (values_bf16.dtype == torch.bfloat16 and
+                                 values_bf16.numel() == values.numel())
+  lls, fls = ctypes.c_longlong * n, ctypes.c_float * n
+  _lib.call("c2d_adagrad_step_multi", _p(values), _p(grads), _p(accum), n,
+            lls(*[int(s[0]) for s in segments]), lls(*[int(s[1]) for s in segments]),
+            fls(*[float(s[2]) for s in segments]), fls(*[float(s[3]) for s in segments]),
+            float(lr), float(grad_scale), None if values_bf16 is None else _p(values_bf16),
+            _stream())
 
 
 def l2_loss(w, weight, out):

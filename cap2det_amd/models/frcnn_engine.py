@@ -1304,8 +1304,17 @@ class FrcnnEngine(object):
                 folds=dev(np.array(folds, dtype=fdt)) if folds else None, nfolds=len(folds),
                 chans=chans)
 
-  def refresh(self, only_trainable=False):
-    """Re-derives every (trainable) layer's kernel operands with two batched launches."""
+  def values_mirror(self):
+    """The bf16 mirror of the variable store when this is a bf16 network whose mirrors exist
+    (an optimiser kernel that updates it itself saves refresh() a cast pass), else None."""
+    if self.act_dtype == torch.float32:
+      return None
+    return getattr(self.store, "values_bf16", None)
+
+  def refresh(self, only_trainable=False, values_mirrored=False):
+    """Re-derives every (trainable) layer's kernel operands with two batched launches.
+    values_mirrored: the caller's optimiser kernel has already written the bf16 mirror of the
+    updated variables (c2d_adagrad_step_multi)."""
     if not only_trainable:
       self._refresh_stem()
       self.invalidate_prefetch()             # frozen weights may have changed under a look-ahead
@@ -1313,18 +1322,30 @@ class FrcnnEngine(object):
     if self._tables.get("key") != key:
       self._tables = dict(key=key, t=self._build_tables(only_trainable))
     t = self._tables["t"]
+    low = self.act_dtype != torch.float32
+    # bf16 mirrors of the variables (dgrad operand) and of the derived operands (forward).  The
+    # per-step refresh of the trainable layers writes the mirror of a transposed operand with the
+    # operand (the folded BatchNorm scale / shift are read in fp32 only); the full refresh casts
+    # both buffers whole.
+    fused_mirror = low and only_trainable and os.environ.get("C2D_REFRESH_CAST") != "1"
+    if low:
+      any_layer = next(iter(self.second.layers.values()))
+      any_layer.w_for(self.act_dtype); any_layer.wt_for(self.act_dtype)     # (allocate once)
     if t["ntrans"]:
-      ops.transpose_taps_batched(t["trans"], t["ntrans"], t["tiles"], self.store.values,
-                                 self.stats.der_flat)
+      if fused_mirror:
+        ops.transpose_taps_batched_mirror(t["trans"], t["ntrans"], t["tiles"], self.store.values,
+                                          self.stats.der_flat, self.stats.der_bf16)
+      else:
+        ops.transpose_taps_batched(t["trans"], t["ntrans"], t["tiles"], self.store.values,
+                                   self.stats.der_flat)
     if t["nfolds"]:
       ops.bn_fold_batched(t["folds"], t["nfolds"], t["chans"], self.store.values,
                           self.stats.stat_flat, BN_EPS, self.stats.der_flat)
-    if self.act_dtype != torch.float32:
-      # bf16 mirrors of the variables (dgrad operand) and of the derived operands (forward)
-      any_layer = next(iter(self.second.layers.values()))
-      any_layer.w_for(self.act_dtype); any_layer.wt_for(self.act_dtype)     # (allocate once)
-      ops.cast_bf16(self.store.values, self.store.values_bf16)
-      ops.cast_bf16(self.stats.der_flat, self.stats.der_bf16)
+    if low:
+      if not values_mirrored:
+        ops.cast_bf16(self.store.values, self.store.values_bf16)
+      if not fused_mirror:
+        ops.cast_bf16(self.stats.der_flat, self.stats.der_bf16)
 
   def _refresh_stem(self):
     """Folds depthwise(7x7, x8) o pointwise(1x1) into one 7x7 kernel over the 4-channel padded

@@ -312,6 +312,16 @@ class Trainer(object):
       self._apply_other_optimizer(scale, lr, lr_dev, clipped)
       self.model.refresh(only_trainable=True)
       return
+    if (not clipped and lr_dev is None and len(self.segments) <= 8 and
+        all(cols is None and l1 == 0.0 for _, _, _, l1, _, cols, _ in self.segments) and
+        os.environ.get("C2D_ADAGRAD_MULTI", "1") != "0"):
+      # the common case in ONE launch; a bf16 network's mirror of the variables is written by the
+      # same pass, the mirror of the derived operands by the transposes of refresh()
+      mirror = self.model.engine.values_mirror()
+      ops.adagrad_step_multi(v, g, a, [(off, end, m, l2) for off, end, m, _, l2, _, _ in self.segments],
+                             lr, scale, mirror)
+      self.model.engine.refresh(only_trainable=True, values_mirrored=mirror is not None)
+      return
     for off, end, m, l1, l2, cols, mask in self.segments:
       if clipped:
         # the descriptors applied scale / regularisers / multipliers; what is left is the

@@ -220,6 +220,12 @@ int c2d_transpose_taps(const float* w, float* wt, int taps, int rows, int cols, 
  *              gamma/beta index `vars`, mean/var index `stats`, scale/shift index `out`. */
 int c2d_transpose_taps_batched(const void* desc, int num, int total_tiles, const float* src_base,
                                float* dst_base, void* stream);
+/* c2d_transpose_taps_batched that also leaves the bf16 mirror of every transposed operand at the
+ * same element offsets of dst_bf16 (bf16 networks read their forward weights from it): replaces a
+ * cast pass over the whole derived-operand buffer after every optimiser step (round 5). */
+int c2d_transpose_taps_batched_mirror(const void* desc, int num, int total_tiles,
+                                      const float* src_base, float* dst_base, void* dst_bf16,
+                                      void* stream);
 int c2d_bn_fold_batched(const void* desc, int num, int total_channels, const float* vars,
                         const float* stats, float eps, float* out, void* stream);
 
@@ -515,6 +521,15 @@ int c2d_sum_small(const float* x, int n, float* out, void* stream);
 int c2d_adagrad_step_ex(float* w, const float* g, float* acc, long long n, float lr,
                         const float* lr_dev, float l1, float l2, float mult, float grad_scale,
                         const float* col_mult, int ld, void* stream);
+/* c2d_adagrad_step over up to 8 segments [offsets[i], ends[i]) of the flat value / gradient /
+ * accumulator buffers in ONE launch (HOST arrays; segment i with its own multiplier and L2 weight:
+ * the runs of variables train/trainer.py:104-125 gives one gradient multiplier), bitwise the
+ * separate calls.  values_bf16 != NULL: the bf16 mirror of every updated value is written as well
+ * (same element offsets; bf16 networks read their input-gradient weights from it). */
+int c2d_adagrad_step_multi(float* values, const float* grads, float* accum, int num_segments,
+                           const long long* offsets, const long long* ends, const float* mults,
+                           const float* l2s, float lr, float grad_scale, void* values_bf16,
+                           void* stream);
 
 /* The reference's other optimisers (core/training_utils.py:14-71 `build_optimizer`: sgd, momentum,
  * adam, rmsprop; every shipped config uses adagrad), TensorFlow 1.x update rules on the gradient

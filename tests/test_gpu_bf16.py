@@ -455,3 +455,76 @@ def test_conv3x3_wgrad_multi_bf16(n, hw, layers):
   x = torch.zeros(n * hw * hw, 40, device=DEV, dtype=torch.bfloat16)
   dc = torch.zeros(n * hw * hw, 64, device=DEV, dtype=torch.bfloat16)
   assert ops.conv3x3_wgrad_multi([(x, 40, 0, dc, 64, 0, torch.zeros(9, 40, 64, device=DEV), 40, 64)], n, hw) is False
+
+
+def test_adagrad_step_multi_equals_the_separate_calls():
+  """c2d_adagrad_step_multi: several segments (own multiplier / L2 weight, gaps between them) in one
+  launch — values and accumulators BITWISE those of one c2d_adagrad_step per segment, elements
+  outside the segments untouched, and the bf16 mirror equal to the rounded new values."""
+  from cap2det_amd import hip_ops as ops
+  g = torch.Generator(device="cpu"); g.manual_seed(5)
+  n = 1_300_003
+  v0 = torch.randn(n, generator=g).to(DEV); gr = torch.randn(n, generator=g).to(DEV)
+  a0 = (torch.rand(n, generator=g) + 0.1).to(DEV)
+  segs = [(0, 700_001, 1.0, 0.0), (700_004, 700_004, 3.0, 0.0), (800_000, 1_250_000, 1.0, 1e-4),
+          (1_299_000, 1_300_003, 2.0, 0.0)]
+  v1, a1 = v0.clone(), a0.clone()
+  for off, end, m, l2 in segs:
+    if end > off:
+      ops.adagrad_step(v1[off:end], gr[off:end], a1[off:end], 0.01, l2, m, 0.5)
+  for mirror in (False, True):
+    v2, a2 = v0.clone(), a0.clone()
+    m16 = torch.full((n,), 7.0, device=DEV, dtype=torch.bfloat16) if mirror else None
+    ops.adagrad_step_multi(v2, gr, a2, segs, 0.01, 0.5, m16)
+    torch.cuda.synchronize()
+    assert torch.equal(v1, v2) and torch.equal(a1, a2)
+    assert not torch.equal(v0, v2)
+    if mirror:
+      inside = torch.zeros(n, dtype=torch.bool, device=DEV)
+      for off, end, _, _ in segs:
+        inside[off:end] = True
+      assert torch.equal(m16[inside], v2[inside].to(torch.bfloat16))
+      assert bool((m16[~inside] == 7.0).all())
+
+
+def test_step_leaves_consistent_bf16_mirrors(monkeypatch):
+  """After optimiser steps of a bf16 network the bf16 mirrors the NEXT forward / backward pass reads
+  are the rounded fp32 originals: every variable's mirror (written by c2d_adagrad_step_multi) and
+  every layer's transposed operand (written by c2d_transpose_taps_batched_mirror) — and the same
+  holds on the cast path (C2D_ADAGRAD_MULTI=0 C2D_REFRESH_CAST=1) the fused writes replace."""
+  from cap2det_amd.train.trainer import Trainer
+  from tests import util_model
+  dm, hw, n, nums = 0.5, (64, 64), 9, [9, 6]
+  rng = np.random.default_rng(77)
+  for fused in (True, False):
+    if not fused:
+      monkeypatch.setenv("C2D_ADAGRAD_MULTI", "0")
+      monkeypatch.setenv("C2D_REFRESH_CAST", "1")
+    pipeline = util_model.load_pipeline()
+    trainer = Trainer(pipeline, device=DEV, depth_multiplier=dm, compute_dtype="bf16")
+    model = trainer.model
+    classes = model.label_extractor.classes
+    P32, _ = util_model.oracle_state(6, len(classes), 3, dm)
+    model.load_state_dict(P32)
+    ex = util_model.make_examples(rng, 2, hw[0], hw[1], n, nums, classes)
+    dev = dict(ex)
+    for key in ("image", "proposals"):
+      dev[key] = torch.from_numpy(ex[key]).to(DEV).contiguous()
+    dev["number_of_proposals"] = torch.from_numpy(ex["number_of_proposals"]).to(DEV)
+    before = model.store.values.clone()
+    for _ in range(2):
+      trainer.train_step(dev)
+    torch.cuda.synchronize()
+    eng, store = model.engine, model.store
+    assert not torch.equal(before, store.values)
+    assert torch.equal(store.values_bf16, store.values.to(torch.bfloat16))
+    checked = 0
+    for net in (eng.first, eng.second):
+      for L in net.layers.values():
+        wt16 = L.wt_for(torch.bfloat16)
+        assert torch.equal(wt16, L.wt.to(torch.bfloat16)), L.name
+        w = store.var[L.name + "/weights"]
+        assert torch.equal(L.wt.reshape(L.k * L.k, L.cout, L.cin),
+                           w.reshape(L.k * L.k, L.cin, L.cout).transpose(1, 2)), L.name
+        checked += 1
+    assert checked > 20
