@@ -2280,6 +2280,13 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
   // stride 2: one launch per parity class (py, px) of the input pixel; a pixel of the class
   // only meets the taps with ky = (py + pad_t) mod 2 (+2, ...), i.e. 2.25 taps per pixel on
   // average for a 3x3 kernel instead of 9 mostly-empty ones.
+  // bf16: the four classes are 141-250 workgroups each — less than one per CU, most of a launch ramp
+  // and epilogue: they leave as ONE grouped launch (igemm_bf16.hip: ring_group_begin / _end) when
+  // they pick the same ring instance.  C2D_TUNE=1 C2D_DGRAD_S2_GROUP=0: four launches.
+  static const bool group_off = getenv("C2D_TUNE") && getenv("C2D_DGRAD_S2_GROUP") &&
+                                getenv("C2D_DGRAD_S2_GROUP")[0] == '0';
+  const bool grouped = es == 2 && !query && !ws.ptr && !group_off;
+  if (grouped) ring_group_begin();
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       IgemmArgs b = a;
@@ -2295,9 +2302,16 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
       b.M = n * b.g.rh * b.g.rw;
       b.fpart_row0 = blocks;                        // (fused: each class owns its rows of partials)
       rc = run_igemm(b, (hipStream_t)stream, ws);   // (launches of one stream run in order: the
-      if (rc) return rc;                             //  four classes share the workspace)
+      if (rc) {                                      //  four classes share the workspace)
+        if (grouped) ring_group_end((hipStream_t)stream);
+        return rc;
+      }
       blocks += g_last_m_tiles;
     }
+  if (grouped) {
+    rc = ring_group_end((hipStream_t)stream);
+    if (rc) return rc;
+  }
   if (fb && fb->blocks_out) *fb->blocks_out = blocks;
   return C2D_OK;
 }

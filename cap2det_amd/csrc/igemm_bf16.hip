@@ -53,11 +53,10 @@ constexpr int ring_blocks_per_cu(int lds_bytes) {
 // FUSED: the instance whose epilogue carries the producer layer's BN/ReLU backward (IgemmArgs::fy;
 // input-gradient launches of bf16 networks).  Its own instantiation: the epilogue's column sums and
 // per-column facts must not cost the plain kernels a register.
+// (the body: `bid` of `nbid` blocks of the problem `a` — the launch's own block index, or the index
+//  inside one problem of a grouped launch, igemm_ring_group_kernel below)
 template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED = false>
-__global__ __launch_bounds__(WM * WN * 64,
-                             ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 > 0
-                                 ? ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 : 1)
-void igemm_ring_kernel(IgemmArgs a) {
+__device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bid, const int nbid) {
   constexpr int RB = BKT * ES;                  // bytes per staged row (128 or 64)
   constexpr int CPR = RB / 16;                  // 16-byte chunks per row (8 or 4)
   constexpr int KS = ES == 2 ? BKT / 16 : CPR / 2;   // bf16: MFMA k-steps per stage; fp32: 16-byte
@@ -105,7 +104,7 @@ void igemm_ring_kernel(IgemmArgs a) {
   const bool b_last = !B_TAIL || wave * (1024 / RB) + (B_LOADS - 1) * ROWS_PER_PASS < BN;
 
   int mt, nt;
-  block_tile(a.g, a.n_tiles, blockIdx.x, gridDim.x, &mt, &nt);
+  block_tile(a.g, a.n_tiles, bid, nbid, &mt, &nt);
   const int m0 = mt * BM, n0 = nt * BN;
   const int ntaps = a.g.nky * a.g.nkx;
   const int kslabs = (a.K + BKT - 1) / BKT;
@@ -802,6 +801,36 @@ void igemm_ring_kernel(IgemmArgs a) {
 #endif
 }
 
+#define C2D_RING_BOUNDS                                                                          \
+  __launch_bounds__(WM * WN * 64,                                                                \
+                    ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 > 0 \
+                        ? ring_blocks_per_cu(D * (WM * MT + WN * NT) * 32 * BKT * ES) * (WM * WN) / 4 : 1)
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED = false>
+__global__ C2D_RING_BOUNDS void igemm_ring_kernel(IgemmArgs a) {
+  igemm_ring_body<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Up to four INDEPENDENT problems of one instance in one launch: the parity classes of a stride-2
+// input gradient (conv_gemm.hip conv_dgrad_impl: four launches of 141-250 workgroups — less than one
+// per CU each, 14-27 us apiece, most of it ramp and epilogue — whose workgroups now share the CUs).
+// Block b belongs to problem p with first[p] <= b < first[p + 1] and is its block b - first[p].
+struct IgemmRingGroup {
+  IgemmArgs a[4];
+  int first[5];
+  int num;
+};
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED = false>
+__global__ C2D_RING_BOUNDS void igemm_ring_group_kernel(IgemmRingGroup g) {
+  int p = 0;
+  for (int i = 1; i < g.num; ++i)
+    if ((int)blockIdx.x >= g.first[i]) p = i;
+  p = __builtin_amdgcn_readfirstlane(p);
+  igemm_ring_body<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED>(g.a[p], (int)blockIdx.x - g.first[p],
+                                                                g.first[p + 1] - g.first[p]);
+}
+#undef C2D_RING_BOUNDS
+
 // ---- host side ---------------------------------------------------------------------------------
 // Tuning hooks (read once, only with C2D_TUNE=1): C2D_RING_BK=32|64, C2D_RING_D=2|3 (more in a
 // -DC2D_RING_SWEEP build) force the stage depth / ring depth where an instance exists;
@@ -824,6 +853,41 @@ const RingTune& ring_tune() {
   return t;
 }
 
+// Collector of ring_group_begin() .. ring_group_end(): launches of group-eligible instances are held
+// back (every problem with the launchers of ITS instance) and leave as one grouped launch when they
+// all chose the same instance, one by one otherwise.
+struct RingCollect {
+  bool active;
+  int num;
+  IgemmArgs a[4];
+  int (*single[4])(const IgemmArgs&, hipStream_t);
+  int (*group[4])(const IgemmRingGroup&, hipStream_t);
+};
+thread_local RingCollect g_ring_collect = {false, 0, {}, {}, {}};
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED>
+int ring_launch_single(const IgemmArgs& a, hipStream_t s) {
+  // (spelled as rocprofv3 prints the instance: the FUSED flag included)
+  dispatch_note_ext(PM ? (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, true>"
+                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, false>")
+                       : (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true>"
+                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false>"),
+                    MODE, WM, WN, MT, NT, BKT, D, ES);
+  hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED>),
+                     dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
+  return c2d_launch_status();
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED>
+int ring_launch_group(const IgemmRingGroup& g, hipStream_t s) {
+  dispatch_note_ext(FUSED ? "igemm_ring_group_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true>"
+                          : "igemm_ring_group_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false>",
+                    MODE, WM, WN, MT, NT, BKT, D, ES);
+  hipLaunchKernelGGL((igemm_ring_group_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED>),
+                     dim3(g.first[g.num]), dim3(WM * WN * 64), 0, s, g);
+  return c2d_launch_status();
+}
+
 template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES = 2>
 int launch_one(IgemmArgs a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -838,25 +902,37 @@ int launch_one(IgemmArgs a, hipStream_t s) {
 #ifdef C2D_RING_TRACE
   a.trace = g_ring_trace;
 #endif
+  // the row-major input-gradient instances of the stride-2 layers' tiles can leave in a grouped launch
+  constexpr bool GROUPABLE = MODE == 1 && ES == 2 && !PM && WM == 2 && MT <= 2 &&
+                             ((WN == 4 && MT == 2 && NT == 2) || (WN == 2 && NT == 1));
   if constexpr (MODE == 1 && ES == 2) {
     if (a.fy != nullptr) {      // the producer's BN/ReLU backward rides in the epilogue
-      dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, true>"
-                           : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true>",
-                        MODE, WM, WN, MT, NT, BKT, D, ES);
-      hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES, true>),
-                         dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
-      return c2d_launch_status();
+      if constexpr (GROUPABLE) {
+        RingCollect& c = g_ring_collect;
+        if (c.active && c.num < 4) {
+          c.a[c.num] = a;
+          c.single[c.num] = &ring_launch_single<MODE, WM, WN, MT, NT, PM, BKT, D, ES, true>;
+          c.group[c.num] = &ring_launch_group<MODE, WM, WN, MT, NT, PM, BKT, D, ES, true>;
+          ++c.num;
+          return C2D_OK;
+        }
+      }
+      return ring_launch_single<MODE, WM, WN, MT, NT, PM, BKT, D, ES, true>(a, s);
     }
   } else if (a.fy != nullptr) {
     return C2D_ERR_UNSUPPORTED;   // (fp32 networks fuse in igemm_nt_kernel, conv_gemm.hip)
   }
-  // (spelled as rocprofv3 prints the instance: the FUSED flag included)
-  dispatch_note_ext(PM ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, false>"
-                       : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false>",
-                    MODE, WM, WN, MT, NT, BKT, D, ES);
-  hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES>),
-                     dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
-  return c2d_launch_status();
+  if constexpr (GROUPABLE) {
+    RingCollect& c = g_ring_collect;
+    if (c.active && c.num < 4) {
+      c.a[c.num] = a;
+      c.single[c.num] = &ring_launch_single<MODE, WM, WN, MT, NT, PM, BKT, D, ES, false>;
+      c.group[c.num] = &ring_launch_group<MODE, WM, WN, MT, NT, PM, BKT, D, ES, false>;
+      ++c.num;
+      return C2D_OK;
+    }
+  }
+  return ring_launch_single<MODE, WM, WN, MT, NT, PM, BKT, D, ES, false>(a, s);
 }
 
 // (stage depth, ring depth) of a block tile, measured per GEMM call of the step (tools/
@@ -982,6 +1058,43 @@ int launch_igemm_f32_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bo
 
 namespace {
 }  // namespace
+
+void ring_group_begin() {
+  g_ring_collect.active = true;
+  g_ring_collect.num = 0;
+}
+
+int ring_group_end(hipStream_t s) {
+  RingCollect& c = g_ring_collect;
+  c.active = false;
+  const int num = c.num;
+  c.num = 0;
+  if (num == 0) return C2D_OK;
+  bool same = num > 1;
+  for (int i = 1; i < num; ++i) same = same && c.group[i] == c.group[0];
+  if (!same) {
+    for (int i = 0; i < num; ++i) {
+      const int rc = c.single[i](c.a[i], s);
+      if (rc) return rc;
+    }
+    return C2D_OK;
+  }
+  IgemmRingGroup g;
+  g.num = num;
+  int blocks = 0;
+  for (int i = 0; i < 4; ++i) {
+    g.first[i] = blocks;
+    if (i < num) {
+      g.a[i] = c.a[i];
+      blocks += c.a[i].m_tiles * c.a[i].n_tiles;
+    } else {
+      g.a[i] = c.a[0];
+    }
+  }
+  g.first[4] = blocks;
+  for (int i = num; i < 4; ++i) g.first[i] = blocks;
+  return c.group[0](g, s);
+}
 
 int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
                            hipStream_t s, int* m_tiles_out, bool query) {

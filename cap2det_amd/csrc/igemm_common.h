@@ -402,6 +402,12 @@ void dispatch_note_ext(const char* fmt, int a = 0, int b = 0, int c = 0, int d =
 // Returns C2D_ERR_UNSUPPORTED when no instance exists for the tile (the caller keeps its own).
 int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
                            hipStream_t s, int* m_tiles_out, bool query);
+// Between ring_group_begin() and ring_group_end(s) the calling thread's launch_igemm_bf16_ring calls
+// that pick a groupable instance (row-major bf16 input gradients on the 128x256 / 128x64 / 64x64
+// tiles) are held back; ring_group_end launches them — ONE launch when they all picked the same
+// instance (igemm_ring_group_kernel), one by one otherwise.  At most four independent problems.
+void ring_group_begin();
+int ring_group_end(hipStream_t s);
 // The same ring on fp32 operands (v_mfma_f32_32x32x2_f32); C2D_ERR_UNSUPPORTED unless enabled / an
 // instance exists for the tile.
 int launch_igemm_f32_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,

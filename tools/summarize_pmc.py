@@ -30,6 +30,7 @@ FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
     ("igemm", "igemm_nt_kernel"),
     ("igemm", "igemm_small_kernel"),
     ("igemm", "igemm_ring_kernel"),      # (fp32 instances: the bf16 ones are matched first)
+    ("igemm", "igemm_ring_group_kernel"),
     ("wgrad", "wgrad_tn_kernel"),
     ("wgrad", "wgrad3x3_kernel"),
     ("roi_crop_pool_fwd", "roi_crop_pool_fwd_kernel"),
@@ -41,6 +42,7 @@ FAMILIES = [   # (family key used by bench.py, substring of the kernel name)
     ("bn_relu_bwd", "bn_relu_bwd_kernel"),
     ("pool3x3", "pool3x3_"),
     ("adagrad", "adagrad_kernel"),
+    ("adagrad", "adagrad_multi_kernel"),
 ]
 
 
@@ -56,9 +58,10 @@ DEFAULT_FETCH_FACTOR = 2.0
 def family_of(name):
   # bf16-operand kernels (bench.py --dtype bf16) are separate families: their roofline is the
   # bf16 MFMA peak
-  if "wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16_kernel" in name or "wgrad_reduce_kernel" in name:
+  if ("wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16" in name or "wgrad1x1_bf16_ring" in name or
+      "wgrad_reduce_kernel" in name):
     return "wgrad_bf16"
-  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring_kernel<[^>]*, 2(?:, (?:true|false))?>", name):
+  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 2(?:, (?:true|false))?>", name):
     return "igemm_bf16"
   if re.search(r"igemm_small(_group)?_kernel<\d, 2>", name):
     return "igemm_small_bf16"      # the bf16 step's single-image first stage
