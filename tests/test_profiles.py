@@ -78,3 +78,32 @@ def test_bench_reports_unparsable_summaries(tmp_path, monkeypatch):
   src = open(os.path.join(ROOT, "bench.py")).read()
   assert "pmc_summaries_error" in src
   assert "except Exception:\n        pass" not in src
+
+
+def test_every_gemm_kernel_of_the_committed_profiles_has_a_pmc_family():
+  """tools/summarize_pmc.family_of decides which roofline family a kernel's counters go to; a GEMM
+  kernel it does not know silently drops out of `traffic` / `mfma_busy` (round 5 found the grouped
+  bf16 1x1 filter-gradient kernel unclassified).  Every igemm / wgrad / roi / pool / bn / adagrad
+  kernel name of the newest committed kernel-stats summaries must map to a family, bf16 instances to
+  the bf16 families."""
+  import csv
+  import sys
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  from summarize_pmc import family_of
+  seen = 0
+  for cfg in ("c1", "c2"):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats_%s_serial.csv" % cfg)))
+    assert files, cfg
+    with open(files[-1]) as f:
+      for row in csv.DictReader(f):
+        name = row["Name"]
+        if not re.search(r"igemm|wgrad|roi_crop|roi_bwd|pool3x3|bn_relu_bwd|adagrad", name):
+          continue
+        fam = family_of(name)
+        assert fam, (files[-1], name)
+        seen += 1
+        if re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 2, (?:true|false)>", name):
+          assert fam == "igemm_bf16", (name, fam)
+        if "bf16" in name and "wgrad" in name:
+          assert fam == "wgrad_bf16", (name, fam)
+  assert seen >= 30

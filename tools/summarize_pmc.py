@@ -71,6 +71,10 @@ def family_of(name):
   for fam, sub in FAMILIES:
     if sub in name:
       return fam
+  if "wgrad" in name:       # any other filter-gradient kernel (wgrad3x3_s2_kernel, wgrad_tn_group_kernel, ...)
+    return "wgrad_bf16" if "bf16" in name else "wgrad"
+  if "igemm" in name:       # (igemm_small_group_kernel<*, 4>: the fp32 first stage's grouped launches)
+    return "igemm"
   return None
 
 
