@@ -98,6 +98,33 @@ def test_roi_crop_pool_bwd_workspace_form_is_exact_and_deterministic(ops):
 
 
 
+@pytest.mark.parametrize("hf,wf,d,n", [(32, 32, 576, 500), (13, 9, 32, 70), (63, 84, 64, 120)])
+def test_roi_crop_pool_bwd_halves_equal_the_one_call_form(ops, hf, wf, d, n):
+  """c2d_roi_crop_pool_bwd_prepare + _run (the halves the training step queues on two streams) are
+  bitwise the one-call form, fp32 and bf16 pooled gradients, with rows no box touches (the boxes
+  stay in the upper half of image 0 and image 1 gets none) left at their old value."""
+  rng = np.random.default_rng(17 + n)
+  boxes = _edge_boxes(rng, n)
+  boxes[:, 0] *= 0.45; boxes[:, 2] *= 0.45           # ymin, ymax: upper half only
+  ind = np.zeros(n, np.int32)
+  p = 7
+  arg = rng.integers(0, 4, (n, p, p, d)).astype(np.uint8)
+  dout = rng.standard_normal((n, p, p, d)).astype(np.float32)
+  ws = torch.empty(ops.roi_crop_pool_bwd_workspace_bytes(2, hf, wf, d, n, 14, 2, 2), dtype=torch.uint8,
+                   device=DEV)
+  tb, ti, ta = _t(boxes), _t(ind), _t(arg)
+  for dt in (torch.float32, torch.bfloat16):
+    g = _t(dout).to(dt)
+    want = torch.full((2, hf, wf, d), 0.125, device=DEV)
+    ops.roi_crop_pool_bwd_ws(g, ta, tb, ti, want, 14, 2, 2, ws)
+    got = torch.full((2, hf, wf, d), 0.125, device=DEV)
+    ops.roi_crop_pool_bwd_prepare(tb, ti, 2, hf, wf, d, 14, 2, 2, ws)
+    ops.roi_crop_pool_bwd_run(g, ta, tb, ti, got, 14, 2, 2, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert float((got[0, :hf // 3] - 0.125).abs().max()) > 0 and bool((got[1] == 0.125).all())
+
+
 @pytest.mark.parametrize("kind,hf,wf,d,n", [("one", 32, 32, 64, 1), ("few", 32, 32, 64, 3),
                                             ("band", 20, 17, 48, 40), ("one_image", 16, 16, 32, 50),
                                             ("padded", 12, 12, 32, 9)])
