@@ -345,6 +345,10 @@ def parse_args(argv=None):
   ap.add_argument("--reader-records", type=int, default=64, help="--reader: records per run (cycled)")
   ap.add_argument("--reader-workers", type=int, default=10,
                   help="--reader: map_num_parallel_calls (host decode threads; the shipped configs say 10)")
+  ap.add_argument("--f32x9", action="store_true",
+                  help="SECONDARY measurement (fp32 configs): the second stage's forward / input-gradient "
+                       "GEMMs as nine bf16 partial products on the bf16 matrix pipe (csrc/igemm_x9.hip); "
+                       "measured and NOT the default, profiles/r06_f32x9/README.md")
   ap.add_argument("--dtype", choices=["fp32", "bf16"], default=None,
                   help="override the config's precision: fp32 = exact fp32 everywhere; bf16 = the "
                        "convolution towers behind the stem (first stage, ROI crop output, second stage) "
@@ -695,6 +699,8 @@ def main(argv=None):
                       compute_dtype=args.dtype, allow_missing_pretrained=True)
   finally:
     shutil.rmtree(scratch, ignore_errors=True)
+  if args.f32x9:
+    trainer.model.engine.enable_f32x9()
   classes = trainer.model.label_extractor.classes
   assert len(classes) == spec["classes"]
   # the headline workload, unless --image-hw / --batch / --proposals name a secondary point
@@ -834,7 +840,12 @@ def main(argv=None):
                    "baseline_config": args.config, "pipeline": spec["pipeline"] + ".pbtxt",
                    "images_per_gpu": images_per_gpu, "image_hw": list(image_hw),
                    "proposals": num_proposals, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay" if args.graph else "eager"},
+                   "launch": "hipGraph replay" if args.graph else "eager",
+                   "gemm_method": ("f32x9 (second-stage forward / input-gradient GEMMs: nine bf16 partial "
+                                   "products, fp32 accumulate; filter gradients on the fp32 pipe)"
+                                   if args.f32x9 else
+                                   ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32"
+                                    else "bf16 MFMA (v_mfma_f32_32x32x16_bf16)"))},
         "world_size": world,
         "final_total_loss": total_loss,
     }

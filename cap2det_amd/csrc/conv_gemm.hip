@@ -1927,9 +1927,62 @@ struct SmallCollect {
 };
 static thread_local SmallCollect* g_collect = nullptr;
 
-int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{nullptr, 0}) {
+// f32x9 (igemm_x9.hip): does every weight operand of `a` lie in an arena bound with c2d_f32x9_bind?
+// Fills the plane pointers when so.
+bool x9_resolve(IgemmArgs* a) {
+  if (a->es != 4 || a->N % 4 != 0 || a->K % 16 != 0) return false;
+  long long stride = 0, st = 0;
+  if (a->nseg > 1) {
+    for (int i = 0; i < a->nseg; ++i) {
+      if (a->segK[i] % 16 != 0) return false;
+      a->segBp[i] = x9_planes_of(a->segB[i], (long long)a->N * a->segK[i] * 4, &st);
+      if (!a->segBp[i] || (i && st != stride)) return false;
+      stride = st;
+    }
+    a->Bp = a->segBp[0];
+  } else {
+    const long long bytes = a->mo_n ? a->mo_bbytes : (long long)a->g.kh * a->g.kw * a->N * a->K * 4;
+    a->Bp = x9_planes_of(a->Bt, bytes, &stride);
+    if (!a->Bp) return false;
+  }
+  a->bp_stride = stride;
+  return true;
+}
+
+// f32x9 block tile: 128 rows (four waves of 32 rows: no two waves split the same activation rows) x
+// 32 NT columns.  Pixel-major launches (one pixel of 128 images per block, 4 - 9 taps of work):
+// 128-column tiles (tools/sweep_x9.sh: 64-column tiles re-stream the activations once more for
+// nothing, wider ones leave too few blocks for the heavy-first order to even the CUs out);
+// row-major launches: the NT in 2..5 that pads the output width least, the widest on a tie.
+int x9_launch(IgemmArgs a, bool pm, hipStream_t s) {
+  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  static const int force_nt = (tune && getenv("C2D_X9_NT")) ? atoi(getenv("C2D_X9_NT")) : 0;
+  static const int force_nt_pm = (tune && getenv("C2D_X9_NT_PM")) ? atoi(getenv("C2D_X9_NT_PM")) : 0;
+  int best_nt = a.N > 64 ? 4 : 2;
+  if (!pm) {
+    int best_cols = 1 << 30;
+    for (int nt = 5; nt >= 2; --nt) {
+      const int cols = c2d_ceil_div(a.N, nt * 32) * nt * 32;
+      if (cols < best_cols) { best_cols = cols; best_nt = nt; }
+    }
+  }
+  int wm = 4, wn = 1, mt = 1;
+  const int f = pm ? force_nt_pm : force_nt;
+  if (f >= 2 && f <= 6) best_nt = f;
+  if (f == 22 || f == 24) { wm = 2; wn = 2; mt = 2; best_nt = f - 20; }      // (the 2 x 2 wave forms)
+  if (f == 42) { wm = 2; wn = 4; mt = 2; best_nt = 2; }
+  int mtiles = 0;
+  const int rc = launch_igemm_x9_ring(a, wm, wn, mt, best_nt, pm, s, &mtiles, g_tile_query);
+  g_last_m_tiles = mtiles;
+  return rc;
+}
+
+int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws_in = IgemmWs{nullptr, 0}) {
   IgemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) { g_last_m_tiles = 0; return g_collect ? C2D_ERR_UNSUPPORTED : C2D_OK; }
+  // fp32 operands whose weights have bf16 planes bound: nine partial products on the bf16 pipe
+  const bool x9 = !g_collect && x9_resolve(&a);
+  const IgemmWs ws = x9 ? IgemmWs{nullptr, 0} : ws_in;
   // Pixel-major rows for multi-tap convolutions over small per-ROI maps (see decompose<true>).
   const int hw = a.g.rh * a.g.rw;
   // Tuning hooks for tools/sweep_igemm.py (read only when C2D_TUNE is set at load time):
@@ -2022,6 +2075,8 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
       return launch_igemm_bf16<1, 2, 4, 2, 2, true>(a, s);
     }
     if (force == 7 && a.es == 2) return launch_igemm_bf16_wide<true>(a, s);
+    // (x9: one-pixel blocks only — its stage loop has no per-tile tap test)
+    if (x9 && a.g.pm == 7) return x9_launch(a, true, s);
     if (force != 3) return launch_igemm<2, 2, 2, 1, 32, true>(a, s, ws);
     return launch_igemm<2, 2, 2, 2, 32, true>(a, s, ws);
   }
@@ -2081,6 +2136,8 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws = IgemmWs{
     return launch_igemm_bf16<1, 2, 4, 2, 2, false>(a, s);
   } else if (force == 7 && a.es == 2) {
     return launch_igemm_bf16_wide<false>(a, s);
+  } else if (x9) {
+    return x9_launch(a, false, s);
   } else if (narrow) {
     // N = 192, 320, 576, 160 ...: 128x64 tiles (waves 2x2, each 64x32) waste at most half a
     // 64-wide tile instead of half a 128-wide one, and the smaller accumulator file leaves room

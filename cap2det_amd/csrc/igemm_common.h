@@ -176,6 +176,9 @@ struct IgemmArgs {
   const float* A; int lda; int a_off;
   long long a_rows;         // rows of the A operand's buffer (for the buffer-load range check)
   const float* Bt;          // [taps][N][K]
+  // f32x9 launches (igemm_x9.hip): the weights as three bf16 planes — plane p of the element at Bt[i]
+  // is ((const bf16*)Bp)[i] bp_stride BYTES further per plane; segBp[s] likewise for segB[s]
+  const void* Bp; long long bp_stride; const void* segBp[4];
   float* C; int ldc; int c_off;
   const float* scale;       // [N] or null (=1)
   const float* shift;       // [N] or null (=0)
@@ -402,6 +405,15 @@ void dispatch_note_ext(const char* fmt, int a = 0, int b = 0, int c = 0, int d =
 // Returns C2D_ERR_UNSUPPORTED when no instance exists for the tile (the caller keeps its own).
 int launch_igemm_bf16_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm,
                            hipStream_t s, int* m_tiles_out, bool query);
+// fp32 operands as nine bf16 partial products (igemm_x9.hip): as launch_igemm_bf16_ring for the 128 x
+// (64 NT) tiles (wm = wn = mt = 2, nt = 1..4) and 64 x 64; a.Bp / a.bp_stride / a.segBp filled by the
+// caller from x9_planes_of (null: the weight operand lies in no bound arena).
+int launch_igemm_x9_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm, hipStream_t s,
+                         int* m_tiles_out, bool query);
+const void* x9_planes_of(const void* w, long long bytes, long long* stride_bytes);
+#ifdef C2D_RING_TRACE
+unsigned long long* ring_trace_buffer();     // diagnostic build: the buffer c2d_debug_set_ring_trace set
+#endif
 // Between ring_group_begin() and ring_group_end(s) the calling thread's launch_igemm_bf16_ring calls
 // that pick a groupable instance (row-major bf16 input gradients on the 128x256 / 128x64 / 64x64
 // tiles) are held back; ring_group_end launches them — ONE launch when they all picked the same

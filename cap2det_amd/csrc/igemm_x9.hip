@@ -1,0 +1,232 @@
+// fp32 convolutions on the bf16 matrix pipe: every fp32 operand value is the EXACT sum of three
+// bf16 terms (truncation split, 8 + 8 + 8 significant bits), every product of two terms is exact in
+// fp32, so nine v_mfma_f32_32x32x16_bf16 per 16 k accumulate the fp32 product in fp32 at 288
+// matrix-pipe cycles instead of the 512 of eight v_mfma_f32_32x32x2_f32 ("f32x9"; slim.conv2d of
+// models/utils.py:165-167 and its input gradient at the reference's own precision).
+//
+// Round 5 measured the idea on the register-staged fp32 skeleton, whose loads the shorter MFMA
+// phase no longer covered (profiles/r05_experiments/README.md).  Here it runs on the DMA ring of
+// igemm_ring.h:
+//   * WEIGHTS are split once per optimiser step into three bf16 planes in HBM (c2d_split3_bf16,
+//     this file) and reach LDS by buffer_load ... lds like any bf16 operand;
+//   * ACTIVATIONS (and activation gradients) stay fp32 in HBM and in LDS — no producer kernel
+//     changes, 4 instead of 6 bytes per element — and are split by the lane that reads a fragment:
+//     44 single-issue vector instructions per 8-element fragment, issued in the gaps of the
+//     9 x NT MFMAs the fragment feeds (igemm_ring.h: split3_frag).
+// The fp32 entry points of conv_gemm.hip take this path for a weight operand that lies inside an
+// arena bound with c2d_f32x9_bind (the one piece of process state behind the C-ABI: a table of at
+// most 64 (fp32 arena, plane arena) pairs, written before the step loop, read-only inside it).
+#include "igemm_ring.h"
+#include <mutex>
+
+namespace c2d_ig {
+namespace {
+
+// ---- the split --------------------------------------------------------------------------------
+// One thread per four elements; planes[p][i] = plane p of src[i], plane p at planes + p * stride
+// elements.  Non-finite values: hi carries them, mid / lo are zero (Inf x w stays Inf x w).
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src,
+                                                     unsigned short* __restrict__ planes,
+                                                     long long stride, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
+  unsigned short h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned u = __float_as_uint(v[e]);
+    const float r1 = v[e] - __uint_as_float(u & 0xffff0000u);
+    const unsigned u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+    const bool finite = (u & 0x7f800000u) != 0x7f800000u;
+    h[e] = (unsigned short)(u >> 16);
+    m[e] = finite ? (unsigned short)(u1 >> 16) : (unsigned short)0;
+    l[e] = finite ? (unsigned short)(__float_as_uint(r2) >> 16) : (unsigned short)0;
+  }
+  typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<u16x4*>(planes + i * 4) = u16x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<u16x4*>(planes + stride + i * 4) = u16x4{m[0], m[1], m[2], m[3]};
+  *reinterpret_cast<u16x4*>(planes + 2 * stride + i * 4) = u16x4{l[0], l[1], l[2], l[3]};
+}
+
+// ---- the bindings -----------------------------------------------------------------------------
+struct X9Arena {
+  const char* base;          // fp32 arena
+  long long bytes;
+  const char* planes;        // plane 0 of element 0
+  long long stride_bytes;    // plane p + 1 sits this many bytes behind plane p
+};
+constexpr int X9_MAX_ARENAS = 64;
+X9Arena g_arena[X9_MAX_ARENAS];
+int g_narena = 0;
+int g_enabled = 1;
+std::mutex g_arena_mu;
+
+// ---- launchers ----------------------------------------------------------------------------------
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, bool FUSED>
+int x9_launch(const IgemmArgs& a, hipStream_t s) {
+  dispatch_note_ext(PM ? (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, 4, true, 3>"
+                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, 4, false, 3>")
+                       : (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, 4, true, 3>"
+                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, 4, false, 3>"),
+                    MODE, WM, WN, MT, NT, BKT, D);
+  hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, 4, FUSED, 3>),
+                     dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
+  return c2d_launch_status();
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D>
+int x9_one(IgemmArgs a, hipStream_t s) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  a.m_tiles = c2d_ceil_div(a.M, BM);
+  a.n_tiles = c2d_ceil_div(a.N, BN);
+  if (a.nseg > 1) {
+    a.total_slabs = 0;
+    for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], BKT);
+  }
+  static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
+  a.dbg = dbg_env;
+#ifdef C2D_RING_TRACE
+  a.trace = ring_trace_buffer();
+#endif
+  if constexpr (MODE == 1) {
+    if (a.fy != nullptr) return x9_launch<MODE, WM, WN, MT, NT, PM, BKT, D, true>(a, s);
+  } else if (a.fy != nullptr) {
+    return C2D_ERR_UNSUPPORTED;
+  }
+  return x9_launch<MODE, WM, WN, MT, NT, PM, BKT, D, false>(a, s);
+}
+
+// Ring geometry per tile (tools/sweep_x9.sh, tools/x9_probe.py; a -DC2D_X9_SWEEP build holds the other
+// combinations behind C2D_TUNE=1 C2D_X9_BK / C2D_X9_D): 32-deep stages (128-byte activation rows,
+// 64-byte weight-plane rows) in two buffers up to 128 columns — 80 KiB for a 128 x 128 tile, two
+// workgroups of four waves per CU; 16-deep stages in two buffers beyond.  Every combination measured
+// within 10 % of every other: what bounds these kernels is the clock the chip holds under bf16 MFMAs
+// (1.70 - 1.84 GHz against 2.39 GHz under the fp32 MFMA kernel, tools/x9_clock.py), not the ring.
+struct X9Tune { int bk, d; };
+const X9Tune& x9_tune() {
+  static const X9Tune t = [] {
+    X9Tune r = {0, 0};
+    if (getenv("C2D_TUNE")) {
+      if (const char* e = getenv("C2D_X9_BK")) r.bk = atoi(e);
+      if (const char* e = getenv("C2D_X9_D")) r.d = atoi(e);
+    }
+    return r;
+  }();
+  return t;
+}
+
+template <int MODE, int WM, int WN, int MT, int NT, bool PM>
+int x9_tile(const IgemmArgs& a, hipStream_t s) {
+  constexpr int ROWB = (WM * MT * 4 + WN * NT * 6) * 32;      // bytes per unit of stage depth
+  constexpr bool DEEP = WN * NT <= 4 && 2 * ROWB * 32 <= 160 * 1024;
+#ifdef C2D_X9_SWEEP
+  const X9Tune& t = x9_tune();
+  const int bk = t.bk ? t.bk : (DEEP ? 32 : 16), d = t.d ? t.d : 2;
+  if (bk == 16 && d == 2) return x9_one<MODE, WM, WN, MT, NT, PM, 16, 2>(a, s);
+  if constexpr (3 * ROWB * 16 <= 160 * 1024)
+    if (bk == 16 && d == 3) return x9_one<MODE, WM, WN, MT, NT, PM, 16, 3>(a, s);
+  if constexpr (4 * ROWB * 16 <= 160 * 1024)
+    if (bk == 16 && d == 4) return x9_one<MODE, WM, WN, MT, NT, PM, 16, 4>(a, s);
+  if constexpr (2 * ROWB * 32 <= 160 * 1024)
+    if (bk == 32 && d == 2) return x9_one<MODE, WM, WN, MT, NT, PM, 32, 2>(a, s);
+#endif
+  if constexpr (DEEP) return x9_one<MODE, WM, WN, MT, NT, PM, 32, 2>(a, s);
+  else return x9_one<MODE, WM, WN, MT, NT, PM, 16, 2>(a, s);
+}
+
+template <int WM, int WN, int MT, int NT>
+int x9_shape(const IgemmArgs& a, bool pm, hipStream_t s) {
+  if (a.g.mode == 0)
+    return pm ? x9_tile<0, WM, WN, MT, NT, true>(a, s) : x9_tile<0, WM, WN, MT, NT, false>(a, s);
+  return pm ? x9_tile<1, WM, WN, MT, NT, true>(a, s) : x9_tile<1, WM, WN, MT, NT, false>(a, s);
+}
+
+}  // namespace
+
+// Plane pointer of the fp32 weight operand [w, w + bytes): null when no bound arena holds it.
+const void* x9_planes_of(const void* w, long long bytes, long long* stride_bytes) {
+  if (!g_enabled) return nullptr;
+  const char* p = (const char*)w;
+  for (int i = 0; i < g_narena; ++i) {
+    const X9Arena& r = g_arena[i];
+    if (p >= r.base && p + bytes <= r.base + r.bytes) {
+      *stride_bytes = r.stride_bytes;
+      return r.planes + (p - r.base) / 2;
+    }
+  }
+  return nullptr;
+}
+
+int launch_igemm_x9_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, bool pm, hipStream_t s,
+                         int* m_tiles_out, bool query) {
+  const int key = ((wm * 10 + wn) * 10 + mt) * 10 + nt;
+  switch (key) {
+    case 4112: case 4113: case 4114: case 4115: case 4116: case 2222: case 2224: case 2422:
+      break;
+    default:
+      return C2D_ERR_UNSUPPORTED;
+  }
+  if (m_tiles_out) *m_tiles_out = c2d_ceil_div(a.M, wm * mt * 32);
+  if (query) return C2D_OK;
+  switch (key) {
+    // four waves of 32 rows x every column of the tile: a lane splits its activation fragment once
+    // for 9 x NT MFMAs and no two waves split the same rows
+    case 4112: return x9_shape<4, 1, 1, 2>(a, pm, s);      // 128 x 64
+    case 4113: return x9_shape<4, 1, 1, 3>(a, pm, s);      // 128 x 96
+    case 4114: return x9_shape<4, 1, 1, 4>(a, pm, s);      // 128 x 128
+    case 4115: return x9_shape<4, 1, 1, 5>(a, pm, s);      // 128 x 160
+    case 4116: return x9_shape<4, 1, 1, 6>(a, pm, s);      // 128 x 192
+    case 2222: return x9_shape<2, 2, 2, 2>(a, pm, s);      // 128 x 128, waves 2 x 2
+    case 2422: return x9_shape<2, 4, 2, 2>(a, pm, s);      // 128 x 256, eight waves 2 x 4
+    default: return x9_shape<2, 2, 2, 4>(a, pm, s);        // 128 x 256, waves 2 x 2
+  }
+}
+
+}  // namespace c2d_ig
+
+using namespace c2d_ig;
+
+extern "C" int c2d_split3_bf16(const float* src, void* planes, long long plane_stride, long long n,
+                               void* stream) {
+  C2D_CHECK_ARG(src && planes && n > 0 && n % 4 == 0 && plane_stride >= n && plane_stride % 4 == 0);
+  C2D_CHECK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)planes & 7) == 0);
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, (unsigned short*)planes, plane_stride, n4);
+  return c2d_launch_status();
+}
+
+extern "C" int c2d_f32x9_bind(const float* arena, long long numel, const void* planes,
+                              long long plane_stride) {
+  C2D_CHECK_ARG(arena && planes && numel > 0 && plane_stride >= numel);
+  C2D_CHECK_ARG(((uintptr_t)arena & 15) == 0 && ((uintptr_t)planes & 15) == 0 && plane_stride % 8 == 0);
+  // (the ring reaches plane 2 through a 32-bit scalar offset of a descriptor over all three planes)
+  C2D_CHECK_ARG(plane_stride * 2 * 3 < (long long)OOB_OFFSET);
+  std::lock_guard<std::mutex> lock(g_arena_mu);
+  int slot = g_narena;
+  for (int i = 0; i < g_narena; ++i)
+    if (g_arena[i].base == (const char*)arena) slot = i;
+  if (slot == X9_MAX_ARENAS) return C2D_ERR_WORKSPACE;
+  g_arena[slot] = X9Arena{(const char*)arena, numel * 4, (const char*)planes, plane_stride * 2};
+  if (slot == g_narena) ++g_narena;
+  return C2D_OK;
+}
+
+extern "C" int c2d_f32x9_unbind(const float* arena) {
+  std::lock_guard<std::mutex> lock(g_arena_mu);
+  for (int i = 0; i < g_narena; ++i) {
+    if (arena == nullptr || g_arena[i].base == (const char*)arena) {
+      g_arena[i] = g_arena[g_narena - 1];
+      --g_narena;
+      --i;
+    }
+  }
+  return C2D_OK;
+}
+
+extern "C" int c2d_f32x9_enable(int on) {
+  const int was = g_enabled;
+  g_enabled = on != 0;
+  return was;
+}

@@ -780,3 +780,38 @@ def wgrad_reduce_descriptors(records, device):
 def wgrad_reduce_batched(desc, num, total_chunks, workspace, grads):
   _lib.call("c2d_wgrad_reduce_batched", _p(desc), num, total_chunks, _p(workspace), _p(grads),
             _stream())
+
+
+# -- f32x9: fp32 convolutions as nine bf16 partial products (csrc/igemm_x9.hip) -------------------
+
+def split3_bf16(src, planes):
+  """planes [3, >= src.numel()] bf16 <- the truncation split of the flat fp32 tensor `src`."""
+  assert src.dtype == torch.float32 and planes.dtype == torch.bfloat16 and planes.dim() == 2
+  assert planes.shape[0] == 3 and planes.shape[1] >= src.numel()
+  _lib.call("c2d_split3_bf16", _p(src), _p(planes), planes.shape[1], src.numel(), _stream())
+  return planes
+
+
+def f32x9_bind(arena, planes):
+  """GEMM calls whose fp32 weight operand lies inside the flat tensor `arena` run as nine bf16
+  partial products on the planes [3, n] (kept current by the caller: split3_bf16)."""
+  assert arena.dtype == torch.float32 and planes.dtype == torch.bfloat16 and planes.shape[0] == 3
+  _lib.call("c2d_f32x9_bind", _p(arena), arena.numel(), _p(planes), planes.shape[1])
+
+
+def f32x9_unbind(arena=None):
+  _lib.call("c2d_f32x9_unbind", _p(arena))
+
+
+def f32x9_enable(on):
+  """Returns the previous setting."""
+  return bool(_lib.load().c2d_f32x9_enable(1 if on else 0))
+
+
+def x9_planes(t):
+  """A fresh plane arena for the flat fp32 tensor t (row length padded to 8 elements), bound."""
+  n = -(-t.numel() // 8) * 8
+  planes = torch.zeros(3, n, device=t.device, dtype=torch.bfloat16)
+  split3_bf16(t.view(-1), planes)
+  f32x9_bind(t.view(-1), planes)
+  return planes

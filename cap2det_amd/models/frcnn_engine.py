@@ -1346,6 +1346,33 @@ class FrcnnEngine(object):
         ops.cast_bf16(self.store.values, self.store.values_bf16)
       if not fused_mirror:
         ops.cast_bf16(self.stats.der_flat, self.stats.der_bf16)
+    if getattr(self, "_x9", None) is not None:
+      self._x9_split()
+
+  def enable_f32x9(self, on=True):
+    """Opt-in (bench.py --f32x9; measured, not the default: profiles/r06_f32x9/README.md): the fp32
+    second stage's forward / input-gradient GEMMs as nine bf16 partial products.  Binds bf16 plane
+    arenas to the variable store and to the derived operands (c2d_f32x9_bind) and keeps them
+    current in refresh()."""
+    if self.act_dtype != torch.float32:
+      raise ValueError("f32x9 is a form of the fp32 network")
+    if not on:
+      if getattr(self, "_x9", None) is not None:
+        ops.f32x9_unbind(self.store.values)
+        ops.f32x9_unbind(self.stats.der_flat)
+      self._x9 = None
+      return
+    pv = torch.zeros(3, -(-self.store.values.numel() // 8) * 8, device=self.device, dtype=torch.bfloat16)
+    pd = torch.zeros(3, -(-self.stats.der_flat.numel() // 8) * 8, device=self.device, dtype=torch.bfloat16)
+    ops.f32x9_bind(self.store.values, pv)
+    ops.f32x9_bind(self.stats.der_flat, pd)
+    self._x9 = (pv, pd)
+    self._x9_split()
+
+  def _x9_split(self):
+    pv, pd = self._x9
+    ops.split3_bf16(self.store.values, pv)
+    ops.split3_bf16(self.stats.der_flat, pd)
 
   def _refresh_stem(self):
     """Folds depthwise(7x7, x8) o pointwise(1x1) into one 7x7 kernel over the 4-channel padded

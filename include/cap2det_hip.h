@@ -33,9 +33,9 @@ extern "C" {
 #define C2D_ERR_DATA (-5)        /* malformed input data (record framing, protobuf, JPEG stream) */
 
 /* ABI version, bumped whenever an entry point is added or a signature changes (round 1: 100 with
- * 28 entry points; round 4: 400; round 5: 500).  c2d_version() returns the value the library was built with:
+ * 28 entry points; round 4: 400; round 5: 500; round 6: 600).  c2d_version() returns the value the library was built with:
  * a host side compiled against another header must refuse to run (cap2det_amd/_lib.py does). */
-#define C2D_ABI_VERSION 500
+#define C2D_ABI_VERSION 600
 int c2d_version(void);
 /* Human readable message for a C2D_ERR_* code (static storage). */
 const char* c2d_error_string(int code);
@@ -211,6 +211,42 @@ int c2d_conv_wgrad(const float* x, int ldx, int xoff, const float* dc, int ldc, 
 
 /* wt[t][j][i] = w[t][i][j] for t < taps (HWIO <-> per-tap transposed weights). */
 int c2d_transpose_taps(const float* w, float* wt, int taps, int rows, int cols, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * f32x9: the fp32 convolutions on the bf16 matrix pipe  (same reference ops as above — slim.conv2d
+ * of models/utils.py:165-167 and its gradients, at the reference's own fp32 precision)
+ *
+ * Every fp32 value is the exact sum of three bf16 terms (truncation split: 8 + 8 + 8 significant
+ * bits), every product of two terms is exact in fp32; nine v_mfma_f32_32x32x16_bf16 per 16 k
+ * accumulate the fp32 product in fp32 at 288 instead of 512 matrix-pipe cycles.  The WEIGHT
+ * operand is split once per optimiser step into three bf16 planes (c2d_split3_bf16); the
+ * activation operand stays fp32 and is split in registers by the kernel.
+ *
+ * State: c2d_f32x9_bind registers (fp32 arena, plane arena) pairs — at most 64, the one piece of
+ * process-wide state behind this header.  c2d_conv_fwd / c2d_conv1x1_fwd_multi / c2d_conv_dgrad* /
+ * c2d_conv1x1_dgrad_multi* calls whose weight operand lies inside a bound arena (and whose GEMM
+ * has at least 256 tiles of 128 x 128) take the f32x9 kernels; every other call is unchanged.
+ * The caller keeps the planes current (c2d_split3_bf16 after every update of the arena); bind /
+ * unbind / enable are not to be called while GEMM calls are in flight on other threads.
+ * ------------------------------------------------------------------------------------- */
+
+/* planes[p * plane_stride + i] (bf16, p = 0 hi, 1 mid, 2 lo) = plane p of src[i], i < n:
+ * hi = the top 16 bits of src[i], mid = the top 16 bits of src[i] - hi, lo = src[i] - hi - mid.
+ * hi + mid + lo == src[i] exactly for |src[i]| >= 2^-110 (below: to within bf16's subnormal
+ * spacing 2^-133); Inf / NaN: hi carries it, mid = lo = 0.  n and plane_stride multiples of 4,
+ * src 16-byte and planes 8-byte aligned. */
+int c2d_split3_bf16(const float* src, void* planes, long long plane_stride, long long n,
+                    void* stream);
+/* Binds the plane arena `planes` (3 x plane_stride bf16, plane_stride >= numel, a multiple of 8,
+ * 6 * plane_stride < 2^31) to the fp32 arena [arena, arena + numel): element i of the arena has its
+ * planes at planes[p * plane_stride + i].  Re-binding an arena replaces its entry.
+ * C2D_ERR_WORKSPACE: all 64 slots taken. */
+int c2d_f32x9_bind(const float* arena, long long numel, const void* planes, long long plane_stride);
+/* Removes the binding of `arena` (NULL: all bindings). */
+int c2d_f32x9_unbind(const float* arena);
+/* on = 0: bound arenas are ignored (every call takes the fp32-MFMA kernels); returns the previous
+ * setting (> 0: on).  For A/B measurements and tests. */
+int c2d_f32x9_enable(int on);
 
 /* Batched forms for the per-step refresh of every trainable layer in ONE launch each.  `desc`
  * is a DEVICE array of `num` records sorted by their begin field:

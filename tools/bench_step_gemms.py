@@ -4,7 +4,9 @@ convolutions, their input gradients (four parity launches for stride 2) and the 
 block-entry input gradients — each timed ALONE (20 back-to-back launches), with the kernel
 instance it dispatched.  Prints per call and per-step totals.
 
-  python tools/bench_step_gemms.py [bf16|fp32] [fwd|dgrad|wgrad|all]
+  python tools/bench_step_gemms.py [bf16|fp32|x9] [fwd|dgrad|wgrad|all]
+
+x9: fp32 operands, the weights bound to bf16 planes (c2d_f32x9_bind): the f32x9 kernels.
 
 Tuning hooks (C2D_TUNE=1 ...) select variants; tools/sweep_step_gemms.sh runs them side by side."""
 import os
@@ -16,7 +18,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cap2det_amd import hip_ops as ops  # noqa: E402
 
 dev = "cuda:0"
-DT = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] == "fp32") else torch.bfloat16
+X9 = len(sys.argv) > 1 and sys.argv[1] == "x9"
+DT = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] in ("fp32", "x9")) else torch.bfloat16
+_planes = []
+
+
+def bind(t):
+  if X9:
+    _planes.append(ops.x9_planes(t))
+  return t
 WHAT = sys.argv[2] if len(sys.argv) > 2 else "all"
 PEAK = 157.3 if DT == torch.float32 else 2500.0
 ITERS = int(os.environ.get("C2D_BENCH_ITERS", "20"))
@@ -69,7 +79,8 @@ def add_conv(label, hw, cin, cout, k, st):
   fl = 2.0 * n * oh * oh * cin * cout * k * k
   x = rnd(n * hw * hw, cin)
   w = (torch.randn(k * k, cin, cout, device=dev) / (k * k * cin) ** 0.5).to(DT)
-  wt = w.permute(0, 2, 1).contiguous()
+  wt = bind(w.permute(0, 2, 1).contiguous())
+  bind(w)
   y = torch.empty(n * oh * oh, cout, device=dev, dtype=DT)
   dy = rnd(n * oh * oh, cout)
   dx = torch.empty_like(x)
@@ -87,16 +98,19 @@ def add_conv(label, hw, cin, cout, k, st):
 def add_entry(label, hw, cin, couts, accumulate=True):
   rows = n * hw * hw
   x = rnd(rows, cin)
-  flat = (torch.randn(sum(couts) * cin, device=dev) / cin ** 0.5).to(DT)
+  flat = bind((torch.randn(sum(couts) * cin, device=dev) / cin ** 0.5).to(DT))
   outs, off = [], 0
   dcs, ws = [], []
+  wflat = bind((torch.randn(sum(couts) * cin, device=dev) / cin ** 0.5).to(DT))   # (one arena, as the engine's)
+  woff = 0
   for c in couts:
     wt = flat[off:off + c * cin].view(1, c, cin)
     off += c * cin
     outs.append((wt, torch.ones(c, device=dev), torch.zeros(c, device=dev),
                  torch.empty(rows, c, device=dev, dtype=DT), c, 0, c, True))
     dcs.append(rnd(rows, c))
-    ws.append((torch.randn(cin, c, device=dev) / c ** 0.5).to(DT))
+    ws.append(wflat[woff:woff + cin * c].view(cin, c))
+    woff += cin * c
   arr = ops.conv_outs(outs)
   fl = 2.0 * rows * cin * sum(couts)
   calls.append(("fwd", label + " entry x%d" % len(couts), fl,
