@@ -328,8 +328,9 @@ def parse_args(argv=None):
                        "headline keeps its inputs resident in HBM)")
   ap.add_argument("--per-call", action="store_true",
                   help="also print one line per timed conv / ROI-crop call (stderr)")
-  ap.add_argument("--graph", action="store_true", help="hipGraph replay of the step on one stream (measured, profiles/r03_bench_c{1,2}_graph.json: "
-                       "12.52 vs 11.80 ms eager for c1, 3.77 vs 3.42 for c2: eager with its side streams wins)")
+  ap.add_argument("--no-plan", action="store_true",
+                  help="A/B: queue every step from Python (~140 ctypes calls) instead of replaying the "
+                       "recorded step plan (cap2det_amd/step_plan.py, csrc/plan.hip)")
   ap.add_argument("--image-hw", type=int, nargs=2, default=None, metavar=("H", "W"),
                   help="SECONDARY operating point (never the headline metric): image size, e.g. the "
                        "reference's keep-aspect 1000-px training images (--image-hw 1000 1333)")
@@ -552,7 +553,7 @@ def reader_main(args):
   try:
     pipeline = synthetic.baseline_pipeline(args.config, scratch)
     trainer = Trainer(pipeline, device=device, seed=1234, compute_dtype=args.dtype,
-                      allow_missing_pretrained=True)
+                      allow_missing_pretrained=True, use_plan=not args.no_plan)
     classes = trainer.model.label_extractor.classes
     rng = np.random.default_rng(77)
     t_w = time.perf_counter()
@@ -581,6 +582,9 @@ def reader_main(args):
       if step == args.warmup:
         torch.cuda.synchronize()
         clock["t0"] = time.perf_counter()
+
+    if args.warmup == 0:             # (no warm-up step to start the clock behind)
+      clock["t0"] = time.perf_counter()
 
     # (a) reader-fed: ONE Trainer.train call; the clock starts behind the warm-up steps
     losses = trainer.train(input_fn(), max_steps=total, log=log)
@@ -625,6 +629,7 @@ def reader_main(args):
       "host_ms_per_step": {"waiting_for_input": 1000.0 * input_wait / total,
                            "queueing_the_step": 1000.0 * enqueue / total},
       "reader_over_resident": resident / fed,
+      "steps_replayed_from_a_plan": trainer.plan_replays,
       "final_total_loss": fed_loss,
   }
   print(json.dumps(result))
@@ -695,7 +700,7 @@ def main(argv=None):
   scratch = tempfile.mkdtemp(prefix="c2d_bench_")      # synthetic GloVe / classifier files (c3, c4)
   try:
     pipeline = synthetic.baseline_pipeline(args.config, scratch)
-    trainer = Trainer(pipeline, device=device, seed=1234, use_graph=args.graph,
+    trainer = Trainer(pipeline, device=device, seed=1234, use_plan=not args.no_plan,
                       compute_dtype=args.dtype, allow_missing_pretrained=True)
   finally:
     shutil.rmtree(scratch, ignore_errors=True)
@@ -730,6 +735,7 @@ def main(argv=None):
   # p10 / p50 / p90 spread (SURVEY.md §8d "timing method")
   second = trainer.model.engine.second
   marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+  replays_before = trainer.plan_replays
   t0 = time.perf_counter()
   marks[0].record()
   host = None
@@ -758,7 +764,7 @@ def main(argv=None):
       # measures that kernel alone (in the other steps the filter gradients overlap the
       # input-gradient GEMMs on a side stream)
       timer.enabled = True
-      trainer.use_graph = False
+      trainer.use_plan = False
       side, second.side = second.side, None
       alt, second.alt = second.alt, None
       first_net = trainer.model.engine.first
@@ -777,7 +783,7 @@ def main(argv=None):
       losses = trainer.train_step(batch, dropout_seed=args.warmup + i, prefetch=nxt)
     if instrument:
       timer.enabled = False
-      trainer.use_graph = args.graph
+      trainer.use_plan = not args.no_plan
       second.side = side
       second.alt = alt
       first_net.alt = alt1
@@ -790,6 +796,18 @@ def main(argv=None):
                     for i in range(args.steps - (0 if args.no_kernel_timing else 1)))
   timer.enabled = False
   total_loss = float(losses["total_loss"].item())
+  # Host time to ISSUE one step, outside the timed region: with the GPU idle at the start of every
+  # step nothing blocks on a full queue, so this is the host's own cost per step (a Python-driven
+  # step: ~140 ctypes calls; a planned step: one c2d_plan_replay call) — `host_enqueue_ms_per_step`
+  # below is the wall time of the timed loop's queueing, which in a GPU-bound run is the GPU's pace.
+  issue = []
+  if host is None:
+    for i in range(14):
+      t_i = time.perf_counter()
+      trainer.train_step(batch, dropout_seed=args.warmup + args.steps + i, prefetch=batch)
+      issue.append(time.perf_counter() - t_i)
+      torch.cuda.synchronize()
+    issue = sorted(issue[4:])
   ranks_counted = None
   if grouped:
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -819,6 +837,7 @@ def main(argv=None):
         # time the host needed to QUEUE the timed steps (no synchronisation inside): well below
         # ms_per_step = the GPU is the bottleneck, equal to it = the step is launch-bound
         "host_enqueue_ms_per_step": 1000.0 * host_enqueue / args.steps,
+        "host_issue_ms_per_step": 1000.0 * issue[len(issue) // 2] if issue else None,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -840,7 +859,10 @@ def main(argv=None):
                    "baseline_config": args.config, "pipeline": spec["pipeline"] + ".pbtxt",
                    "images_per_gpu": images_per_gpu, "image_hw": list(image_hw),
                    "proposals": num_proposals, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay" if args.graph else "eager",
+                   "launch": ("step plan replay: %d of the %d timed steps issued by one c2d_plan_replay call "
+                              "each, the others (first / last two) queued from Python"
+                              % (trainer.plan_replays - replays_before, args.steps)
+                              if trainer.plan_replays > replays_before else "eager (every call queued from Python)"),
                    "gemm_method": ("f32x9 (second-stage forward / input-gradient GEMMs: nine bf16 partial "
                                    "products, fp32 accumulate; filter gradients on the fp32 pipe)"
                                    if args.f32x9 else

@@ -93,6 +93,22 @@ def check(code, what):
     raise Cap2DetHipError("%s failed: %s (%d)" % (what, msg, code))
 
 
+# The step-plan recorder (cap2det_amd/step_plan.py) while a step is being recorded, else None: every
+# call below is then also appended to the plan (after it ran: a recorded step is a real step).
+recorder = None
+
+
 def call(name, *args):
   """Calls C-ABI function `name`; raises Cap2DetHipError on a non-zero return."""
   check(getattr(load(), name)(*args), name)
+  if recorder is not None:
+    recorder.add_call(name, args)
+
+
+def call_sym(name, *args):
+  """`call` for the few entry points that take per-step scalars (dropout key, learning rate): an
+  argument may be a step_plan.Sym — its value now, its binding slot in a recorded plan."""
+  check(getattr(load(), name)(*[getattr(a, "value", a) if a.__class__.__name__ == "Sym" else a
+                                for a in args]), name)
+  if recorder is not None:
+    recorder.add_call(name, args)

@@ -442,6 +442,11 @@ def cast_bf16(src, dst):
   _lib.call("c2d_cast_bf16", _p(src), _p(dst), src.numel(), _stream())
 
 
+def copy_bytes(src, dst):
+  assert src.numel() * src.element_size() == dst.numel() * dst.element_size()
+  _lib.call("c2d_copy_bytes", _p(src), _p(dst), src.numel() * src.element_size(), _stream())
+
+
 def cast_f32(src, dst):
   assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src.numel() == dst.numel()
   _lib.call("c2d_cast_f32", _p(src), _p(dst), src.numel(), _stream())
@@ -479,8 +484,10 @@ def spatial_mean_dropout_bwd(dy, lddy, dyoff, dx, mask, rows, spatial, c, keep_p
 
 
 def dropout_mask(mask, seed, keep_prob):
-  _lib.call("c2d_dropout_mask", _p(mask), mask.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF,
-            float(keep_prob), _stream())
+  """seed: an int, or a step_plan.Sym (the per-step dropout key of a recorded step)."""
+  from cap2det_amd.step_plan import sym_like
+  _lib.call_sym("c2d_dropout_mask", _p(mask), mask.numel(), sym_like(seed, int(seed) & 0xFFFFFFFFFFFFFFFF),
+                float(keep_prob), _stream())
 
 
 def dropout_mask_dev(mask, seed_dev, keep_prob):
@@ -681,11 +688,12 @@ def adagrad_step_multi(values, grads, accum, segments, lr, grad_scale=1.0, value
   assert values_bf16 is None or (values_bf16.dtype == torch.bfloat16 and
                                  values_bf16.numel() == values.numel())
   lls, fls = ctypes.c_longlong * n, ctypes.c_float * n
-  _lib.call("c2d_adagrad_step_multi", _p(values), _p(grads), _p(accum), n,
-            lls(*[int(s[0]) for s in segments]), lls(*[int(s[1]) for s in segments]),
-            fls(*[float(s[2]) for s in segments]), fls(*[float(s[3]) for s in segments]),
-            float(lr), float(grad_scale), None if values_bf16 is None else _p(values_bf16),
-            _stream())
+  from cap2det_amd.step_plan import sym_like
+  _lib.call_sym("c2d_adagrad_step_multi", _p(values), _p(grads), _p(accum), n,
+                lls(*[int(s[0]) for s in segments]), lls(*[int(s[1]) for s in segments]),
+                fls(*[float(s[2]) for s in segments]), fls(*[float(s[3]) for s in segments]),
+                sym_like(lr, float(lr)), float(grad_scale),
+                None if values_bf16 is None else _p(values_bf16), _stream())
 
 
 def l2_loss(w, weight, out):

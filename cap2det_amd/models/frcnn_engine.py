@@ -808,9 +808,13 @@ class Net(object):
     if plan.get("side_pending"):
       torch.cuda.current_stream().wait_stream(self.side)      # join: gradients complete below here
       plan["side_pending"] = False
+      # (the rotation starts over: every step takes the same scratch slots in the same order, so a
+      #  recorded step plan — cap2det_amd/step_plan.py — holds for every later step)
       plan["scr"]["events"] = [None] * len(plan["scr"]["events"])
+      plan["scr"]["slot"] = 0
       if plan["scr_b"] is not None:
         plan["scr_b"]["events"] = [None] * len(plan["scr_b"]["events"])
+        plan["scr_b"]["slot"] = 0
 
   def backward(self, plan, x_in, first_idx=0, dx_in=None, after_step=None, join=True):
     """join=False: the caller calls join(plan) itself, later (FrcnnEngine.backward: behind the
@@ -1526,29 +1530,7 @@ class FrcnnEngine(object):
     # to another tensor, so "same data_ptr and version" really means "same pixels")
     bufs["prefetched"] = (image, image._version, done)
 
-  external_prefix = False    # see forward(): set by Trainer._graph_step around its capture
-
-  def prefix_output(self, bufs):
-    """(last prefix step, its output tensor) of this shape, or (None, None) without a prefix."""
-    upto = self._prefix_len(bufs)
-    if upto <= 0:
-      return None, None
-    last = bufs["plan1"]["steps"][upto - 1]
-    return last, last["y"].t
-
-  def run_prefix_into(self, bufs, image, out):
-    """The frozen first-stage prefix of `image` with its OUTPUT redirected to `out` (a tensor shaped
-    like the prefix output); the internal buffers of the prefix are the shape's own.  Runs on the
-    current stream (the hipGraph look-ahead branch, and its eager priming)."""
-    last, cur = self.prefix_output(bufs)
-    refs = self._output_refs(last)
-    for r in refs:
-      r.t = out
-    try:
-      self._run_prefix(bufs, image, self._prefix_len(bufs))
-    finally:
-      for r in refs:
-        r.t = cur
+  static_prefix = False      # see forward(): set by a Trainer that replays step plans
 
   def step_zero_list(self, image_shape, num_proposals):
     """Gradient maps the coming backward pass of this input shape accumulates into (the ROI-crop
@@ -1579,19 +1561,23 @@ class FrcnnEngine(object):
     bufs = self._buffers(b, h, w, n, is_training)
     upto = self._prefix_len(bufs)
     pre = bufs.pop("prefetched", None)
-    if self.external_prefix and upto > 0:
-      # hipGraph capture with look-ahead (Trainer._graph_step): the prefix output buffer already
-      # holds this image's prefix (copied there from the look-ahead branch's buffer)
-      assert pre is None
-    elif (pre is not None and upto > 0 and pre[0].data_ptr() == image.data_ptr() and
+    if (pre is not None and upto > 0 and pre[0].data_ptr() == image.data_ptr() and
         pre[0].shape == image.shape and pre[0]._version == pre[1] == image._version):
-      # the look-ahead of the previous step computed this image's prefix: swap its buffer in
+      # the look-ahead of the previous step computed this image's prefix ...
       last = bufs["plan1"]["steps"][upto - 1]
       cur = last["y"].t
-      for r in self._output_refs(last):
-        r.t = bufs["prefix_alt"]
-      bufs["prefix_alt"] = cur
-      torch.cuda.current_stream().wait_event(pre[2])
+      if self.static_prefix:
+        # ... into the look-ahead buffer, copied into place (2.4 MB): every step then reads and
+        # writes the SAME buffers, which is what a recorded step plan needs (the addresses of the
+        # prefix output also sit inside host descriptor tables of the grouped launches)
+        torch.cuda.current_stream().wait_event(pre[2])
+        ops.copy_bytes(bufs["prefix_alt"], cur)
+      else:
+        # ... swap its buffer in
+        for r in self._output_refs(last):
+          r.t = bufs["prefix_alt"]
+        bufs["prefix_alt"] = cur
+        torch.cuda.current_stream().wait_event(pre[2])
     else:
       if pre is not None:
         torch.cuda.current_stream().wait_event(pre[2])   # (unused look-ahead: just order after it)

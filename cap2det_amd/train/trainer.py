@@ -59,8 +59,13 @@ def dropout_key(seed, global_step, rank, world_size):
 class Trainer(object):
   """Owns the model, the optimiser state and the data-parallel reduction."""
 
-  def __init__(self, pipeline_proto, device="cuda:0", model=None, use_graph=False,
+  def __init__(self, pipeline_proto, device="cuda:0", model=None, use_plan=True,
                **model_kwargs):
+    """use_plan: record the launch list of a step once per input signature and replay it with one
+    native call (cap2det_amd/step_plan.py, csrc/plan.hip) instead of queueing ~140 ctypes calls
+    from Python every step; steps a plan cannot express (data-parallel hooks, injected dropout
+    masks, optimisers other than the one-launch Adagrad, the first and last steps of a run) run
+    eagerly.  Replayed and eager steps launch the same kernels with the same arguments."""
     pipeline_proto = unwrap(pipeline_proto)
     if not isinstance(pipeline_proto, pipeline_pb2.Pipeline):
       raise ValueError('pipeline_proto has to be an instance of Pipeline.')
@@ -77,8 +82,6 @@ class Trainer(object):
       raise ValueError('Invalid optimizer: {}.'.format(opt))
     self.opt_kind = opt
     self.opt_options = getattr(self.train_config.optimizer, opt)
-    if use_graph and opt == 'adam':
-      raise ValueError('hipGraph replay freezes Adam\'s bias correction: use_graph=False with adam')
     self.global_step = 0
     store = self.model.store
     # slot buffers (flat, mirroring the variables): `accum` is slot 0
@@ -183,11 +186,15 @@ class Trainer(object):
     cuts = sorted(set([0] + list(starts.values()) + [self.bucket[1] - lo]))
     self._block_cuts = cuts
     self._block_range = {i: cuts.index(o) for i, o in starts.items()}
-    # hipGraph replay of the (static) step: removes the ~6 us host gap after each of the ~240
-    # launches.  Inputs are staged into fixed device buffers; the dropout seed lives in HBM.
-    self.use_graph = bool(use_graph)
-    self._graphs = None
-    self._static = None
+    self.use_plan = bool(use_plan) and self.device.type == "cuda"
+    # (planned steps read and write the same buffers every step: the look-ahead's prefix is copied
+    #  into place instead of swapped in, FrcnnEngine.forward)
+    self.model.engine.static_prefix = self.use_plan
+    self._plans = {}            # input signature -> dict(plan, eager steps seen, look-ahead phase)
+    self._announced = None      # (image tensor, version) the last step ran its look-ahead for
+    self._next_labels = None    # labels of the announced batch, extracted under the last step
+    self.plan_replays = 0       # steps issued by c2d_plan_replay so far (tests / bench)
+    self._last_replayed = False
 
   # -- checkpoint / resume (reference: tf.estimator saves `model.ckpt-<step>` in model_dir,
   #    train/trainer.py:174-208; here one .npz per step under the reference variable names) ----
@@ -233,7 +240,6 @@ class Trainer(object):
       self.global_step = int(arrays.pop("global_step", 0))
       self.model.load_state_dict(arrays, strict="checkpoint")
       self.model.load_optimizer_slots(arrays)
-      self._graphs = None
       return
     arrays = dict(np.load(path if path.endswith(".npz") else path + ".npz"))
     self.global_step = int(arrays.pop("__global_step"))
@@ -243,7 +249,6 @@ class Trainer(object):
     self.model.store.accum.copy_(torch.from_numpy(accum).to(self.device))
     for k, a in extra.items():
       self.model.store.slots[int(k[len("__optimizer_slot"):])].copy_(torch.from_numpy(a).to(self.device))
-    self._graphs = None
 
   def learning_rate(self):
     tc = self.train_config
@@ -385,9 +390,10 @@ class Trainer(object):
       # slim.dropout draws a fresh mask every step on every worker (models/utils.py:171-174):
       # the counter-based generator is keyed on (trainer seed, global step, rank)
       kwargs["dropout_seed"] = dropout_key(self.seed, self.global_step, self.rank, self.world_size)
-    if (self.use_graph and "dropout_mask" not in kwargs and
-        not self.model.engine.dropout_on_feature_map):
-      return self._graph_step(examples, prefetch=prefetch, prefetch_ready=prefetch_ready, **kwargs)
+    if self.use_plan and self._plan_eligible(kwargs):
+      return self._plan_step(examples, prefetch, prefetch_ready, kwargs)
+    self._announced = self._next_labels = None
+    self._leave_replay()
     kwargs["prefetch"] = prefetch
     kwargs["prefetch_ready"] = prefetch_ready
     store = self.model.store
@@ -409,7 +415,135 @@ class Trainer(object):
     self.predictions = predictions
     return losses
 
-  # -- hipGraph path ------------------------------------------------------------------
+  # -- step plans ----------------------------------------------------------------------
+  def _plan_eligible(self, kwargs):
+    return (self.world_size == 1 and not data_parallel.collectives_on() and
+            self.opt_kind == 'adagrad' and self._clip is None and len(self.segments) <= 8 and
+            all(cols is None and l1 == 0.0 for _, _, _, l1, _, cols, _ in self.segments) and
+            kwargs.get("dropout_mask") is None and kwargs.get("labels") is None and
+            not self.model.engine.dropout_on_feature_map and
+            getattr(self.model.engine, "_x9", None) is None)
+
+  def _join_streams(self):
+    """The current stream waits for everything queued on the engine's other streams."""
+    eng = self.model.engine
+    for s in (eng.prefetch_stream, eng.second.side, eng.second.alt, eng.first.alt):
+      if s is not None:
+        torch.cuda.current_stream().wait_stream(s)
+
+  def _leave_replay(self):
+    """In front of a Python-driven step that follows a replayed one: the replay's other streams are
+    joined (its events are the plan's own, unknown to the engine's bookkeeping) and the engine's
+    look-ahead record — the recorded step's, stale by now — is dropped."""
+    if self._last_replayed:
+      self._join_streams()
+      self.model.engine.invalidate_prefetch()
+      self._last_replayed = False
+
+  @staticmethod
+  def _signature(examples, prefetch):
+    def sig(d):
+      if d is None:
+        return None
+      return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in d.items()
+                          if isinstance(v, torch.Tensor) and v.is_cuda))
+    return sig(examples), sig(prefetch)
+
+  def _eager_core(self, examples, labels, seed, lr, prefetch, prefetch_ready):
+    """The step as train_step queues it, labels given: what a plan records."""
+    reducer = data_parallel.OverlappedReducer(self.model.store.grads[self.bucket[0]:self.bucket[1]],
+                                              self._tail_split)
+    predictions, losses = self._forward_backward(examples, None, labels=labels, dropout_seed=seed,
+                                                 prefetch=prefetch, prefetch_ready=prefetch_ready)
+    scale = reducer.finish()
+    self._apply_gradients(scale, lr)
+    losses['total_loss'] = self.model.total_loss()
+    return predictions, losses
+
+  def _plan_step(self, examples, prefetch, prefetch_ready, kwargs):
+    """One step through a recorded plan when one exists for this input signature and the look-
+    ahead of the previous step was for this batch; the third such eager step is the one recorded
+    (by then every buffer of the shape exists and the look-ahead alternates in steady state)."""
+    from cap2det_amd.core.standard_fields import InputDataFields as F
+    from cap2det_amd.step_plan import StepPlan, Sym
+    model, eng = self.model, self.model.engine
+    image = examples[F.image]
+    seed = kwargs.get("dropout_seed")
+    lr = self.learning_rate()
+    # labels: extracted under the previous step for the batch it announced, else now
+    nl, self._next_labels = self._next_labels, None
+    if nl is not None and nl[0] is image and nl[1] == image._version:
+      labels = nl[2]
+      torch.cuda.current_stream().wait_event(nl[3])
+    else:
+      labels = model.label_extractor.extract_labels(examples)
+    steady = (self._announced is not None and self._announced[0] is image and
+              self._announced[1] == image._version)
+    key = self._signature(examples, prefetch)
+    st = self._plans.setdefault(key, dict(plan=None, eager=0, failed=False))
+    b, h, w, _ = image.shape
+    n = examples[F.proposals].shape[1]
+    look = prefetch is not None and getattr(eng, "prefetch_stream", None) is not None
+    if st["plan"] is not None and steady and look:
+      plan = st["plan"]
+      tensors = {"ex." + k: v for k, v in examples.items() if isinstance(v, torch.Tensor) and v.is_cuda}
+      tensors.update({"next." + k: v for k, v in prefetch.items()
+                      if isinstance(v, torch.Tensor) and v.is_cuda})
+      tensors["labels"] = labels
+      if prefetch_ready is not None:
+        eng.prefetch_stream.wait_event(prefetch_ready)
+      if not self._last_replayed:
+        self._join_streams()     # a plan starts from joined streams (c2d_plan_finish)
+      plan.replay(tensors, {"seed": int(seed) & 0xFFFFFFFFFFFFFFFF, "lr": lr})
+      self.plan_replays += 1
+      self._last_replayed = True
+      predictions, losses = st["result"]
+    else:
+      record = (st["plan"] is None and not st["failed"] and steady and look and st["eager"] >= 2)
+      self._leave_replay()
+      if record:
+        bufs = eng._buffers(b, h, w, n, True)
+        upto = eng._prefix_len(bufs)
+        record = upto > 0 and bufs.get("prefetched") is not None and "prefix_alt" in bufs
+      if record:
+        plan = StepPlan()
+        for k, v in examples.items():
+          if isinstance(v, torch.Tensor) and v.is_cuda:
+            plan.bind_tensor("ex." + k, v)
+        for k, v in prefetch.items():
+          if isinstance(v, torch.Tensor) and v.is_cuda:
+            plan.bind_tensor("next." + k, v)
+        plan.bind_tensor("labels", labels)
+        try:
+          with plan.recording():
+            predictions, losses = self._eager_core(examples, labels, Sym("seed", seed), Sym("lr", lr),
+                                                   prefetch, prefetch_ready)
+        except Exception:
+          st["failed"] = True
+          raise
+        st.update(plan=plan, result=(predictions, losses))
+      else:
+        predictions, losses = self._eager_core(examples, labels, seed, lr, prefetch, prefetch_ready)
+        st["eager"] += 1
+    self.global_step += 1
+    self.predictions = predictions
+    # what the next step may rely on: the look-ahead ran for `prefetch`, whose labels are extracted
+    # now, under this step's kernels
+    self._announced = None
+    if look:
+      nxt = prefetch[F.image]
+      self._announced = (nxt, nxt._version)
+      stream = eng.prefetch_stream
+      if getattr(model.label_extractor, "overlaps_forward", False):
+        with torch.cuda.stream(stream):
+          nlab = model.label_extractor.extract_labels(prefetch)
+          ready = torch.cuda.Event()
+          ready.record()
+        nlab.record_stream(torch.cuda.current_stream())
+        self._next_labels = (nxt, nxt._version, nlab, ready)
+    return losses
+
+  # -- the training loop -----------------------------------------------------------------
   def train(self, batches, max_steps=None, save_dir=None, save_every=None, log=None,
             prefetch_depth=2):
     """train/trainer.py:210-235 (`tf.estimator.train_and_evaluate`'s training half): consumes an
@@ -430,15 +564,6 @@ class Trainer(object):
     # steps (tests/test_gpu_reader.py::test_train_overlaps_the_uploads).
     src = DevicePrefetcher(batches, self.device, depth=prefetch_depth)
     eng = self.model.engine
-    # Two Python threads now share the interpreter lock: this one queues ~250 launches per step,
-    # the input thread assembles batches.  Both hold the lock for microseconds at a time, but a
-    # thread that WANTS it only asks the holder to let go after the switch interval — 5 ms by
-    # default, longer than a whole bf16 step.  Measured on configs[2] (bench.py --reader, 3.18 ms per
-    # step on resident inputs): 3.97 ms at the default, 3.54 at 0.5 ms, 3.21 at 50 us.
-    import sys
-    switch_interval = sys.getswitchinterval()
-    sys.setswitchinterval(min(switch_interval, float(os.environ.get("C2D_SWITCH_INTERVAL", "5e-5"))))
-
     import time
     self.input_wait_s = 0.0        # host time this thread spent waiting for the input thread
     self.enqueue_s = 0.0           # host time inside train_step (queueing the step's launches)
@@ -470,131 +595,5 @@ class Trainer(object):
           self.save_checkpoint(save_dir)
         cur = nxt
     finally:
-      sys.setswitchinterval(switch_interval)
       src.close()
     return losses
-
-  def _graph_step(self, examples, dropout_seed=None, prefetch=None, prefetch_ready=None, **kwargs):
-    """hipGraph replay of the step WITH the eager schedule's streams (round 4): inside the capture
-    the filter gradients fork onto the side stream exactly as in the eager step (event record /
-    wait are capturable, the graph gets parallel branches), and the look-ahead — the frozen
-    first-stage prefix of the NEXT image — is a third branch of the same graph: it reads a static
-    `next image` buffer and writes the alternate prefix buffer, which the following replay copies
-    (2.4 MB) into place before its own Mixed_4e reads it.  `prefetch` must therefore be the batch
-    the caller passes as `examples` next (as in the eager look-ahead); if it was not, the prefix of
-    the current image is recomputed eagerly in front of the replay.  C2D_GRAPH_STREAMS=0 captures
-    everything on one stream (the round-3 form)."""
-    from cap2det_amd.core.standard_fields import InputDataFields as F
-    model, store = self.model, self.model.store
-    eng = model.engine
-    lo, hi = self.bucket
-    lr = self.learning_rate()
-    labels = model.label_extractor.extract_labels(examples)      # host lookup + small kernel
-    streams = os.environ.get("C2D_GRAPH_STREAMS", "1") != "0" and eng.second.side is not None
-    if not streams:
-      eng.second.side = None        # one stream inside the captured graph
-      eng.prefetch_stream = None
-    if self._lr_dev is None:
-      self._lr_dev = torch.zeros(1, device=self.device)
-    # the learning rate lives in device memory (like the dropout seed): a continuous
-    # exponential_decay changes it every step without a re-capture
-    self._lr_dev.fill_(lr)
-    lr_dev = self._lr_dev
-    image = examples[F.image]
-    key = (tuple(image.shape), tuple(examples[F.proposals].shape))
-    if self._graphs is None or self._graphs["key"] != key:
-      # eager warm-up on this shape (allocates every buffer), then capture
-      st = {F.image: image.clone(), F.proposals: examples[F.proposals].clone(),
-            F.num_proposals: examples[F.num_proposals].clone(), "labels": labels.clone(),
-            "seed": torch.zeros(1, dtype=torch.int64, device=self.device),
-            "next_image": image.clone()}
-      ex = {F.image: st[F.image], F.proposals: st[F.proposals],
-            F.num_proposals: st[F.num_proposals]}
-      # (every optimiser slot: rmsprop keeps momentum / mean-gradient slots beside slot 0)
-      state = (store.values.clone(), [sl.clone() for sl in store.slots])
-      eng.invalidate_prefetch()
-      pre_keep, alt_keep, alt1_keep = eng.prefetch_stream, eng.second.alt, eng.first.alt
-      eng.prefetch_stream = None          # (the eager look-ahead machinery stays out of the graph)
-      # (the branch stream too: ending a capture that forked five streams crashes inside
-      #  hipStreamEndCapture on ROCm 7.2 — and replay gains nothing from the branches, profiles/
-      #  r04_graph_concurrency.json)
-      eng.second.alt = None
-      eng.first.alt = None
-      try:
-        self._forward_backward(ex, labels=st["labels"], dropout_seed=st["seed"])
-        self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
-        torch.cuda.synchronize()
-        store.values.copy_(state[0])                                # undo the warm-up update
-        for sl, saved in zip(store.slots, state[1]):
-          sl.copy_(saved)
-        self.model.refresh(only_trainable=True)
-        bufs = eng._buffers(image.shape[0], image.shape[1], image.shape[2],
-                            examples[F.proposals].shape[1], True)
-        last, p_cur = eng.prefix_output(bufs)
-        lookahead = streams and last is not None
-        p_next = torch.empty_like(p_cur) if lookahead else None
-        branch = torch.cuda.Stream() if lookahead else None
-        cap = torch.cuda.Stream()
-        cap.wait_stream(torch.cuda.current_stream())
-        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.stream(cap):
-          with torch.cuda.graph(g_fb, stream=cap):
-            if lookahead:
-              p_cur.copy_(p_next)                   # the previous replay's look-ahead result
-              fork = torch.cuda.Event()
-              fork.record()
-              branch.wait_event(fork)
-              with torch.cuda.stream(branch):
-                eng.run_prefix_into(bufs, st["next_image"], p_next)
-                joined = torch.cuda.Event()
-                joined.record()
-              eng.external_prefix = True
-            try:
-              predictions, losses = self._forward_backward(ex, labels=st["labels"],
-                                                           dropout_seed=st["seed"])
-            finally:
-              eng.external_prefix = False
-            if lookahead:
-              torch.cuda.current_stream().wait_event(joined)
-          with torch.cuda.graph(g_opt, stream=cap):
-            self._apply_gradients(1.0 / self.world_size, lr, lr_dev)
-            total = self.model.total_loss()
-        torch.cuda.current_stream().wait_stream(cap)
-      finally:
-        # (also when the warm-up or the capture raises: the eager path must find its streams again)
-        eng.prefetch_stream = pre_keep
-        eng.second.alt = alt_keep
-        eng.first.alt = alt1_keep
-      losses['total_loss'] = total
-      self._graphs = dict(key=key, fb=g_fb, opt=g_opt, predictions=predictions, losses=losses,
-                          lookahead=lookahead, bufs=bufs, p_next=p_next, primed=None)
-      self._static = st
-    st, gr = self._static, self._graphs
-    st[F.image].copy_(image, non_blocking=True)
-    st[F.proposals].copy_(examples[F.proposals], non_blocking=True)
-    st[F.num_proposals].copy_(examples[F.num_proposals], non_blocking=True)
-    st["labels"].copy_(labels, non_blocking=True)
-    st["seed"].fill_(int(dropout_seed) if dropout_seed is not None else self.global_step)
-    if gr["lookahead"]:
-      primed = gr["primed"]
-      if primed is None or primed[0] is not image or primed[1] != image._version:
-        # the look-ahead of the previous replay was not for this image (first step, or a caller
-        # that does not announce its batches): compute this image's prefix now
-        eng.run_prefix_into(gr["bufs"], st[F.image], gr["p_next"])
-      nxt = prefetch[F.image] if prefetch is not None else None
-      if nxt is not None and tuple(nxt.shape) == tuple(st["next_image"].shape):
-        if prefetch_ready is not None:
-          torch.cuda.current_stream().wait_event(prefetch_ready)
-        st["next_image"].copy_(nxt, non_blocking=True)
-        # (the announced tensor is HELD: while it is referenced its memory cannot be handed to
-        # another tensor, so "same tensor, same version" below really means "same pixels" — a bare
-        # (data_ptr, version) pair matched a freshly allocated image at a recycled address, ADVICE r4)
-        gr["primed"] = (nxt, nxt._version)
-      else:
-        gr["primed"] = None
-    gr["fb"].replay()
-    data_parallel.allreduce_bucket(store.grads[lo:hi])
-    gr["opt"].replay()
-    self.global_step += 1
-    self.predictions = gr["predictions"]
-    return gr["losses"]

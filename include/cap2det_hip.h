@@ -834,6 +834,41 @@ int c2d_text_pool_bwd(const float* dhidden, const float* pre, const int32_t* ids
                       int num_tokens, int hidden_units, int vocab_size, const uint8_t* keep_mask,
                       float keep_prob, float* dpre, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Step plan: the call list of one training step, recorded once, replayed by ONE call
+ * (replaces the per-step session.run of slim.learning.train, train/trainer.py:141-146: the
+ * reference hands its whole step to the TensorFlow runtime; here the step is ~140 of the entry points
+ * above on four streams, which cap2det_amd/step_plan.py records while a step runs eagerly)
+ *
+ * A plan is an ordered list of nodes: CALL (an entry point of this header, by name, with its
+ * argument words), RECORD (plan event e on a stream) and WAIT (a stream waits for plan event e).
+ * Argument words are 64-bit: pointers and integers as they are, floats in the low 32 bits.
+ * kinds[i]: 0 = the word is a constant; 1 = a pointer into the tensor bound to slots[i] (the word is
+ * the byte offset from its base); 2 = the word itself comes from binding slots[i] (a scalar).
+ * Host arrays passed by pointer (descriptor tables) must outlive the plan unchanged.
+ * Not thread-safe per plan; replays of one plan must not overlap.
+ * ------------------------------------------------------------------------------------- */
+long long c2d_plan_create(void);                 /* handle (pass as void*), 0 on failure */
+/* dst[0..bytes) = src[0..bytes) (device to device, a copy kernel) on `stream`: the hand-over of the
+ * look-ahead's first-stage prefix to the step that consumes it.  16-byte aligned, bytes % 16 == 0. */
+int c2d_copy_bytes(const void* src, void* dst, long long bytes, void* stream);
+int c2d_plan_destroy(void* plan);
+/* C2D_ERR_UNSUPPORTED: no entry point `name` returning int; C2D_ERR_INVALID_ARG: wrong nargs. */
+int c2d_plan_add_call(void* plan, const char* name, int nargs, const long long* vals,
+                      const uint8_t* kinds, const int* slots);
+int c2d_plan_add_event_record(void* plan, int event, void* stream);
+int c2d_plan_add_stream_wait(void* plan, void* stream, int event);
+/* Closes the plan: every other stream of its RECORD / WAIT nodes records a plan event behind its last
+ * node, which main_stream waits for at the start of the NEXT replay; a stream that does not begin
+ * with a wait for an event of main_stream starts behind main_stream's position at the replay call.
+ * The first replay after anything else ran on those streams needs them joined by the caller. */
+int c2d_plan_finish(void* plan, void* main_stream);
+int c2d_plan_size(void* plan);                   /* nodes, boundary nodes included */
+/* Issues the plan: bindings[s] = the base pointer (kind 1) or the word (kind 2) of slot s.
+ * Stops at the first failing node: its C2D_ERR_* code is returned, its index stored in
+ * *failed_node (may be NULL). */
+int c2d_plan_replay(void* plan, const long long* bindings, int num_bindings, int* failed_node);
+
 #ifdef __cplusplus
 }
 #endif

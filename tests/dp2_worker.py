@@ -46,14 +46,9 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
   pipeline = util_model.load_pipeline()
-  graph = launch == "graph"
-  if graph:
-    # the captured step draws its dropout mask from a device-resident seed over the rows of ITS
-    # batch; two one-image ranks and one batch-of-2 process cannot share that draw, so the graph
-    # comparison runs without dropout (the eager comparison injects the masks)
-    m = pipeline.model.Extensions[cap2det_model_pb2.Cap2DetModel.ext]
-    m.frcnn_options.dropout_keep_prob = 1.0
-  trainer = Trainer(pipeline, device=dev, depth_multiplier=DM, use_graph=graph, compute_dtype=dtype)
+  assert launch == "eager"         # (injected dropout masks and data-parallel hooks: Python-driven steps)
+  graph = False
+  trainer = Trainer(pipeline, device=dev, depth_multiplier=DM, compute_dtype=dtype)
   model = trainer.model
   classes = model.label_extractor.classes
   P32, d = util_model.oracle_state(11, len(classes), K, DM, head_std=0.01 if DM == 1.0 else 0.05)

@@ -869,89 +869,97 @@ def test_full_size_all_oov_caption(tmp_path, config, dtype):
     np.testing.assert_allclose(float(losses[k].item()), v, rtol=2e-4, err_msg=k)
 
 
+def _plan_batches(rng, classes, n, nums, count):
+  return [_to_dev(util_model.make_examples(rng, 2, 40, 56, n, nums, classes)) for _ in range(count)]
+
+
 @pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("n,nums", [(9, [9, 4]), (32, [32, 20])])
-def test_graph_step_equals_eager_step(n, nums, compute_dtype):
-  """`Trainer(use_graph=True)` (hipGraph capture and replay of the step, one stream, dropout seed
-  and learning rate read from device memory) against the eager step on the same inputs, state
-  and dropout seed: the same losses and the same updated variables up to the fp32 atomics' order
-  after ONE step (later steps see those rounding differences through the discrete OICR box
-  selection and ReLU masks, so they are only required to replay and stay finite).  The second
-  case has 64 per-ROI maps (the fused BN/ReLU-backward plan, commuted pooling branch and fused
-  block-entry GEMMs inside the captured graph).  bf16: both towers in bf16 storage (the grouped
-  bf16 first-stage launches and the casts around the ROI crop inside the graph); an atomics-order
-  difference of the filter gradients can move a bf16 rounding, so 2 % / 5 %."""
+def test_plan_step_equals_eager_step(n, nums, compute_dtype):
+  """Step plans (cap2det_amd/step_plan.py, csrc/plan.hip): a `Trainer` records the call list of its
+  third look-ahead step and issues the following ones with ONE c2d_plan_replay call.
+  (1) The launch list is step-invariant: a second plan recorded several steps later (other batch,
+      other dropout key, the look-ahead ping-pong in its other phase) holds node for node the same
+      entry points, constants, streams and event structure, and the same bindings.
+  (2) A replayed step equals the Python-driven step from the SAME state on the same inputs: losses
+      and updated variables to the order of the step's fp32 atomics (the tolerance the two eager
+      runs of the old hipGraph test were held to; bf16: an atomics-order difference of a filter
+      gradient can move a bf16 rounding).
+  The second case has 64 per-ROI maps (fused BN/ReLU-backward plan, commuted pooling branch, fused
+  block-entry GEMMs, branch streams)."""
   from cap2det_amd.train.trainer import Trainer
   pipeline = util_model.load_pipeline()
   rng = np.random.default_rng(17)
-  results, ex = [], None
   ltol, stol = (1e-5, 5e-5) if compute_dtype == "fp32" else (2e-2, 5e-2)
-  for use_graph in (False, True):
-    trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, use_graph=use_graph,
-                      compute_dtype=compute_dtype)
-    model = trainer.model
-    classes = model.label_extractor.classes
-    P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
-    model.load_state_dict(P32)
-    if ex is None:
-      ex = _to_dev(util_model.make_examples(rng, 2, 40, 56, n, nums, classes))
-    losses = trainer.train_step(ex, dropout_seed=100)
-    torch.cuda.synchronize()
-    first = {k: float(v) for k, v in losses.items()}
-    state = {k: np.array(v, copy=True) for k, v in model.state_dict().items()}
-    later = []
-    for step in (1, 2):            # (graph: replays of the captured step with new seeds)
-      losses = trainer.train_step(ex, dropout_seed=100 + step)
-      torch.cuda.synchronize()
-      later.append(float(losses["total_loss"]))
-    assert all(np.isfinite(v) for v in later) and later[0] != first["total_loss"]
-    results.append((first, state))
-  (le, state_e), (lg, state_g) = results
-  assert le.keys() == lg.keys()
-  for k in le:
-    assert abs(le[k] - lg[k]) <= ltol * max(1.0, abs(le[k])), (k, le[k], lg[k])
-  for k in state_e:
-    a, b = state_e[k].astype(np.float64), state_g[k].astype(np.float64)
+  trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, compute_dtype=compute_dtype)
+  model, store = trainer.model, trainer.model.store
+  classes = model.label_extractor.classes
+  P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
+  model.load_state_dict(P32)
+  batches = _plan_batches(rng, classes, n, nums, 9)
+  key = None
+  for i in range(4):                 # 0, 1 eager; 2 recorded; 3 replayed
+    trainer.train_step(batches[i], dropout_seed=100 + i, prefetch=batches[i + 1])
+  torch.cuda.synchronize()
+  assert trainer.plan_replays == 1
+  (key, st), = [(k, v) for k, v in trainer._plans.items() if v["plan"] is not None]
+  first = st["plan"]
+  assert first.calls > 50 and first.external_waits >= 1 and first.size() > first.calls
+  # (2): snapshot, replay step 4, restore, drive the same step from Python
+  snap = (store.values.clone(), store.accum.clone(), trainer.global_step)
+  losses = trainer.train_step(batches[4], dropout_seed=104, prefetch=batches[5])
+  torch.cuda.synchronize()
+  assert trainer.plan_replays == 2
+  got = ({k: float(v) for k, v in losses.items()}, model.state_dict())
+  got = (got[0], {k: np.array(v, copy=True) for k, v in got[1].items()})
+  store.values.copy_(snap[0]); store.accum.copy_(snap[1]); trainer.global_step = snap[2]
+  model.refresh(only_trainable=True)
+  trainer.use_plan = False
+  losses = trainer.train_step(batches[4], dropout_seed=104, prefetch=batches[5])
+  torch.cuda.synchronize()
+  want = ({k: float(v) for k, v in losses.items()}, model.state_dict())
+  assert got[0].keys() == want[0].keys()
+  for k in want[0]:
+    assert abs(want[0][k] - got[0][k]) <= ltol * max(1.0, abs(want[0][k])), (k, want[0][k], got[0][k])
+  for k in want[1]:
+    a, b = np.asarray(want[1][k], np.float64), got[1][k].astype(np.float64)
     assert np.abs(a - b).max() <= stol * max(np.abs(a).max(), 1e-3), k
+  # (1): two more look-ahead steps from Python, then a fresh recording; compare the node lists
+  trainer.use_plan = True
+  st["plan"], st["eager"] = None, 0
+  for i in range(5, 8):              # 5 (announces), 6 eager, 7 recorded
+    trainer.train_step(batches[i], dropout_seed=100 + i, prefetch=batches[i + 1])
+  torch.cuda.synchronize()
+  second = st["plan"]
+  assert second is not None and second is not first
+  assert first.structure() == second.structure()
 
 
-def test_graph_step_equals_eager_step_rmsprop_slots():
-  """the eager warm-up in front of the graph capture must be undone in EVERY optimiser
-  slot.  Centered rmsprop with momentum keeps three (rms, momentum, mean gradient): after one
-  step the graph trainer's variables and all three slots equal the eager trainer's (atomics-order
-  tolerance) — a warm-up update left in the momentum / mean-gradient slots shows as a step of
-  roughly twice the size."""
+def test_steps_a_plan_cannot_express_run_eagerly():
+  """Optimisers other than the one-launch Adagrad, injected dropout masks and steps without a
+  look-ahead batch stay Python-driven."""
   from cap2det_amd.train.trainer import Trainer
   pipeline = util_model.load_pipeline()
   sub = pipeline.train_config.optimizer.rmsprop
   sub.decay, sub.momentum, sub.epsilon, sub.centered = 0.9, 0.5, 1e-10, True
   pipeline.train_config.learning_rate = 0.001
   rng = np.random.default_rng(23)
-  out, ex = [], None
-  for use_graph in (False, True):
-    trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, use_graph=use_graph)
-    model = trainer.model
-    assert len(model.store.slots) == 3
-    classes = model.label_extractor.classes
-    P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
-    model.load_state_dict(P32)
-    if ex is None:
-      ex = _to_dev(util_model.make_examples(rng, 2, 40, 56, 9, [9, 4], classes))
-    trainer.train_step(ex, dropout_seed=7)
-    torch.cuda.synchronize()
-    lo, hi = trainer.bucket
-    out.append((model.store.values[lo:hi].double().cpu().numpy().copy(),
-                [sl[lo:hi].double().cpu().numpy().copy() for sl in model.store.slots],
-                model.store.grads[lo:hi].double().cpu().numpy().copy()))
-  (ve, se, ge), (vg, sg, gg) = out
-  # the slots are functions of the gradient: rms and the mean gradient directly
-  for i, (a, b) in enumerate(zip(se, sg)):
-    assert np.abs(a - b).max() <= 1e-4 * max(np.abs(a).max(), 1e-6), "slot %d" % i
-  # g / sqrt(rms - mg^2 + eps) is ill-conditioned where |g| is at the fp32 noise of the gradient:
-  # compare the variables where the gradient is well above it
-  well = np.abs(ge) > 1e-3 * np.abs(ge).max()
-  assert well.sum() > 1000
-  assert np.abs(ve - vg)[well].max() <= 2e-2 * 0.001 * 3.2, np.abs(ve - vg)[well].max()
+  trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5)
+  classes = trainer.model.label_extractor.classes
+  P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
+  trainer.model.load_state_dict(P32)
+  batches = _plan_batches(rng, classes, 9, [9, 4], 6)
+  for i in range(5):
+    losses = trainer.train_step(batches[i], dropout_seed=i, prefetch=batches[i + 1])
+  torch.cuda.synchronize()
+  assert trainer.plan_replays == 0 and np.isfinite(float(losses["total_loss"]))
+  pipeline = util_model.load_pipeline()
+  trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5)
+  trainer.model.load_state_dict(P32)
+  for i in range(5):                 # no look-ahead batch: nothing to record
+    trainer.train_step(batches[i], dropout_seed=i)
+  torch.cuda.synchronize()
+  assert trainer.plan_replays == 0
 
 
 @pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])

@@ -52,7 +52,7 @@ def main():
   pipeline = synthetic.load_pipeline()
   batches = None
 
-  def run(force, use_graph):
+  def run(force, use_graph=False):
     nonlocal batches
     if force:
       os.environ["C2D_FORCE_ALLREDUCE"] = "1"
@@ -60,7 +60,7 @@ def main():
       os.environ.pop("C2D_FORCE_ALLREDUCE", None)
     assert data_parallel.collectives_on() == bool(force)
     before = calls["n"]
-    trainer = Trainer(pipeline, device=dev, seed=21, use_graph=use_graph)
+    trainer = Trainer(pipeline, device=dev, seed=21)
     classes = trainer.model.label_extractor.classes
     if batches is None:
       rng = np.random.default_rng(5)
@@ -90,7 +90,7 @@ def main():
   report = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "size": size,
             "checks": []}
   ok = True
-  for use_graph in (False, True):
+  for use_graph in (False,):
     ref = run(False, use_graph)
     got = run(True, use_graph)
     name = "graph" if use_graph else "eager"
