@@ -13,6 +13,12 @@ static inline int c2d_launch_status() {
   return hipGetLastError() == hipSuccess ? C2D_OK : C2D_ERR_LAUNCH;
 }
 
+// Tuning / ablation hooks of the tools (tools/sweep_*.sh, tools/ablate_x9.sh ...): ONE environment
+// variable, C2D_TUNE="key=value,key=value", parsed once at first use; unset in production, where
+// every hook takes its default.  c2d_tune_get: the value string of `key`, or null.
+bool c2d_tune_on();
+const char* c2d_tune_get(const char* key);
+
 static inline int c2d_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Wave64 reductions (CDNA4 wavefront = 64 lanes).

@@ -107,12 +107,12 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
   const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime();
   int tr_iters = 0;
   unsigned long long tr_seg[5] = {0, 0, 0, 0, 0}, tr_a, tr_b;
-#define C2D_STAMP(v)                                                                   \
+#define K_STAMP(v)                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                   \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");            \
   __builtin_amdgcn_sched_barrier(0);
 #else
-#define C2D_STAMP(v)
+#define K_STAMP(v)
 #endif
 
   // ---- work range of this workgroup ---------------------------------------------------------
@@ -276,7 +276,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     // next tap (every K/BKT slabs; never for a 1x1 convolution), so the per-slab address work is
     // one add per load instead of the whole gather arithmetic.
     unsigned aoff[A_LOADS], boff[B_LOADS];   // per-lane BYTE offsets (operands are < 2 GB)
-#define C2D_RETAP()                                                                            \
+#define K_RETAP()                                                                            \
   {                                                                                            \
     const int delta = __builtin_amdgcn_readlane(tab_delta, tap);                               \
     _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                        \
@@ -291,8 +291,8 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
       tv_load = ((unsigned)__builtin_amdgcn_readlane((int)tab_tv, tap) >> (wm * MT)) &         \
                 ((1u << MT) - 1u);                                                             \
   }
-#define C2D_TAP_FROM_MASK() tap = taps_left ? __builtin_ctzll(taps_left) : 0;
-#define C2D_ISSUE()                                                                            \
+#define K_TAP_FROM_MASK() tap = taps_left ? __builtin_ctzll(taps_left) : 0;
+#define K_ISSUE()                                                                            \
   {                                                                                            \
     const int soff = kc * ES;                                                                  \
     if (kc + BKT <= Kc) {      /* whole slab inside K: offsets as they stand */                \
@@ -313,9 +313,9 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
     // K is a multiple of 16, not necessarily of BKT: lanes past the end of the last slab re-read
     // the row's last float4 (in bounds) and contribute zeros through the A mask.
     if (cnt > 0) {   // (a stride-2 parity class can have no tap at all: it just stores zeros)
-      C2D_TAP_FROM_MASK();
-      C2D_RETAP();
-      C2D_ISSUE();
+      K_TAP_FROM_MASK();
+      K_RETAP();
+      K_ISSUE();
     }
     for (int it = 0; it < cnt; ++it) {
       if (SK) {
@@ -330,7 +330,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
           default: __builtin_amdgcn_s_setprio(3); break;
         }
       }
-      C2D_STAMP(tr_a)
+      K_STAMP(tr_a)
       tv_mma = tv_load;   // validity of the slab now in registers (to be staged + multiplied)
       // tiles beyond M / N or (PM) in the SAME padding of this tap cost no MFMA time
       unsigned onbits = tile_bits;
@@ -347,11 +347,11 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
       for (int i = 0; i < B_LOADS; ++i)
         *reinterpret_cast<f32x4*>(&Bs[brow_l[i] * LDS_STRIDE + q4f]) = rb[i];
 #ifdef C2D_TRACE
-      C2D_STAMP(tr_b) tr_seg[0] += tr_b - tr_a;    // wait for the loads + LDS stores
+      K_STAMP(tr_b) tr_seg[0] += tr_b - tr_a;    // wait for the loads + LDS stores
 #endif
       __syncthreads();
 #ifdef C2D_TRACE
-      C2D_STAMP(tr_a) tr_seg[1] += tr_a - tr_b;    // barrier 1
+      K_STAMP(tr_a) tr_seg[1] += tr_a - tr_b;    // barrier 1
 #endif
       {
         // advance the wave-uniform cursor (saturating at the last slab)
@@ -367,16 +367,16 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
               rsB = make_rsrc_b(a.segB[sgi], (long long)a.N * Kc * ES);
             } else {
               taps_left &= taps_left - 1ull;   // next tap that is real for some tile of the block
-              C2D_TAP_FROM_MASK();
+              K_TAP_FROM_MASK();
             }
-            C2D_RETAP();
+            K_RETAP();
           }
         }
-        C2D_ISSUE();
+        K_ISSUE();
       }
       __builtin_amdgcn_sched_barrier(0);
 #ifdef C2D_TRACE
-      C2D_STAMP(tr_b) tr_seg[2] += tr_b - tr_a;    // cursor + issue of the next slab's loads
+      K_STAMP(tr_b) tr_seg[2] += tr_b - tr_a;    // cursor + issue of the next slab's loads
 #endif
 
       if constexpr (ES == 4) {
@@ -440,16 +440,16 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a, const SkPlan& sk)
             }
       }
 #ifdef C2D_TRACE
-      C2D_STAMP(tr_a) tr_seg[3] += tr_a - tr_b;    // fragment reads + MFMA issue
+      K_STAMP(tr_a) tr_seg[3] += tr_a - tr_b;    // fragment reads + MFMA issue
 #endif
       __syncthreads();
 #ifdef C2D_TRACE
-      C2D_STAMP(tr_b) tr_seg[4] += tr_b - tr_a;    // barrier 2
+      K_STAMP(tr_b) tr_seg[4] += tr_b - tr_a;    // barrier 2
 #endif
     }
-#undef C2D_RETAP
-#undef C2D_ISSUE
-#undef C2D_TAP_FROM_MASK
+#undef K_RETAP
+#undef K_ISSUE
+#undef K_TAP_FROM_MASK
 #ifdef C2D_TRACE
     tr_iters += cnt;
 #endif
@@ -680,7 +680,7 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
     unsigned okb[SETS];
     const __bf16* const A16 = reinterpret_cast<const __bf16*>(a.A);
     const __bf16* const B16 = reinterpret_cast<const __bf16*>(a.Bt);
-#define C2D_SMB_LOAD(SLABI, SET)                                                               \
+#define K_SMB_LOAD(SLABI, SET)                                                               \
   {                                                                                            \
     const int tp = (SLABI) / kslabs;                                                           \
     const int kc = ((SLABI) - tp * kslabs) * 64 + lh * 8;                                      \
@@ -698,7 +698,7 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
       gb[SET][v] = *reinterpret_cast<const bf16x8*>(bp + kk);                                  \
     }                                                                                          \
   }
-#define C2D_SMB_MMA(SET)                                                                       \
+#define K_SMB_MMA(SET)                                                                       \
   {                                                                                            \
     _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                            \
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                    \
@@ -708,23 +708,23 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
   }
 #pragma unroll
     for (int q = 0; q < SETS - 1; ++q)
-      if (sbeg + q < send) C2D_SMB_LOAD(sbeg + q, q);
+      if (sbeg + q < send) K_SMB_LOAD(sbeg + q, q);
     for (int sl = sbeg; sl < send; sl += SETS) {
 #pragma unroll
       for (int q = 0; q < SETS; ++q) {
         if (sl + q < send) {
-          if (sl + q + SETS - 1 < send) C2D_SMB_LOAD(sl + q + SETS - 1, (q + SETS - 1) % SETS);
-          C2D_SMB_MMA(q);
+          if (sl + q + SETS - 1 < send) K_SMB_LOAD(sl + q + SETS - 1, (q + SETS - 1) % SETS);
+          K_SMB_MMA(q);
         }
       }
     }
-#undef C2D_SMB_LOAD
-#undef C2D_SMB_MMA
+#undef K_SMB_LOAD
+#undef K_SMB_MMA
   } else {
   f32x4 fa[2][4], fb[2][4];
   unsigned okm[2] = {0u, 0u};
   // slab index -> (tap, kc)
-#define C2D_SM_LOAD(SLAB, SET)                                                                 \
+#define K_SM_LOAD(SLAB, SET)                                                                 \
   {                                                                                            \
     const int tp = (SLAB) / kslabs;                                                            \
     const int kc = ((SLAB) - tp * kslabs) * 32 + lh * 16;                                      \
@@ -742,7 +742,7 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
       fb[SET][v] = *reinterpret_cast<const f32x4*>(bp + kk);                                   \
     }                                                                                          \
   }
-#define C2D_SM_MMA(SET)                                                                        \
+#define K_SM_MMA(SET)                                                                        \
   {                                                                                            \
     _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                            \
       const f32x4 av = mask4(fa[SET][v], (okm[SET] >> v) & 1u);                                \
@@ -754,17 +754,17 @@ __device__ __forceinline__ void igemm_small_body(const IgemmArgs& a, const int t
     }                                                                                          \
   }
 
-  if (sbeg < send) C2D_SM_LOAD(sbeg, 0);
+  if (sbeg < send) K_SM_LOAD(sbeg, 0);
   for (int sl = sbeg; sl < send; sl += 2) {
-    if (sl + 1 < send) C2D_SM_LOAD(sl + 1, 1);
-    C2D_SM_MMA(0);
+    if (sl + 1 < send) K_SM_LOAD(sl + 1, 1);
+    K_SM_MMA(0);
     if (sl + 1 < send) {
-      if (sl + 2 < send) C2D_SM_LOAD(sl + 2, 0);
-      C2D_SM_MMA(1);
+      if (sl + 2 < send) K_SM_LOAD(sl + 2, 0);
+      K_SM_MMA(1);
     }
   }
-#undef C2D_SM_LOAD
-#undef C2D_SM_MMA
+#undef K_SM_LOAD
+#undef K_SM_MMA
   }
 
   // sum the 4 partial tiles; C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -901,7 +901,7 @@ __device__ __forceinline__ void wgrad_tn_body(const WgradArgs& a, const WgradBlo
     aoffs[u] = (unsigned)((kr + u * 8) * a.lda) * (unsigned)ES + acol;
     goffs[u] = (unsigned)((kr + u * 8) * a.ldg) * (unsigned)ES + gcol;
   }
-#define C2D_WG_LOAD(MB)                                                                        \
+#define K_WG_LOAD(MB)                                                                        \
   {                                                                                            \
     if (PLAIN) {                                                                               \
       const int sa = (MB) * a.lda * ES, sg = (MB) * a.ldg * ES;                                \
@@ -921,7 +921,7 @@ __device__ __forceinline__ void wgrad_tn_body(const WgradArgs& a, const WgradBlo
       }                                                                                        \
     }                                                                                          \
   }
-  C2D_WG_LOAD(mbeg);
+  K_WG_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += WBK) {
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
@@ -929,7 +929,7 @@ __device__ __forceinline__ void wgrad_tn_body(const WgradArgs& a, const WgradBlo
       if (gload) *reinterpret_cast<f32x4*>(&Gs[(kr + u * 8) * WG_STRIDE + c4]) = rg[u];
     }
     __syncthreads();
-    C2D_WG_LOAD(mb + WBK);   // next slab (rows past `mend` come back as zeros / are never used)
+    K_WG_LOAD(mb + WBK);   // next slab (rows past `mend` come back as zeros / are never used)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kc = 0; kc < WBK / 16; ++kc) {
@@ -957,7 +957,7 @@ __device__ __forceinline__ void wgrad_tn_body(const WgradArgs& a, const WgradBlo
     __syncthreads();
   }
 
-#undef C2D_WG_LOAD
+#undef K_WG_LOAD
   // split-K result: atomics into dW, or this split's own slab (see wgrad_tn_bf16_kernel)
   float* dw = a.dW + (size_t)tap * a.I * a.J + (size_t)blk.z * a.part_stride;
   const bool part = a.part_stride > 0;
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
   }
   f32x4 rg[G_LD], ra[A_LD];
 
-#define C2D_W3_LOAD(MB)                                                                        \
+#define K_W3_LOAD(MB)                                                                        \
   {                                                                                            \
     const int sg = (MB) * a.ldg * ES, sa = (MB) * a.lda * ES;                                  \
     _Pragma("unroll") for (int u = 0; u < G_LD; ++u)                                           \
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
   const float* const apl = &As[(PAIR ? lh * PIMG : 0) * W3_ASTR + li];
   const float* const gpl = &Gs[(PAIR ? lh * HW : lh) * W3_GSTR + wave * 32 + li];
 
-  C2D_W3_LOAD(mbeg);
+  K_W3_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += R) {
 #pragma unroll
     for (int u = 0; u < G_LD; ++u)
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
       if (ar0 + u * 32 < AROWS)
         *reinterpret_cast<f32x4*>(&As[(ar0 + u * 32) * W3_ASTR + aq4]) = ra[u];
     __syncthreads();
-    C2D_W3_LOAD(mb + R);
+    K_W3_LOAD(mb + R);
     __builtin_amdgcn_sched_barrier(0);
     if (wave_on) {
       if constexpr (PAIR) {
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(Wgrad3Args a) {
     }
     __syncthreads();
   }
-#undef C2D_W3_LOAD
+#undef K_W3_LOAD
 
   if (wave_on) {
     const int jj = j0 + wave * 32 + li;
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_s2_kernel(Wgrad3Args a) {
     aoffs[u] = real ? (unsigned)(apix * a.lda + i0 + aq4) * (unsigned)ES : OOB_OFFSET;
   }
   f32x4 rg[G_LD], ra[A_LD];
-#define C2D_W3S_LOAD(MB)                                                                       \
+#define K_W3S_LOAD(MB)                                                                       \
   {                                                                                            \
     const int sg = (MB) * a.ldg * ES, sa = ((MB) / HWO) * HWI * a.lda * ES;                    \
     _Pragma("unroll") for (int u = 0; u < G_LD; ++u)                                           \
@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_s2_kernel(Wgrad3Args a) {
   const float* const apl = &As[(lh * PIMG) * W3_ASTR + li];           // upper half-wave: odd image
   const float* const gpl = &Gs[(lh * HWO) * W3_GSTR + wave * 32 + li];
 
-  C2D_W3S_LOAD(mbeg);
+  K_W3S_LOAD(mbeg);
   for (int mb = mbeg; mb < mend; mb += R) {
 #pragma unroll
     for (int u = 0; u < G_LD; ++u)
@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_s2_kernel(Wgrad3Args a) {
       if (ar0 + u * 32 < AROWS)
         *reinterpret_cast<f32x4*>(&As[(ar0 + u * 32) * W3_ASTR + aq4]) = ra[u];
     __syncthreads();
-    C2D_W3S_LOAD(mb + R);
+    K_W3S_LOAD(mb + R);
     __builtin_amdgcn_sched_barrier(0);
     if (wave_on) {
 #pragma unroll
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_s2_kernel(Wgrad3Args a) {
     }
     __syncthreads();
   }
-#undef C2D_W3S_LOAD
+#undef K_W3S_LOAD
   static_assert(STEPS == HWO, "one image pair per slab");
 
   if (wave_on) {
@@ -1389,7 +1389,7 @@ void wgrad_tn_bf16_kernel(WgradArgs a) {
   }
   // (PLAIN: rows >= M lie outside the descriptors and come back as zeros; a group's rows end
   // where the next group's begin, so no row is counted twice)
-#define C2D_WB_LOAD(MB)                                                                        \
+#define K_WB_LOAD(MB)                                                                        \
   {                                                                                            \
     if (PLAIN) {                                                                               \
       const int sa = (MB) * a.lda * 2, sg = (MB) * a.ldg * 2;                                  \
@@ -1412,7 +1412,7 @@ void wgrad_tn_bf16_kernel(WgradArgs a) {
   const char* const apl = As + (8 * lh + tq) * WB_RS + (wm * 64 + 16 * tg + 4 * tp) * 2;
   const char* const gpl = Gs + (8 * lh + tq) * WB_RS + (wn * NTJ * 32 + 16 * tg + 4 * tp) * 2;
 
-  C2D_WB_LOAD(mbeg);
+  K_WB_LOAD(mbeg);
   for (int sl = 0, mb = mbeg; sl < nslabs; ++sl, mb += WB_KB) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1420,7 +1420,7 @@ void wgrad_tn_bf16_kernel(WgradArgs a) {
       if (gload) *reinterpret_cast<f32x4*>(Gs + (kr + u * 16) * WB_RS + c8 * 2) = rg[u];
     }
     __syncthreads();
-    C2D_WB_LOAD(mb + WB_KB);
+    K_WB_LOAD(mb + WB_KB);
     __builtin_amdgcn_sched_barrier(0);
     {
       bf16x8 af[2][2], bf[NTJ][2];
@@ -1443,7 +1443,7 @@ void wgrad_tn_bf16_kernel(WgradArgs a) {
     }
     __syncthreads();
   }
-#undef C2D_WB_LOAD
+#undef K_WB_LOAD
 
   // K-groups 1 .. KG-1 hand their accumulators to group 0 through LDS, one 32x32 tile per round
   // ((KG - 1) x 16 KiB of the staging buffers); group 0 sums in group order
@@ -1571,7 +1571,7 @@ __device__ __forceinline__ void wgrad3x3_bf16_body(const Wgrad3Args& a, const in
     gdst[u] = on ? k * W3B_RSG + c * 16 : -1;
   }
   f32x4 rg[G_LD], ra[A_LD];
-#define C2D_W3B_LOAD(MB)                                                                       \
+#define K_W3B_LOAD(MB)                                                                       \
   {                                                                                            \
     const int sg = (MB) * a.ldg * 2, sa = (MB) * a.lda * 2;                                    \
     _Pragma("unroll") for (int u = 0; u < G_LD; ++u) rg[u] = buf_load4(rsG, goffs[u], sg);     \
@@ -1593,7 +1593,7 @@ __device__ __forceinline__ void wgrad3x3_bf16_body(const Wgrad3Args& a, const in
       arow[s][u] = (im * PIMG + (y + 1) * PW + x + 1) * W3B_RSA;
     }
 
-  C2D_W3B_LOAD(mbeg);
+  K_W3B_LOAD(mbeg);
   __syncthreads();
   for (int sl = 0, mb = mbeg; sl < nslabs; ++sl, mb += R) {
 #pragma unroll
@@ -1603,7 +1603,7 @@ __device__ __forceinline__ void wgrad3x3_bf16_body(const Wgrad3Args& a, const in
     for (int u = 0; u < A_LD; ++u)
       if (adst[u] >= 0) *reinterpret_cast<f32x4*>(As + adst[u]) = ra[u];
     __syncthreads();
-    C2D_W3B_LOAD(mb + R);
+    K_W3B_LOAD(mb + R);
     __builtin_amdgcn_sched_barrier(0);
     if (wave_on) {
 #pragma unroll
@@ -1624,7 +1624,7 @@ __device__ __forceinline__ void wgrad3x3_bf16_body(const Wgrad3Args& a, const in
     }
     __syncthreads();
   }
-#undef C2D_W3B_LOAD
+#undef K_W3B_LOAD
 
   // K-groups 1 .. KG-1 hand their nine accumulators to group 0 through LDS, three taps per round
   if constexpr (KG > 1) {
@@ -1812,9 +1812,9 @@ bool make_sk_plan(const IgemmArgs& a, int slots, const IgemmWs& ws, SkPlan* sk, 
 }
 
 bool sk_disabled_by_env() {
-  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  static const bool tune = c2d_tune_on();
   if (!tune) return false;
-  const char* e = getenv("C2D_IGEMM_SK");
+  const char* e = c2d_tune_get("igemm_sk");
   return e && e[0] == '0';
 }
 
@@ -1893,15 +1893,15 @@ int launch_igemm_bf16(IgemmArgs a, hipStream_t s) {
 template <bool PM>
 int launch_igemm_bf16_wide(const IgemmArgs& a, hipStream_t s) {
   const int nt = c2d_ceil_div(a.N, 64);
-#define C2D_WIDE(NT_)                                                                 \
+#define K_WIDE(NT_)                                                                 \
   case NT_:                                                                           \
     if (a.g.mode == 0) return launch_igemm_bf16<0, 4, 2, 1, NT_, PM>(a, s);           \
     return launch_igemm_bf16<1, 4, 2, 1, NT_, PM>(a, s);
   switch (nt) {
-    C2D_WIDE(2) C2D_WIDE(3) C2D_WIDE(4) C2D_WIDE(5) C2D_WIDE(6)
+    K_WIDE(2) K_WIDE(3) K_WIDE(4) K_WIDE(5) K_WIDE(6)
     default: break;
   }
-#undef C2D_WIDE
+#undef K_WIDE
   if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 4, 2, 2, PM>(a, s);
   return launch_igemm_bf16<1, 2, 4, 2, 2, PM>(a, s);
 }
@@ -1955,9 +1955,9 @@ bool x9_resolve(IgemmArgs* a) {
 // nothing, wider ones leave too few blocks for the heavy-first order to even the CUs out);
 // row-major launches: the NT in 2..5 that pads the output width least, the widest on a tie.
 int x9_launch(IgemmArgs a, bool pm, hipStream_t s) {
-  static const bool tune = getenv("C2D_TUNE") != nullptr;
-  static const int force_nt = (tune && getenv("C2D_X9_NT")) ? atoi(getenv("C2D_X9_NT")) : 0;
-  static const int force_nt_pm = (tune && getenv("C2D_X9_NT_PM")) ? atoi(getenv("C2D_X9_NT_PM")) : 0;
+  static const bool tune = c2d_tune_on();
+  static const int force_nt = (tune && c2d_tune_get("x9_nt")) ? atoi(c2d_tune_get("x9_nt")) : 0;
+  static const int force_nt_pm = (tune && c2d_tune_get("x9_nt_pm")) ? atoi(c2d_tune_get("x9_nt_pm")) : 0;
   int best_nt = a.N > 64 ? 4 : 2;
   if (!pm) {
     int best_cols = 1 << 30;
@@ -1986,15 +1986,15 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws_in = Igemm
   // Pixel-major rows for multi-tap convolutions over small per-ROI maps (see decompose<true>).
   const int hw = a.g.rh * a.g.rw;
   // Tuning hooks for tools/sweep_igemm.py (read only when C2D_TUNE is set at load time):
-  // C2D_IGEMM_ROW_MAJOR=1 disables the pixel-major order, C2D_IGEMM_CFG=2|3 forces the 128x64 /
-  // 128x128 tile, C2D_IGEMM_SK=0 the one-tile-per-block form.
-  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  // igemm_row_major=1 disables the pixel-major order, igemm_cfg=2|3 forces the 128x64 /
+  // 128x128 tile, igemm_sk=0 the one-tile-per-block form.
+  static const bool tune = c2d_tune_on();
   bool row_major_only = false;
   int force = 0;   // 2: 128x64, 3: 128x128, 4-6: bf16-only forms (see below)
   if (tune) {
-    const char* e = getenv("C2D_IGEMM_ROW_MAJOR");
+    const char* e = c2d_tune_get("igemm_row_major");
     row_major_only = e && e[0] == '1';
-    e = getenv("C2D_IGEMM_CFG");
+    e = c2d_tune_get("igemm_cfg");
     force = e ? atoi(e) : 0;
   }
   // bf16 (igemm_ring_kernel<..., 2>) block tile by output width, measured per GEMM call of the step
@@ -2031,8 +2031,8 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws_in = Igemm
     if (g_collect) return C2D_ERR_UNSUPPORTED;
     // image groups of 128 (= the rows of every pixel-major block tile: all of a block's MFMA tiles
     // are then ONE pixel, see decompose<true>) unless rounding the image count up to 128 would add
-    // more than 10 % of empty rows; C2D_TUNE=1 C2D_PM_GROUP=32 keeps round 3's groups of 32
-    static const int pm_force = (tune && getenv("C2D_PM_GROUP")) ? atoi(getenv("C2D_PM_GROUP")) : 0;
+    // more than 10 % of empty rows; C2D_TUNE=pm_group=32 keeps round 3's groups of 32
+    static const int pm_force = (tune && c2d_tune_get("pm_group")) ? atoi(c2d_tune_get("pm_group")) : 0;
     const int n128 = c2d_ceil_div(a.g.nimg, 128) * 128;
     // (the stream-K form — a workspace was passed — keeps groups of 32: its cost model,
     // make_sk_plan, walks the pixels of a block's four tiles)
@@ -2040,7 +2040,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws_in = Igemm
     a.M = c2d_ceil_div(a.g.nimg, 1 << a.g.pm) * (1 << a.g.pm) * hw;
     // heavy pixels first (ConvGeom::lpt_ngx): every non-tuning pixel-major tile has 128 rows = one
     // pixel of one image group; the image groups must split evenly over the 8 XCDs
-    static const bool lpt_off = tune && getenv("C2D_PM_LPT") && getenv("C2D_PM_LPT")[0] == '0';
+    static const bool lpt_off = tune && c2d_tune_get("pm_lpt") && c2d_tune_get("pm_lpt")[0] == '0';
     const int ngrp = c2d_ceil_div(a.g.nimg, 128);
     a.g.lpt_ngx = 0;
     if (a.g.pm == 7 && ngrp % 8 == 0 && !lpt_off && force != 4 && force != 5 && !ws.ptr) {
@@ -2086,15 +2086,15 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws_in = Igemm
   //  2000 x 416 x 1024: 0.85 GFLOP — is better off on 64x64 tiles through LDS than on the
   //  one-tile-per-block kernel, whose fragments come straight from memory: forward 37.8 -> 29.2 us;
   //  the 112-column heads of the 20-class configs stay: 12.7 against 27.7 us)
-  static const bool keep_small = tune && getenv("C2D_IGEMM_KEEP_SMALL") != nullptr;
+  static const bool keep_small = tune && c2d_tune_get("igemm_keep_small") != nullptr;
   const bool deep_1x1 = a.g.kh * a.g.kw == 1 && a.M >= 1024 &&
                         (long long)a.M * a.N * a.K >= 600000000ll && !keep_small;
   // (up to 8192 rows: the 10,584-row maps of two 1000-px images — Mixed_4a-e at the reference's
   //  as-shipped operating point — are better off on the 64x64 LDS tiles: 3.54 -> 3.17 ms per bf16
   //  step of two images, 9.04 -> 8.78 fp32; the benchmark's 500x500 image keeps its 1024- and
   //  3969-row layers here and moves Conv2d_2b/2c, 15,625 rows: 3.05 -> 3.02 / 10.83 -> 10.84 ms.
-  //  C2D_TUNE=1 C2D_IGEMM_SMALL_MAX_M=<rows>)
-  static const int small_max_m = (tune && getenv("C2D_IGEMM_SMALL_MAX_M")) ? atoi(getenv("C2D_IGEMM_SMALL_MAX_M")) : 8192;
+  //  C2D_TUNE=igemm_small_max_m=<rows>)
+  static const int small_max_m = (tune && c2d_tune_get("igemm_small_max_m")) ? atoi(c2d_tune_get("igemm_small_max_m")) : 8192;
   if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= small_max_m && !a.fy && !a.mo_n && !deep_1x1) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
@@ -2339,9 +2339,9 @@ static int conv_dgrad_impl(const float* dc, int ldc, int coff, const float* w, f
   // average for a 3x3 kernel instead of 9 mostly-empty ones.
   // bf16: the four classes are 141-250 workgroups each — less than one per CU, most of a launch ramp
   // and epilogue: they leave as ONE grouped launch (igemm_bf16.hip: ring_group_begin / _end) when
-  // they pick the same ring instance.  C2D_TUNE=1 C2D_DGRAD_S2_GROUP=0: four launches.
-  static const bool group_off = getenv("C2D_TUNE") && getenv("C2D_DGRAD_S2_GROUP") &&
-                                getenv("C2D_DGRAD_S2_GROUP")[0] == '0';
+  // they pick the same ring instance.  C2D_TUNE=dgrad_s2_group=0: four launches.
+  static const bool group_off = c2d_tune_on() && c2d_tune_get("dgrad_s2_group") &&
+                                c2d_tune_get("dgrad_s2_group")[0] == '0';
   const bool grouped = es == 2 && !query && !ws.ptr && !group_off;
   if (grouped) ring_group_begin();
   for (int py = 0; py < 2; ++py)
@@ -2668,15 +2668,15 @@ extern "C" int c2d_conv1x1_dgrad_multi_bf16(int nseg, const void* const* dcs, co
                           IgemmWs{nullptr, 0}, stream, 2);
 }
 
-// Tuning hooks (read only when C2D_TUNE is set at load time): C2D_WGRAD_BF16_MFMA=0 sends bf16
-// operands through the widening fp32 kernels, C2D_WGRAD3_WI forces the i-groups per block.
+// Tuning hooks (read only when C2D_TUNE is set at load time): wgrad_bf16_mfma=0 sends bf16
+// operands through the widening fp32 kernels, wgrad3_wi forces the i-groups per block.
 static bool wgrad_bf16_mfma_enabled() {
-  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  static const bool tune = c2d_tune_on();
   if (!tune) return true;
-  const char* e = getenv("C2D_WGRAD_BF16_MFMA");
+  const char* e = c2d_tune_get("wgrad_bf16_mfma");
   return !(e && e[0] == '0');
 }
-// C2D_WGRAD_BF16_SLOTS=<percent>: resident-workgroup budget of the bf16 filter-gradient launches
+// wgrad_bf16_slots=<percent>: resident-workgroup budget of the bf16 filter-gradient launches
 // relative to the default (fewer workgroups = fewer split-K atomics, less latency hiding).
 // Round 5: 75 % of a resident round by default.  A filter-gradient workgroup on a CU (59 KB of LDS
 // for the nine-tap kernel) leaves room for ONE of the main stream's ring-GEMM workgroups instead
@@ -2684,17 +2684,17 @@ static bool wgrad_bf16_mfma_enabled() {
 // filter-gradient workgroups measured 2.922-2.926 against 2.945-3.002 ms per bf16 step over three
 // alternating runs (85 %: 2.948-2.959, 65 %: 2.934-2.949, 50 %: 2.99).
 static int wgrad_bf16_slots(int slots) {
-  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  static const bool tune = c2d_tune_on();
   if (tune) {
-    const char* e = getenv("C2D_WGRAD_BF16_SLOTS");
+    const char* e = c2d_tune_get("wgrad_bf16_slots");
     if (e && atoi(e) > 0) return slots * atoi(e) / 100;
   }
   return slots * 3 / 4;
 }
 static int wgrad3_bf16_igroups(int cin) {
-  static const bool tune = getenv("C2D_TUNE") != nullptr;
+  static const bool tune = c2d_tune_on();
   if (tune) {
-    const char* e = getenv("C2D_WGRAD3_WI");
+    const char* e = c2d_tune_get("wgrad3_wi");
     if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
   }
   (void)cin;
@@ -2736,8 +2736,8 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     // workgroups (half the atomic bytes) win over the extra latency hiding (tools/bench_wgrad_bf16.py)
     // K-groups per block (wgrad3x3_bf16_kernel): two groups of four waves sharing an output tile
     // measured 2-6 % faster alone and 1 % slower inside the step (4.177 against 4.127 ms): off.
-    // C2D_TUNE=1 C2D_WGRAD3_KG=1|2.
-    static const int kg_env = (getenv("C2D_TUNE") && getenv("C2D_WGRAD3_KG")) ? atoi(getenv("C2D_WGRAD3_KG")) : 0;
+    // C2D_TUNE=wgrad3_kg=1|2.
+    static const int kg_env = (c2d_tune_on() && c2d_tune_get("wgrad3_kg")) ? atoi(c2d_tune_get("wgrad3_kg")) : 0;
     const int kg = wi != 1 ? 1 : (kg_env == 1 || kg_env == 2) ? kg_env : 1;
     int splits = wgrad_bf16_slots(wi != 1 || kg != 1 ? 256 : iw == 4 ? 256 : 384) / b.tiles;
     if (splits < 1) splits = 1;
@@ -2766,7 +2766,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     b.M = n * ih * iw; b.I = cin; b.J = cout; b.h = ih; b.w = iw;
     b.itiles = cin / 32; b.jtiles = c2d_ceil_div(cout, 128); b.tiles = b.itiles * b.jtiles;
     C2D_CHECK_ARG((long long)b.M * ldx * 4 < (long long)OOB_OFFSET && (long long)b.M * ldc * 4 < (long long)OOB_OFFSET);
-    static const int pair7 = (getenv("C2D_TUNE") && getenv("C2D_WGRAD3_PAIR7")) ? atoi(getenv("C2D_WGRAD3_PAIR7")) : 1;
+    static const int pair7 = (c2d_tune_on() && c2d_tune_get("wgrad3_pair7")) ? atoi(c2d_tune_get("wgrad3_pair7")) : 1;
     const int slab = iw == 4 ? 32 : pair7 ? 98 : 49;       // whole images per slab
     const int nslabs = c2d_ceil_div(b.M, slab);
     // 2 blocks per CU in ONE round: rounding the split count UP put a handful of blocks into a
@@ -2820,7 +2820,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   const bool narrow = cout % 128 != 0 && cout % 128 <= 64;   // 128x64 block tiles
   const int bj = narrow ? 64 : 128;
   const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, bj);
-  static const int fp32_slots = (getenv("C2D_TUNE") && getenv("C2D_WGRAD_SLOTS")) ? atoi(getenv("C2D_WGRAD_SLOTS")) : 1024;
+  static const int fp32_slots = (c2d_tune_on() && c2d_tune_get("wgrad_slots")) ? atoi(c2d_tune_get("wgrad_slots")) : 1024;
   int splits = (bf16_mfma ? wgrad_bf16_slots(512) : fp32_slots) / tiles;   // 4 (bf16: 2) blocks per CU, one round
   const int max_splits = c2d_ceil_div(a.M, 4 * WBK);      // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
@@ -2847,8 +2847,8 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     // seven per-tap shapes of the second stage): alone 384 us with one group, 359 with two, 321
     // with four; INSIDE the training step, where these launches share the CUs with the input-
     // gradient GEMMs of the main stream, 4.127 / 4.113 / 4.166 ms per step — the 1024-thread,
-    // 80-KiB blocks of four groups no longer fit beside a GEMM block.  C2D_TUNE=1 C2D_WGRAD_KG=1|2|4.
-    static const int kg_env = (getenv("C2D_TUNE") && getenv("C2D_WGRAD_KG")) ? atoi(getenv("C2D_WGRAD_KG")) : 0;
+    // 80-KiB blocks of four groups no longer fit beside a GEMM block.  C2D_TUNE=wgrad_kg=1|2|4.
+    static const int kg_env = (c2d_tune_on() && c2d_tune_get("wgrad_kg")) ? atoi(c2d_tune_get("wgrad_kg")) : 0;
     const int kg = kg_env == 1 || kg_env == 2 || kg_env == 4 ? kg_env : 2;
     if (kg > 1) {
       splits = wgrad_bf16_slots(256) / tiles;
@@ -2864,7 +2864,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     grid.x = a.tiles_x * a.tiles_y * a.nsplits;
     dispatch_note(plain ? "wgrad_tn_bf16_kernel<%d, true, %d>" : "wgrad_tn_bf16_kernel<%d, false, %d>",
                   narrow ? 1 : 2, kg);
-#define C2D_WB_LAUNCH(KG_)                                                                      \
+#define K_WB_LAUNCH(KG_)                                                                      \
   {                                                                                            \
     const dim3 blockdim(256 * KG_);                                                            \
     if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<1, true, KG_>), grid, blockdim, 0, st, a);   \
@@ -2872,8 +2872,8 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     else if (plain) hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, true, KG_>), grid, blockdim, 0, st, a);        \
     else hipLaunchKernelGGL((wgrad_tn_bf16_kernel<2, false, KG_>), grid, blockdim, 0, st, a);                  \
   }
-    if (kg == 4) C2D_WB_LAUNCH(4) else if (kg == 2) C2D_WB_LAUNCH(2) else C2D_WB_LAUNCH(1)
-#undef C2D_WB_LAUNCH
+    if (kg == 4) K_WB_LAUNCH(4) else if (kg == 2) K_WB_LAUNCH(2) else K_WB_LAUNCH(1)
+#undef K_WB_LAUNCH
     return c2d_launch_status();
   }
   if (splits_out) *splits_out = a.nsplits;

@@ -870,7 +870,7 @@ int launch_bn_relu_bwd(const T* dy, int lddy, int dyoff, const T* y, int ldy, in
   const int c4n = c / 4;
   const int blocks = c2d_ceil_div(rows, rows_per_block);
   const HeadGrad hg = head ? *head : HeadGrad{nullptr, 0, 0, nullptr, 0, 0, 1, 1.0f, 0};
-#define C2D_BNB(TX)                                                                          \
+#define K_BNB(TX)                                                                          \
   {                                                                                          \
     if (head && head->dmean)                                                                 \
       hipLaunchKernelGGL((bn_relu_bwd_kernel<TX, T, true>), dim3(blocks), dim3(256), 0, s, dy, lddy, \
@@ -881,11 +881,11 @@ int launch_bn_relu_bwd(const T* dy, int lddy, int dyoff, const T* y, int ldy, in
                          dyoff, y, ldy, yoff, scale, beta, gamma, dc, dbeta, dgamma, partials, rows, \
                          c4n, rows_per_block, hg);                                           \
   }
-  if (c4n <= 16) C2D_BNB(16)
-  else if (c4n <= 32) C2D_BNB(32)
-  else if (c4n <= 64) C2D_BNB(64)
-  else C2D_BNB(128)
-#undef C2D_BNB
+  if (c4n <= 16) K_BNB(16)
+  else if (c4n <= 32) K_BNB(32)
+  else if (c4n <= 64) K_BNB(64)
+  else K_BNB(128)
+#undef K_BNB
   return c2d_launch_status();
 }
 
@@ -903,13 +903,13 @@ int pool3x3_fwd_impl(const T* x, int ldx, int xoff, T* y, int ldy, int yoff, uin
     // per-ROI maps of the second stage: whole-map kernel, every input element fetched once
     const dim3 grid(grid_for((long long)n * (c / 4))), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define C2D_POOL_F(IH, S, MD)                                                                    \
+#define K_POOL_F(IH, S, MD)                                                                    \
   hipLaunchKernelGGL((pool3x3_map_fwd_kernel<IH, S, MD, T>), grid, block, 0, st, x, ldx, xoff, y, \
                      ldy, yoff, argmax, n, c / 4)
-    if (ih == 4 && mode == 0) C2D_POOL_F(4, 1, 0);
-    else if (ih == 4) C2D_POOL_F(4, 1, 1);
-    else C2D_POOL_F(7, 2, 0);
-#undef C2D_POOL_F
+    if (ih == 4 && mode == 0) K_POOL_F(4, 1, 0);
+    else if (ih == 4) K_POOL_F(4, 1, 1);
+    else K_POOL_F(7, 2, 0);
+#undef K_POOL_F
     return c2d_launch_status();
   }
   hipLaunchKernelGGL(pool3x3_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0,
@@ -931,14 +931,14 @@ int pool3x3_bwd_impl(const T* dy, int lddy, int dyoff, const uint8_t* argmax, T*
       ((ih == 4 && stride == 1) || (ih == 7 && stride == 2 && mode == 0))) {
     const dim3 grid(grid_for((long long)n * (c / 4))), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define C2D_POOL_B(IH, S, MD, YM)                                                                 \
+#define K_POOL_B(IH, S, MD, YM)                                                                 \
   hipLaunchKernelGGL((pool3x3_map_bwd_kernel<IH, S, MD, T, YM>), grid, block, 0, st, dy, lddy,     \
                      dyoff, argmax, dx, lddx, dxoff, n, c / 4, accumulate, ymask, ldym, ymoff)
-    if (ih == 4 && mode == 0) C2D_POOL_B(4, 1, 0, false);
-    else if (ih == 4 && ymask) C2D_POOL_B(4, 1, 1, true);
-    else if (ih == 4) C2D_POOL_B(4, 1, 1, false);
-    else C2D_POOL_B(7, 2, 0, false);
-#undef C2D_POOL_B
+    if (ih == 4 && mode == 0) K_POOL_B(4, 1, 0, false);
+    else if (ih == 4 && ymask) K_POOL_B(4, 1, 1, true);
+    else if (ih == 4) K_POOL_B(4, 1, 1, false);
+    else K_POOL_B(7, 2, 0, false);
+#undef K_POOL_B
     return c2d_launch_status();
   }
   hipLaunchKernelGGL(pool3x3_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0,

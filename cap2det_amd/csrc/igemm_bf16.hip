@@ -24,9 +24,9 @@ namespace {
 
 
 // ---- host side ---------------------------------------------------------------------------------
-// Tuning hooks (read once, only with C2D_TUNE=1): C2D_RING_BK=32|64, C2D_RING_D=2|3 (more in a
+// Tuning hooks (read once, only with C2D_TUNE=1): ring_bk=32|64, ring_d=2|3 (more in a
 // -DC2D_RING_SWEEP build) force the stage depth / ring depth where an instance exists;
-// C2D_RING=0 makes every bf16 convolution fail with C2D_ERR_UNSUPPORTED (there is no second bf16
+// ring=0 makes every bf16 convolution fail with C2D_ERR_UNSUPPORTED (there is no second bf16
 // GEMM: a check that nothing falls back silently).
 #ifdef C2D_RING_TRACE
 unsigned long long* g_ring_trace = nullptr;
@@ -35,10 +35,10 @@ struct RingTune { int bk, d, off; };
 const RingTune& ring_tune() {
   static const RingTune t = [] {
     RingTune r = {0, 0, 0};
-    if (getenv("C2D_TUNE")) {
-      if (const char* e = getenv("C2D_RING_BK")) r.bk = atoi(e);
-      if (const char* e = getenv("C2D_RING_D")) r.d = atoi(e);
-      if (const char* e = getenv("C2D_RING")) r.off = e[0] == '0';
+    if (c2d_tune_on()) {
+      if (const char* e = c2d_tune_get("ring_bk")) r.bk = atoi(e);
+      if (const char* e = c2d_tune_get("ring_d")) r.d = atoi(e);
+      if (const char* e = c2d_tune_get("ring")) r.off = e[0] == '0';
     }
     return r;
   }();
@@ -89,7 +89,7 @@ int launch_one(IgemmArgs a, hipStream_t s) {
     a.total_slabs = 0;
     for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], BKT);
   }
-  static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
+  static const int dbg_env = (c2d_tune_on() && c2d_tune_get("igemm_dbg")) ? atoi(c2d_tune_get("igemm_dbg")) : 0;
   a.dbg = dbg_env;
 #ifdef C2D_RING_TRACE
   a.trace = g_ring_trace;
@@ -129,7 +129,7 @@ int launch_one(IgemmArgs a, hipStream_t s) {
 
 // (stage depth, ring depth) of a block tile, measured per GEMM call of the step (tools/
 // sweep_step_gemms.sh + tools/sweep_cold.py, N = 2000 ROIs; with the operands warm from the previous
-// repetition and, as inside a step, cold: C2D_BENCH_COLD=1).  What decides is how many workgroups
+// repetition and, as inside a step, cold: bench_cold=1).  What decides is how many workgroups
 // share a CU, not how deep one workgroup prefetches: these GEMMs are short (K = 128 .. 2304: 2 - 36
 // stages), so a workgroup spends as long in its ramp (first stages in flight) and its epilogue as
 // in its K loop, and only ANOTHER workgroup's K loop fills the matrix pipe meanwhile.  Rings of
@@ -145,9 +145,9 @@ int launch_one(IgemmArgs a, hipStream_t s) {
 //     142 -> 102 us);
 //   * everything else: 64-deep stages, two buffers.
 #ifdef C2D_RING_SWEEP
-#define C2D_RING_COMBOS(X) X(64, 2) X(32, 3) X(64, 3) X(32, 4)
+#define K_RING_COMBOS(X) X(64, 2) X(32, 3) X(64, 3) X(32, 4)
 #else
-#define C2D_RING_COMBOS(X) X(64, 2) X(32, 3)
+#define K_RING_COMBOS(X) X(64, 2) X(32, 3)
 #endif
 template <int MODE, int WM, int WN, int MT, int NT, bool PM>
 int launch_tile(const IgemmArgs& a, hipStream_t s) {
@@ -161,11 +161,11 @@ int launch_tile(const IgemmArgs& a, hipStream_t s) {
   if (WM == 2 && WN == 2 && MT == 2 && NT == 1 && blocks > 768) { bk = 32; d = 3; }
   if (t.bk) bk = t.bk;
   if (t.d) d = t.d;
-#define C2D_RING_CASE(BKT_, D_)                                                                \
+#define K_RING_CASE(BKT_, D_)                                                                \
   if constexpr (D_ * ROWS * BKT_ * 2 <= LDS && (D_ - 2) * (ROWS * BKT_ * 2 / (WM * WN * 1024) + 1) <= 63) \
     if (bk == BKT_ && d == D_) return launch_one<MODE, WM, WN, MT, NT, PM, BKT_, D_>(a, s);
-  C2D_RING_COMBOS(C2D_RING_CASE)
-#undef C2D_RING_CASE
+  K_RING_COMBOS(K_RING_CASE)
+#undef K_RING_CASE
   // (a forced combination that does not exist for this tile: the default)
   return launch_one<MODE, WM, WN, MT, NT, PM, 64, 2>(a, s);
 }
@@ -184,16 +184,16 @@ int launch_shape(const IgemmArgs& a, bool pm, hipStream_t s) {
 // under the MFMAs of the three others on its CU — with ONE exception the default takes: the 3x3
 // forward convolutions with 257..384 output columns on the per-ROI maps (192->320 of Mixed_5b/5c:
 // five 64-column tiles per row block), 284 -> 234 us per call with 16-float stages in two buffers
-// (24 KiB: five workgroups per CU).  C2D_TUNE=1 C2D_RING_FP32=1|0 forces the ring on (all tiles,
-// sweep build) / off; C2D_RINGF_BK = 16 | 32, C2D_RINGF_D = ring depth (sweep build).
+// (24 KiB: five workgroups per CU).  C2D_TUNE=ring_fp32=1|0 forces the ring on (all tiles,
+// sweep build) / off; ringf_bk = 16 | 32, ringf_d = ring depth (sweep build).
 struct RingF32Tune { int on, bk, d; };
 const RingF32Tune& ringf_tune() {
   static const RingF32Tune t = [] {
     RingF32Tune r = {-1, 0, 0};
-    if (getenv("C2D_TUNE")) {
-      if (const char* e = getenv("C2D_RING_FP32")) r.on = atoi(e);
-      if (const char* e = getenv("C2D_RINGF_BK")) r.bk = atoi(e);
-      if (const char* e = getenv("C2D_RINGF_D")) r.d = atoi(e);
+    if (c2d_tune_on()) {
+      if (const char* e = c2d_tune_get("ring_fp32")) r.on = atoi(e);
+      if (const char* e = c2d_tune_get("ringf_bk")) r.bk = atoi(e);
+      if (const char* e = c2d_tune_get("ringf_d")) r.d = atoi(e);
     }
     return r;
   }();
@@ -397,7 +397,7 @@ __device__ __forceinline__ void wgrad1x1_bf16_ring_body(const WgradArgs& a, cons
 
   // stage `st` (rows mbeg + st * BKT ...) into ring slot `slot`; rows >= M lie outside the
   // descriptors and come back as zeros (splits end on stage boundaries: no row is counted twice)
-#define C2D_W_ISSUE(SLOT, ST)                                                                  \
+#define K_W_ISSUE(SLOT, ST)                                                                  \
   {                                                                                            \
     const int m0 = mbeg + (ST) * BKT;                                                          \
     _Pragma("unroll") for (int p = 0; p < A_LOADS; ++p)                                        \
@@ -411,7 +411,7 @@ __device__ __forceinline__ void wgrad1x1_bf16_ring_body(const WgradArgs& a, cons
   }
 #pragma unroll
   for (int d = 0; d < D - 1; ++d)
-    if (d < cnt) C2D_W_ISSUE(d, d)
+    if (d < cnt) K_W_ISSUE(d, d)
 
   // transposed-read addresses: k rows 16 s + 8 lh + tq (+4), 64-byte granule of the tile's columns
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
@@ -431,7 +431,7 @@ __device__ __forceinline__ void wgrad1x1_bf16_ring_body(const WgradArgs& a, cons
     else if (D > 2 && ahead >= 1) wait_vmcnt<(D > 2 ? 1 : 0) * PER>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (it + D - 1 < cnt) C2D_W_ISSUE(slot_in, it + D - 1)
+    if (it + D - 1 < cnt) K_W_ISSUE(slot_in, it + D - 1)
     const char* const As = smem + slot * A_BYTES;
     const char* const Gs = smemG + slot * G_BYTES;
     bf16x8 af[2][KS], bf[NTJ][KS];
@@ -458,7 +458,7 @@ __device__ __forceinline__ void wgrad1x1_bf16_ring_body(const WgradArgs& a, cons
     if (++slot == D) slot = 0;
     if (++slot_in == D) slot_in = 0;
   }
-#undef C2D_W_ISSUE
+#undef K_W_ISSUE
 
   // split-K result: fp32 atomics into dW, or (part_stride > 0) plain stores into this split's slab
   float* dw = a.dW + (size_t)blk.z * a.part_stride;
@@ -479,31 +479,31 @@ __device__ __forceinline__ void wgrad1x1_bf16_ring_body(const WgradArgs& a, cons
   }
 }
 
-#define C2D_WRING_BOUNDS(NTJ, BKT, D)                                                            \
+#define K_WRING_BOUNDS(NTJ, BKT, D)                                                            \
   __launch_bounds__(256, (160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 3                      \
                              ? 3 : ((160 * 1024) / (D * BKT * (128 + NTJ * 64) * 2) >= 2 ? 2 : 1))
 template <int NTJ, int BKT, int D>
-__global__ C2D_WRING_BOUNDS(NTJ, BKT, D) void wgrad1x1_bf16_ring_kernel(WgradArgs a) {
+__global__ K_WRING_BOUNDS(NTJ, BKT, D) void wgrad1x1_bf16_ring_kernel(WgradArgs a) {
   wgrad1x1_bf16_ring_body<NTJ, BKT, D>(a, wgrad_block(a));
 }
 // several filter gradients of one input in one launch (see WgradGroupArgs)
 template <int NTJ, int BKT, int D>
-__global__ C2D_WRING_BOUNDS(NTJ, BKT, D) void wgrad1x1_bf16_ring_group_kernel(WgradGroupArgs g) {
+__global__ K_WRING_BOUNDS(NTJ, BKT, D) void wgrad1x1_bf16_ring_group_kernel(WgradGroupArgs g) {
   int p;
   const WgradBlock blk = wgrad_group_block(g, &p);
   wgrad1x1_bf16_ring_body<NTJ, BKT, D>(g.a[p], blk);
 }
-#undef C2D_WRING_BOUNDS
+#undef K_WRING_BOUNDS
 
 struct WgradTune { int bk, d, slots, off; };
 const WgradTune& wgrad_tune() {
   static const WgradTune t = [] {
     WgradTune r = {0, 0, 0, 0};
-    if (getenv("C2D_TUNE")) {
-      if (const char* e = getenv("C2D_WRING_BK")) r.bk = atoi(e);
-      if (const char* e = getenv("C2D_WRING_D")) r.d = atoi(e);
-      if (const char* e = getenv("C2D_WRING_SLOTS")) r.slots = atoi(e);
-      if (const char* e = getenv("C2D_WRING")) r.off = e[0] == '0';
+    if (c2d_tune_on()) {
+      if (const char* e = c2d_tune_get("wring_bk")) r.bk = atoi(e);
+      if (const char* e = c2d_tune_get("wring_d")) r.d = atoi(e);
+      if (const char* e = c2d_tune_get("wring_slots")) r.slots = atoi(e);
+      if (const char* e = c2d_tune_get("wring")) r.off = e[0] == '0';
     }
     return r;
   }();
@@ -524,7 +524,7 @@ int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool 
   // of 129..256 columns (576->192: 68 -> 49 us, 1024->192: 40 -> 33, 1024->160: 39 -> 30);
   // 128-wide layers stay on the two-K-group kernel of conv_gemm.hip (30 us); the 352-wide ones
   // measured equal with warm operands (49 us either way) and 78 -> 65 us with cold ones
-  // (C2D_BENCH_COLD=1: what the step sees), so they take the ring as well.
+  // (bench_cold=1: what the step sees), so they take the ring as well.
   if (!t.bk && !t.d && !t.slots && !(a.J > 128 && a.J <= 384)) return C2D_ERR_UNSUPPORTED;
   const bool narrow = a.J % 128 != 0 && a.J % 128 <= 64;    // 128 x 64 block tiles
   const int bj = narrow ? 64 : 128;
@@ -544,13 +544,13 @@ int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool 
   if (splits_only) return C2D_OK;
   const dim3 grid(tiles * a.nsplits), block(256);
   dispatch_note_ext("wgrad1x1_bf16_ring_kernel<%d, %d, %d>", narrow ? 1 : 2, bk, d);
-#define C2D_WR(NTJ_, BK_, D_)                                                                   \
+#define K_WR(NTJ_, BK_, D_)                                                                   \
   if ((narrow ? 1 : 2) == NTJ_ && bk == BK_ && d == D_) {                                      \
     hipLaunchKernelGGL((wgrad1x1_bf16_ring_kernel<NTJ_, BK_, D_>), grid, block, 0, s, a);      \
     return c2d_launch_status();                                                                \
   }
-  C2D_WR(1, 64, 2) C2D_WR(2, 64, 2) C2D_WR(1, 32, 3) C2D_WR(2, 32, 3)
-#undef C2D_WR
+  K_WR(1, 64, 2) K_WR(2, 64, 2) K_WR(1, 32, 3) K_WR(2, 32, 3)
+#undef K_WR
   return C2D_ERR_UNSUPPORTED;
 }
 

@@ -213,7 +213,7 @@ struct IgemmArgs {
   long long mo_boff[4]; long long mo_bbytes;
   float* mo_C[4]; int mo_ldc[4], mo_coff[4];
   const float* mo_scale[4]; const float* mo_shift[4];
-  int dbg;                  // ablation bits (C2D_TUNE=1 C2D_IGEMM_DBG; ring kernel): 2 no weight DMA, 4 no MFMA, 8 no epilogue, 16 no B fragment reads, 64 no DMA after the prologue
+  int dbg;                  // ablation bits (C2D_TUNE=igemm_dbg; ring kernel): 2 no weight DMA, 4 no MFMA, 8 no epilogue, 16 no B fragment reads, 64 no DMA after the prologue
   ConvGeom g;
   unsigned long long* trace;   // diagnostic build (C2D_TRACE) only: 8 x u64 per block (tools/trace_igemm.py)
 };

@@ -264,7 +264,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
   unsigned tvq_lo = ~0u, tvq_hi = ~0u;   // tap validity bits (8 per ring slot) of the stages in the ring
   unsigned aoff[A_LOADS], boff[B_LOADS1];
 
-#define C2D_RETAP()                                                                            \
+#define K_RETAP()                                                                            \
   {                                                                                            \
     const int delta = __builtin_amdgcn_readlane(tab_delta, cur.tap);                           \
     const int toff = __builtin_amdgcn_readlane(tab_toff, cur.tap);                             \
@@ -278,31 +278,31 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
                 ((1u << MT) - 1u);                                                             \
   }
   // one DMA piece (8 or 16 rows x 128 / 64 B per wave-instruction); lanes past a K tail fetch zeros
-#define C2D_PIECE_A(SLOT, I)                                                                   \
+#define K_PIECE_A(SLOT, I)                                                                   \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                    \
       rsA, (lds_void_t*)(smem + (SLOT) * A_BYTES + wave * 1024 + (I) * ROWS_PER_PASS * RB), 16, \
       (int)(cur.kc + q4 < cur.Kc ? aoff[I] : OOB_OFFSET), cur.kc * ES, 0, 0);
-#define C2D_PIECE_B1(SLOT, I, P)                                                               \
+#define K_PIECE_B1(SLOT, I, P)                                                               \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                    \
       rsB, (lds_void_t*)(smemB + (SLOT) * B_BYTES + (P) * BP_BYTES + wave * 1024 +             \
                          (I) * ROWS_PER_PASS_B * RBB), 16,                                     \
       (int)(cur.kc + q4B < cur.Kc ? boff[I] : OOB_OFFSET), cur.kc * ESB + (P) * bp_stride, 0, 0);
-#define C2D_PIECE_B(SLOT, I)                                                                   \
-  { _Pragma("unroll") for (int pl = 0; pl < BP; ++pl) { C2D_PIECE_B1(SLOT, I, pl) } }
-#define C2D_NOTE_TV(SLOT)                                                                      \
+#define K_PIECE_B(SLOT, I)                                                                   \
+  { _Pragma("unroll") for (int pl = 0; pl < BP; ++pl) { K_PIECE_B1(SLOT, I, pl) } }
+#define K_NOTE_TV(SLOT)                                                                      \
   {                                                                                            \
     if ((SLOT) < 4) tvq_lo = (tvq_lo & ~(0xffu << (8 * ((SLOT) & 3)))) | ((tv_load & 0xffu) << (8 * ((SLOT) & 3))); \
     else tvq_hi = (tvq_hi & ~(0xffu << (8 * ((SLOT) & 3)))) | ((tv_load & 0xffu) << (8 * ((SLOT) & 3))); \
   }
-#define C2D_ISSUE_ALL(SLOT)                                                                    \
+#define K_ISSUE_ALL(SLOT)                                                                    \
   {                                                                                            \
     _Pragma("unroll") for (int i = 0; i < B_LOADS1; ++i)                                       \
-      if (i + 1 < B_LOADS1 || b_last) { C2D_PIECE_B(SLOT, i) }                                 \
-    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(SLOT, i) }               \
-    C2D_NOTE_TV(SLOT)                                                                          \
+      if (i + 1 < B_LOADS1 || b_last) { K_PIECE_B(SLOT, i) }                                 \
+    _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) { K_PIECE_A(SLOT, i) }               \
+    K_NOTE_TV(SLOT)                                                                          \
   }
   // advance the cursor by one stage (next K stage, next real tap, or next segment)
-#define C2D_ADVANCE()                                                                          \
+#define K_ADVANCE()                                                                          \
   {                                                                                            \
     cur.kc += BKT;                                                                             \
     if (cur.kc >= cur.Kc) {                                                                    \
@@ -318,19 +318,19 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
         cur.taps_left &= cur.taps_left - 1ull;                                                 \
         cur.tap = cur.taps_left ? __builtin_ctzll(cur.taps_left) : 0;                          \
       }                                                                                        \
-      C2D_RETAP();                                                                             \
+      K_RETAP();                                                                             \
     }                                                                                          \
   }
   // prologue: stages 0 .. D - 2
   if (cnt > 0) {
     cur.tap = cur.taps_left ? __builtin_ctzll(cur.taps_left) : 0;
-    C2D_RETAP();
-    C2D_ISSUE_ALL(0);
+    K_RETAP();
+    K_ISSUE_ALL(0);
 #pragma unroll
     for (int d = 1; d < D - 1; ++d)
       if (d < cnt) {
-        C2D_ADVANCE();
-        C2D_ISSUE_ALL(d);
+        K_ADVANCE();
+        K_ISSUE_ALL(d);
       }
   }
   // fragment addresses inside a stage buffer: row r, chunk c -> r * RB + ((c ^ swz(r)) << 4)
@@ -387,7 +387,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
     tr_wait += tw1 - tw0;
 #endif
     const bool more = STEADY || (it + D - 1 < cnt && !(a.dbg & 64));
-    if (more) C2D_ADVANCE();
+    if (more) K_ADVANCE();
     // (row-major launches compute every 32-row tile: rows beyond M are zeros and are not stored)
     unsigned onbits = ~0u;
     if (PM || !STEADY) {
@@ -417,7 +417,7 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
       // third of a stage at one wave per SIMD).
       constexpr int GROUPS = KS * MT * NT;
       (void)onbits;
-      if (more) C2D_NOTE_TV(slot_in)
+      if (more) K_NOTE_TV(slot_in)
       int piece_q = 0;
 #pragma unroll
       for (int st = 0; st < KS; ++st) {
@@ -467,9 +467,9 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
               for (int q = 0; q < PER; ++q) {
                 if (q >= piece_q && q < q_end) {
                   if (q < B_LOADS) {
-                    if (q / BP + 1 < B_LOADS1 || b_last) { C2D_PIECE_B1(slot_in, q / BP, q % BP) }
+                    if (q / BP + 1 < B_LOADS1 || b_last) { K_PIECE_B1(slot_in, q / BP, q % BP) }
                   } else {
-                    C2D_PIECE_A(slot_in, q - B_LOADS)
+                    K_PIECE_A(slot_in, q - B_LOADS)
                   }
                 }
               }
@@ -482,10 +482,10 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
       if (more) {
 #pragma unroll
         for (int i = 0; i < B_LOADS1; ++i)
-          if (i + 1 < B_LOADS1 || b_last) { C2D_PIECE_B(slot_in, i) }
+          if (i + 1 < B_LOADS1 || b_last) { K_PIECE_B(slot_in, i) }
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
-        C2D_NOTE_TV(slot_in)
+        for (int i = 0; i < A_LOADS; ++i) { K_PIECE_A(slot_in, i) }
+        K_NOTE_TV(slot_in)
       }
 #ifdef C2D_RING_TRACE
       tr_issue += __builtin_amdgcn_s_memtime() - tw1;
@@ -532,11 +532,11 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
         if (STEADY || !(a.dbg & 2)) {
   #pragma unroll
           for (int i = 0; i < B_LOADS1; ++i)
-            if (i + 1 < B_LOADS1 || b_last) { C2D_PIECE_B(slot_in, i) }
+            if (i + 1 < B_LOADS1 || b_last) { K_PIECE_B(slot_in, i) }
         }
   #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) { C2D_PIECE_A(slot_in, i) }
-        C2D_NOTE_TV(slot_in)
+        for (int i = 0; i < A_LOADS; ++i) { K_PIECE_A(slot_in, i) }
+        K_NOTE_TV(slot_in)
       }
   #ifdef C2D_RING_TRACE
       tr_issue += __builtin_amdgcn_s_memtime() - tw1;
@@ -588,13 +588,13 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
     if (++slot == D) slot = 0;
     if (++slot_in == D) slot_in = 0;
   }
-#undef C2D_RETAP
-#undef C2D_PIECE_A
-#undef C2D_PIECE_B
-#undef C2D_PIECE_B1
-#undef C2D_NOTE_TV
-#undef C2D_ISSUE_ALL
-#undef C2D_ADVANCE
+#undef K_RETAP
+#undef K_PIECE_A
+#undef K_PIECE_B
+#undef K_PIECE_B1
+#undef K_NOTE_TV
+#undef K_ISSUE_ALL
+#undef K_ADVANCE
 #ifdef C2D_RING_TRACE
   const unsigned long long tr2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -951,16 +951,16 @@ __device__ __forceinline__ void igemm_ring_body(const IgemmArgs& a, const int bi
 
 // (x9: the accumulators, three weight planes per column tile and the split need the registers of
 //  at most two waves per SIMD)
-#define C2D_RING_LDS (D * (WM * MT * ES + WN * NT * (BP == 3 ? 6 : ES)) * 32 * BKT)
-#define C2D_RING_BOUNDS                                                                          \
+#define K_RING_LDS (D * (WM * MT * ES + WN * NT * (BP == 3 ? 6 : ES)) * 32 * BKT)
+#define K_RING_BOUNDS                                                                          \
   __launch_bounds__(WM * WN * 64,                                                                \
-                    BP == 3 ? (ring_blocks_per_cu(C2D_RING_LDS) * (WM * WN) / 4 >= 2 ? 2 : 1)    \
-                    : ring_blocks_per_cu(C2D_RING_LDS) * (WM * WN) / 4 > 0                       \
-                        ? ring_blocks_per_cu(C2D_RING_LDS) * (WM * WN) / 4 : 1)
+                    BP == 3 ? (ring_blocks_per_cu(K_RING_LDS) * (WM * WN) / 4 >= 2 ? 2 : 1)    \
+                    : ring_blocks_per_cu(K_RING_LDS) * (WM * WN) / 4 > 0                       \
+                        ? ring_blocks_per_cu(K_RING_LDS) * (WM * WN) / 4 : 1)
 
 template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED = false,
           int BP = 1>
-__global__ C2D_RING_BOUNDS void igemm_ring_kernel(IgemmArgs a) {
+__global__ K_RING_BOUNDS void igemm_ring_kernel(IgemmArgs a) {
   igemm_ring_body<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED, BP>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -975,7 +975,7 @@ struct IgemmRingGroup {
 };
 template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED = false,
           int BP = 1>
-__global__ C2D_RING_BOUNDS void igemm_ring_group_kernel(IgemmRingGroup g) {
+__global__ K_RING_BOUNDS void igemm_ring_group_kernel(IgemmRingGroup g) {
   int p = 0;
   for (int i = 1; i < g.num; ++i)
     if ((int)blockIdx.x >= g.first[i]) p = i;
@@ -983,8 +983,8 @@ __global__ C2D_RING_BOUNDS void igemm_ring_group_kernel(IgemmRingGroup g) {
   igemm_ring_body<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED, BP>(g.a[p], (int)blockIdx.x - g.first[p],
                                                                     g.first[p + 1] - g.first[p]);
 }
-#undef C2D_RING_BOUNDS
-#undef C2D_RING_LDS
+#undef K_RING_BOUNDS
+#undef K_RING_LDS
 
 }  // namespace
 }  // namespace c2d_ig

@@ -84,7 +84,7 @@ int x9_one(IgemmArgs a, hipStream_t s) {
     a.total_slabs = 0;
     for (int i = 0; i < a.nseg; ++i) a.total_slabs += c2d_ceil_div(a.segK[i], BKT);
   }
-  static const int dbg_env = (getenv("C2D_TUNE") && getenv("C2D_IGEMM_DBG")) ? atoi(getenv("C2D_IGEMM_DBG")) : 0;
+  static const int dbg_env = (c2d_tune_on() && c2d_tune_get("igemm_dbg")) ? atoi(c2d_tune_get("igemm_dbg")) : 0;
   a.dbg = dbg_env;
 #ifdef C2D_RING_TRACE
   a.trace = ring_trace_buffer();
@@ -98,7 +98,7 @@ int x9_one(IgemmArgs a, hipStream_t s) {
 }
 
 // Ring geometry per tile (tools/sweep_x9.sh, tools/x9_probe.py; a -DC2D_X9_SWEEP build holds the other
-// combinations behind C2D_TUNE=1 C2D_X9_BK / C2D_X9_D): 32-deep stages (128-byte activation rows,
+// combinations behind C2D_TUNE=x9_bk / x9_d): 32-deep stages (128-byte activation rows,
 // 64-byte weight-plane rows) in two buffers up to 128 columns — 80 KiB for a 128 x 128 tile, two
 // workgroups of four waves per CU; 16-deep stages in two buffers beyond.  Every combination measured
 // within 10 % of every other: what bounds these kernels is the clock the chip holds under bf16 MFMAs
@@ -107,9 +107,9 @@ struct X9Tune { int bk, d; };
 const X9Tune& x9_tune() {
   static const X9Tune t = [] {
     X9Tune r = {0, 0};
-    if (getenv("C2D_TUNE")) {
-      if (const char* e = getenv("C2D_X9_BK")) r.bk = atoi(e);
-      if (const char* e = getenv("C2D_X9_D")) r.d = atoi(e);
+    if (c2d_tune_on()) {
+      if (const char* e = c2d_tune_get("x9_bk")) r.bk = atoi(e);
+      if (const char* e = c2d_tune_get("x9_d")) r.d = atoi(e);
     }
     return r;
   }();

@@ -847,7 +847,7 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
   using Raw = typename std::conditional<sizeof(TG) == 2, unsigned short, unsigned>::type;
   Raw g[U], gn[U];              // raw loaded values: nothing consumes them before their trip
   unsigned k[U], kn[U];
-#define C2D_STRIP_FETCH(G, K, I0)                                                              \
+#define K_STRIP_FETCH(G, K, I0)                                                              \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
     const int o = list[(I0) + u].cell_off;                                                     \
     if (C2D_STRIP_DBG & 1) { (G)[u] = (Raw)(o + u); (K)[u] = o + u; continue; }                \
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
   }
   /* (all scalar entry loads of the trip first: SMEM and LDS share one wait counter, and an  */
   /*  entry load in flight would turn every LDS wait below into a wait for it as well)       */
-#define C2D_STRIP_ADD(G, K, I0)                                                                \
+#define K_STRIP_ADD(G, K, I0)                                                                \
   {                                                                                            \
     RowEntry e[U];                                                                             \
     _Pragma("unroll") for (int u = 0; u < U; ++u) e[u] = list[(I0) + u];                       \
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
       for (int x = 0; x < wf; ++x) drow[(size_t)x * depth] = acc[x * CHUNK + tid];
   };
   int i0 = __builtin_amdgcn_readfirstlane(trip[2 * tb]);
-  C2D_STRIP_FETCH(g, k, i0);
+  K_STRIP_FETCH(g, k, i0);
   for (int t = tb; t < te; ++t) {                  // fixed order: the sum is reproducible
     const int r = __builtin_amdgcn_readfirstlane(trip[2 * t + 1]);
     if (r != row) {
@@ -899,17 +899,17 @@ __global__ __launch_bounds__(CHUNK) void roi_bwd_strip_kernel(
     }
     const int tn = min(t + 1, te - 1);             // (the last trip re-reads itself: harmless)
     const int inext = __builtin_amdgcn_readfirstlane(trip[2 * tn]);
-    C2D_STRIP_FETCH(gn, kn, i0 + U);               // (reads into the zero-weight tail at most)
+    K_STRIP_FETCH(gn, kn, i0 + U);               // (reads into the zero-weight tail at most)
     __builtin_amdgcn_sched_barrier(0);
-    C2D_STRIP_ADD(g, k, i0);
+    K_STRIP_ADD(g, k, i0);
     __builtin_amdgcn_sched_barrier(0);
-    C2D_STRIP_FETCH(g, k, inext);
+    K_STRIP_FETCH(g, k, inext);
     __builtin_amdgcn_sched_barrier(0);
-    C2D_STRIP_ADD(gn, kn, i0 + U);
+    K_STRIP_ADD(gn, kn, i0 + U);
     i0 = inext;
   }
-#undef C2D_STRIP_ADD
-#undef C2D_STRIP_FETCH
+#undef K_STRIP_ADD
+#undef K_STRIP_FETCH
   if (C2D_STRIP_DBG & 2) acc[tid] = dbg_acc;
   flush(slot);
 }
@@ -987,17 +987,17 @@ __global__ __launch_bounds__(256) void roi_crop_pool2_fwd_rowwalk_kernel(
 }  // namespace
 
 // 2x2 / stride-2 pooling over an even crop: the column-streaming kernel (C2D_TUNE=1
-// C2D_CROP_STREAM=0 keeps the generic one, for A/B timing).
+// crop_stream=0 keeps the generic one, for A/B timing).
 static int crop_stream_splits() {
   // measured (tools/bench_crop_fwd.py, N = 2000): 1 -> 119.6 us, 2 -> 107.0, 4 -> 104.6
-  static const char* e = getenv("C2D_TUNE") ? getenv("C2D_CROP_SPLIT") : nullptr;
+  static const char* e = c2d_tune_on() ? c2d_tune_get("crop_split") : nullptr;
   const int v = e ? atoi(e) : 4;
   return v >= 1 && v <= 8 ? v : 1;
 }
 
 static int crop_stream_form(int crop, int pool_k, int pool_s, int pout, int hf, int wf,
                             int depth) {
-  static const char* e = getenv("C2D_TUNE") ? getenv("C2D_CROP_STREAM") : nullptr;
+  static const char* e = c2d_tune_on() ? c2d_tune_get("crop_stream") : nullptr;
   const int want = e ? atoi(e) : 2;       // 2: row-walking form (round 4), 1: column-streaming form
   // the stream kernels address ONE image's map through a raw buffer descriptor with 32-bit byte
   // offsets: maps of 2 GiB and more take the generic kernel (64-bit pointer arithmetic)
@@ -1096,7 +1096,7 @@ extern "C" int c2d_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax,
     if (groups > num_boxes / 16) groups = num_boxes / 16 > 0 ? num_boxes / 16 : 1;
     const dim3 grid(chunks, groups, batch);
     const size_t smem = pix_bytes * ch;
-#define C2D_BWD_LDS(CHV)                                                                      \
+#define K_BWD_LDS(CHV)                                                                      \
   static const hipError_t attr_##CHV = hipFuncSetAttribute(                                   \
       (const void*)roi_crop_pool_bwd_lds_kernel<CHV>,                                         \
       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                \
@@ -1104,9 +1104,9 @@ extern "C" int c2d_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax,
   hipLaunchKernelGGL((roi_crop_pool_bwd_lds_kernel<CHV>), grid, dim3(512), smem,              \
                      (hipStream_t)stream, dout, argmax, boxes, box_ind, dfeat, hf, wf, depth, \
                      num_boxes, crop, pool_k, pool_s, pout)
-    if (ch == 16) { C2D_BWD_LDS(16); }
-    else { C2D_BWD_LDS(8); }
-#undef C2D_BWD_LDS
+    if (ch == 16) { K_BWD_LDS(16); }
+    else { K_BWD_LDS(8); }
+#undef K_BWD_LDS
     return c2d_launch_status();
   }
   hipLaunchKernelGGL(roi_crop_pool_bwd_kernel, dim3(num_boxes), dim3(256), 0,
@@ -1125,10 +1125,10 @@ extern "C" int c2d_roi_crop_pool_bwd(const float* dout, const uint8_t* argmax,
 // whole rows 210 / 206, strips of 42: 129 / 124, 28: 114 / 112, 20: 121 / 119, 14: 127 / 127;
 // 63 x 63: 151 / 145 -> 96 / 94 (32 columns); 48 x 48, 2000 boxes: 224 / 202 -> 179 / 156 (24); the
 // 32 x 32 map LOSES with two strips of 16 (144 / 131 -> 165 / 141) and keeps whole rows.
-// C2D_TUNE=1 C2D_ROI_STRIP_COLS=<columns> (0: whole rows).
+// C2D_TUNE=roi_strip_cols=<columns> (0: whole rows).
 static void strip_ranges(int wf, int* nr, int* wr) {
-  static const int target = (getenv("C2D_TUNE") && getenv("C2D_ROI_STRIP_COLS"))
-                                ? atoi(getenv("C2D_ROI_STRIP_COLS")) : 32;
+  static const int target = (c2d_tune_on() && c2d_tune_get("roi_strip_cols"))
+                                ? atoi(c2d_tune_get("roi_strip_cols")) : 32;
   const int t = target > 0 ? target : wf;
   *nr = (wf + t - 1) / t;
   *wr = (wf + *nr - 1) / *nr;
@@ -1266,15 +1266,15 @@ static int roi_crop_pool_bwd_ws_impl(const TG* dout, const uint8_t* argmax, cons
                        counts, plan, R, W, cap);
   }
   if (phase == 1) return c2d_launch_status();
-#define C2D_STRIP(CHV)                                                                          \
+#define K_STRIP(CHV)                                                                          \
   hipLaunchKernelGGL((roi_bwd_strip_kernel<CHV, TG>), dim3(W * nchunks), dim3(CHV), lds, st,    \
                      dout, argmax, lists, plan, parts, R, W, wr, depth,                         \
                      (long long)num_boxes * pout * pout * depth)
-  if (chunk == 256) { C2D_STRIP(256); }
-  else if (chunk == 192) { C2D_STRIP(192); }
-  else if (chunk == 128) { C2D_STRIP(128); }
-  else { C2D_STRIP(64); }
-#undef C2D_STRIP
+  if (chunk == 256) { K_STRIP(256); }
+  else if (chunk == 192) { K_STRIP(192); }
+  else if (chunk == 128) { K_STRIP(128); }
+  else { K_STRIP(64); }
+#undef K_STRIP
   const int row4 = wr * depth / 4;
   hipLaunchKernelGGL(roi_bwd_sum_parts_kernel, dim3((row4 + 255) / 256, R), dim3(256), 0, st,
                      (const float4*)parts, plan, (float4*)dfeat, W, R, nr, wr, wf, depth / 4);

@@ -36,7 +36,7 @@ class Model(ModelBase):
     (configs[2], [4]: the convolution towers behind the stem — the single-image first stage, the ROI
     crop output and the second stage — in bf16 storage with fp32 accumulation; the stem, the map
     the ROI crop interpolates, heads, losses, variables and optimiser stay fp32;
-    C2D_FIRST_STAGE_FP32=1 keeps the first stage in fp32 as well).
+    C2D_TUNE=first_stage_fp32=1 keeps the first stage in fp32 as well).
     allow_missing_pretrained: keep the synthetic initial values when
     `frcnn_options.checkpoint_path` names a file that does not exist (benchmarks and tests; the
     reference's tf.train.init_from_checkpoint fails hard, models/utils.py:181-186, and so does
@@ -454,7 +454,7 @@ class Model(ModelBase):
     # s0 = concat(0, proba or scores): the class columns are searched directly (:306-312)
     s0 = bufs["proba"] if options.oicr_use_proba_r_given_c else bufs["scores0"]
     s0_ld, s0_off = c, 0
-    if k > 0 and os.environ.get("C2D_OICR_STAGEWISE") != "1":
+    if k > 0:
       # all stages in three launches: stage i + 1 selects on softmax(scores_i)[..., 1:] (:328),
       # which depends on the forward pass only, not on the loss of stage i
       ops.oicr_refine_fwd_bwd(bufs["logits"], self._npad, 2 * c, k, s0, s0_ld, s0_off, proposals,
@@ -464,16 +464,6 @@ class Model(ModelBase):
       for i in range(k):
         loss_dict['oicr_cross_entropy_loss_at_{}'.format(i + 1)] = losses[i + 1]
       return loss_dict
-    for i in range(k):
-      off = 2 * c + i * (c + 1)
-      ops.oicr_select(s0, s0_ld, s0_off, num_proposals, proposals, bufs["idx"][i],
-                      bufs["top_boxes"][i], b, n, c)
-      ops.oicr_loss_fwd_bwd(bufs["logits"], self._npad, off, bufs["top_boxes"][i], proposals, labels,
-                            num_proposals, options.oicr_iou_threshold, options.oicr_loss_weight, b,
-                            n, c, losses[i + 1:i + 2], bufs["dlogits"], self._npad, off,
-                            bufs["softmax"][i])
-      loss_dict['oicr_cross_entropy_loss_at_{}'.format(i + 1)] = losses[i + 1]
-      s0, s0_ld, s0_off = bufs["softmax"][i], c + 1, 1       # softmax(scores_1)[..., 1:] (:328)
     return loss_dict
 
   def regularization_loss(self, step_zeroed=False):

@@ -20,6 +20,7 @@ import os
 import torch
 
 from cap2det_amd import hip_ops as ops
+from cap2det_amd import tune
 
 BN_EPS = 0.001
 FIRST_SCOPE = "first_stage_feature_extraction/InceptionV2/"
@@ -79,13 +80,8 @@ SECOND_STAGE = [
 GROUP_MAX_ROWS = 16384   # block inputs up to this many rows use grouped launches per level
 # block inputs from this many rows on take ONE grouped filter-gradient launch for their 1x1 entry
 # convolutions (c2d_conv1x1_wgrad_multi); below, the row splits of one output already fill the chip
-WGRAD_MULTI_MIN_ROWS = int(os.environ.get("C2D_WGRAD_MULTI_MIN_ROWS", "8192"))
-# bf16 networks, C2D_WGRAD3_GROUP=1: one grouped launch for the nine-tap filter gradients of a
-# block's 3x3 layers (Net._w3_flush; Mixed_5b's three layers 176 -> 116 us alone, a third of their
-# split-K atomics).  Measured NEUTRAL inside the step (2.909-2.917 against 2.910-2.927 ms, three
-# alternating runs): off by default, like every change that is faster alone and equal in the step.
-W3_GROUP = os.environ.get("C2D_WGRAD3_GROUP", "0") == "1"
-DC_SLOTS = max(2, int(os.environ.get("C2D_DC_SLOTS", "2")))   # dC scratch buffers per stream (see _prepare_backward)
+WGRAD_MULTI_MIN_ROWS = 8192
+DC_SLOTS = 2   # dC scratch buffers per stream (see _prepare_backward)
 
 
 def _out_hw(h, w, stride):
@@ -281,38 +277,6 @@ class Ref(object):
 # network executor
 # ----------------------------------------------------------------------------------------
 
-def _bf16_padded_width(n):
-  """Output columns the bf16 ring GEMM computes for n real ones (the tile rule of run_igemm,
-  csrc/conv_gemm.hip): full-width / 64-column tiles up to 384 columns (193..256: one 256-wide
-  tile), 256-wide tiles beyond unless more than 35 % of the last one would be padding."""
-  c64 = -(-n // 64) * 64
-  if n <= 384:
-    return 256 if 192 < n <= 256 else c64
-  c256 = -(-n // 256) * 256
-  return c256 if (c256 - n) * 20 <= 7 * n else c64
-
-
-def _bf16_entry_groups(couts):
-  """Partition of a block's 1x1 entry convolutions (by index) into one or two GEMM launches with
-  the fewest padded output columns: Mixed_5b's 352 + 192 + 160 + 128 = 832 columns are 1024 as one
-  launch of 256-wide tiles (a fifth of its MFMAs and weight stages on padding) and 512 + 320 as
-  {352, 160} + {192, 128}.  Two launches only when they save a tenth of the columns.
-  Opt-in (C2D_BF16_ENTRY_SPLIT=1): measured 3.129-3.133 ms per bf16 step against 3.118-3.128 with one
-  launch each (ring kernels 1.33 against 1.30 ms per step) — a second launch's ramp, epilogue and
-  extra pass over the input cost more than the padded columns, whose MFMAs ran in an idle pipe."""
-  n = len(couts)
-  best, best_cost = [list(range(n))], _bf16_padded_width(sum(couts))
-  limit = 0.9 * best_cost
-  for mask in range(1, 1 << (n - 1)):          # (index n - 1 always in the second group)
-    a = [i for i in range(n) if (mask >> i) & 1]
-    b = [i for i in range(n) if not (mask >> i) & 1]
-    cost = _bf16_padded_width(sum(couts[i] for i in a)) + _bf16_padded_width(sum(couts[i] for i in b))
-    if cost < best_cost and cost <= limit:
-      best, best_cost = [a, b], cost
-  return best
-
-
-
 class Net(object):
   """A stack of conv / pool / Inception-block ops with a static plan per input shape."""
 
@@ -345,7 +309,7 @@ class Net(object):
     self._plans = {}
 
   side = None   # torch.cuda.Stream for the filter gradients, set by FrcnnEngine (eager mode only)
-  alt = None    # torch.cuda.Stream for the short branches of an Inception block (C2D_BRANCH_STREAMS)
+  alt = None    # torch.cuda.Stream for the short branches of an Inception block (C2D_TUNE=branch_streams=0: off)
   alt_min_n = 64    # ... of blocks over at least this many maps (the single-image first stage: 1 —
                     # its backward pass is a chain of 10-30 us launches, three branches side by side)
 
@@ -392,7 +356,7 @@ class Net(object):
     is the no-ReLU form (c2d_bn_bwd_partial), which exists for trainable layers only — a frozen
     layer inside the backward range keeps the reference order (pool in front)."""
     if not (n >= 64 and len(branch) == 2 and branch[0][0] == "avg" and branch[0][2] == 1 and
-            branch[1][0] == "conv" and os.environ.get("C2D_COMMUTE_AVGPOOL", "1") != "0"):
+            branch[1][0] == "conv" and tune.on("commute_avgpool")):
       return False
     layer = self.layers[self.scope + block + "/" + branch[1][1]]
     return layer.k == 1 and layer.stride == 1 and (layer.trainable or not training)
@@ -519,26 +483,17 @@ class Net(object):
       # over the sum of their output channels (c2d_conv1x1_fwd_multi: the input streams from HBM
       # once, wider tiles; every output element is the same K-ordered sum, bitwise equal results).
       fused = ()
-      if os.environ.get("C2D_FUSE_ENTRY_FWD", "1") != "0":
-        entry = [(bi, b[0]) for bi, b in enumerate(st["branches"])
-                 if b[0]["kind"] == "conv" and b[0]["layer"].k == 1 and b[0]["layer"].stride == 1]
-        if 2 <= len(entry) <= 4:
-          cache = st.setdefault("entry_fwd", {})
-          key = (x.t.data_ptr(), x.ld, x.off)
-          if key not in cache:
-            keep = [(b["layer"].wt_for(self.dtype), b["layer"].scale, b["layer"].shift, b["y"].t,
-                     b["y"].ld, b["y"].off, b["layer"].cout, b.get("relu", True)) for _, b in entry]
-            groups = ([list(range(len(entry)))]
-                      if self.dtype == torch.float32 or os.environ.get("C2D_BF16_ENTRY_SPLIT", "0") != "1"
-                      else _bf16_entry_groups([b["layer"].cout for _, b in entry]))
-            cache[key] = ([(ops.conv_outs([keep[i] for i in g]) if len(g) > 1 else None, g)
-                           for g in groups], keep)
-          for outs, g in cache[key][0]:
-            if outs is not None:
-              ops.conv1x1_fwd_multi(x.t, x.ld, x.off, outs, st["n"] * st["ih"] * st["iw"], st["cin"])
-            else:
-              self._fwd_step(entry[g[0]][1], x)
-          fused = tuple(bi for bi, _ in entry)
+      entry = [(bi, b[0]) for bi, b in enumerate(st["branches"])
+               if b[0]["kind"] == "conv" and b[0]["layer"].k == 1 and b[0]["layer"].stride == 1]
+      if 2 <= len(entry) <= 4:
+        cache = st.setdefault("entry_fwd", {})
+        key = (x.t.data_ptr(), x.ld, x.off)
+        if key not in cache:
+          keep = [(b["layer"].wt_for(self.dtype), b["layer"].scale, b["layer"].shift, b["y"].t,
+                   b["y"].ld, b["y"].off, b["layer"].cout, b.get("relu", True)) for _, b in entry]
+          cache[key] = (ops.conv_outs(keep), keep)
+        ops.conv1x1_fwd_multi(x.t, x.ld, x.off, cache[key][0], st["n"] * st["ih"] * st["iw"], st["cin"])
+        fused = tuple(bi for bi, _ in entry)
       if self.alt is not None and st["n"] >= 64:
         # the long branch on this stream, the others on the branch stream beside it: a 3x3
         # convolution over 2000 4x4 maps is ONE round of 250 workgroups (one per CU) and leaves
@@ -655,9 +610,8 @@ class Net(object):
     # than the launches it removed); round 5 rebuilt the ring kernel's fused epilogue on LDS tables
     # and 16-byte stores as an instance of its own (igemm_bf16.hip, FUSED): 2.925 -> 2.915 ms per
     # step and 26 -> 12 bn_relu_bwd launches, so both storage modes fuse now.
-    # C2D_FUSE_BN_BWD=0|1 forces either form.
-    fuse = os.environ.get("C2D_FUSE_BN_BWD")
-    if fuse != "0":
+    # (C2D_TUNE=fuse_bn_bwd=0: the separate launches, for the A/B tests)
+    if tune.on("fuse_bn_bwd"):
       for i in range(first_idx, len(steps)):
         if steps[i]["kind"] != "block":
           continue
@@ -715,7 +669,7 @@ class Net(object):
     # the averaged features directly (plan["head_grad"], set by the caller of backward()).
     last = steps[-1]
     plan["head_ok"] = False
-    if (os.environ.get("C2D_FUSE_BN_BWD", "1") != "0" and last["kind"] == "block" and last["n"] >= 64 and
+    if (tune.on("fuse_bn_bwd") and last["kind"] == "block" and last["n"] >= 64 and
         all(b[-1]["kind"] == "conv" and b[-1]["layer"].trainable for b in last["branches"])):
       plan["head_ok"] = True
       for b in last["branches"]:
@@ -749,36 +703,6 @@ class Net(object):
       recs.append((ws_size, voff[L.name + "/BatchNorm/beta"][0], g, nb, L.cout, chunks, 0))
       ws_size += nb * 2 * L.cout
       chunks += -(-L.cout // 64)
-    # The split-K results of the per-ROI filter gradients go to per-split slabs (plain stores) and
-    # a reduction launch right behind each of them adds the slabs into the flat gradient buffer in
-    # split order — instead of fp32 atomics (c2d_conv_wgrad_partial; reproducible as a side effect)
-    wrecs, woff = [], 0
-    # Opt-in (C2D_WGRAD_PARTIALS=1): measured at the benchmark size the slabs cost what they save
-    # (fp32 step 12.77 ms against 12.48 ms with atomics — the atomics of one workgroup hide under
-    # the MFMAs of the others —, bf16 4.22 against 4.22); what they buy is bitwise reproducible
-    # filter gradients.
-    if os.environ.get("C2D_WGRAD_PARTIALS", "0") == "1":
-      for st in convs:
-        L = st["layer"]
-        # (per-ROI maps only: on the single first-stage image a launch has too few workgroups for
-        # its atomics to matter)
-        if not L.trainable or st["n"] < 64:
-          continue
-        x = st["x"]
-        ldx, xoff = (x.ld, x.off) if x is not None else (self.cin, 0)
-        splits = ops.conv_wgrad_splits(self.dtype, ldx, xoff, L.cout, 0, st["n"], st["ih"], st["iw"],
-                                       L.cin, L.cout, L.k, L.k, L.stride)
-        if splits <= 1:
-          continue
-        numel = L.k * L.k * L.cin * L.cout
-        # (its own one-layer descriptor: the slabs are added right behind the launch that wrote
-        # them, on the same stream, while they still sit in the Infinity Cache)
-        st["wpart"] = (woff, splits * numel,
-                       ops.wgrad_reduce_descriptors(
-                           [(woff, voff[L.name + "/weights"][0], numel, splits)], dev))
-        wrecs.append(st)
-        woff += splits * numel
-    plan["wpart_ws"] = torch.empty(max(woff, 4), device=dev) if wrecs else None
     plan["bn_ws"] = torch.empty(max(ws_size, 4), device=dev)
     plan["bn_desc"] = (torch.from_numpy(np.array(recs, dtype=ddt).view(np.uint8).copy()).to(dev)
                        if recs else None)
@@ -857,15 +781,8 @@ class Net(object):
 
   def _wgrad(self, plan, st, x, dc, dcld, dcoff):
     L = st["layer"]
-    part = st.get("wpart")
-    if part is not None:
-      off, size, (desc, num, chunks) = part
-      ops.conv_wgrad_partial(x.t, x.ld, x.off, dc, dcld, dcoff, plan["wpart_ws"][off:off + size],
-                             st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
-      ops.wgrad_reduce_batched(desc, num, chunks, plan["wpart_ws"], self.store.grads)
-    else:
-      ops.conv_wgrad(x.t, x.ld, x.off, dc, dcld, dcoff, self.store.grad[L.name + "/weights"],
-                     st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
+    ops.conv_wgrad(x.t, x.ld, x.off, dc, dcld, dcoff, self.store.grad[L.name + "/weights"],
+                   st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride)
 
   def _conv_bwd(self, plan, st, x, gx, accumulate, dc=None, defer=None):
     """BN/ReLU backward -> dc, filter gradient, and (when gx is given) the input gradient.
@@ -882,16 +799,6 @@ class Net(object):
       # the consumer's fused input-gradient launch left this layer's dc in its gradient buffer
       # (an inner layer's own dense buffer, or its columns of a concat gradient)
       dc, dcld, dcoff = gy.t, gy.ld, gy.off
-    # bf16 networks: the nine-tap filter gradients of a block's 3x3 layers go out as ONE grouped
-    # launch at the end of the block (_w3_flush).  A deferred layer's dc must outlive the block: a
-    # layer whose dc would sit in the rotating scratch gets a buffer of its own.
-    group3 = (plan.get("w3_pending") is not None and L.trainable and L.k == 3 and L.stride == 1 and
-              st["ih"] == st["iw"] and st["ih"] in (4, 7) and st["n"] >= 256 and L.cin % 32 == 0 and
-              L.cout % 32 == 0 and st.get("wpart") is None and defer is None)
-    if dc is None and group3 and "fused_blocks" not in st:
-      if "dc_own" not in st:
-        st["dc_own"] = torch.empty(rows, L.cout, device=self.store.device, dtype=self.dtype)
-      dc = st["dc_own"]
     if dc is None:
       buf = scr["dc"]
       if side is not None:
@@ -935,10 +842,8 @@ class Net(object):
                       g[L.name + "/BatchNorm/beta"] if tr else None,
                       g[L.name + "/BatchNorm/gamma"] if (tr and gamma is not None) else None,
                       rows, L.cout)
-    if tr and defer is not None and slot is None and st.get("wpart") is None:
+    if tr and defer is not None and slot is None:
       defer.append((st, dc, dcld, dcoff))
-    elif group3 and slot is None:
-      plan["w3_pending"].append((st, x, dc, dcld, dcoff))
     elif tr and side is not None:
       # dW only meets the rest of the step at the all-reduce / optimiser: it runs on a side stream
       # beside the input-gradient GEMM of the same layer, each filling the other's partial rounds
@@ -967,36 +872,6 @@ class Net(object):
     elif gx is not None:
       ops.conv_dgrad(dc, dcld, dcoff, L.w_for(self.dtype), gx.t, gx.ld, gx.off,
                      st["n"], st["ih"], st["iw"], L.cin, L.cout, L.k, L.k, L.stride, accumulate)
-
-  def _w3_flush(self, plan):
-    """The nine-tap filter gradients a block deferred (_conv_bwd, group3) as ONE launch on the
-    filter-gradient stream: c2d_conv3x3_wgrad_multi_bf16 shares the row splits between the layers,
-    so three layers cost a third of the split-K atomics and of the ramps of three launches
-    (Mixed_5b: 176 -> 116 us alone).  Called on the stream that has seen every deferred dc."""
-    pending, plan["w3_pending"] = plan.get("w3_pending"), None
-    if not pending:
-      return
-    side = self.side if plan["scr"]["dc_alt"] is not None else None
-
-    def launch():
-      st0 = pending[0][0]
-      if len(pending) >= 2 and ops.conv3x3_wgrad_multi(
-          [(x.t, x.ld, x.off, dc, dcld, dcoff, self.store.grad[st["layer"].name + "/weights"],
-            st["layer"].cin, st["layer"].cout) for st, x, dc, dcld, dcoff in pending],
-          st0["n"], st0["ih"]):
-        return
-      for st, x, dc, dcld, dcoff in pending:
-        self._wgrad(plan, st, x, dc, dcld, dcoff)
-
-    if side is not None:
-      ready = torch.cuda.Event()
-      ready.record()
-      side.wait_event(ready)
-      with torch.cuda.stream(side):
-        launch()
-      plan["side_pending"] = True
-    else:
-      launch()
 
   def _entry_wgrads(self, plan, x, deferred):
     """Filter gradients of a block's 1x1 entry convolutions, which all read the block input: ONE
@@ -1079,7 +954,6 @@ class Net(object):
           self._conv_bwd(plan, b0, x, None, False, dc=b0["dc_entry"], defer=got)
           entry_wg[rest_owner] = got
       early = None       # a pooling FIRST op whose gradient goes out on the branch stream (below)
-      plan["w3_pending"] = [] if (self.dtype == torch.bfloat16 and W3_GROUP) else None
       if self.alt is not None and plan["scr_b"] is None and st["n"] >= self.alt_min_n:
         plan["scr_b"] = plan["scratch_set"]()
       if self.alt is not None and plan["scr_b"] is not None and st["n"] >= self.alt_min_n:
@@ -1125,7 +999,6 @@ class Net(object):
       else:
         for bi in range(len(st["branches"])):
           tail(bi)
-      self._w3_flush(plan)
       written = early is not None
       owner = st.get("fuse_out")
       if owner is not None and gx is not None and len(fused) >= 2:
@@ -1155,24 +1028,10 @@ class Net(object):
         rows = st["n"] * st["ih"] * st["iw"]
         segs = [self._entry_dc(b) for b in fused]
         cin = st["cin"]
-        cuts = [0, cin]
-        if self.dtype != torch.float32 and os.environ.get("C2D_BF16_ENTRY_SPLIT", "0") == "1":
-          # the same tile fit for the block-input gradient (its columns = the block's input
-          # channels): Mixed_5a's 576 columns are 768 as one launch, 384 + 192 as two column ranges
-          # (the weights of a 1x1 convolution are [cin][cout]: a column range is a row range)
-          whole = _bf16_padded_width(cin)
-          best = None
-          for c in range(64, cin, 64):
-            cost = _bf16_padded_width(c) + _bf16_padded_width(cin - c)
-            if cost <= 0.9 * whole and (best is None or (cost, -min(c, cin - c)) < best[0]):
-              best = ((cost, -min(c, cin - c)), c)       # fewest columns, then the evenest cut
-          if best is not None:
-            cuts = [0, best[1], cin]
-        for c0, c1 in zip(cuts, cuts[1:]):
-          ops.conv1x1_dgrad_multi(
-              [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],
-              [b["layer"].w_for(self.dtype)[:, :, c0:c1, :] for b in fused],
-              [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off + c0, rows, c1 - c0, written)
+        ops.conv1x1_dgrad_multi(
+            [t for t, _, _ in segs], [ld for _, ld, _ in segs], [off for _, _, off in segs],
+            [b["layer"].w_for(self.dtype) for b in fused],
+            [b["layer"].cout for b in fused], gx.t, gx.ld, gx.off, rows, cin, written)
         written = True
       for bi, b in enumerate(firsts):
         if any(b is f for f in fused) or bi == early:
@@ -1196,14 +1055,13 @@ class FrcnnEngine(object):
     """options: FRCNN proto (protos/frcnn.proto:4-33).  act_dtype: storage of the per-ROI
     tensors (ROI crop output, second stage activations and gradients): fp32, or bf16 with fp32
     accumulation.  first_stage_dtype: storage of the single-image tower behind the stem
-    convolution (default: act_dtype; C2D_FIRST_STAGE_FP32=1 keeps it fp32 in a bf16 network, as
+    convolution (default: act_dtype; C2D_TUNE=first_stage_fp32=1 keeps it fp32 in a bf16 network, as
     rounds 2-3a ran it).  The stem, the ROI crop's input map and its gradient, the heads, all
     statistics and all variables stay fp32."""
     self.store = store
     self.act_dtype = act_dtype
     if first_stage_dtype is None:
-      first_stage_dtype = (torch.float32 if os.environ.get("C2D_FIRST_STAGE_FP32", "0") == "1"
-                           else act_dtype)
+      first_stage_dtype = torch.float32 if tune.get("first_stage_fp32") == "1" else act_dtype
     self.first_dtype = first_stage_dtype
     self.device = store.device
     self.options = options
@@ -1242,19 +1100,18 @@ class FrcnnEngine(object):
                       dtype=act_dtype)
     self.feature_dims = self.second.cout
     # Second-stage filter gradients run on a side stream beside the input-gradient GEMMs (Net.
-    # _conv_bwd): -4 % step time.  C2D_WGRAD_SIDE_STREAM=0 keeps everything on one stream (per-
+    # _conv_bwd): -4 % step time.  C2D_TUNE=streams=0 keeps everything on one stream (per-
     # kernel durations are then separable: profiles/README.md); hipGraph capture turns it off too.
     self.prefetch_stream = None
-    if os.environ.get("C2D_WGRAD_SIDE_STREAM", "1") != "0" and torch.device(store.device).type == "cuda":
+    if tune.on("streams") and torch.device(store.device).type == "cuda":
       self.second.side = torch.cuda.Stream(device=store.device)
       self.prefetch_stream = torch.cuda.Stream(device=store.device)
       # the short branches of a second-stage Inception block on a branch stream beside the long one
       # (Net._fwd_step / _bwd_step): measured fp32 11.40 -> 11.27 ms, bf16 3.37 -> 3.26 ms per step
-      if os.environ.get("C2D_BRANCH_STREAMS", "1") != "0":
+      if tune.on("branch_streams"):
         self.second.alt = torch.cuda.Stream(device=store.device)
-        if os.environ.get("C2D_BRANCH_STREAMS_FIRST", "1") != "0":
-          self.first.alt = self.second.alt
-          self.first.alt_min_n = 1
+        self.first.alt = self.second.alt
+        self.first.alt_min_n = 1
     self._shape_cache = {}
     self.first_trainable_idx = None
     self.last_crop_bwd = None      # which ROI-crop backward the last backward() ran (bench / tests)
@@ -1331,7 +1188,7 @@ class FrcnnEngine(object):
     # per-step refresh of the trainable layers writes the mirror of a transposed operand with the
     # operand (the folded BatchNorm scale / shift are read in fp32 only); the full refresh casts
     # both buffers whole.
-    fused_mirror = low and only_trainable and os.environ.get("C2D_REFRESH_CAST") != "1"
+    fused_mirror = low and only_trainable
     if low:
       any_layer = next(iter(self.second.layers.values()))
       any_layer.w_for(self.act_dtype); any_layer.wt_for(self.act_dtype)     # (allocate once)
@@ -1672,8 +1529,7 @@ class FrcnnEngine(object):
     # The second stage's filter gradients (side stream) are joined at the END of this function when
     # nobody asks for them earlier: the ROI-crop backward and Mixed_4e's backward pass — 0.3 ms in
     # which the chip is half empty — then run beside the filter gradients the side stream still owes.
-    lazy = (after_second_stage is None and need_first and self.second.side is not None and
-            os.environ.get("C2D_LAZY_JOIN", "1") != "0")
+    lazy = after_second_stage is None and need_first and self.second.side is not None
     self.second.backward(plan2, bufs["pooled"], 0, dpooled, after_step=after_block, join=not lazy)
     if after_second_stage is not None:
       after_second_stage()

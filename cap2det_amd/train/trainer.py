@@ -273,9 +273,8 @@ class Trainer(object):
     # instead of between its forward pass and its losses (0.2-0.3 ms per step for the text-
     # classifier extractors); build_loss waits for the event.
     stream = getattr(model.engine, "prefetch_stream", None)
-    want = os.environ.get("C2D_LABELS_SIDE_STREAM")     # "1" / "0" force either form
     if (kwargs.get("labels") is None and stream is not None and
-        (want == "1" or (want != "0" and getattr(model.label_extractor, "overlaps_forward", False)))):
+        getattr(model.label_extractor, "overlaps_forward", False)):
       main = torch.cuda.current_stream()
       fork = torch.cuda.Event(); fork.record()
       stream.wait_event(fork)
@@ -318,8 +317,7 @@ class Trainer(object):
       self.model.refresh(only_trainable=True)
       return
     if (not clipped and lr_dev is None and len(self.segments) <= 8 and
-        all(cols is None and l1 == 0.0 for _, _, _, l1, _, cols, _ in self.segments) and
-        os.environ.get("C2D_ADAGRAD_MULTI", "1") != "0"):
+        all(cols is None and l1 == 0.0 for _, _, _, l1, _, cols, _ in self.segments)):
       # the common case in ONE launch; a bf16 network's mirror of the variables is written by the
       # same pass, the mirror of the derived operands by the transposes of refresh()
       mirror = self.model.engine.values_mirror()

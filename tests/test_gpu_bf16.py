@@ -248,11 +248,11 @@ def _rel_l2(got, want):
 @pytest.mark.parametrize("first_stage", ["bf16", "fp32"])
 @pytest.mark.parametrize("dm,hw,n,nums", [(1.0, (64, 48), 6, [6, 4]), (0.5, (40, 72), 9, [9, 0])])
 def test_train_step_bf16_tracks_the_fp64_oracle(monkeypatch, dm, hw, n, nums, first_stage):
-  """first_stage = "fp32": the single-image tower kept in fp32 (C2D_FIRST_STAGE_FP32=1, the bf16
+  """first_stage = "fp32": the single-image tower kept in fp32 (C2D_TUNE=first_stage_fp32=1, the bf16
   mode of rounds 2-3a) holds the tighter bounds of TOL_FP32_FIRST."""
   from oracle import ref_labels
   from tests import util_model
-  monkeypatch.setenv("C2D_FIRST_STAGE_FP32", "1" if first_stage == "fp32" else "0")
+  monkeypatch.setenv("C2D_TUNE", "first_stage_fp32=%s" % ("1" if first_stage == "fp32" else "0"))
   _check_train_step_bf16(
       util_model.load_pipeline(), dm, hw, n, nums,
       lambda ex, classes: ref_labels.groundtruth_extract(ex["object_texts"], classes),
@@ -490,16 +490,12 @@ def test_adagrad_step_multi_equals_the_separate_calls():
 def test_step_leaves_consistent_bf16_mirrors(monkeypatch):
   """After optimiser steps of a bf16 network the bf16 mirrors the NEXT forward / backward pass reads
   are the rounded fp32 originals: every variable's mirror (written by c2d_adagrad_step_multi) and
-  every layer's transposed operand (written by c2d_transpose_taps_batched_mirror) — and the same
-  holds on the cast path (C2D_ADAGRAD_MULTI=0 C2D_REFRESH_CAST=1) the fused writes replace."""
+  every layer's transposed operand (written by c2d_transpose_taps_batched_mirror)."""
   from cap2det_amd.train.trainer import Trainer
   from tests import util_model
   dm, hw, n, nums = 0.5, (64, 64), 9, [9, 6]
   rng = np.random.default_rng(77)
-  for fused in (True, False):
-    if not fused:
-      monkeypatch.setenv("C2D_ADAGRAD_MULTI", "0")
-      monkeypatch.setenv("C2D_REFRESH_CAST", "1")
+  for fused in (True,):
     pipeline = util_model.load_pipeline()
     trainer = Trainer(pipeline, device=DEV, depth_multiplier=dm, compute_dtype="bf16")
     model = trainer.model

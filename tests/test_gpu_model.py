@@ -965,7 +965,7 @@ def test_steps_a_plan_cannot_express_run_eagerly():
 @pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
 def test_branch_streams_are_neutral(compute_dtype):
   """Round 4: the short branches of a second-stage Inception block run on a branch stream beside
-  the long one (Net._fwd_step / _bwd_step, C2D_BRANCH_STREAMS) with their own dC scratch set.  The
+  the long one (Net._fwd_step / _bwd_step, C2D_TUNE=branch_streams) with their own dC scratch set.  The
   schedule must not change a number: the forward pass is bitwise equal to the one-stream order,
   gradients and the update equal it to the order of the filter gradients' fp32 atomics (64 ROIs:
   the per-ROI plan with fused block-entry GEMMs; three steps so that a missing cross-stream wait

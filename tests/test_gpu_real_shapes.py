@@ -478,9 +478,8 @@ def test_second_stage_fwd_bwd_dm1_n128(monkeypatch, fuse_bn_bwd, commute):
   BN/ReLU backward of the inner convolutions fused into their consumers' input-gradient GEMMs
   (c2d_conv_dgrad_bn_relu, nine producer layers here; c2d_conv1x1_dgrad_multi_bn_relu at the two
   block boundaries, six more) and as separate launches."""
-  monkeypatch.setenv("C2D_FUSE_BN_BWD", fuse_bn_bwd)
   # (Mixed_5b's average-pooling branch runs as 1x1 conv -> BN -> pool -> ReLU unless switched off)
-  monkeypatch.setenv("C2D_COMMUTE_AVGPOOL", commute)
+  monkeypatch.setenv("C2D_TUNE", "fuse_bn_bwd=%s,commute_avgpool=%s" % (fuse_bn_bwd, commute))
   from cap2det_amd import hip_ops
   from cap2det_amd.models.frcnn_engine import SECOND_SCOPE, SECOND_STAGE, DerivedStore, Net, Ref, VariableStore
   n, hw, cin = 128, 7, 576

@@ -96,8 +96,7 @@ def test_second_stage_backward_plan(monkeypatch, fuse, commute, want):
   owns exactly one row range of the partial-sum workspace."""
   import torch
   from cap2det_amd.models.frcnn_engine import SECOND_SCOPE, SECOND_STAGE, DerivedStore, Net, VariableStore
-  monkeypatch.setenv("C2D_FUSE_BN_BWD", fuse)
-  monkeypatch.setenv("C2D_COMMUTE_AVGPOOL", commute)
+  monkeypatch.setenv("C2D_TUNE", "fuse_bn_bwd=%s,commute_avgpool=%s" % (fuse, commute))
   dev = torch.device("cpu")
   store, stats = VariableStore(dev), DerivedStore(dev)
   net = Net(store, stats, SECOND_STAGE, SECOND_SCOPE, 576, True, 1.0)

@@ -4,7 +4,6 @@
 #  64 no DMA after the prologue, 8 no epilogue).
 out=gpurun_out/${1:-x9abl}
 mkdir -p $out
-export C2D_TUNE=1
 for dbg in 0 1 4 32 64 8 36 68 100 108; do
-  C2D_IGEMM_DBG=$dbg python tools/bench_step_gemms.py x9 fwd > $out/fwd_dbg$dbg.txt 2>&1
+  C2D_TUNE=igemm_dbg=$dbg python tools/bench_step_gemms.py x9 fwd > $out/fwd_dbg$dbg.txt 2>&1
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Two PMC passes over the ROI-crop forward alone (tools/bench_crop_fwd.py): instruction counts and
-# wave-cycle breakdown of whichever form the library dispatches (C2D_TUNE=1 C2D_CROP_STREAM=1|2).
+# wave-cycle breakdown of whichever form the library dispatches (C2D_TUNE=crop_stream=1|2).
 # Separate runs per counter set, the program directly after `--` (GPU box, repo root).
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/crop_fwd_pmc${1:+_$1}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp

@@ -6,7 +6,7 @@ POOL images cycled, so the detector can fit them and the loss falls), with the S
 in three storage modes:
 
   fp32            : everything fp32 (the reference's arithmetic, configs[1] / [3])
-  bf16_fp32first  : second stage bf16, single-image first stage fp32 (rounds 2-3a; C2D_FIRST_STAGE_FP32=1)
+  bf16_fp32first  : second stage bf16, single-image first stage fp32 (rounds 2-3a; C2D_TUNE=first_stage_fp32=1)
   bf16            : both towers bf16 behind the fp32 stem (round 3b default of compute_dtype="bf16")
 
 and reports the loss curves (every loss term, mean over windows of WINDOW steps), how far the
@@ -57,9 +57,9 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
   batches, init = None, None
   for name, dtype, first_fp32 in modes:
     if first_fp32 is None:
-      os.environ.pop("C2D_FIRST_STAGE_FP32", None)
+      os.environ.pop("C2D_TUNE", None)
     else:
-      os.environ["C2D_FIRST_STAGE_FP32"] = first_fp32
+      os.environ["C2D_TUNE"] = "first_stage_fp32=%s" % first_fp32
     trainer = Trainer(pipeline, device=device, depth_multiplier=dm, compute_dtype=dtype, seed=seed)
     model = trainer.model
     if init is None:
@@ -134,7 +134,7 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
     }
     del trainer, model
     torch.cuda.empty_cache()
-  os.environ.pop("C2D_FIRST_STAGE_FP32", None)
+  os.environ.pop("C2D_TUNE", None)
   ref = out["curves"][modes[0][0]]["windows"]
   out["deviation_from_fp32"] = {}
   for name, _, _ in modes[1:]:

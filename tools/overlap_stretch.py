@@ -1,6 +1,6 @@
 """What the stream overlap costs, kernel by kernel: the committed rocprofv3 kernel statistics of the
 default schedule (filter gradients on the side stream, look-ahead prefix on a third) against the
-same step on ONE stream (`C2D_WGRAD_SIDE_STREAM=0`).  Prints the per-step sums, the filter-gradient
+same step on ONE stream (`C2D_TUNE=streams=0`).  Prints the per-step sums, the filter-gradient
 share and the kernels that stretch most when they share the chip.
 
   python tools/overlap_stretch.py [c1|c2] [tag]      (reads profiles/<tag>_bench_kernel_stats_*.csv)"""

@@ -1,6 +1,6 @@
 # Round profile set (run on the GPU box from the repo root: `bash tools/profile_round.sh`).
 # For the headline config (c1, fp32) and the bf16 config (c2): kernel statistics of the default
-# command, the same with every kernel on ONE stream (C2D_WGRAD_SIDE_STREAM=0: no side-stream filter
+# command, the same with every kernel on ONE stream (C2D_TUNE=streams=0: no side-stream filter
 # gradients, no first-stage look-ahead, so a kernel's duration is that kernel alone), three PMC
 # passes (FETCH_SIZE, WRITE_SIZE, matrix-pipe busy cycles: separate runs, never combined with
 # tracing domains other than --kernel-trace, the program directly after `--`), and the plain
@@ -15,12 +15,12 @@ cd /tmp; export TMPDIR=/tmp
 for CFG in ${PROFILE_CFGS:-c1 c2}; do
   B="python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_${CFG}_stats -o s -- $B > $O/${T}_${CFG}_stats.log 2>&1
-  export C2D_WGRAD_SIDE_STREAM=0
+  export C2D_TUNE=streams=0
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_${CFG}_serial_stats -o s -- $B > $O/${T}_${CFG}_serial_stats.log 2>&1
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_${CFG}_fetch -o f -- $B --no-kernel-timing > $O/${T}_${CFG}_fetch.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}_${CFG}_write -o w -- $B --no-kernel-timing > $O/${T}_${CFG}_write.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${T}_${CFG}_mfma -o m -- $B --no-kernel-timing > $O/${T}_${CFG}_mfma.log 2>&1
-  unset C2D_WGRAD_SIDE_STREAM
+  unset C2D_TUNE
 done
 cd $R
 mkdir -p $O/${T}_summaries
@@ -38,8 +38,8 @@ find $O -name "*kernel_trace.csv" -path "*${T}_c*" -delete
 find $O -name "*counter_collection.csv" -path "*${T}_c*" -delete
 timeout 400 python bench.py > $O/${T}_summaries/${T}_bench_c1.json 2> $O/${T}_bench_c1.err
 for CFG in c2 c3 c4; do timeout 300 python bench.py --config $CFG --no-cpu-baseline > $O/${T}_summaries/${T}_bench_${CFG}.json 2> $O/${T}_bench_${CFG}.err; done
-C2D_WGRAD_SIDE_STREAM=0 timeout 300 python bench.py --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c1_serial.json 2> $O/${T}_bench_c1_serial.err
-C2D_WGRAD_SIDE_STREAM=0 timeout 300 python bench.py --config c2 --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c2_serial.json 2> $O/${T}_bench_c2_serial.err
+C2D_TUNE=streams=0 timeout 300 python bench.py --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c1_serial.json 2> $O/${T}_bench_c1_serial.err
+C2D_TUNE=streams=0 timeout 300 python bench.py --config c2 --no-cpu-baseline > $O/${T}_summaries/${T}_bench_c2_serial.json 2> $O/${T}_bench_c2_serial.err
 # (gloo prints its connection banner to stdout: keep the JSON line only)
 timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2> $O/${T}_bench_gpus2.err | grep '^{' | tail -1 > $O/${T}_summaries/${T}_bench_gpus2_same_device.json
 ls -la $O/${T}_summaries; du -sh $O/${T}_*

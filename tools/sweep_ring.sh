@@ -5,6 +5,6 @@ O=gpurun_out/ring_sweep; mkdir -p $O
 python tools/bench_conv_bf16.py igemm > $O/default.log 2>&1
 for cfg in ${RING_CFGS:-"64 2" "64 3" "32 2" "32 3" "32 4"}; do
   set -- $cfg
-  C2D_TUNE=1 C2D_RING_BK=$1 C2D_RING_D=$2 python tools/bench_conv_bf16.py igemm > $O/bk$1_d$2.log 2>&1
+  C2D_TUNE=ring_bk=$1,ring_d=$2 python tools/bench_conv_bf16.py igemm > $O/bk$1_d$2.log 2>&1
 done
 for f in $O/*.log; do echo $f; tail -n 2 $f; done

@@ -7,7 +7,7 @@
 CFG=${1:-c1}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/valu_util_$CFG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-C2D_WGRAD_SIDE_STREAM=0 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc -o c -- python3 $R/bench.py --config $CFG --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/pmc.log 2>&1 || echo "pmc pass failed"
+C2D_TUNE=streams=0 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc -o c -- python3 $R/bench.py --config $CFG --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/pmc.log 2>&1 || echo "pmc pass failed"
 python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); dur = collections.defaultdict(float)

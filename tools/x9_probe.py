@@ -36,5 +36,5 @@ for cin, cout in ((1408, 256), (1408, 224), (1024, 736)):
   subprocess.run([sys.executable, __file__, "fp32", str(cin), str(cout)])
   for nt in ("2", "4", "6", "22", "24", "42"):
     for bk, d in (("16", "2"), ("16", "3"), ("32", "2")):
-      env = dict(os.environ, C2D_TUNE="1", C2D_X9_NT=nt, C2D_X9_BK=bk, C2D_X9_D=d, CFG="nt%s bk%s d%s" % (nt, bk, d))
+      env = dict(os.environ, C2D_TUNE="x9_nt=%s,x9_bk=%s,x9_d=%s" % (nt, bk, d), CFG="nt%s bk%s d%s" % (nt, bk, d))
       subprocess.run([sys.executable, __file__, "x9", str(cin), str(cout)], env=env)
