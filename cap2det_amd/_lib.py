@@ -11,6 +11,7 @@ binding cannot drift from the header.
 import ctypes
 import os
 import re
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # C2D_LIB: tools-only override (the diagnostic trace build); the product always loads the in-tree
@@ -96,12 +97,14 @@ def check(code, what):
 # The step-plan recorder (cap2det_amd/step_plan.py) while a step is being recorded, else None: every
 # call below is then also appended to the plan (after it ran: a recorded step is a real step).
 recorder = None
+recorder_thread = None      # only calls of the thread that records belong to the plan (an input
+                            # thread queues its reader kernels through this module at the same time)
 
 
 def call(name, *args):
   """Calls C-ABI function `name`; raises Cap2DetHipError on a non-zero return."""
   check(getattr(load(), name)(*args), name)
-  if recorder is not None:
+  if recorder is not None and threading.get_ident() == recorder_thread:
     recorder.add_call(name, args)
 
 
@@ -110,5 +113,5 @@ def call_sym(name, *args):
   argument may be a step_plan.Sym — its value now, its binding slot in a recorded plan."""
   check(getattr(load(), name)(*[getattr(a, "value", a) if a.__class__.__name__ == "Sym" else a
                                 for a in args]), name)
-  if recorder is not None:
+  if recorder is not None and threading.get_ident() == recorder_thread:
     recorder.add_call(name, args)

@@ -2405,6 +2405,8 @@ extern "C" int c2d_conv_dgrad_bn_relu_bf16(const void* dc, int ldc, int coff, co
                                            const float* beta, const float* gamma, void* dc_out,
                                            float* partials, int n, int ih, int iw, int cin,
                                            int cout, int kh, int kw, int stride, void* stream) {
+  // (the fused epilogue reads the producer's y in 16-byte chunks: 8 bf16)
+  C2D_CHECK_ARG(ldy % 8 == 0 && yoff % 8 == 0);
   return conv_dgrad_bn_relu_impl<c2d_bf16>((const c2d_bf16*)dc, ldc, coff, (const c2d_bf16*)w,
                                            (const c2d_bf16*)y, ldy, yoff, scale, beta, gamma,
                                            (c2d_bf16*)dc_out, partials, n, ih, iw, cin, cout, kh, kw,

@@ -28,6 +28,8 @@ class DevicePrefetcher(object):
     self._q = queue.Queue(maxsize=max(int(depth), 1))
     self._stop = threading.Event()
     self._it = iter(batches)
+    # (an iterator handed in by the caller stays the caller's: close() ends only what iter() made here)
+    self._own_iterator = self._it is not batches
     self._thread = threading.Thread(target=self._run, name="c2d-input-prefetch", daemon=True)
     self._thread.start()
 
@@ -85,9 +87,10 @@ class DevicePrefetcher(object):
     except queue.Empty:
       pass
     self._thread.join(timeout=5.0)
-    # (a generator source may own resources — the reader's input process and its shared memory:
-    #  end it here, once the thread that was running it has stopped)
-    closer = getattr(self._it, "close", None)
+    # (an iterator made HERE from the caller's iterable may own resources: end it, once the thread
+    #  that was running it has stopped; an iterator the caller handed in is the caller's to close or
+    #  to keep pulling from — the batches this prefetcher had already taken from it are dropped)
+    closer = getattr(self._it, "close", None) if self._own_iterator else None
     if closer is not None and not self._thread.is_alive():
       try:
         closer()

@@ -14,6 +14,7 @@ events) is not recorded: c2d_plan_finish orders every other stream of the plan b
 stream at the start of a replay and joins it at the end.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -51,7 +52,7 @@ class _RecEvent(object):
   def record(self, stream=None):
     s = stream if stream is not None else torch.cuda.current_stream()
     self.real.record(s)
-    if _lib.recorder is self.rec:
+    if _recorder() is self.rec:
       self.rec.add_record(self.index, s.cuda_stream)
 
   def __getattr__(self, k):        # synchronize / query / elapsed_time / wait
@@ -63,8 +64,16 @@ _real_wait_event = torch.cuda.Stream.wait_event
 _real_wait_stream = torch.cuda.Stream.wait_stream
 
 
-def _event_factory(*args, **kwargs):
+def _recorder():
+  """The active recorder if the CALLING thread is the one recording, else None."""
   rec = _lib.recorder
+  if rec is not None and threading.get_ident() == _lib.recorder_thread:
+    return rec
+  return None
+
+
+def _event_factory(*args, **kwargs):
+  rec = _recorder()
   if rec is None:
     return _RealEvent(*args, **kwargs)
   return _RecEvent(rec, *args, **kwargs)
@@ -73,17 +82,18 @@ def _event_factory(*args, **kwargs):
 def _wait_event(self, event):
   if isinstance(event, _RecEvent):
     _real_wait_event(self, event.real)
-    rec = _lib.recorder
+    rec = _recorder()
     if rec is not None and rec is event.rec:
       rec.add_wait(self.cuda_stream, event.index)
     return
   _real_wait_event(self, event)
-  if _lib.recorder is not None:
-    _lib.recorder.external_waits += 1
+  rec = _recorder()
+  if rec is not None:
+    rec.external_waits += 1
 
 
 def _wait_stream(self, stream):
-  rec = _lib.recorder
+  rec = _recorder()
   if rec is None:
     return _real_wait_stream(self, stream)
   ev = _RecEvent(rec)
@@ -163,6 +173,7 @@ class StepPlan(object):
       def __enter__(self):
         assert _lib.recorder is None and not plan.finished
         plan.main_stream = torch.cuda.current_stream().cuda_stream
+        _lib.recorder_thread = threading.get_ident()
         _lib.recorder = plan
         return plan
 

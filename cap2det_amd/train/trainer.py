@@ -316,7 +316,7 @@ class Trainer(object):
       self._apply_other_optimizer(scale, lr, lr_dev, clipped)
       self.model.refresh(only_trainable=True)
       return
-    if (not clipped and lr_dev is None and len(self.segments) <= 8 and
+    if (not clipped and lr_dev is None and self.segments and len(self.segments) <= 8 and
         all(cols is None and l1 == 0.0 for _, _, _, l1, _, cols, _ in self.segments)):
       # the common case in ONE launch; a bf16 network's mirror of the variables is written by the
       # same pass, the mirror of the derived operands by the transposes of refresh()

@@ -685,6 +685,7 @@ int c2d_bn_relu_bwd_partial_head_bf16(const float* dmean, int ldd, int doff, con
                                       float* partials, int rows, int c, void* stream);
 int c2d_conv1x1_fwd_multi_bf16(const void* x, int ldx, int xoff, int nout, const C2dConvOut* outs,
                                int rows, int cin, void* stream);
+/* (ldy and yoff multiples of 8: the fused epilogue reads the producer's y in 16-byte chunks) */
 int c2d_conv_dgrad_bn_relu_bf16(const void* dc, int ldc, int coff, const void* w, const void* y,
                                 int ldy, int yoff, const float* scale, const float* beta,
                                 const float* gamma, void* dc_out, float* partials, int n, int ih,

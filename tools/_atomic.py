@@ -7,7 +7,7 @@ import os
 
 
 def write_json(path, doc, **kw):
-  text = json.dumps(doc, **kw)
+  text = json.dumps(doc, allow_nan=False, **kw)       # (NaN / Infinity are not JSON: fail here)
   json.loads(text)                      # what we are about to commit parses
   tmp = "%s.tmp.%d" % (path, os.getpid())
   with open(tmp, "w") as f:
