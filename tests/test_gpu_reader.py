@@ -283,6 +283,8 @@ def test_train_overlaps_the_uploads():
   ex = util_model.make_examples(rng, 1, 192, 192, n, [n], classes)
   host = {k: torch.from_numpy(ex[k]).pin_memory() for k in ("image", "proposals", "number_of_proposals")}
   payload = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+  from cap2det_amd import hip_ops
+  probe_src, probe_dst = torch.ones(64, device=DEV), torch.zeros(64, device=DEV, dtype=torch.bfloat16)
   ups = []
 
   def batches(count, with_payload):
@@ -294,6 +296,7 @@ def test_train_overlaps_the_uploads():
         b[k] = v.to(DEV, non_blocking=True)
       if with_payload:
         b["_payload"] = payload.to(DEV, non_blocking=True)
+      hip_ops.cast_bf16(probe_src, probe_dst)     # a C-ABI call of the INPUT thread (a reader's resize would be)
       e.record()
       ups.append((s, e))
       yield b
@@ -316,10 +319,19 @@ def test_train_overlaps_the_uploads():
 
   run(True)                                   # warm-up: buffers, pinned staging, allocator pools
   t_plain = min(run(False) for _ in range(2))
-  t_fed = run(True)
+  t_fed = min(run(True) for _ in range(2))    # (as the plain runs: the first run after a change of
+                                              #  batch signature pays one-off allocations)
   assert len(ends) == steps and len(ups) >= steps
   copy_ms = sum(s.elapsed_time(e) for s, e in ups[:steps])
   ahead = sum(1 for k in range(2, steps - 1) if ends[k - 1].elapsed_time(ups[k + 1][0]) < 0.0)
   assert ahead >= 0.8 * (steps - 3), (ahead, steps)          # upload k+1 starts before step k-1 ends
   assert copy_ms > 0.2 * 1e3 * t_plain, (copy_ms, t_plain)    # (the payload is not negligible)
   assert t_fed < t_plain + 0.6 * copy_ms * 1e-3, (t_fed, t_plain, copy_ms)
+  # the steps were replayed from step plans, and a plan holds the TRAINING thread's calls only: the
+  # input thread's events and C-ABI calls (here: the probe cast, absent from an fp32 step) stay out
+  assert trainer.plan_replays >= 3 * (steps - 4)
+  plans = [st["plan"] for st in trainer._plans.values() if st["plan"] is not None]
+  assert plans
+  for plan in plans:
+    names = set(node[1] for node in plan.nodes if node[0] == "call")
+    assert "c2d_cast_bf16" not in names and "c2d_conv_fwd" in names, sorted(names)[:8]
