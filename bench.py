@@ -346,6 +346,14 @@ def parse_args(argv=None):
   ap.add_argument("--reader-records", type=int, default=64, help="--reader: records per run (cycled)")
   ap.add_argument("--reader-workers", type=int, default=10,
                   help="--reader: map_num_parallel_calls (host decode threads; the shipped configs say 10)")
+  ap.add_argument("--available-cus", type=int, default=None,
+                  help="CUs the launch plans may count on (c2d_set_available_cus; default 256): what a "
+                       "data-parallel rank should say when its RCCL channel kernels hold CUs under the "
+                       "backward pass (tools/cu_withhold.py measures the sensitivity)")
+  ap.add_argument("--nccl-max-nchannels", type=int, default=None,
+                  help="NCCL_MAX_NCHANNELS for the ranks (set before anything touches the GPU): fewer RCCL "
+                       "channels = fewer CUs taken from the step")
+  ap.add_argument("--nccl-min-nchannels", type=int, default=None, help="NCCL_MIN_NCHANNELS, likewise")
   ap.add_argument("--f32x9", action="store_true",
                   help="SECONDARY measurement (fp32 configs): the second stage's forward / input-gradient "
                        "GEMMs as nine bf16 partial products on the bf16 matrix pipe (csrc/igemm_x9.hip); "
@@ -437,6 +445,7 @@ def stub_main(args):
   split = 1_110_000
   # the per-block cuts of the real bucket, [Mixed_4e | Mixed_5a | 5b | 5c + heads] (Trainer._block_cuts)
   cuts = [0, 1_110_000, 2_030_000, 4_480_000, 7_100_000]
+  exposed = []
   def step(i):
     bucket.fill_(float(rank + 1 + i))
     if i % 2 == 0:
@@ -449,7 +458,9 @@ def stub_main(args):
       for blk in (3, 2, 1):
         if not (i % 4 == 3 and blk == 2):
           red.start(blk)
+    t_f = time.perf_counter()
     scale = red.finish()
+    exposed.append(time.perf_counter() - t_f)      # (CPU stub: the host clock around finish())
     want = sum(r + 1 + i for r in range(world)) * scale
     got = bucket * scale
     for q in (0, cuts[1], cuts[2], cuts[3] - 1, -1):
@@ -464,12 +475,24 @@ def stub_main(args):
   if world > 1:
     dist.barrier()
   elapsed = time.perf_counter() - t0
+  mine_step = 1000.0 * elapsed / max(args.steps, 1)
+  mine_exposed = 1000.0 * sum(exposed[args.warmup:]) / max(args.steps, 1)
+  stats = torch.tensor([mine_step, -mine_step, mine_exposed, -mine_exposed], dtype=torch.float64)
   if world > 1:
     t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    dist.all_reduce(stats, op=dist.ReduceOp.MAX)
   if rank == 0:
     print(json.dumps({"metric": "STUB (no training step): launcher + gradient exchange only",
+                      "process_group": {"backend": "gloo", "world_size": world,
+                                        "step_ms_max_over_ranks": float(stats[0]),
+                                        "step_ms_min_over_ranks": -float(stats[1]),
+                                        "allreduce_exposed_ms_max_over_ranks": float(stats[2]),
+                                        "allreduce_exposed_ms_min_over_ranks": -float(stats[3]),
+                                        "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                                        "nccl_min_nchannels": os.environ.get("NCCL_MIN_NCHANNELS")},
+                      "available_cus": args.available_cus or 256,
                       "value": world * args.steps / elapsed, "unit": "exchanges/s",
                       "n_gpus": args.gpus, "world_size": world, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -642,6 +665,10 @@ def main(argv=None):
   args = parse_args(argv)
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(launch_ranks(args, argv))
+  if args.nccl_max_nchannels is not None:
+    os.environ["NCCL_MAX_NCHANNELS"] = str(args.nccl_max_nchannels)
+  if args.nccl_min_nchannels is not None:
+    os.environ["NCCL_MIN_NCHANNELS"] = str(args.nccl_min_nchannels)
   if os.environ.get("C2D_BENCH_STUB") == "1":
     sys.exit(stub_main(args))
   if args.reader:
@@ -670,6 +697,10 @@ def main(argv=None):
   # of one rank over nccl, and the reducers issue their collectives (data_parallel.collectives_on)
   forced = world == 1 and os.environ.get("C2D_FORCE_ALLREDUCE") == "1"
   grouped = world > 1 or forced
+  if args.nccl_max_nchannels is not None:
+    os.environ["NCCL_MAX_NCHANNELS"] = str(args.nccl_max_nchannels)
+  if args.nccl_min_nchannels is not None:
+    os.environ["NCCL_MIN_NCHANNELS"] = str(args.nccl_min_nchannels)
   if grouped:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -689,6 +720,12 @@ def main(argv=None):
   import tempfile
   from cap2det_amd import hip_ops, synthetic
   from cap2det_amd.train.trainer import Trainer
+  from cap2det_amd import _lib as c2d_lib
+  from cap2det_amd.train import data_parallel
+  if args.available_cus is not None:
+    c2d_lib.call("c2d_set_available_cus", int(args.available_cus))
+  if grouped:
+    data_parallel.exposed_events = []
   timer = KernelTimer()
   if not args.no_kernel_timing:
     timer.wrap(hip_ops)
@@ -817,6 +854,17 @@ def main(argv=None):
     ones = torch.ones(1, device=device, dtype=torch.int32)
     dist.all_reduce(ones, op=dist.ReduceOp.SUM)
     ranks_counted = int(ones.item())
+    # per rank: its own step time (GPU events, median) and the GPU time its compute stream spent
+    # inside the reducers' finish() — between "all gradients queued" and "all collectives done"
+    mine_step = per_step[len(per_step) // 2] if per_step else 0.0
+    pairs = data_parallel.exposed_events or []
+    mine_exposed = (sum(a.elapsed_time(b) for a, b in pairs) / max(len(pairs), 1)) if pairs else 0.0
+    stats = torch.tensor([mine_step, -mine_step, mine_exposed, -mine_exposed], device=device,
+                         dtype=torch.float64)
+    dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    rank_stats = {"step_ms_max_over_ranks": float(stats[0]), "step_ms_min_over_ranks": -float(stats[1]),
+                  "allreduce_exposed_ms_max_over_ranks": float(stats[2]),
+                  "allreduce_exposed_ms_min_over_ranks": -float(stats[3])}
 
   if rank == 0:
     images = world * args.steps * images_per_gpu
@@ -876,7 +924,11 @@ def main(argv=None):
     if grouped:
       result["process_group"] = {"backend": backend, "world_size": dist.get_world_size(),
                                  "ranks_counted_by_all_reduce": ranks_counted,
-                                 "forced_at_one_rank": forced}
+                                 "forced_at_one_rank": forced,
+                                 "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                                 "nccl_min_nchannels": os.environ.get("NCCL_MIN_NCHANNELS")}
+      result["process_group"].update(rank_stats)
+    result["available_cus"] = int(c2d_lib.load().c2d_get_available_cus())
     crop_path = getattr(trainer.model.engine, "last_crop_bwd", None)
     if crop_path:
       result["config"]["roi_crop_backward"] = crop_path

@@ -26,6 +26,15 @@ const std::vector<std::pair<std::string, std::string>>& tune_table() {
 }
 }  // namespace
 
+static int g_available_cus = 256;
+int c2d_available_cus() { return g_available_cus; }
+extern "C" int c2d_set_available_cus(int cus) {
+  C2D_CHECK_ARG(cus >= 8 && cus <= 256);
+  g_available_cus = cus;
+  return C2D_OK;
+}
+extern "C" int c2d_get_available_cus(void) { return g_available_cus; }
+
 bool c2d_tune_on() { return getenv("C2D_TUNE") != nullptr; }
 const char* c2d_tune_get(const char* key) {
   for (const auto& kv : tune_table())

@@ -19,6 +19,17 @@ static inline int c2d_launch_status() {
 bool c2d_tune_on();
 const char* c2d_tune_get(const char* key);
 
+// CUs this process may count on (c2d_set_available_cus; default 256 = the whole MI355X).  The launch
+// plans that size a launch as "one round of resident workgroups" — split counts of the filter
+// gradients, the small-problem threshold — scale their budgets with it: a rank whose RCCL channel
+// kernels hold CUs under the backward pass would otherwise launch a round and a bit.
+int c2d_available_cus();
+static inline int c2d_cu_scaled(int per_256_cus) {
+  const int n = c2d_available_cus();
+  const int v = (int)((long long)per_256_cus * n / 256);
+  return v > 0 ? v : 1;
+}
+
 static inline int c2d_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Wave64 reductions (CDNA4 wavefront = 64 lanes).

@@ -2095,7 +2095,8 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws_in = Igemm
   //  3969-row layers here and moves Conv2d_2b/2c, 15,625 rows: 3.05 -> 3.02 / 10.83 -> 10.84 ms.
   //  C2D_TUNE=igemm_small_max_m=<rows>)
   static const int small_max_m = (tune && c2d_tune_get("igemm_small_max_m")) ? atoi(c2d_tune_get("igemm_small_max_m")) : 8192;
-  if (big_blocks < 256 && a.nseg == 1 && a.N % 4 == 0 && a.M <= small_max_m && !a.fy && !a.mo_n && !deep_1x1) {
+  const int cus = c2d_available_cus();
+  if (big_blocks < cus && a.nseg == 1 && a.N % 4 == 0 && a.M <= small_max_m && !a.fy && !a.mo_n && !deep_1x1) {
     // small problems (first stage): one 32x32 tile per block, K split over the 4 waves
     IgemmArgs b = a;
     b.m_tiles = c2d_ceil_div(a.M, 32);
@@ -2123,7 +2124,7 @@ int run_igemm(const IgemmArgs& a_in, hipStream_t s, const IgemmWs& ws_in = Igemm
     return c2d_launch_status();
   } else if (g_collect) {
     return C2D_ERR_UNSUPPORTED;     // not a small problem: the caller launches it on its own
-  } else if (big_blocks < 256) {
+  } else if (big_blocks < cus) {
     return launch_igemm<2, 2, 1, 1, 32>(a, s, IgemmWs{nullptr, 0});          // 64x64 tiles
   } else if (force == 4 && a.es == 2) {
     if (a.g.mode == 0) return launch_igemm_bf16<0, 2, 2, 4, 2, false>(a, s);
@@ -2689,9 +2690,9 @@ static int wgrad_bf16_slots(int slots) {
   static const bool tune = c2d_tune_on();
   if (tune) {
     const char* e = c2d_tune_get("wgrad_bf16_slots");
-    if (e && atoi(e) > 0) return slots * atoi(e) / 100;
+    if (e && atoi(e) > 0) return c2d_cu_scaled(slots) * atoi(e) / 100;
   }
-  return slots * 3 / 4;
+  return c2d_cu_scaled(slots) * 3 / 4;
 }
 static int wgrad3_bf16_igroups(int cin) {
   static const bool tune = c2d_tune_on();
@@ -2823,7 +2824,7 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   const int bj = narrow ? 64 : 128;
   const int tiles = kh * kw * c2d_ceil_div(cin, 128) * c2d_ceil_div(cout, bj);
   static const int fp32_slots = (c2d_tune_on() && c2d_tune_get("wgrad_slots")) ? atoi(c2d_tune_get("wgrad_slots")) : 1024;
-  int splits = (bf16_mfma ? wgrad_bf16_slots(512) : fp32_slots) / tiles;   // 4 (bf16: 2) blocks per CU, one round
+  int splits = (bf16_mfma ? wgrad_bf16_slots(512) : c2d_cu_scaled(fp32_slots)) / tiles;   // 4 (bf16: 2) blocks per CU, one round
   const int max_splits = c2d_ceil_div(a.M, 4 * WBK);      // at least 4 slabs per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

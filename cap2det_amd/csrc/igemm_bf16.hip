@@ -534,7 +534,7 @@ int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool 
   a.tiles_y = c2d_ceil_div(a.J, bj);
   const int tiles = a.tiles_x * a.tiles_y;
   // two workgroups per CU in one round; at least 4 stages per workgroup
-  int splits = (t.slots > 0 ? t.slots : 512) / tiles;
+  int splits = (t.slots > 0 ? t.slots : c2d_cu_scaled(512)) / tiles;
   const int max_splits = c2d_ceil_div(a.M, 4 * bk);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -572,7 +572,7 @@ int launch_wgrad1x1_bf16_ring_group(WgradArgs* a, int num, hipStream_t s) {
   }
   for (int p = num; p <= WGRAD_GROUP_MAX; ++p) g.first_tile[p] = tiles;
   const WgradTune& t = wgrad_tune();
-  int splits = (t.slots > 0 ? t.slots : 512) / tiles;       // two workgroups per CU in one round
+  int splits = (t.slots > 0 ? t.slots : c2d_cu_scaled(512)) / tiles;       // two workgroups per CU in one round
   const int max_splits = c2d_ceil_div(a[0].M, 4 * 64);      // at least 4 stages per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -87,6 +87,30 @@ extern "C" int c2d_copy_bytes(const void* src, void* dst, long long bytes, void*
   return c2d_launch_status();
 }
 
+// Rehearsal of CUs lost to a collective (tools/cu_withhold.py): `workgroups` blocks of 1024 threads
+// with the whole LDS of a CU each, asleep until `microseconds` have passed on the 100-MHz counter.
+__global__ __launch_bounds__(1024) void hold_cus_kernel(long long ticks, int* sink) {
+  extern __shared__ int lds[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) lds[0] = 1;
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(64);
+  if (sink && threadIdx.x == 0 && lds[0] == 2) *sink = 1;
+}
+extern "C" int c2d_debug_hold_cus(int workgroups, long long microseconds, void* stream) {
+  C2D_CHECK_ARG(workgroups >= 0 && workgroups <= 256 && microseconds >= 0 && microseconds <= 5000000);
+  if (workgroups == 0) return C2D_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)hold_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return C2D_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(hold_cus_kernel, dim3(workgroups), dim3(1024), 160 * 1024, (hipStream_t)stream,
+                     microseconds * 100, (int*)nullptr);
+  return c2d_launch_status();
+}
+
 extern "C" long long c2d_plan_create(void) { return (long long)(uintptr_t) new Plan(); }
 
 extern "C" int c2d_plan_destroy(void* plan) {

@@ -8,6 +8,7 @@ The reference shards records across its async workers with a hash filter
 """
 import os
 
+import torch
 import torch.distributed as dist
 
 
@@ -51,6 +52,26 @@ def allreduce_bucket(flat, group=None):
   return 1.0 / world
 
 
+# bench.py --gpus N: event pairs around every finish() (GPU time the compute stream spends between
+# "all gradients queued" and "all collectives done": what the overlap did NOT hide), when enabled
+exposed_events = None
+
+
+def _finish_begin():
+  if exposed_events is None:
+    return None
+  ev = torch.cuda.Event(enable_timing=True)
+  ev.record()
+  return ev
+
+
+def _finish_end(ev0):
+  if ev0 is not None:
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    exposed_events.append((ev0, ev1))
+
+
 class OverlappedReducer(object):
   """Two-bucket reduction of the flat gradient buffer, the big one under the tail of backward.
 
@@ -75,12 +96,14 @@ class OverlappedReducer(object):
 
   def finish(self):
     if self.on:
+      ev0 = _finish_begin()
       head = self.flat[:self.split] if self._work is not None else self.flat
       if head.numel():
         dist.all_reduce(head, op=dist.ReduceOp.SUM, group=self.group)
       if self._work is not None:
         self._work.wait()
         self._work = None
+      _finish_end(ev0)
     return 1.0 / self.world
 
 
@@ -118,6 +141,7 @@ class BlockReducer(object):
 
   def finish(self):
     if self.on:
+      ev0 = _finish_begin()
       # what is left, as few collectives as possible: runs of adjacent unstarted ranges
       i, n = 0, self.num_ranges()
       while i < n:
@@ -133,4 +157,5 @@ class BlockReducer(object):
       for w in self._works.values():
         w.wait()
       self._works = {}
+      _finish_end(ev0)
     return 1.0 / self.world

@@ -835,6 +835,17 @@ int c2d_text_pool_bwd(const float* dhidden, const float* pre, const int32_t* ids
                       int num_tokens, int hidden_units, int vocab_size, const uint8_t* keep_mask,
                       float keep_prob, float* dpre, void* stream);
 
+/* CUs this process may count on when it sizes "one round of workgroups" launches (split counts of
+ * the filter gradients, the small-problem threshold): 256 by default, fewer for a data-parallel rank
+ * whose RCCL channel kernels hold CUs under the backward pass (train_wsod.sh:46-88 runs one
+ * process per GPU; bench.py --available-cus).  8..256; process-wide, set before the step loop. */
+int c2d_set_available_cus(int cus);
+int c2d_get_available_cus(void);
+
+/* Diagnostic (tools/cu_withhold.py): occupies `workgroups` CUs (one 160-KiB-LDS workgroup each) on
+ * `stream` for `microseconds` — the rehearsal of a collective's channel kernels on a one-GPU box. */
+int c2d_debug_hold_cus(int workgroups, long long microseconds, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Step plan: the call list of one training step, recorded once, replayed by ONE call
  * (replaces the per-step session.run of slim.learning.train, train/trainer.py:141-146: the

@@ -34,12 +34,20 @@ def test_plain_command_launches_eight_ranks():
   through the launcher, both gradient exchanges over the REAL per-block cuts of the bucket (the
   per-block reducer with uneven start() coverage on odd steps), one disjoint core set per rank chosen
   in-process and reported in the line."""
-  r = _run({"C2D_BENCH_STUB": "1"}, "--gpus", "8", "--steps", "4", "--warmup", "1")
+  r = _run({"C2D_BENCH_STUB": "1"}, "--gpus", "8", "--steps", "4", "--warmup", "1",
+           "--nccl-max-nchannels", "4", "--available-cus", "224")
   assert r.returncode == 0, r.stderr[-2000:]
   lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
   assert len(lines) == 1, r.stdout
   out = json.loads(lines[0])
   assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["stub"] is True
+  # SCALE readiness, part 2 (VERDICT r5 #6): per-rank step time and the time the compute stream spends
+  # inside the reducers' finish(), min / max over the ranks; the channel budget reaches the ranks
+  pg = out["process_group"]
+  assert pg["world_size"] == 8 and pg["nccl_max_nchannels"] == "4" and out["available_cus"] == 224
+  assert 0 < pg["step_ms_min_over_ranks"] <= pg["step_ms_max_over_ranks"]
+  assert 0 <= pg["allreduce_exposed_ms_min_over_ranks"] <= pg["allreduce_exposed_ms_max_over_ranks"]
+  assert pg["allreduce_exposed_ms_max_over_ranks"] <= pg["step_ms_max_over_ranks"] * 1.01
   aff = out["cpu_affinity"]
   ncores = len(os.sched_getaffinity(0))
   if ncores >= 8:
