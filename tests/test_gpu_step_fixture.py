@@ -94,26 +94,32 @@ def _check_mlp_decided_the_labels(trainer, case, fix):
   assert ref_labels.match_labels(case["caption"], case["classes"]).sum() == 0
 
 
-@pytest.mark.parametrize("n", [256, 1100, "full", "full_c4"])
+@pytest.mark.parametrize("n", [256, 1100, "full", "full_c2", "full_c4"])
 def test_train_step_bf16_replays_the_float64_fixture(n, tmp_path):
   """The same fixtures through compute_dtype="bf16" (BASELINE configs[2] / [4] storage mode: first
   stage, ROI crop output and second stage in bf16, fp32 accumulation) on the benchmark's launch
   plan.  There is no bf16 reference; the bounds (BF16_TOL) are what the roundings allow, the
   observed deviations at n = 1100 / 256: scores 3.8 % / 2.5 % of the per-class maximum (MIDN
   probabilities; the OICR softmax scores 1.0 % / 1.1 %), logits 0.8 % / 0.5 %, losses <= 0.2 % /
-  0.3 %, gradient samples 1.7 % / 2.2 % of the tensor's scale, gradient norms 0.6 %."""
+  0.3 %, gradient samples 1.7 % / 2.2 % of the tensor's scale, gradient norms 0.6 %.
+  "full_c2" (round 6): BASELINE configs[2] ITSELF in its own storage mode — coco17_extend_match, 80
+  classes, 2000 proposals, bf16 — against its float64 fixture, the labels extracted from the caption
+  inside the step."""
+  from cap2det_amd import synthetic
   from cap2det_amd.train.trainer import Trainer
   tc = n if n in ("full_c3", "full_c4") else None     # BASELINE configs[4]: the text classifier decides the labels
+  c2 = n == "full_c2"
   fix, n, hw = _fixture(n)
   if tc:
     trainer, case, ex, P32, mask, real = _text_classifier_setup(tc, tmp_path, "bf16")
     model = trainer.model
   else:
-    pipeline = util_model.load_pipeline()
+    pipeline = synthetic.baseline_pipeline("c2") if c2 else util_model.load_pipeline()
     trainer = Trainer(pipeline, device=DEV, depth_multiplier=gen.DM, compute_dtype="bf16")
     model = trainer.model
     classes = model.label_extractor.classes
-    ex, P32, mask, real = gen.inputs(n, classes, hw)
+    assert len(classes) == (80 if c2 else 20)
+    ex, P32, mask, real = gen.inputs(n, list(classes), hw, captions=c2)
   assert model.engine.first.dtype == torch.bfloat16 and model.engine.second.dtype == torch.bfloat16
   np.testing.assert_allclose(gen.checksum(ex, P32, mask), fix["checksum"], rtol=1e-12)
   model.load_state_dict(P32)
