@@ -826,6 +826,7 @@ def main(argv=None):
       first_net.alt = alt1
     marks[i + 1].record()
   host_enqueue = time.perf_counter() - t0       # the host is done queueing; the GPU may still run
+  replays_timed = trainer.plan_replays - replays_before
   sync()
   elapsed = time.perf_counter() - t0
   # (the last step carries the per-kernel event pairs and is left out of the spread)
@@ -909,8 +910,8 @@ def main(argv=None):
                    "proposals": num_proposals, "parallelism": "dp%d" % world,
                    "launch": ("step plan replay: %d of the %d timed steps issued by one c2d_plan_replay call "
                               "each, the others (first / last two) queued from Python"
-                              % (trainer.plan_replays - replays_before, args.steps)
-                              if trainer.plan_replays > replays_before else "eager (every call queued from Python)"),
+                              % (replays_timed, args.steps)
+                              if replays_timed > 0 else "eager (every call queued from Python)"),
                    "gemm_method": ("f32x9 (second-stage forward / input-gradient GEMMs: nine bf16 partial "
                                    "products, fp32 accumulate; filter gradients on the fp32 pipe)"
                                    if args.f32x9 else

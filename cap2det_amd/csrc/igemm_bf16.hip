@@ -60,10 +60,10 @@ thread_local RingCollect g_ring_collect = {false, 0, {}, {}, {}};
 template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED>
 int ring_launch_single(const IgemmArgs& a, hipStream_t s) {
   // (spelled as rocprofv3 prints the instance: the FUSED flag included)
-  dispatch_note_ext(PM ? (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, true>"
-                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, false>")
-                       : (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true>"
-                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false>"),
+  dispatch_note_ext(PM ? (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, true, 1>"
+                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, true, %d, %d, %d, false, 1>")
+                       : (FUSED ? "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true, 1>"
+                                : "igemm_ring_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false, 1>"),
                     MODE, WM, WN, MT, NT, BKT, D, ES);
   hipLaunchKernelGGL((igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED>),
                      dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, s, a);
@@ -72,8 +72,8 @@ int ring_launch_single(const IgemmArgs& a, hipStream_t s) {
 
 template <int MODE, int WM, int WN, int MT, int NT, bool PM, int BKT, int D, int ES, bool FUSED>
 int ring_launch_group(const IgemmRingGroup& g, hipStream_t s) {
-  dispatch_note_ext(FUSED ? "igemm_ring_group_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true>"
-                          : "igemm_ring_group_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false>",
+  dispatch_note_ext(FUSED ? "igemm_ring_group_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, true, 1>"
+                          : "igemm_ring_group_kernel<%d, %d, %d, %d, %d, false, %d, %d, %d, false, 1>",
                     MODE, WM, WN, MT, NT, BKT, D, ES);
   hipLaunchKernelGGL((igemm_ring_group_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES, FUSED>),
                      dim3(g.first[g.num]), dim3(WM * WN * 64), 0, s, g);

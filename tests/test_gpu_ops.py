@@ -448,7 +448,7 @@ def test_conv1x1_dgrad_multi_bn_relu(ops, rows, cin, couts, widths, accumulate, 
                                   list(couts), _t(y).to(dtype), cin, 0, ops.bn_producers(prods), out,
                                   cin, 0, part, rows, cin, accumulate)
   if low:
-    assert ops.last_dispatch()[0].endswith(", 2, true>"), ops.last_dispatch()    # the fused ring instance
+    assert ops.last_dispatch()[0].endswith(", 2, true, 1>"), ops.last_dispatch()    # the fused ring instance
   sc = np.abs(want).max()
   if low:
     assert np.abs(_n(out.float()) - want).max() <= 1.1 * 2.0 ** -8 * sc

@@ -58,6 +58,11 @@ def test_bench_line_reports_the_process_group():
   assert r.returncode == 0 and lines, (r.returncode, r.stderr[-4000:])
   out = json.loads(lines[-1])
   pg = out["process_group"]
-  assert pg == {"backend": "nccl", "world_size": 1, "ranks_counted_by_all_reduce": 1,
-                "forced_at_one_rank": True}
+  assert {k: pg[k] for k in ("backend", "world_size", "ranks_counted_by_all_reduce", "forced_at_one_rank")} == {
+      "backend": "nccl", "world_size": 1, "ranks_counted_by_all_reduce": 1, "forced_at_one_rank": True}
+  # round 6: per-rank step time and the GPU time inside the reducers' finish(), min / max over the ranks
+  assert 0 < pg["step_ms_min_over_ranks"] <= pg["step_ms_max_over_ranks"]
+  assert 0 <= pg["allreduce_exposed_ms_min_over_ranks"] <= pg["allreduce_exposed_ms_max_over_ranks"]
+  assert pg["allreduce_exposed_ms_max_over_ranks"] < pg["step_ms_max_over_ranks"]
+  assert out["available_cus"] == 256
   assert out["n_gpus"] == 1 and out["value"] > 0 and "RCCL" in out["config"]["workload"]

@@ -280,7 +280,7 @@ def test_second_stage_fused_dgrad_bf16(ops, layer):
     return inst
 
   want_inst = run(N_BENCH, False)
-  assert all(i.endswith(", true>") for i in want_inst), want_inst
+  assert all(i.endswith(", true, 1>") for i in want_inst), want_inst
   for n in (256, 704, N_BENCH):
     if run(n, False) == want_inst:
       assert run(n, True) == want_inst
@@ -348,7 +348,7 @@ def test_block_entry_dgrad_multi_fused_bf16(ops, block):
     return inst
 
   want_inst = run(N_BENCH, False)
-  assert all(i.endswith(", true>") for i in want_inst), want_inst
+  assert all(i.endswith(", true, 1>") for i in want_inst), want_inst
   for n in (256, 704, N_BENCH):
     if run(n, False) == want_inst:
       assert run(n, True) == want_inst
@@ -580,7 +580,7 @@ def test_every_benchmark_kernel_instance_was_compared_with_the_oracle():
   # layers), row-major and pixel-major, forward and input gradient, both ring forms:
   # igemm_ring_kernel<MODE, WM, WN, MT, NT, PM, BKT, D, ES = 2, FUSED>
   import re
-  inst = [re.match(r"igemm_ring_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d+), (\d), 2, (?:true|false)>", k)
+  inst = [re.match(r"igemm_ring_kernel<(\d), (\d), (\d), (\d), (\d), (true|false), (\d+), (\d), 2, (?:true|false), 1>", k)
           for k in _seen]
   inst = [m.groups() for m in inst if m]
   for mode in ("0", "1"):

@@ -102,7 +102,7 @@ def test_every_gemm_kernel_of_the_committed_profiles_has_a_pmc_family():
         fam = family_of(name)
         assert fam, (files[-1], name)
         seen += 1
-        if re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 2, (?:true|false)>", name):
+        if re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 2, (?:true|false)(?:, 1)?>", name):
           assert fam == "igemm_bf16", (name, fam)
         if "bf16" in name and "wgrad" in name:
           assert fam == "wgrad_bf16", (name, fam)

@@ -39,7 +39,7 @@ from summarize_pmc import family_of  # noqa: E402
 
 
 def family(name):
-  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 2(?:, (?:true|false))?>", name):
+  if "igemm_bf16_kernel" in name or re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 2(?:, (?:true|false))?(?:, 1)?>", name):
     return "igemm_bf16"
   if "wgrad_reduce_kernel" in name:
     return "wgrad_bf16"
