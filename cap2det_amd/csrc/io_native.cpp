@@ -10,12 +10,13 @@
 //     record_reader.cc, lib/hash/crc32c.h;
 //   * tf.Example wire format (protobuf): Example{1: Features{1: map<string, Feature>}} with
 //     Feature{1: BytesList | 2: FloatList | 3: Int64List}, packed or unpacked repeated scalars;
-//   * baseline / extended-sequential Huffman JPEG decoding with libjpeg's default decompression
+//   * baseline / extended-sequential AND progressive (SOF2, multi-scan) Huffman JPEG decoding with libjpeg's default decompression
 //     choices, which tf.image.decode_jpeg uses (dct_method "" = JDCT_ISLOW, fancy_upscaling =
 //     True): the integer "slow-but-accurate" IDCT of jidctint.c, triangle-filter ("fancy")
 //     chroma upsampling of jdsample.c and the 16-bit fixed-point YCbCr->RGB of jdcolor.c, so the
 //     decoded pixels are bit-identical to libjpeg(-turbo)'s (tests pin this against the system
-//     libjpeg-turbo through Pillow).  Progressive JPEGs return C2D_ERR_UNSUPPORTED;
+//     libjpeg-turbo through Pillow, progressive files included; arithmetic-coded and lossless
+//     files return C2D_ERR_UNSUPPORTED);
 //   * tf.strings.to_hash_bucket (the reader's shard filter, readers/cap2det_reader.py:201-211):
 //     TensorFlow's Hash64 (a MurmurHash64A variant, seed 0xDECAFCAFFE) modulo the bucket count.
 // Entropy decoding is inherently serial, so it stays on host threads (ctypes releases the GIL
