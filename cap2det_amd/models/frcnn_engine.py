@@ -1251,8 +1251,11 @@ class FrcnnEngine(object):
                 sv[self.STEM + "/BatchNorm/moving_variance"], BN_EPS, self.stem_scale,
                 self.stem_shift)
 
+  generation = 0     # bumped whenever launch plans / buffers are dropped: recorded step plans die with them
+
   def set_trainable(self, trainable_names):
     """trainable_names: set of variable names with a positive gradient multiplier."""
+    self.generation += 1
     idx = None
     for net in (self.first, self.second):
       for layer in net.layers.values():

@@ -194,6 +194,7 @@ class Trainer(object):
     self._announced = None      # (image tensor, version) the last step ran its look-ahead for
     self._next_labels = None    # labels of the announced batch, extracted under the last step
     self.plan_replays = 0       # steps issued by c2d_plan_replay so far (tests / bench)
+    self._plan_generation = self.model.engine.generation
     self._last_replayed = False
 
   # -- checkpoint / resume (reference: tf.estimator saves `model.ckpt-<step>` in model_dir,
@@ -465,6 +466,11 @@ class Trainer(object):
     from cap2det_amd.core.standard_fields import InputDataFields as F
     from cap2det_amd.step_plan import StepPlan, Sym
     model, eng = self.model, self.model.engine
+    if self._plan_generation != eng.generation:
+      # the engine dropped its launch plans / buffers (set_trainable): recorded addresses are gone
+      self._plans.clear()
+      self._plan_generation = eng.generation
+      self._leave_replay()
     image = examples[F.image]
     seed = kwargs.get("dropout_seed")
     lr = self.learning_rate()

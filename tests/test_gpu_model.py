@@ -935,6 +935,31 @@ def test_plan_step_equals_eager_step(n, nums, compute_dtype):
   assert first.structure() == second.structure()
 
 
+def test_plans_die_with_the_engines_launch_plans():
+  """`set_trainable` drops the engine's launch plans and buffers (the addresses a recorded step plan
+  holds): the trainer drops its step plans with them, steps on from Python and records again."""
+  from cap2det_amd.train.trainer import Trainer
+  pipeline = util_model.load_pipeline()
+  rng = np.random.default_rng(29)
+  trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5)
+  classes = trainer.model.label_extractor.classes
+  P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
+  trainer.model.load_state_dict(P32)
+  batches = _plan_batches(rng, classes, 9, [9, 4], 12)
+  for i in range(5):
+    trainer.train_step(batches[i], dropout_seed=i, prefetch=batches[i + 1])
+  torch.cuda.synchronize()
+  assert trainer.plan_replays == 2
+  trainer.model.set_trainable(trainer.multipliers.keys())
+  assert trainer.model.engine.generation != trainer._plan_generation
+  for i in range(5, 10):               # 5, 6 Python-driven, 7 recorded, 8 and 9 replayed from the new plan
+    losses = trainer.train_step(batches[i], dropout_seed=i, prefetch=batches[i + 1])
+    if i == 5:
+      assert not any(st["plan"] is not None for st in trainer._plans.values())
+  torch.cuda.synchronize()
+  assert trainer.plan_replays == 4 and np.isfinite(float(losses["total_loss"]))
+
+
 def test_steps_a_plan_cannot_express_run_eagerly():
   """Optimisers other than the one-launch Adagrad, injected dropout masks and steps without a
   look-ahead batch stay Python-driven."""
