@@ -9,6 +9,7 @@ gradient bucket and divided by the world size (synchronous data parallel, equiva
 reference's `SyncReplicasOptimizer` option, train/trainer.py:90-94).
 """
 import math
+import time
 
 import os
 import torch
@@ -194,6 +195,7 @@ class Trainer(object):
     self._announced = None      # (image tensor, version) the last step ran its look-ahead for
     self._next_labels = None    # labels of the announced batch, extracted under the last step
     self.plan_replays = 0       # steps issued by c2d_plan_replay so far (tests / bench)
+    self.replay_s = 0.0
     self._plan_generation = self.model.engine.generation
     self._last_replayed = False
 
@@ -415,6 +417,8 @@ class Trainer(object):
     return losses
 
   # -- step plans ----------------------------------------------------------------------
+  MAX_PLANS = 16      # recorded plans kept (one per input signature; least recently used dropped)
+
   def _plan_eligible(self, kwargs):
     return (self.world_size == 1 and not data_parallel.collectives_on() and
             self.opt_kind == 'adagrad' and self._clip is None and len(self.segments) <= 8 and
@@ -498,9 +502,12 @@ class Trainer(object):
         eng.prefetch_stream.wait_event(prefetch_ready)
       if not self._last_replayed:
         self._join_streams()     # a plan starts from joined streams (c2d_plan_finish)
+      t_r = time.perf_counter()
       plan.replay(tensors, {"seed": int(seed) & 0xFFFFFFFFFFFFFFFF, "lr": lr})
+      self.replay_s += time.perf_counter() - t_r     # host time inside c2d_plan_replay (tools/host_time.py)
       self.plan_replays += 1
       self._last_replayed = True
+      st["used"] = self.global_step
       predictions, losses = st["result"]
     else:
       record = (st["plan"] is None and not st["failed"] and steady and look and st["eager"] >= 2)
@@ -525,7 +532,11 @@ class Trainer(object):
         except Exception:
           st["failed"] = True
           raise
-        st.update(plan=plan, result=(predictions, losses))
+        st.update(plan=plan, result=(predictions, losses), used=self.global_step)
+        # (a reader with many input shapes: keep the plans of the most recently used signatures)
+        live = [(v["used"], k) for k, v in self._plans.items() if v["plan"] is not None]
+        for _, k in sorted(live)[:-self.MAX_PLANS]:
+          self._plans[k].update(plan=None, result=None, eager=0)
       else:
         predictions, losses = self._eager_core(examples, labels, seed, lr, prefetch, prefetch_ready)
         st["eager"] += 1

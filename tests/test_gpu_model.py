@@ -889,9 +889,14 @@ def test_plan_step_equals_eager_step(n, nums, compute_dtype):
   block-entry GEMMs, branch streams)."""
   from cap2det_amd.train.trainer import Trainer
   pipeline = util_model.load_pipeline()
+  # the learning rate halves every step: a replay that froze the recorded step's rate (or its dropout
+  # key) would take a step of another size than the Python-driven one below
+  pipeline.train_config.learning_rate_decay.decay_steps = 1
+  pipeline.train_config.learning_rate_decay.decay_rate = 0.5
   rng = np.random.default_rng(17)
   ltol, stol = (1e-5, 5e-5) if compute_dtype == "fp32" else (2e-2, 5e-2)
   trainer = Trainer(pipeline, device=DEV, depth_multiplier=0.5, compute_dtype=compute_dtype)
+  assert trainer.learning_rate() > 0
   model, store = trainer.model, trainer.model.store
   classes = model.label_extractor.classes
   P32, d = util_model.oracle_state(5, len(classes), 3, 0.5)
@@ -912,7 +917,10 @@ def test_plan_step_equals_eager_step(n, nums, compute_dtype):
   assert trainer.plan_replays == 2
   got = ({k: float(v) for k, v in losses.items()}, model.state_dict())
   got = (got[0], {k: np.array(v, copy=True) for k, v in got[1].items()})
+  assert not torch.equal(store.values, snap[0])
+  lr_replayed = trainer.learning_rate()          # (of the NEXT step: the replayed one ran at twice this)
   store.values.copy_(snap[0]); store.accum.copy_(snap[1]); trainer.global_step = snap[2]
+  assert trainer.learning_rate() == 2.0 * lr_replayed
   model.refresh(only_trainable=True)
   trainer.use_plan = False
   losses = trainer.train_step(batches[4], dropout_seed=104, prefetch=batches[5])
