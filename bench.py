@@ -722,6 +722,11 @@ def main(argv=None):
   from cap2det_amd.train.trainer import Trainer
   from cap2det_amd import _lib as c2d_lib
   from cap2det_amd.train import data_parallel
+  if args.available_cus is None and world > 1 and not same_device:
+    # ranks of a real multi-GPU run share their CUs with RCCL's channel kernels under the backward
+    # pass: plans sized for 224 CUs cost nothing when all 256 are free (10.67-10.82 ms either way)
+    # and 14-16 % less than plans sized for 256 when 32 are taken (profiles/r06_cu_withhold.json)
+    args.available_cus = 224
   if args.available_cus is not None:
     c2d_lib.call("c2d_set_available_cus", int(args.available_cus))
   if grouped:

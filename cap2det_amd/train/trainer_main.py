@@ -71,6 +71,10 @@ def main(argv=None):
   torch.cuda.set_device(local_rank)
   if world > 1:
     dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    # a rank shares its CUs with RCCL's channel kernels under the backward pass: size the one-round
+    # launch budgets for 224 of the 256 (free when nothing is taken, profiles/r06_cu_withhold.json)
+    from cap2det_amd import _lib
+    _lib.call("c2d_set_available_cus", 224)
     reader = pipeline_proto.train_reader.cap2det_reader
     if not reader.shard_indicator:
       reader.shard_indicator = "%d/%d" % (rank, world)
