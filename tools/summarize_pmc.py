@@ -78,6 +78,16 @@ def family_of(name):
   return None
 
 
+def instance_of(name):
+  """Kernel name reduced to its template instance (no argument list, no namespaces)."""
+  n = re.sub(r"\(anonymous namespace\)::|c2d_ig::|^void ", "", name)
+  m = re.match(r"([A-Za-z_0-9]+(?:<[^>]*>)?)", n)
+  return m.group(1) if m else n[:80]
+
+
+PER_KERNEL = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))   # counter -> instance -> [KiB, launches]
+
+
 def read_counter(directory, counter):
   """-> ({family: [sum_KiB, launches]}, steps)"""
   out = collections.defaultdict(lambda: [0.0, 0])
@@ -97,6 +107,9 @@ def read_counter(directory, counter):
         if fam:
           out[fam][0] += float(row["Counter_Value"])
           out[fam][1] += 1
+          rec = PER_KERNEL[counter][instance_of(name)]
+          rec[0] += float(row["Counter_Value"])
+          rec[1] += 1
   return out, steps
 
 
@@ -130,6 +143,18 @@ def main():
                      "128-byte LDS-DMA rows: profiles/r04_counter_calibration.json); WRITE_SIZE as "
                      "read (calibrated 1.000)",
       "families": fams,
+      # per template instance (what a launch of that instance moves, averaged over its launches):
+      # the table behind "which kernel wastes traffic" — algorithmic bytes per launch are a property
+      # of the call (bench.py --per-call), not of the instance
+      "per_kernel": {
+          inst: {"family": family_of(inst) or family_of(inst + "("),
+                 "launches_per_step": PER_KERNEL["FETCH_SIZE"][inst][1] / float(max(fsteps, 1)),
+                 "hbm_read_bytes_per_launch": (FETCH_FACTORS.get(family_of(inst), DEFAULT_FETCH_FACTOR) *
+                                               PER_KERNEL["FETCH_SIZE"][inst][0] * 1024.0 /
+                                               max(PER_KERNEL["FETCH_SIZE"][inst][1], 1)),
+                 "hbm_write_bytes_per_launch": (PER_KERNEL["WRITE_SIZE"][inst][0] * 1024.0 /
+                                                max(PER_KERNEL["WRITE_SIZE"][inst][1], 1))}
+          for inst in sorted(set(PER_KERNEL["FETCH_SIZE"]) | set(PER_KERNEL["WRITE_SIZE"]))},
   }
   write_json(out_path, doc, indent=1, sort_keys=True)
   for fam, v in fams.items():
