@@ -209,6 +209,19 @@ extern "C" int c2d_plan_finish(void* plan, void* main_stream) {
         Node w = {}; w.kind = NODE_WAIT; w.event = e0; w.stream = s;
         head.push_back(w);
       }
+      // a stream whose last node is a record that the main stream waits for later in the plan is
+      // joined inside the step (the filter-gradient and branch streams are): nothing to carry over
+      bool joined = false;
+      for (size_t i = p->nodes.size(); i-- > 0;) {
+        const Node& n = p->nodes[i];
+        if (n.kind == NODE_CALL || n.stream != s) continue;
+        if (n.kind == NODE_RECORD)
+          for (size_t j = i + 1; j < p->nodes.size(); ++j)
+            if (p->nodes[j].kind == NODE_WAIT && p->nodes[j].event == n.event && p->nodes[j].stream == mainst)
+              joined = true;
+        break;
+      }
+      if (joined) continue;
       const int ei = (int)p->events.size();
       const int rc = ensure_event(p, ei);
       if (rc) return rc;
