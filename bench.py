@@ -166,6 +166,12 @@ class KernelTimer(object):
         except Exception:
           nbytes = 0.0
         fam = family + ("_bf16" if low else "")
+        # fp32 operands on the f32x9 kernels (csrc/igemm_x9.hip): a family of its own, priced against
+        # the pipe it runs on (bf16 MFMA / 9), never against the fp32 matrix peak
+        if fam == "igemm_nt":
+          inst = ops.last_dispatch()
+          if inst and all(i.endswith(", 3>") for i in inst):
+            fam = "igemm_x9"
         # the bf16 step's single-image first stage runs on its own kernel (igemm_small_kernel<*, 2>:
         # one 32x32 tile per workgroup, launch-bound): its own family, not the ring kernel's
         if fam == "igemm_nt_bf16" and small_rows(fn.__name__, args):
@@ -233,12 +239,17 @@ class KernelTimer(object):
       d["bytes"] += nbytes
       if not family.startswith("roi_crop") and work > 0:
         # the roofline that binds THIS call: matrix pipe or HBM (operands and result once)
-        peak = PEAK_BF16_MFMA_TFLOPS if family.endswith("_bf16") else PEAK_FP32_MFMA_TFLOPS
+        peak = (PEAK_BF16_MFMA_TFLOPS if family.endswith("_bf16") else
+                PEAK_F32X9_TFLOPS if family == "igemm_x9" else PEAK_FP32_MFMA_TFLOPS)
         t_mfma = work / (peak * 1e12) * 1e3
         t_hbm = nbytes / (PEAK_HBM_GBPS * 1e9) * 1e3
         d["ideal_ms"] += max(t_mfma, t_hbm)
         d["hbm_bound_calls"] += int(t_hbm > t_mfma)
     return out
+
+
+# fp32 GEMMs as nine bf16 partial products: 2.5 PFLOP/s of bf16 MFMAs / 9 products per fp32 product
+PEAK_F32X9_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 9.0
 
 
 def cpu_baseline(pipeline, classes, num_proposals, budget_s=100.0, warmup=3, max_timed=10):
@@ -354,10 +365,10 @@ def parse_args(argv=None):
                   help="NCCL_MAX_NCHANNELS for the ranks (set before anything touches the GPU): fewer RCCL "
                        "channels = fewer CUs taken from the step")
   ap.add_argument("--nccl-min-nchannels", type=int, default=None, help="NCCL_MIN_NCHANNELS, likewise")
-  ap.add_argument("--f32x9", action="store_true",
-                  help="SECONDARY measurement (fp32 configs): the second stage's forward / input-gradient "
-                       "GEMMs as nine bf16 partial products on the bf16 matrix pipe (csrc/igemm_x9.hip); "
-                       "measured and NOT the default, profiles/r06_f32x9/README.md")
+  ap.add_argument("--no-f32x9", action="store_true",
+                  help="A/B (fp32 configs): every GEMM on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) "
+                       "instead of the big forward / input-gradient GEMMs as nine bf16 partial products "
+                       "(csrc/igemm_x9.hip; DESIGN.md section 5)")
   ap.add_argument("--dtype", choices=["fp32", "bf16"], default=None,
                   help="override the config's precision: fp32 = exact fp32 everywhere; bf16 = the "
                        "convolution towers behind the stem (first stage, ROI crop output, second stage) "
@@ -746,8 +757,9 @@ def main(argv=None):
                       compute_dtype=args.dtype, allow_missing_pretrained=True)
   finally:
     shutil.rmtree(scratch, ignore_errors=True)
-  if args.f32x9:
-    trainer.model.engine.enable_f32x9()
+  if args.no_f32x9:
+    trainer.model.engine.enable_f32x9(False)
+  x9_on = getattr(trainer.model.engine, "_x9", None) is not None
   classes = trainer.model.label_extractor.classes
   assert len(classes) == spec["classes"]
   # the headline workload, unless --image-hw / --batch / --proposals name a secondary point
@@ -917,9 +929,12 @@ def main(argv=None):
                               "each, the others (first / last two) queued from Python"
                               % (replays_timed, args.steps)
                               if replays_timed > 0 else "eager (every call queued from Python)"),
-                   "gemm_method": ("f32x9 (second-stage forward / input-gradient GEMMs: nine bf16 partial "
-                                   "products, fp32 accumulate; filter gradients on the fp32 pipe)"
-                                   if args.f32x9 else
+                   "gemm_method": ("f32x9: the forward / input-gradient GEMMs of 256 and more 128x128 tiles "
+                                   "as nine EXACT bf16 partial products per fp32 product (x = hi + mid + lo, "
+                                   "v_mfma_f32_32x32x16_bf16, fp32 accumulate: results within the fp32 "
+                                   "kernels' tolerance of the float64 oracle); filter gradients, first stage "
+                                   "and heads on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32)"
+                                   if x9_on else
                                    ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32"
                                     else "bf16 MFMA (v_mfma_f32_32x32x16_bf16)"))},
         "world_size": world,
@@ -1005,9 +1020,12 @@ def main(argv=None):
                               "all kernels on one stream (the other steps overlap the filter "
                               "gradients with the input-gradient GEMMs on a side stream)"}
 
+      # (the committed PMC passes are of the default build: with --no-f32x9 on an fp32 network their
+      #  "igemm" family holds only the launches f32x9 leaves on the fp32 pipe — no traffic figure then)
+      ig32_key = "igemm" if (low or x9_on or "igemm_x9" not in traffic) else "igemm (no PMC pass of this mode)"
       ig32 = mfma_family("igemm_nt", "igemm_nt_kernel<*> + igemm_small_kernel<*> (implicit-GEMM conv "
                          "fwd + dgrad + heads GEMM, fp32 MFMA 32x32x2; a stride-2 dgrad call = 4 launches)",
-                         "igemm", PEAK_FP32_MFMA_TFLOPS)
+                         ig32_key, PEAK_FP32_MFMA_TFLOPS)
       wg32 = mfma_family("wgrad_tn", "wgrad_tn_kernel<*> + wgrad3x3_kernel<*> (conv filter gradient, "
                          "fp32 MFMA)", "wgrad", PEAK_FP32_MFMA_TFLOPS)
       # whole-step view, independent of how kernels overlap: all MFMA work of a step over the
@@ -1018,9 +1036,23 @@ def main(argv=None):
         result["step_mfma"] = {"algorithmic_gflop_per_step": gemm_flops / 1e9,
                                "achieved": gemm_flops / p50 / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": gemm_flops / p50 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                               "over": "median step time (all kernels of the step)"}
+                               "over": "median step time (all kernels of the step); against the fp32 "
+                                       "matrix peak whatever pipe the GEMMs ran on (with f32x9 part of "
+                                       "the FLOPs run on the bf16 pipe: this is a rate, not a utilisation)"}
+      igx9 = mfma_family("igemm_x9", "igemm_ring_kernel<*, 4, *, 3> (f32x9: implicit-GEMM conv fwd + dgrad on "
+                         "fp32 operands as nine bf16 partial products, DMA ring; peak = 2.5 PFLOP/s of bf16 "
+                         "MFMAs / 9 = the fp32-equivalent rate of the pipe actually used)", "igemm_x9",
+                         PEAK_F32X9_TFLOPS)
+      if igx9:
+        igx9["bound"] = "mfma bf16x9"
       if not low:
-        if ig32: result["roofline"] = ig32
+        if igx9:
+          # the dominant family; the GEMMs that stay on the fp32 pipe (first stage, heads, launches of
+          # fewer than 256 tiles) beside it
+          result["roofline"] = igx9
+          if ig32: result["roofline_fp32_igemm"] = ig32
+        elif ig32:
+          result["roofline"] = ig32
         if wg32: result["roofline_wgrad"] = wg32
       else:
         # second stage on bf16 operands (MFMA 32x32x16 bf16, fp32 accumulate); the frozen /

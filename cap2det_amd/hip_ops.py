@@ -800,6 +800,14 @@ def split3_bf16(src, planes):
   return planes
 
 
+def split3_span(src, planes, lo, hi):
+  """split3_bf16 of the elements [lo, hi) of the flat tensor `src` into the same columns of `planes`
+  (lo, hi multiples of 4)."""
+  assert src.dtype == torch.float32 and planes.dtype == torch.bfloat16 and planes.shape[0] == 3
+  assert 0 <= lo < hi <= src.numel() <= planes.shape[1] and lo % 4 == 0 and hi % 4 == 0
+  _lib.call("c2d_split3_bf16", _p(src) + 4 * lo, _p(planes) + 2 * lo, planes.shape[1], hi - lo, _stream())
+
+
 def f32x9_bind(arena, planes):
   """GEMM calls whose fp32 weight operand lies inside the flat tensor `arena` run as nine bf16
   partial products on the planes [3, n] (kept current by the caller: split3_bf16)."""

@@ -1045,6 +1045,16 @@ class Net(object):
 # the Fast-RCNN feature path
 # ----------------------------------------------------------------------------------------
 
+def _x9_unbind(*arena_ptrs):
+  """weakref.finalize callback of FrcnnEngine.enable_f32x9 (module level: holds no engine)."""
+  from cap2det_amd import _lib
+  try:
+    for ptr in arena_ptrs:
+      _lib.call("c2d_f32x9_unbind", ptr)
+  except Exception:   # noqa: BLE001 -- interpreter shutdown
+    pass
+
+
 class FrcnnEngine(object):
   """extract_frcnn_feature (models/utils.py:108-188) on MI355X."""
 
@@ -1127,6 +1137,11 @@ class FrcnnEngine(object):
     self.stats.finalize()
     self._extra_transposes = list(extra_transposes)
     self._tables = {}
+    # fp32 networks on a GPU: the big forward / input-gradient GEMMs as nine bf16 partial products
+    # (C2D_TUNE=f32x9=0 keeps them on the fp32 matrix pipe)
+    if (self.act_dtype == torch.float32 and torch.device(self.device).type == "cuda" and
+        self.store.values is not None and tune.on("f32x9")):
+      self.enable_f32x9()
 
   def _layers(self, only_trainable):
     out = []
@@ -1208,32 +1223,63 @@ class FrcnnEngine(object):
       if not fused_mirror:
         ops.cast_bf16(self.stats.der_flat, self.stats.der_bf16)
     if getattr(self, "_x9", None) is not None:
-      self._x9_split()
+      self._x9_split(only_trainable)
 
   def enable_f32x9(self, on=True):
-    """Opt-in (bench.py --f32x9; measured, not the default: profiles/r06_f32x9/README.md): the fp32
-    second stage's forward / input-gradient GEMMs as nine bf16 partial products.  Binds bf16 plane
-    arenas to the variable store and to the derived operands (c2d_f32x9_bind) and keeps them
-    current in refresh()."""
+    """The fp32 network's forward / input-gradient GEMMs as nine bf16 partial products (DESIGN.md
+    section 5, profiles/r06_f32x9/): binds bf16 plane arenas to the variable store and to the derived
+    operands (c2d_f32x9_bind) and keeps them current in refresh().  The bindings are keyed by
+    address: they are removed when this engine (and with it the two arenas) goes away."""
     if self.act_dtype != torch.float32:
       raise ValueError("f32x9 is a form of the fp32 network")
+    if getattr(self, "_x9_finalizer", None) is not None:
+      self._x9_finalizer()              # unbinds (idempotent)
+      self._x9_finalizer = None
+    self._x9 = None
     if not on:
-      if getattr(self, "_x9", None) is not None:
-        ops.f32x9_unbind(self.store.values)
-        ops.f32x9_unbind(self.stats.der_flat)
-      self._x9 = None
       return
     pv = torch.zeros(3, -(-self.store.values.numel() // 8) * 8, device=self.device, dtype=torch.bfloat16)
     pd = torch.zeros(3, -(-self.stats.der_flat.numel() // 8) * 8, device=self.device, dtype=torch.bfloat16)
     ops.f32x9_bind(self.store.values, pv)
     ops.f32x9_bind(self.stats.der_flat, pd)
     self._x9 = (pv, pd)
+    import weakref
+    self._x9_finalizer = weakref.finalize(self, _x9_unbind, self.store.values.data_ptr(),
+                                          self.stats.der_flat.data_ptr())
     self._x9_split()
 
-  def _x9_split(self):
+  def _x9_split(self, only_trainable=False):
+    """Re-splits the weight planes: whole arenas, or (the per-step refresh) the two spans the
+    optimiser step and the operand refresh of the trainable layers just rewrote."""
     pv, pd = self._x9
+    if only_trainable:
+      spans = self._x9_spans()
+      if spans is not None:
+        (vlo, vhi), (dlo, dhi) = spans
+        ops.split3_span(self.store.values, pv, vlo, vhi)
+        ops.split3_span(self.stats.der_flat, pd, dlo, dhi)
+        return
     ops.split3_bf16(self.store.values, pv)
     ops.split3_bf16(self.stats.der_flat, pd)
+
+  def _x9_spans(self):
+    """((lo, hi) of the variable store, (lo, hi) of the derived operands) covering every trainable
+    convolution's weights / transposed weights and the extra transposes (the heads); None when
+    nothing trains.  Multiples of 4 elements."""
+    key = tuple(L.name for L in self._layers(True))
+    if getattr(self, "_x9_span_key", None) != key:
+      names = [L.name + "/weights" for L in self._layers(True)] + [v for v, _, _, _, _ in self._extra_transposes]
+      ders = ([(self.stats.der_off[L.name + "/wt"], L.k * L.k * L.cin * L.cout) for L in self._layers(True)] +
+              [(self.stats.der_off[dn], taps * rows * cols) for _, dn, taps, rows, cols in self._extra_transposes])
+      if not names:
+        self._x9_span_val = None
+      else:
+        vlo, vhi = self.store.span(names)
+        dlo = min(o for o, _ in ders) // 4 * 4
+        dhi = -(-max(o + n for o, n in ders) // 4) * 4
+        self._x9_span_val = ((vlo // 4 * 4, -(-vhi // 4) * 4), (dlo, min(dhi, self.stats.der_flat.numel())))
+      self._x9_span_key = key
+    return self._x9_span_val
 
   def _refresh_stem(self):
     """Folds depthwise(7x7, x8) o pointwise(1x1) into one 7x7 kernel over the 4-channel padded

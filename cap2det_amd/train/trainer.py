@@ -424,8 +424,7 @@ class Trainer(object):
             self.opt_kind == 'adagrad' and self._clip is None and len(self.segments) <= 8 and
             all(cols is None and l1 == 0.0 for _, _, _, l1, _, cols, _ in self.segments) and
             kwargs.get("dropout_mask") is None and kwargs.get("labels") is None and
-            not self.model.engine.dropout_on_feature_map and
-            getattr(self.model.engine, "_x9", None) is None)
+            not self.model.engine.dropout_on_feature_map)
 
   def _join_streams(self):
     """The current stream waits for everything queued on the engine's other streams."""

@@ -7,6 +7,7 @@ when an engine or a launch plan is BUILT, never per step:
   fuse_bn_bwd=0        separate BN/ReLU-backward launches instead of the fused input-gradient epilogues
   commute_avgpool=0    average pool in front of its 1x1 convolution (the reference order)
   first_stage_fp32=1   a bf16 network keeps its single-image tower in fp32
+  f32x9=0              an fp32 network keeps every GEMM on the fp32 matrix pipe
 """
 import os
 

@@ -14,7 +14,7 @@ import torch
 
 from oracle import ref_ops, ref_split
 from tests.test_gpu_real_shapes import (DEV, N_BENCH, SECOND_STAGE_LAYERS, FUSED_INNER_LAYERS, _Layer,
-                                        _n, _scale_close, _t)
+                                        _n, _scale_close, _seen, _t)
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -25,14 +25,23 @@ def ops():
   from cap2det_amd import hip_ops
   hip_ops.set_conv_workspace(None)
   yield hip_ops
-  hip_ops.f32x9_unbind(None)
+
+
+_bound = []      # the weight tensors this module bound planes to
+
+
+def _planes(ops, t):
+  _bound.append(t)
+  return ops.x9_planes(t)
 
 
 @pytest.fixture(autouse=True)
 def _unbind(ops):
-  """Bindings are keyed by address: none may outlive the tensors of the test that made it."""
+  """Bindings are keyed by address: none may outlive the tensors of the test that made it (and the
+  bindings of live engines elsewhere in the session stay: no blanket unbind)."""
   yield
-  ops.f32x9_unbind(None)
+  while _bound:
+    ops.f32x9_unbind(_bound.pop().view(-1))
 
 
 def _is_x9(insts):
@@ -67,7 +76,7 @@ def test_split3_bits(ops):
 class _X9Layer(_Layer):
   def __init__(self, ops, *args):
     super().__init__(ops, *args, torch.float32)
-    self.keep = (ops.x9_planes(self.w_), ops.x9_planes(self.wt_))
+    self.keep = (_planes(ops, self.w_), _planes(ops, self.wt_))
 
 
 def _check(ops, name, hw, cin, cout, k, s):
@@ -94,6 +103,7 @@ def _check(ops, name, hw, cin, cout, k, s):
     else:
       want, _ = ref_ops.conv2d_backward(x64, w64, dc64, s, need_dx=True)
     _scale_close(_n(got), want, TOL, "%s %s n=%d %s" % (name, what, n, want_inst))
+    _seen.update(want_inst)          # (the profile-completeness check of tests/test_gpu_real_shapes.py)
     # ... and the fp32-MFMA kernels with the switch off: same numbers to the same tolerance
     was = ops.f32x9_enable(False)
     try:
@@ -133,7 +143,7 @@ def test_block_entry_x9(ops, block):
       v.copy_(_t(a))
       store.append(v)
       off += a.size
-  planes = ops.x9_planes(arena)
+  planes = _planes(ops, arena)
   x_ = _t(x)
   ys = [torch.empty(rows, c, device=DEV) for c in couts]
   ones = [torch.ones(c, device=DEV) for c in couts]
@@ -142,6 +152,7 @@ def test_block_entry_x9(ops, block):
                         for i in range(len(couts))])
   ops.conv1x1_fwd_multi(x_, cin, 0, outs, rows, cin)
   assert _is_x9(ops.last_dispatch()), ops.last_dispatch()
+  _seen.update(ops.last_dispatch())
   for y, w in zip(ys, ws):
     _scale_close(_n(y), x.astype(np.float64) @ w.astype(np.float64), TOL, block + " entry fwd")
   dcs = [rng.standard_normal((rows, c)).astype(np.float32) for c in couts]
@@ -149,6 +160,7 @@ def test_block_entry_x9(ops, block):
   ops.conv1x1_dgrad_multi([_t(a) for a in dcs], couts, [0] * len(couts), w_dev, couts, dx, cin, 0, rows,
                           cin, False)
   assert _is_x9(ops.last_dispatch()), ops.last_dispatch()
+  _seen.update(ops.last_dispatch())
   want = sum(a.astype(np.float64) @ w.astype(np.float64).T for a, w in zip(dcs, ws))
   _scale_close(_n(dx), want, TOL, block + " entry dgrad")
   del planes
@@ -169,7 +181,7 @@ def test_fused_dgrad_bn_relu_x9(ops, layer):
   beta = (0.1 * rng.standard_normal(cin)).astype(np.float32)
   gamma = rng.uniform(0.5, 1.5, cin).astype(np.float32)
   w_ = _t(w).view(k * k, cin, cout)
-  planes = ops.x9_planes(w_)
+  planes = _planes(ops, w_)
   nb = ops.conv_dgrad_bn_relu_blocks(torch.float32, n, hw, hw, cin, cout, k, k, s)
   out = torch.full((n * hw * hw, cin), 9.0, device=DEV)
   part = torch.full((nb, 2, cin), 7.0, device=DEV)
@@ -180,6 +192,7 @@ def test_fused_dgrad_bn_relu_x9(ops, layer):
     assert not _is_x9(inst), inst
   else:
     assert _is_x9(inst) and all(", true, 3>" in i for i in inst), inst
+  _seen.update(inst)
   dx, _ = ref_ops.conv2d_backward(np.zeros((n, hw, hw, cin)), w.astype(np.float64), dc.astype(np.float64), s)
   dz = dx * (y > 0)
   _scale_close(_n(out).reshape(n, hw, hw, cin), dz * scale, TOL, "%s fused dc %s" % (name, inst))
@@ -205,7 +218,7 @@ def test_accumulating_and_offset_outputs_x9(ops):
   dc = rng.standard_normal((n * hw * hw, cout + 32)).astype(np.float32)
   base = rng.standard_normal((n * hw * hw, cin + 64)).astype(np.float32)
   w_ = _t(w).view(9, cin, cout)
-  planes = ops.x9_planes(w_)
+  planes = _planes(ops, w_)
   dx = _t(base).clone()
   ops.conv_dgrad(_t(dc), cout + 32, 16, w_, dx, cin + 64, 32, n, hw, hw, cin, cout, 3, 3, 1, True)
   assert _is_x9(ops.last_dispatch())

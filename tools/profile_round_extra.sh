@@ -14,7 +14,8 @@ for CFG in c1 c2; do
   timeout 600 python bench.py --reader --config $CFG --steps 300 --warmup 20 --image-hw 1000 1333 --batch 2 --proposals 500 > $S/${T}_bench_reader_${CFG}_1000px.json 2> $S/err_reader_${CFG}_1000px.txt
 done
 timeout 600 python bench.py --reader --config c2 --steps 300 --warmup 20 --image-hw 1000 1333 --batch 2 --proposals 500 --no-plan > $S/${T}_bench_reader_c2_1000px_python_driven.json 2> $S/err_reader_c2_1000px_noplan.txt
-timeout 300 python bench.py --f32x9 --no-cpu-baseline > $S/${T}_bench_c1_f32x9.json 2> $S/err_f32x9.txt
+timeout 300 python bench.py --no-f32x9 --no-cpu-baseline > $S/${T}_bench_c1_fp32_mfma.json 2> $S/err_no_f32x9.txt
+timeout 300 python bench.py --config c3 --no-f32x9 --no-cpu-baseline > $S/${T}_bench_c3_fp32_mfma.json 2> $S/err_no_f32x9_c3.txt
 timeout 600 python bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu-baseline --available-cus 224 2> $S/err_gpus8.txt | grep '^{' | tail -1 > $S/${T}_bench_gpus8_same_device.json
 timeout 300 python tools/host_time.py > $S/${T}_host_issue_time.txt 2>&1
 timeout 600 python tools/rccl_rehearsal.py 2> $S/err_rccl.txt | grep '^{' | tail -1 > $S/${T}_rccl_rehearsal.json

@@ -61,6 +61,8 @@ def family_of(name):
   if ("wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16" in name or "wgrad1x1_bf16_ring" in name or
       "wgrad_reduce_kernel" in name):
     return "wgrad_bf16"
+  if re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 4, (?:true|false), 3>", name):
+    return "igemm_x9"         # fp32 operands as nine bf16 partial products (csrc/igemm_x9.hip)
   if "igemm_bf16_kernel" in name or re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 2(?:, (?:true|false))?(?:, 1)?>", name):
     return "igemm_bf16"
   if re.search(r"igemm_small(_group)?_kernel<\d, 2>", name):
