@@ -1958,13 +1958,16 @@ int x9_launch(IgemmArgs a, bool pm, hipStream_t s) {
   static const bool tune = c2d_tune_on();
   static const int force_nt = (tune && c2d_tune_get("x9_nt")) ? atoi(c2d_tune_get("x9_nt")) : 0;
   static const int force_nt_pm = (tune && c2d_tune_get("x9_nt_pm")) ? atoi(c2d_tune_get("x9_nt_pm")) : 0;
-  int best_nt = a.N > 64 ? 4 : 2;
-  if (!pm) {
-    int best_cols = 1 << 30;
-    for (int nt = 5; nt >= 2; --nt) {
-      const int cols = c2d_ceil_div(a.N, nt * 32) * nt * 32;
-      if (cols < best_cols) { best_cols = cols; best_nt = nt; }
-    }
+  // Tile width = NT x 32 columns: the fewest padded columns, the wider tile on a tie.  Pixel-major
+  // launches (3x3 over 4x4 / 7x7 maps) stop at 128 columns: measured per call of the step
+  // (bench.py --per-call, C2D_TUNE=x9_nt_pm=2..6, N = 2000): 192 columns 3 x 64 or 2 x 96 beat
+  // 2 x 128 by 12 - 17 % (input gradient 256 -> 192 on 7x7: 606 -> 509 us), 160 columns 2 x 96
+  // beats 2 x 128 and 1 x 160 (165 / 171 -> 138 us), 320 columns 5 x 64 beats 3 x 128 and 2 x 160
+  // (206 / 191 -> 182 us), 224 and 256 columns stay on 128-wide tiles.
+  int best_nt = 2, best_cols = 1 << 30;
+  for (int nt = pm ? 4 : 5; nt >= 2; --nt) {
+    const int cols = c2d_ceil_div(a.N, nt * 32) * nt * 32;
+    if (cols < best_cols) { best_cols = cols; best_nt = nt; }
   }
   int wm = 4, wn = 1, mt = 1;
   const int f = pm ? force_nt_pm : force_nt;
