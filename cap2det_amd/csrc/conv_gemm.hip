@@ -2885,6 +2885,15 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
   if (splits_out) *splits_out = a.nsplits;
   if (splits_only) return C2D_OK;
   if (partial) { a.part_stride = dw_numel; a.dW = partial; }
+  if (ES == 4 && plain && !partial && x9_active()) {
+    // fp32 networks with f32x9 on: the 1x1 filter gradients as nine bf16 partial products too
+    // (C2D_TUNE=x9_wgrad=0 keeps them on the fp32 pipe)
+    static const bool off = c2d_tune_on() && c2d_tune_get("x9_wgrad") && atoi(c2d_tune_get("x9_wgrad")) == 0;
+    if (!off) {
+      const int rc2 = launch_wgrad1x1_x9(a, st);
+      if (rc2 != C2D_ERR_UNSUPPORTED) return rc2;
+    }
+  }
   dispatch_note(plain ? "wgrad_tn_kernel<%d, true, %d>" : "wgrad_tn_kernel<%d, false, %d>", narrow ? 1 : 2, ES);
   if (narrow && plain) hipLaunchKernelGGL((wgrad_tn_kernel<1, true, ES>), grid, dim3(256), 0, st, a);
   else if (narrow) hipLaunchKernelGGL((wgrad_tn_kernel<1, false, ES>), grid, dim3(256), 0, st, a);

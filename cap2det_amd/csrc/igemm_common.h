@@ -431,5 +431,10 @@ int launch_wgrad1x1_bf16_ring(WgradArgs a, hipStream_t s, int* splits_out, bool 
 // `num` (<= WGRAD_GROUP_MAX) 1x1 / stride-1 filter gradients of ONE input as one launch; fills the
 // tiling fields of a[p] itself (atomics into a[p].dW).
 int launch_wgrad1x1_bf16_ring_group(WgradArgs* a, int num, hipStream_t s);
+// f32x9 (igemm_x9.hip): true when the process has bound weight planes and the switch is on; the
+// filter gradient of a 1x1 / stride-1 convolution on fp32 operands as nine bf16 partial products
+// (fills the tiling fields of `a` itself; atomics into a.dW; C2D_ERR_UNSUPPORTED: not this shape).
+bool x9_active();
+int launch_wgrad1x1_x9(WgradArgs a, hipStream_t s);
 
 }  // namespace c2d_ig

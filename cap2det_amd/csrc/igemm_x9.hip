@@ -183,6 +183,206 @@ int launch_igemm_x9_ring(const IgemmArgs& a, int wm, int wn, int mt, int nt, boo
   }
 }
 
+namespace {
+
+// ---- filter gradient of a 1x1 / stride-1 convolution as nine partial products -------------------
+// dW[i][j] = sum over rows m of x[m][i] * dC[m][j]: BOTH operands are fp32 activations, the contraction
+// runs over rows.  The loader threads split what they fetch — 8 channels of a row = one split3_frag =
+// three 16-byte LDS writes, once per element instead of once per fragment use — into three bf16 plane
+// tiles per operand, staged as they lie in HBM ([row][channel]); the MFMA operands (8 consecutive rows
+// of one channel per lane) come out of ds_read_b64_tr_b16 as in wgrad_tn_bf16_kernel (conv_gemm.hip).
+// Block tile 128 (i) x 64 NTJ (j), four waves 2 x 2, 32-row slabs; 60 KiB of LDS: two blocks per CU.
+// The fp32 kernel this replaces (wgrad_tn_kernel, 16-row register-staged slabs on v_mfma_f32_32x32x2)
+// runs the step's fifteen 1x1 filter gradients at 0.50 - 0.69 of the fp32 matrix peak.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+__device__ __forceinline__ bf16x8 tr_frag_x9(const char* p, int hi_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + hi_off));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+constexpr int WX_KB = 32;           // rows per slab: two 16-row MFMA k-steps
+constexpr int WX_RS = 256 + 64;     // bytes per staged row of a plane tile (128 bf16 + pad: 64 mod 256)
+constexpr int WX_TILE = WX_KB * WX_RS;
+
+template <int NTJ>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_x9_kernel(WgradArgs a) {
+  constexpr int BJ = 2 * NTJ * 32;
+  __shared__ __attribute__((aligned(16))) char smem[6 * WX_TILE];   // A planes 0..2, G planes 0..2
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  char* const As = smem;
+  char* const Gs = smem + 3 * WX_TILE;
+  const WgradBlock blk = wgrad_block(a);
+  const int i0 = blk.x * 128;
+  const int j0 = blk.y * BJ;
+  const int mbeg = blk.z * a.rows_per_split;
+  const int nslabs = (min(a.rows_per_split, a.M - mbeg) + WX_KB - 1) / WX_KB;
+
+  // loader: thread -> rows kr, kr + 16 of the slab, 8 channels c8 (two 16-byte loads per row);
+  // columns beyond I / J are clamped (their products land in dW rows / columns never stored);
+  // rows >= M lie outside the descriptors and come back as zeros
+  const int kr = tid >> 4;
+  const int c8 = (tid & 15) * 8;
+  const bool gload = c8 < BJ;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 4,
+                                                 (a.a_rows * a.lda - a.a_off) * 4);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * 4,
+                                                 ((long long)a.M * a.ldg - a.g_off) * 4);
+  const unsigned acol = (unsigned)min(i0 + c8, a.I - 8) * 4u;
+  const unsigned gcol = (unsigned)min(j0 + min(c8, BJ - 8), a.J - 8) * 4u;
+  unsigned aoffs[2], goffs[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    aoffs[u] = (unsigned)((kr + u * 16) * a.lda) * 4u + acol;
+    goffs[u] = (unsigned)((kr + u * 16) * a.ldg) * 4u + gcol;
+  }
+
+  f32x16 acc[2][NTJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  unsigned tile_bits = 0;   // bit i * NTJ + j: 32 x 32 tile inside I x J (others issue no MFMA)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+      if ((i0 + wm * 64 + i * 32 < a.I) && (j0 + (wn * NTJ + j) * 32 < a.J))
+        tile_bits |= 1u << (i * NTJ + j);
+  tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
+
+  f32x4 ra[2][2], rg[2][2];
+#define K_WX_LOAD(MB)                                                      \
+  {                                                                          \
+    const int sa = (MB) * a.lda * 4, sg = (MB) * a.ldg * 4;                  \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                          \
+      ra[u][0] = buf_load4(rsA, aoffs[u], sa);                               \
+      ra[u][1] = buf_load4(rsA, aoffs[u] + 16u, sa);                         \
+      rg[u][0] = buf_load4(rsG, goffs[u], sg);                               \
+      rg[u][1] = buf_load4(rsG, goffs[u] + 16u, sg);                         \
+    }                                                                        \
+  }
+  // transposed-read bases: row 8 * lh + q, 16-column half (lane >> 4) & 1, 4-column slot p
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const char* const apl = As + (8 * lh + tq) * WX_RS + (wm * 64 + 16 * tg + 4 * tp) * 2;
+  const char* const gpl = Gs + (8 * lh + tq) * WX_RS + (wn * NTJ * 32 + 16 * tg + 4 * tp) * 2;
+
+  K_WX_LOAD(mbeg);
+  for (int sl = 0, mb = mbeg; sl < nslabs; ++sl, mb += WX_KB) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8 h, m, l;
+      char* const wa = As + (kr + u * 16) * WX_RS + c8 * 2;
+      split3_frag(ra[u][0], ra[u][1], h, m, l);
+      *reinterpret_cast<bf16x8*>(wa) = h;
+      *reinterpret_cast<bf16x8*>(wa + WX_TILE) = m;
+      *reinterpret_cast<bf16x8*>(wa + 2 * WX_TILE) = l;
+      if (gload) {
+        char* const wg = Gs + (kr + u * 16) * WX_RS + c8 * 2;
+        split3_frag(rg[u][0], rg[u][1], h, m, l);
+        *reinterpret_cast<bf16x8*>(wg) = h;
+        *reinterpret_cast<bf16x8*>(wg + WX_TILE) = m;
+        *reinterpret_cast<bf16x8*>(wg + 2 * WX_TILE) = l;
+      }
+    }
+    __syncthreads();
+    K_WX_LOAD(mb + WX_KB);     // next slab (rows past M: zeros)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[2][3], bf[NTJ][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i][p] = tr_frag_x9(apl + p * WX_TILE + s * 16 * WX_RS + i * 64, 4 * WX_RS);
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j)
+          bf[j][p] = tr_frag_x9(gpl + p * WX_TILE + s * 16 * WX_RS + j * 64, 4 * WX_RS);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j)
+          if ((tile_bits >> (i * NTJ + j)) & 1u) {
+            // smallest products first (planes 0 hi, 1 mid, 2 lo), as in the ring kernel
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+          }
+    }
+    __syncthreads();
+  }
+#undef K_WX_LOAD
+
+  // split-K result: fp32 atomics into dW (pre-zeroed or accumulated into), as wgrad_tn_kernel
+  float* dw = a.dW;
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j) {
+    const int jj = j0 + (wn * NTJ + j) * 32 + li;
+    if (jj >= a.J) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ii = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ii >= a.I) continue;
+        atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
+      }
+  }
+}
+
+}  // namespace
+
+bool x9_active() { return g_enabled && g_narena > 0; }
+
+int launch_wgrad1x1_x9(WgradArgs a, hipStream_t s) {
+  if (a.I % 8 || a.J % 8 || a.lda % 4 || a.ldg % 4 || a.a_off % 4 || a.g_off % 4 || a.I < 8 || a.J < 8 ||
+      a.part_stride > 0)
+    return C2D_ERR_UNSUPPORTED;
+  // (the single-image first stage — 1024 rows, a handful of blocks of a few slabs — is quicker on
+  //  the fp32 kernel's 16-row slabs: 12.6 - 14.0 against 14.5 - 15.3 us)
+  if (a.M < 8192) return C2D_ERR_UNSUPPORTED;
+  static const bool tune = c2d_tune_on();
+  static const int slots_env = (tune && c2d_tune_get("x9_wgrad_slots")) ? atoi(c2d_tune_get("x9_wgrad_slots")) : 512;
+  // Output widths whose last 128-column tile would be at most half full (192, 160 columns) take
+  // 128 x 64 tiles, where the loader's split arithmetic is spread over half the MFMAs: alone those
+  // launches measure 0.96 - 0.97 x the fp32 kernel (128 and 352 columns: 1.27 - 1.42 x), inside the
+  // step — matrix-pipe-bound across its two streams — they still pay: 9.70 -> 9.63 - 9.68 ms with
+  // them, 9.84 - 9.87 with every filter gradient on the fp32 pipe.  C2D_TUNE=x9_wgrad_narrow=0
+  // leaves them to the fp32 kernel.
+  static const bool skip_narrow = tune && c2d_tune_get("x9_wgrad_narrow") && atoi(c2d_tune_get("x9_wgrad_narrow")) == 0;
+  const bool narrow = a.J % 128 != 0 && a.J % 128 <= 64;      // 128 x 64 block tiles
+  if (narrow && skip_narrow) return C2D_ERR_UNSUPPORTED;
+  const int bj = narrow ? 64 : 128;
+  a.tiles_x = c2d_ceil_div(a.I, 128);
+  a.tiles_y = c2d_ceil_div(a.J, bj);
+  const int tiles = a.tiles_x * a.tiles_y;
+  int splits = c2d_cu_scaled(slots_env) / tiles;               // two blocks per CU, one round
+  const int max_splits = c2d_ceil_div(a.M, 4 * WX_KB);         // at least four slabs per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), WX_KB) * WX_KB;
+  a.nsplits = c2d_ceil_div(a.M, a.rows_per_split);
+  const dim3 grid(tiles * a.nsplits), block(256);
+  dispatch_note_ext("wgrad1x1_x9_kernel<%d>", narrow ? 1 : 2);
+  if (narrow) hipLaunchKernelGGL((wgrad1x1_x9_kernel<1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((wgrad1x1_x9_kernel<2>), grid, block, 0, s, a);
+  return c2d_launch_status();
+}
+
 }  // namespace c2d_ig
 
 using namespace c2d_ig;

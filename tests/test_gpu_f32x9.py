@@ -123,6 +123,50 @@ def test_second_stage_layer_x9(ops, layer):
   _check(ops, *layer)
 
 
+ONE_BY_ONE = [l for l in SECOND_STAGE_LAYERS if l[4] == 1 and l[5] == 1]
+
+
+@pytest.mark.parametrize("layer", ONE_BY_ONE, ids=[l[0] for l in ONE_BY_ONE])
+def test_filter_gradient_1x1_x9(ops, layer):
+  """c2d_conv_wgrad of the 1x1 / stride-1 layers in a process that has planes bound: both fp32
+  operands split by the loader, nine partial products per k16 (wgrad1x1_x9_kernel) — the benchmark's
+  instance against the float64 oracle at the tolerance of the fp32-MFMA kernel, and that kernel with
+  the switch off."""
+  name, hw, cin, cout, k, s = layer
+  big = _X9Layer(ops, N_BENCH, hw, cin, cout, k, s, 1)
+  big.run(ops, "wgrad")
+  want_inst = ops.last_dispatch()
+  assert want_inst and all(i.startswith("wgrad1x1_x9_kernel<") for i in want_inst), want_inst
+  del big
+  for n in (704, N_BENCH):
+    lay = _X9Layer(ops, n, hw, cin, cout, k, s, 7 + len(name))
+    got = lay.run(ops, "wgrad")
+    if ops.last_dispatch() == want_inst:
+      break
+  else:
+    raise AssertionError((name, want_inst))
+  _seen.update(want_inst)
+  _, want = ref_ops.conv2d_backward(lay.x.astype(np.float64), lay.w.astype(np.float64),
+                                    lay.dc.astype(np.float64), s, need_dx=False)
+  _scale_close(_n(got), want, TOL, "%s wgrad n=%d %s" % (name, n, want_inst))
+  was = ops.f32x9_enable(False)
+  try:
+    ref = lay.run(ops, "wgrad")
+    assert all(i.startswith("wgrad_tn_kernel<") for i in ops.last_dispatch()), ops.last_dispatch()
+  finally:
+    ops.f32x9_enable(was)
+  _scale_close(_n(got), _n(ref).astype(np.float64), TOL, "%s wgrad vs fp32 MFMA" % name)
+  # odd row counts: the last slab / split ends inside the descriptor's zeros
+  odd = 8192 // (hw * hw) + 3
+  lay = _X9Layer(ops, odd, hw, cin, cout, k, s, 3)
+  got = lay.run(ops, "wgrad")
+  assert all(i.startswith("wgrad1x1_x9_kernel<") for i in ops.last_dispatch())
+  _, want = ref_ops.conv2d_backward(lay.x.astype(np.float64), lay.w.astype(np.float64),
+                                    lay.dc.astype(np.float64), s, need_dx=False)
+  _scale_close(_n(got), want, TOL, "%s wgrad n=%d" % (name, odd))
+  torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("block", ["Mixed_5a", "Mixed_5b", "Mixed_5c"])
 def test_block_entry_x9(ops, block):
   """The fused block-entry GEMMs: c2d_conv1x1_fwd_multi (one GEMM over the entry convolutions' output
