@@ -191,7 +191,7 @@ namespace {
 // three 16-byte LDS writes, once per element instead of once per fragment use — into three bf16 plane
 // tiles per operand, staged as they lie in HBM ([row][channel]); the MFMA operands (8 consecutive rows
 // of one channel per lane) come out of ds_read_b64_tr_b16 as in wgrad_tn_bf16_kernel (conv_gemm.hip).
-// Block tile 128 (i) x 64 NTJ (j), four waves 2 x 2, 32-row slabs; 60 KiB of LDS: two blocks per CU.
+// Block tile 128 (i) x 64 NTJ (j), four waves 2 x 2, 16-row slabs; 30 KiB of LDS: three blocks per CU.
 // The fp32 kernel this replaces (wgrad_tn_kernel, 16-row register-staged slabs on v_mfma_f32_32x32x2)
 // runs the step's fifteen 1x1 filter gradients at 0.50 - 0.69 of the fp32 matrix peak.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -202,13 +202,15 @@ __device__ __forceinline__ bf16x8 tr_frag_x9(const char* p, int hi_off) {
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-constexpr int WX_KB = 32;           // rows per slab: two 16-row MFMA k-steps
 constexpr int WX_RS = 256 + 64;     // bytes per staged row of a plane tile (128 bf16 + pad: 64 mod 256)
-constexpr int WX_TILE = WX_KB * WX_RS;
 
-template <int NTJ>
-__global__ __launch_bounds__(256, 2) void wgrad1x1_x9_kernel(WgradArgs a) {
+// WX_KB = rows per slab: 32 (two 16-row MFMA k-steps, 60 KiB of LDS: two workgroups per CU) or 16
+// (30 KiB: three workgroups per CU at ~150 registers, twice the barriers per row)
+template <int NTJ, int WX_KB>
+__global__ __launch_bounds__(256, WX_KB == 32 ? 2 : 3) void wgrad1x1_x9_kernel(WgradArgs a) {
   constexpr int BJ = 2 * NTJ * 32;
+  constexpr int WX_TILE = WX_KB * WX_RS;
+  constexpr int LU = WX_KB / 16;      // rows per loader thread
   __shared__ __attribute__((aligned(16))) char smem[6 * WX_TILE];   // A planes 0..2, G planes 0..2
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,9 +236,9 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_x9_kernel(WgradArgs a) {
                                                  ((long long)a.M * a.ldg - a.g_off) * 4);
   const unsigned acol = (unsigned)min(i0 + c8, a.I - 8) * 4u;
   const unsigned gcol = (unsigned)min(j0 + min(c8, BJ - 8), a.J - 8) * 4u;
-  unsigned aoffs[2], goffs[2];
+  unsigned aoffs[LU], goffs[LU];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < LU; ++u) {
     aoffs[u] = (unsigned)((kr + u * 16) * a.lda) * 4u + acol;
     goffs[u] = (unsigned)((kr + u * 16) * a.ldg) * 4u + gcol;
   }
@@ -257,11 +259,11 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_x9_kernel(WgradArgs a) {
         tile_bits |= 1u << (i * NTJ + j);
   tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
 
-  f32x4 ra[2][2], rg[2][2];
+  f32x4 ra[LU][2], rg[LU][2];
 #define K_WX_LOAD(MB)                                                      \
   {                                                                          \
     const int sa = (MB) * a.lda * 4, sg = (MB) * a.ldg * 4;                  \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                          \
+    _Pragma("unroll") for (int u = 0; u < LU; ++u) {                         \
       ra[u][0] = buf_load4(rsA, aoffs[u], sa);                               \
       ra[u][1] = buf_load4(rsA, aoffs[u] + 16u, sa);                         \
       rg[u][0] = buf_load4(rsG, goffs[u], sg);                               \
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_x9_kernel(WgradArgs a) {
   K_WX_LOAD(mbeg);
   for (int sl = 0, mb = mbeg; sl < nslabs; ++sl, mb += WX_KB) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < LU; ++u) {
       bf16x8 h, m, l;
       char* const wa = As + (kr + u * 16) * WX_RS + c8 * 2;
       split3_frag(ra[u][0], ra[u][1], h, m, l);
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_x9_kernel(WgradArgs a) {
     K_WX_LOAD(mb + WX_KB);     // next slab (rows past M: zeros)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < LU; ++s) {
       bf16x8 af[2][3], bf[NTJ][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -371,15 +373,23 @@ int launch_wgrad1x1_x9(WgradArgs a, hipStream_t s) {
   a.tiles_y = c2d_ceil_div(a.J, bj);
   const int tiles = a.tiles_x * a.tiles_y;
   int splits = c2d_cu_scaled(slots_env) / tiles;               // two blocks per CU, one round
-  const int max_splits = c2d_ceil_div(a.M, 4 * WX_KB);         // at least four slabs per block
+  // 16-row slabs (30 KiB of LDS, three workgroups per CU) against 32-row slabs (two): the ten launches
+  // of the step 1.31 -> 1.14 ms in one stream, the step 10.04 - 10.12 -> 9.81 - 9.88 ms on one box
+  static const int kb = (tune && c2d_tune_get("x9_wgrad_kb") && atoi(c2d_tune_get("x9_wgrad_kb")) == 32) ? 32 : 16;
+  const int max_splits = c2d_ceil_div(a.M, 4 * 32);            // at least 128 rows per block
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), WX_KB) * WX_KB;
+  a.rows_per_split = c2d_ceil_div(c2d_ceil_div(a.M, splits), 32) * 32;
   a.nsplits = c2d_ceil_div(a.M, a.rows_per_split);
   const dim3 grid(tiles * a.nsplits), block(256);
-  dispatch_note_ext("wgrad1x1_x9_kernel<%d>", narrow ? 1 : 2);
-  if (narrow) hipLaunchKernelGGL((wgrad1x1_x9_kernel<1>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((wgrad1x1_x9_kernel<2>), grid, block, 0, s, a);
+  dispatch_note_ext("wgrad1x1_x9_kernel<%d, %d>", narrow ? 1 : 2, kb);
+  if (kb == 16) {
+    if (narrow) hipLaunchKernelGGL((wgrad1x1_x9_kernel<1, 16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad1x1_x9_kernel<2, 16>), grid, block, 0, s, a);
+  } else {
+    if (narrow) hipLaunchKernelGGL((wgrad1x1_x9_kernel<1, 32>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad1x1_x9_kernel<2, 32>), grid, block, 0, s, a);
+  }
   return c2d_launch_status();
 }
 
