@@ -174,7 +174,7 @@ class KernelTimer(object):
             fam = "igemm_x9"
         if fam == "wgrad_tn":
           inst = ops.last_dispatch()
-          if inst and all(i.startswith("wgrad1x1_x9_kernel<") for i in inst):
+          if inst and all(i.startswith(("wgrad1x1_x9_kernel<", "wgrad3x3_x9_kernel<")) for i in inst):
             fam = "wgrad_x9"
         # the bf16 step's single-image first stage runs on its own kernel (igemm_small_kernel<*, 2>:
         # one 32x32 tile per workgroup, launch-bound): its own family, not the ring kernel's
@@ -936,9 +936,9 @@ def main(argv=None):
                    "gemm_method": ("f32x9: the forward / input-gradient GEMMs of 256 and more 128x128 tiles "
                                    "as nine EXACT bf16 partial products per fp32 product (x = hi + mid + lo, "
                                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate: results within the fp32 "
-                                   "kernels' tolerance of the float64 oracle), the 1x1 filter gradients of the "
-                                   "second stage likewise; 3x3 filter gradients, first stage and heads on "
-                                   "the fp32 matrix pipe (v_mfma_f32_32x32x2_f32)"
+                                   "kernels' tolerance of the float64 oracle), the stride-1 filter gradients of "
+                                   "the second stage likewise; stride-2 filter gradients, first stage and "
+                                   "heads on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32)"
                                    if x9_on else
                                    ("fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.dtype == "fp32"
                                     else "bf16 MFMA (v_mfma_f32_32x32x16_bf16)"))},
@@ -1050,9 +1050,11 @@ def main(argv=None):
                          PEAK_F32X9_TFLOPS)
       if igx9:
         igx9["bound"] = "mfma bf16x9"
-      wgx9 = mfma_family("wgrad_x9", "wgrad1x1_x9_kernel<*> (f32x9: filter gradients of the 1x1 convolutions, both "
-                         "fp32 operands split into three bf16 planes as they are staged, nine bf16 MFMAs per "
-                         "16 rows, split-K atomics)", "wgrad_x9", PEAK_F32X9_TFLOPS)
+      wgx9 = mfma_family("wgrad_x9", "wgrad1x1_x9_kernel<*> + wgrad3x3_x9_kernel<*> (f32x9: filter gradients of the "
+                         "second stage's stride-1 convolutions, both fp32 operands split into three bf16 planes "
+                         "as they are staged, nine bf16 MFMAs per 16 rows; 3x3: one tap per block over "
+                         "pixel-ordered rows, SAME-padding pairs never staged; split-K atomics)", "wgrad_x9",
+                         PEAK_F32X9_TFLOPS)
       if wgx9:
         wgx9["bound"] = "mfma bf16x9"
       if not low:

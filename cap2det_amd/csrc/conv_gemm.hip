@@ -2765,6 +2765,20 @@ static int conv_wgrad_impl(const float* x, int ldx, int xoff, const float* dc, i
     else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<7, 2, 2, 1>), grid, dim3(512), 0, st, b);
     return c2d_launch_status();
   }
+  if (ES == 4 && !partial && !splits_only && kh == 3 && kw == 3 && ih == iw && n >= 256 &&
+      ((stride == 1 && (iw == 4 || iw == 7)) || (stride == 2 && iw == 7)) && x9_active()) {
+    // fp32 networks with f32x9 on: one tap per block, pixel-ordered rows, nine bf16 partial products
+    // (C2D_TUNE=x9_wgrad3=0 keeps the fp32 nine-tap kernel)
+    static const bool off = c2d_tune_on() && c2d_tune_get("x9_wgrad3") && atoi(c2d_tune_get("x9_wgrad3")) == 0;
+    if (!off) {
+      C2D_CHECK_ARG((long long)n * ih * iw * ldx * 4 < (long long)OOB_OFFSET && (long long)n * ih * iw * ldc * 4 < (long long)OOB_OFFSET);
+      WgradArgs a3;
+      a3.A = x; a3.lda = ldx; a3.a_off = xoff; a3.G = dc; a3.ldg = ldc; a3.g_off = coff; a3.dW = dw;
+      a3.I = cin; a3.J = cout; a3.part_stride = 0; a3.rows_per_split = 0; a3.nsplits = 0;
+      const int rc3 = launch_wgrad3x3_x9(a3, n, iw, stride, (hipStream_t)stream);
+      if (rc3 != C2D_ERR_UNSUPPORTED) return rc3;
+    }
+  }
   if (kh == 3 && kw == 3 && stride == 1 && ih == iw && (iw == 4 || iw == 7) && cin % 32 == 0 &&
       cout % 32 == 0 && n >= 256) {
     Wgrad3Args b;

@@ -436,5 +436,7 @@ int launch_wgrad1x1_bf16_ring_group(WgradArgs* a, int num, hipStream_t s);
 // (fills the tiling fields of `a` itself; atomics into a.dW; C2D_ERR_UNSUPPORTED: not this shape).
 bool x9_active();
 int launch_wgrad1x1_x9(WgradArgs a, hipStream_t s);
+// the same for a 3x3 / SAME convolution over n maps of wcx x wcx input pixels: stride 1 (4 or 7) or 2 (7)
+int launch_wgrad3x3_x9(WgradArgs a, int n, int wcx, int stride, hipStream_t s);
 
 }  // namespace c2d_ig

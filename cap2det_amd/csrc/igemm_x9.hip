@@ -346,6 +346,173 @@ __global__ __launch_bounds__(256, WX_KB == 32 ? 2 : 3) void wgrad1x1_x9_kernel(W
   }
 }
 
+
+// ---- 3x3 / stride-1 / SAME filter gradient over 4x4 / 7x7 maps as nine partial products ----------
+// One TAP per block, rows in pixel order: a 16-row k-step is ONE output pixel of 16 consecutive
+// images (dC rows img * HW + p, x rows img * HW + p + the tap's pixel offset: row stride HW in both),
+// so the (pixel, tap) pairs that fall into the SAME padding are never staged and never multiplied —
+// what the fp32 nine-tap kernel achieves by pairing the same pixel of two images in a k = 2 step, and
+// what a 16-consecutive-row k-step (one 4x4 image) cannot.  The price: x and dC are fetched once per
+// tap that uses them (6.25 of 9 on 4x4 maps) instead of once — from the L2 of the XCD that runs all
+// tiles of a (tap, image range).  Blocks of a tap with fewer valid pixels get more images (equal
+// k-steps per block: one round of resident blocks).  Loader / LDS planes / MFMA order as above.
+struct Wgrad3X9Args {
+  WgradArgs w;        // A, lda, a_off, a_rows, G, ldg, g_off, dW, M, I, J, tiles_x (i), tiles_y (j)
+  int hw, wc, nimg;   // output (dC) pixels per image, output map width, images
+  int hwx, wcx, stride;   // input (x) pixels per image, input map width; 1, or 2 (7x7 -> 4x4)
+  int swapped;        // the 128-wide "i" operand is dC (I = cout) and the "j" operand is x (J = cin):
+                      // fewer padded tile columns for cin = 160 / 192 (host); dW stays [tap][cin][cout]
+  int first[10];      // first logical block of tap t; first[9] = grid size
+  int ipb[9];         // images per block of tap t (a multiple of 16)
+};
+
+template <int NTJ, bool SWAP>
+__global__ __launch_bounds__(256, 3) void wgrad3x3_x9_kernel(Wgrad3X9Args q) {
+  const WgradArgs& a = q.w;
+  constexpr int BJ = 2 * NTJ * 32;
+  constexpr int WX_TILE = 16 * WX_RS;
+  __shared__ __attribute__((aligned(16))) char smem[6 * WX_TILE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  char* const As = smem;
+  char* const Gs = smem + 3 * WX_TILE;
+  const int logical = xcd_remap(blockIdx.x, q.first[9]);
+  int tap = 0;
+#pragma unroll
+  for (int t = 1; t < 9; ++t)
+    if (logical >= q.first[t]) tap = t;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int rblk = logical - q.first[tap];
+  const int split = rblk / tiles;
+  const int tile = rblk - split * tiles;
+  const int by = tile / a.tiles_x, bx = tile - by * a.tiles_x;
+  const int i0 = bx * 128, j0 = by * BJ;
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  const int wc = q.wc, hw = q.hw, hwx = q.hwx, wcx = q.wcx, st = q.stride;
+  // output pixels (y, x) whose source pixel (st y + ky - 1, st x + kx - 1) lies inside the input map
+  const int y0 = ky == 0 ? 1 : 0, y1 = min(wc, (wcx - ky) / st + 1);
+  const int x0 = kx == 0 ? 1 : 0, x1 = min(wc, (wcx - kx) / st + 1);
+  const int doff = (ky - 1) * wcx + (kx - 1);
+  const int img0 = split * q.ipb[tap];
+  const int nsl = (min(q.ipb[tap], q.nimg - img0) + 15) / 16;
+  const int total = (y1 - y0) * (x1 - x0) * nsl;
+
+  // loader: thread -> image kr of the slab, 8 channels c8 (two 16-byte loads); images >= nimg lie
+  // outside the descriptors (zeros); columns beyond I / J are clamped (never stored)
+  const int kr = tid >> 4;
+  const int c8 = (tid & 15) * 8;
+  const bool gload = c8 < BJ;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc_b((const char*)a.A + (size_t)a.a_off * 4,
+                                                 (a.a_rows * a.lda - a.a_off) * 4);
+  const __amdgpu_buffer_rsrc_t rsG = make_rsrc_b((const char*)a.G + (size_t)a.g_off * 4,
+                                                 ((long long)a.M * a.ldg - a.g_off) * 4);
+  const unsigned aoff = (unsigned)(kr * (SWAP ? hw : hwx) * a.lda + min(i0 + c8, a.I - 8)) * 4u;
+  const unsigned goff = (unsigned)(kr * (SWAP ? hwx : hw) * a.ldg + min(j0 + min(c8, BJ - 8), a.J - 8)) * 4u;
+
+  f32x16 acc[2][NTJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  unsigned tile_bits = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+      if ((i0 + wm * 64 + i * 32 < a.I) && (j0 + (wn * NTJ + j) * 32 < a.J))
+        tile_bits |= 1u << (i * NTJ + j);
+  tile_bits = __builtin_amdgcn_readfirstlane(tile_bits);
+
+  f32x4 ra[2], rg[2];
+  int py = y0, px = x0, sl = 0;         // (scalar) the k-step being LOADED
+#define K_W3_LOAD()                                                          \
+  {                                                                            \
+    const int rowc = (img0 + sl * 16) * hw + py * wc + px;                     \
+    const int rowx = (img0 + sl * 16) * hwx + st * (py * wcx + px) + doff;     \
+    const int sg = (SWAP ? rowx : rowc) * a.ldg * 4;                           \
+    const int sa = (SWAP ? rowc : rowx) * a.lda * 4;                           \
+    ra[0] = buf_load4(rsA, aoff, sa);                                          \
+    ra[1] = buf_load4(rsA, aoff + 16u, sa);                                    \
+    rg[0] = buf_load4(rsG, goff, sg);                                          \
+    rg[1] = buf_load4(rsG, goff + 16u, sg);                                    \
+    if (++sl == nsl) { sl = 0; if (++px == x1) { px = x0; ++py; } }            \
+  }
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const char* const apl = As + (8 * lh + tq) * WX_RS + (wm * 64 + 16 * tg + 4 * tp) * 2;
+  const char* const gpl = Gs + (8 * lh + tq) * WX_RS + (wn * NTJ * 32 + 16 * tg + 4 * tp) * 2;
+
+  K_W3_LOAD();
+  for (int step = 0; step < total; ++step) {
+    {
+      bf16x8 h, m, l;
+      char* const wa = As + kr * WX_RS + c8 * 2;
+      split3_frag(ra[0], ra[1], h, m, l);
+      *reinterpret_cast<bf16x8*>(wa) = h;
+      *reinterpret_cast<bf16x8*>(wa + WX_TILE) = m;
+      *reinterpret_cast<bf16x8*>(wa + 2 * WX_TILE) = l;
+      if (gload) {
+        char* const wg = Gs + kr * WX_RS + c8 * 2;
+        split3_frag(rg[0], rg[1], h, m, l);
+        *reinterpret_cast<bf16x8*>(wg) = h;
+        *reinterpret_cast<bf16x8*>(wg + WX_TILE) = m;
+        *reinterpret_cast<bf16x8*>(wg + 2 * WX_TILE) = l;
+      }
+    }
+    __syncthreads();
+    if (step + 1 < total) K_W3_LOAD();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      bf16x8 af[2][3], bf[NTJ][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i][p] = tr_frag_x9(apl + p * WX_TILE + i * 64, 4 * WX_RS);
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) bf[j][p] = tr_frag_x9(gpl + p * WX_TILE + j * 64, 4 * WX_RS);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j)
+          if ((tile_bits >> (i * NTJ + j)) & 1u) {
+            // (SWAP: the operands change places, so that the lanes of the result run along cout —
+            //  the contiguous dimension of dW — in both forms)
+#define K_W3_MFMA(PA, PB)                                                                              \
+  acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB], af[i][PA], acc[i][j], 0, 0, 0)  \
+                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+            K_W3_MFMA(2, 2) K_W3_MFMA(2, 1) K_W3_MFMA(1, 2) K_W3_MFMA(1, 1) K_W3_MFMA(2, 0)
+            K_W3_MFMA(0, 2) K_W3_MFMA(1, 0) K_W3_MFMA(0, 1) K_W3_MFMA(0, 0)
+#undef K_W3_MFMA
+          }
+    }
+    __syncthreads();
+  }
+#undef K_W3_LOAD
+
+  float* dw = a.dW + (size_t)tap * a.I * a.J;
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!((tile_bits >> (i * NTJ + j)) & 1u)) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if constexpr (SWAP) {      // rows of the tile = cin (kernel j), lanes = cout (kernel i)
+          const int jj = j0 + (wn * NTJ + j) * 32 + rr, ii = i0 + wm * 64 + i * 32 + li;
+          if (jj < a.J && ii < a.I) atomicAdd(dw + (size_t)jj * a.I + ii, acc[i][j][r]);
+        } else {
+          const int ii = i0 + wm * 64 + i * 32 + rr, jj = j0 + (wn * NTJ + j) * 32 + li;
+          if (ii < a.I && jj < a.J) atomicAdd(dw + (size_t)ii * a.J + jj, acc[i][j][r]);
+        }
+      }
+    }
+}
+
 }  // namespace
 
 bool x9_active() { return g_enabled && g_narena > 0; }
@@ -389,6 +556,72 @@ int launch_wgrad1x1_x9(WgradArgs a, hipStream_t s) {
   } else {
     if (narrow) hipLaunchKernelGGL((wgrad1x1_x9_kernel<1, 32>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad1x1_x9_kernel<2, 32>), grid, block, 0, s, a);
+  }
+  return c2d_launch_status();
+}
+
+
+// a: A (x), lda, a_off, G (dC), ldg, g_off, dW, I (cin), J (cout) filled; n images of wcx x wcx input
+// pixels, stride 1 (wcx = 4 or 7) or 2 (7 -> 4)
+int launch_wgrad3x3_x9(WgradArgs a, int n, int wcx, int stride, hipStream_t s) {
+  if (a.I % 8 || a.J % 8 || a.lda % 4 || a.ldg % 4 || a.a_off % 4 || a.g_off % 4 || a.I < 8 || a.J < 8 ||
+      a.part_stride > 0 || n < 256 || !((stride == 1 && (wcx == 4 || wcx == 7)) || (stride == 2 && wcx == 7)))
+    return C2D_ERR_UNSUPPORTED;
+  const int wc = (wcx + stride - 1) / stride;
+  static const bool tune = c2d_tune_on();
+  static const int slots_env = (tune && c2d_tune_get("x9_wgrad3_slots")) ? atoi(c2d_tune_get("x9_wgrad3_slots")) : 768;
+  static const int swap_env = (tune && c2d_tune_get("x9_wgrad3_swap")) ? atoi(c2d_tune_get("x9_wgrad3_swap")) : -1;
+  // block tile = 128 columns of one operand x 128 (or 64, when the last 128 would be at most half
+  // full) of the other: the operand roles that pad the I x J output least
+  auto padded = [](int wide, int other) {
+    const bool nar = other % 128 != 0 && other % 128 <= 64;
+    return (long long)c2d_ceil_div(wide, 128) * 128 * c2d_ceil_div(other, nar ? 64 : 128) * (nar ? 64 : 128);
+  };
+  const bool swapped = swap_env >= 0 ? swap_env != 0 : padded(a.J, a.I) < padded(a.I, a.J);
+  a.M = n * wc * wc;                 // rows of the "G" operand's descriptor
+  a.a_rows = (long long)n * wcx * wcx;   // rows of the "A" operand's descriptor
+  if (swapped) {
+    WgradArgs b = a;
+    b.A = a.G; b.lda = a.ldg; b.a_off = a.g_off; b.I = a.J; b.a_rows = a.M;
+    b.G = a.A; b.ldg = a.lda; b.g_off = a.a_off; b.J = a.I; b.M = (int)a.a_rows;
+    a = b;
+  }
+  Wgrad3X9Args q;
+  const bool narrow = a.J % 128 != 0 && a.J % 128 <= 64;
+  const int bj = narrow ? 64 : 128;
+  a.tiles_x = c2d_ceil_div(a.I, 128);
+  a.tiles_y = c2d_ceil_div(a.J, bj);
+  const int tiles = a.tiles_x * a.tiles_y;
+  q.hw = wc * wc; q.wc = wc; q.nimg = n; q.swapped = swapped;
+  q.hwx = wcx * wcx; q.wcx = wcx; q.stride = stride;
+  int valid[9], sum = 0;
+  for (int t = 0; t < 9; ++t) {
+    const int ky = t / 3, kx = t % 3;
+    const int ny = std::min(wc, (wcx - ky) / stride + 1) - (ky == 0), nx = std::min(wc, (wcx - kx) / stride + 1) - (kx == 0);
+    valid[t] = ny * nx;
+    sum += valid[t];
+  }
+  // equal k-steps per block: images per block of tap t = C / valid[t], C from one round of `slots`
+  const long long c = (long long)n * tiles * sum / c2d_cu_scaled(slots_env);
+  int first = 0;
+  for (int t = 0; t < 9; ++t) {
+    int ipb = (int)(c / valid[t]) / 16 * 16;
+    if (ipb < 64) ipb = 64;
+    if (ipb > (n + 15) / 16 * 16) ipb = (n + 15) / 16 * 16;
+    q.ipb[t] = ipb;
+    q.first[t] = first;
+    first += c2d_ceil_div(n, ipb) * tiles;
+  }
+  q.first[9] = first;
+  q.w = a;
+  const dim3 grid(first), block(256);
+  dispatch_note_ext(swapped ? "wgrad3x3_x9_kernel<%d, true>" : "wgrad3x3_x9_kernel<%d, false>", narrow ? 1 : 2);
+  if (swapped) {
+    if (narrow) hipLaunchKernelGGL((wgrad3x3_x9_kernel<1, true>), grid, block, 0, s, q);
+    else hipLaunchKernelGGL((wgrad3x3_x9_kernel<2, true>), grid, block, 0, s, q);
+  } else {
+    if (narrow) hipLaunchKernelGGL((wgrad3x3_x9_kernel<1, false>), grid, block, 0, s, q);
+    else hipLaunchKernelGGL((wgrad3x3_x9_kernel<2, false>), grid, block, 0, s, q);
   }
   return c2d_launch_status();
 }

@@ -226,8 +226,9 @@ int c2d_transpose_taps(const float* w, float* wt, int taps, int rows, int cols, 
  * process-wide state behind this header.  c2d_conv_fwd / c2d_conv1x1_fwd_multi / c2d_conv_dgrad* /
  * c2d_conv1x1_dgrad_multi* calls whose weight operand lies inside a bound arena (and whose GEMM
  * has at least 256 tiles of 128 x 128) take the f32x9 kernels; every other call is unchanged.
- * While at least one arena is bound (and the switch is on), c2d_conv_wgrad of a 1x1 / stride-1
- * convolution over 8192 rows or more takes the nine-product form as well (both operands are
+ * While at least one arena is bound (and the switch is on), c2d_conv_wgrad takes the nine-product
+ * form as well for a 1x1 / stride-1 convolution over 8192 rows or more and for a 3x3 convolution
+ * over 256 or more maps of 4x4 / 7x7 (stride 1) or 7x7 (stride 2) pixels (both operands are
  * activations there: the kernel splits them as it stages them).
  * The caller keeps the planes current (c2d_split3_bf16 after every update of the arena); bind /
  * unbind / enable are not to be called while GEMM calls are in flight on other threads.

@@ -124,19 +124,24 @@ def test_second_stage_layer_x9(ops, layer):
 
 
 ONE_BY_ONE = [l for l in SECOND_STAGE_LAYERS if l[4] == 1 and l[5] == 1]
+THREE_BY_THREE = [l for l in SECOND_STAGE_LAYERS if l[4] == 3]          # (stride 1 and the two stride-2 layers)
 
 
-@pytest.mark.parametrize("layer", ONE_BY_ONE, ids=[l[0] for l in ONE_BY_ONE])
-def test_filter_gradient_1x1_x9(ops, layer):
-  """c2d_conv_wgrad of the 1x1 / stride-1 layers in a process that has planes bound: both fp32
-  operands split by the loader, nine partial products per k16 (wgrad1x1_x9_kernel) — the benchmark's
-  instance against the float64 oracle at the tolerance of the fp32-MFMA kernel, and that kernel with
-  the switch off."""
+@pytest.mark.parametrize("layer", ONE_BY_ONE + THREE_BY_THREE,
+                         ids=[l[0] for l in ONE_BY_ONE + THREE_BY_THREE])
+def test_filter_gradient_x9(ops, layer):
+  """c2d_conv_wgrad of the second-stage layers in a process that has planes bound: both fp32 operands
+  split by the loader, nine partial products per k16 — wgrad1x1_x9_kernel for the 1x1 layers,
+  wgrad3x3_x9_kernel (one tap per block, pixel-ordered rows, padding pairs never staged) for the 3x3
+  layers on 4x4 / 7x7 maps — at the benchmark's instance against the float64 oracle at the tolerance
+  of the fp32-MFMA kernels, and those kernels with the switch off."""
   name, hw, cin, cout, k, s = layer
+  x9_kernel, fp32_kernel = (("wgrad1x1_x9_kernel<", "wgrad_tn_kernel<") if k == 1 else
+                            ("wgrad3x3_x9_kernel<", "wgrad3x3_kernel<" if s == 1 else "wgrad3x3_s2_kernel<"))
   big = _X9Layer(ops, N_BENCH, hw, cin, cout, k, s, 1)
   big.run(ops, "wgrad")
   want_inst = ops.last_dispatch()
-  assert want_inst and all(i.startswith("wgrad1x1_x9_kernel<") for i in want_inst), want_inst
+  assert want_inst and all(i.startswith(x9_kernel) for i in want_inst), want_inst
   del big
   for n in (704, N_BENCH):
     lay = _X9Layer(ops, n, hw, cin, cout, k, s, 7 + len(name))
@@ -152,15 +157,15 @@ def test_filter_gradient_1x1_x9(ops, layer):
   was = ops.f32x9_enable(False)
   try:
     ref = lay.run(ops, "wgrad")
-    assert all(i.startswith("wgrad_tn_kernel<") for i in ops.last_dispatch()), ops.last_dispatch()
+    assert all(i.startswith(fp32_kernel) for i in ops.last_dispatch()), ops.last_dispatch()
   finally:
     ops.f32x9_enable(was)
   _scale_close(_n(got), _n(ref).astype(np.float64), TOL, "%s wgrad vs fp32 MFMA" % name)
-  # odd row counts: the last slab / split ends inside the descriptor's zeros
-  odd = 8192 // (hw * hw) + 3
+  # odd image counts: the last slab / split ends inside the descriptor's zeros
+  odd = max(8192 // (hw * hw) + 3, 261)
   lay = _X9Layer(ops, odd, hw, cin, cout, k, s, 3)
   got = lay.run(ops, "wgrad")
-  assert all(i.startswith("wgrad1x1_x9_kernel<") for i in ops.last_dispatch())
+  assert all(i.startswith(x9_kernel) for i in ops.last_dispatch())
   _, want = ref_ops.conv2d_backward(lay.x.astype(np.float64), lay.w.astype(np.float64),
                                     lay.dc.astype(np.float64), s, need_dx=False)
   _scale_close(_n(got), want, TOL, "%s wgrad n=%d" % (name, odd))

@@ -39,7 +39,7 @@ from summarize_pmc import family_of  # noqa: E402
 
 
 def family(name):
-  if "wgrad1x1_x9_kernel" in name:
+  if "wgrad1x1_x9_kernel" in name or "wgrad3x3_x9_kernel" in name:
     return "wgrad_x9"
   if re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 4, (?:true|false), 3>", name):
     return "igemm_x9"         # fp32 operands as nine bf16 partial products (csrc/igemm_x9.hip)

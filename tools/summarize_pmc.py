@@ -58,7 +58,7 @@ DEFAULT_FETCH_FACTOR = 2.0
 def family_of(name):
   # bf16-operand kernels (bench.py --dtype bf16) are separate families: their roofline is the
   # bf16 MFMA peak
-  if "wgrad1x1_x9_kernel" in name:
+  if "wgrad1x1_x9_kernel" in name or "wgrad3x3_x9_kernel" in name:
     return "wgrad_x9"         # 1x1 filter gradients as nine bf16 partial products (csrc/igemm_x9.hip)
   if ("wgrad_tn_bf16_kernel" in name or "wgrad3x3_bf16" in name or "wgrad1x1_bf16_ring" in name or
       "wgrad_reduce_kernel" in name):
