@@ -1031,8 +1031,11 @@ def main(argv=None):
       ig32 = mfma_family("igemm_nt", "igemm_nt_kernel<*> + igemm_small_kernel<*> (implicit-GEMM conv "
                          "fwd + dgrad + heads GEMM, fp32 MFMA 32x32x2; a stride-2 dgrad call = 4 launches)",
                          ig32_key, PEAK_FP32_MFMA_TFLOPS)
-      wg32 = mfma_family("wgrad_tn", "wgrad_tn_kernel<*> + wgrad3x3_kernel<*> (conv filter gradient, "
-                         "fp32 MFMA)", "wgrad", PEAK_FP32_MFMA_TFLOPS)
+      wg32 = mfma_family("wgrad_tn", ("wgrad_tn_kernel<*> (what f32x9 leaves on the fp32 pipe: the filter gradients "
+                                      "of the single-image first stage and of the heads, launch-latency-bound)"
+                                      if x9_on else
+                                      "wgrad_tn_kernel<*> + wgrad3x3_kernel<*> (conv filter gradient, fp32 MFMA)"),
+                         "wgrad", PEAK_FP32_MFMA_TFLOPS)
       # whole-step view, independent of how kernels overlap: all MFMA work of a step over the
       # median step time (includes every non-GEMM kernel of the step in the denominator)
       gemm_flops = sum(f["work"] for k, f in summ.items() if not k.startswith("roi_crop"))
