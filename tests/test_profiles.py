@@ -106,4 +106,13 @@ def test_every_gemm_kernel_of_the_committed_profiles_has_a_pmc_family():
           assert fam == "igemm_bf16", (name, fam)
         if "bf16" in name and "wgrad" in name:
           assert fam == "wgrad_bf16", (name, fam)
+        # fp32 operands as nine bf16 partial products: families of their own (priced against the
+        # bf16 pipe / 9, never against the fp32 matrix peak)
+        if re.search(r"igemm_ring(?:_group)?_kernel<[^>]*, 4, (?:true|false), 3>", name):
+          assert fam == "igemm_x9", (name, fam)
+        if "wgrad1x1_x9_kernel" in name or "wgrad3x3_x9_kernel" in name:
+          assert fam == "wgrad_x9", (name, fam)
   assert seen >= 30
+  from summarize_mfma import family as mfma_family
+  assert mfma_family("void c2d_ig::(anonymous namespace)::wgrad3x3_x9_kernel<2, true>(Wgrad3X9Args)") == "wgrad_x9"
+  assert mfma_family("void c2d_ig::igemm_ring_kernel<0, 4, 1, 1, 3, true, 32, 2, 4, false, 3>(IgemmArgs)") == "igemm_x9"
