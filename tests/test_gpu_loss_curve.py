@@ -33,6 +33,14 @@ def test_bf16_modes_follow_the_fp32_loss_trajectory():
       assert v <= (2e-2 if term == "total_loss" else 1e-1), (name, term, v)
   moved = doc["curves"]["fp32"]["trajectory"]["distance_moved"]
   assert moved > 0
+  # the shipped fp32 network (second-stage GEMMs as nine bf16 partial products, f32x9) against the
+  # same network with every GEMM on the fp32 matrix pipe: the SAME arithmetic to fp32 rounding — the
+  # two runs stay an order of magnitude closer to each other than the bf16 modes stay to them
+  t = doc["curves"]["fp32_mfma"]["trajectory"]
+  assert t["cosine_with_fp32_displacement"] >= 0.999, t
+  assert t["relative_deviation"] <= 0.03, t
+  for term, v in doc["deviation_from_fp32"]["fp32_mfma"]["max_relative_window_deviation"].items():
+    assert v <= (2e-3 if term == "total_loss" else 2e-2), (term, v)
   for name in ("bf16_fp32first", "bf16"):
     t = doc["curves"][name]["trajectory"]
     # the bf16 runs displace the trainable variables the way the fp32 run does: same direction,

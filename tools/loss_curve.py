@@ -34,7 +34,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-MODES = [("fp32", "fp32", None), ("bf16_fp32first", "bf16", "1"), ("bf16", "bf16", "0")]
+# (name, storage, C2D_TUNE first_stage_fp32, f32x9 off).  "fp32" is the shipped fp32 network — its
+# second-stage GEMMs as nine bf16 partial products (f32x9); "fp32_mfma" the same network with every
+# GEMM on the fp32 matrix pipe: the two must follow the same trajectory to rounding
+MODES = [("fp32", "fp32", None, False), ("fp32_mfma", "fp32", None, True),
+         ("bf16_fp32first", "bf16", "1", False), ("bf16", "bf16", "0", False)]
 
 
 def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, device="cuda:0",
@@ -55,13 +59,17 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
                         learning_rate=pipeline.train_config.learning_rate),
          "curves": {}}
   batches, init = None, None
-  for name, dtype, first_fp32 in modes:
+  for mode in modes:
+    name, dtype, first_fp32 = mode[:3]
+    x9_off = len(mode) > 3 and mode[3]
     if first_fp32 is None:
       os.environ.pop("C2D_TUNE", None)
     else:
       os.environ["C2D_TUNE"] = "first_stage_fp32=%s" % first_fp32
     trainer = Trainer(pipeline, device=device, depth_multiplier=dm, compute_dtype=dtype, seed=seed)
     model = trainer.model
+    if x9_off:
+      model.engine.enable_f32x9(False)
     if init is None:
       # He-normal convolution weights (the trainer's default initialiser is TF-slim's small
       # truncated normal: activations shrink layer by layer, the features of a fresh detector are
@@ -137,7 +145,7 @@ def run_curves(steps=400, hw=500, proposals=2000, dm=1.0, pool=8, window=25, dev
   os.environ.pop("C2D_TUNE", None)
   ref = out["curves"][modes[0][0]]["windows"]
   out["deviation_from_fp32"] = {}
-  for name, _, _ in modes[1:]:
+  for name in [m[0] for m in modes[1:]]:
     cur = out["curves"][name]["windows"]
     dev = {}
     for k in ref:
